@@ -1,0 +1,207 @@
+"""ctypes binding of the CPU oracle (oracle/qtos_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libqtos_oracle.so")
+NEE, MAX_PHASES = 4, 16
+
+
+class QoParams(C.Structure):
+    _fields_ = [
+        ("n_phases", C.c_int * NEE),
+        ("phase_dur", (C.c_double * MAX_PHASES) * NEE),
+        ("dt_base", C.c_double), ("dt_dyn", C.c_double), ("dt_rom", C.c_double),
+        ("force_polys_per_stance", C.c_int),
+        ("mass", C.c_double), ("gravity", C.c_double), ("Ib", C.c_double * 9),
+        ("nominal_stance", (C.c_double * 3) * NEE),
+        ("max_dev", C.c_double * 3),
+        ("mu", C.c_double), ("f_max", C.c_double), ("t_swing_avg", C.c_double),
+        ("height", C.POINTER(C.c_double)),
+        ("hnx", C.c_int), ("hny", C.c_int),
+        ("hcell", C.c_double), ("hx0", C.c_double), ("hy0", C.c_double),
+    ]
+
+
+class QoProblem(C.Structure):
+    _fields_ = [
+        ("s", C.c_double * 3), ("s_ang", C.c_double * 3), ("ee", (C.c_double * 3) * NEE),
+        ("s_vel", C.c_double * 3), ("s_ang_vel", C.c_double * 3), ("g", C.c_double * 3),
+        ("t0", C.c_double),
+    ]
+
+
+class QoLayout(C.Structure):
+    _fields_ = [
+        ("n_base_nodes", C.c_int),
+        ("off_lin", C.c_int), ("off_ang", C.c_int), ("off_eem", C.c_int * NEE),
+        ("off_eef", C.c_int * NEE), ("n_vars", C.c_int),
+        ("n_eem", C.c_int * NEE), ("n_eef", C.c_int * NEE),
+        ("off_terrain", C.c_int * NEE), ("off_dyn", C.c_int), ("off_acc_lin", C.c_int),
+        ("off_acc_ang", C.c_int), ("off_rom", C.c_int * NEE), ("off_force", C.c_int * NEE),
+        ("off_swing", C.c_int * NEE), ("n_cons", C.c_int),
+        ("n_dyn_times", C.c_int), ("n_rom_times", C.c_int), ("T", C.c_double),
+    ]
+
+
+class QoOptions(C.Structure):
+    _fields_ = [
+        ("max_iter", C.c_int), ("tol", C.c_double), ("mu_init", C.c_double),
+        ("mu_min", C.c_double), ("delta_x", C.c_double), ("eps_dual", C.c_double),
+        ("warm_start", C.c_int), ("verbose", C.c_int),
+    ]
+
+
+class QoInfo(C.Structure):
+    _fields_ = [
+        ("status", C.c_int), ("iters", C.c_int), ("inf_pr", C.c_double), ("inf_pr0", C.c_double),
+        ("mu", C.c_double), ("factor_secs", C.c_double), ("eval_secs", C.c_double),
+    ]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "qtos_oracle.c")
+    hdr = os.path.join(_HERE, "qtos_oracle.h")
+    if (force or not os.path.exists(_LIB)
+            or os.path.getmtime(_LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        dp = C.POINTER(C.c_double)
+        _lib.qo_get_layout.argtypes = [C.POINTER(QoParams), C.POINTER(QoLayout)]
+        _lib.qo_var_bounds.argtypes = [C.POINTER(QoParams), C.POINTER(QoProblem), dp, dp]
+        _lib.qo_con_bounds.argtypes = [C.POINTER(QoParams), dp, dp]
+        _lib.qo_initial_guess.argtypes = [C.POINTER(QoParams), C.POINTER(QoProblem), dp]
+        _lib.qo_constraints.argtypes = [C.POINTER(QoParams), dp, dp]
+        _lib.qo_jacobian.argtypes = [C.POINTER(QoParams), dp, dp]
+        _lib.qo_sample.argtypes = [C.POINTER(QoParams), dp, C.c_double, C.c_double, C.c_int, dp]
+        _lib.qo_terrain_height.argtypes = [C.POINTER(QoParams), C.c_double, C.c_double]
+        _lib.qo_terrain_height.restype = C.c_double
+        _lib.qo_max_violation.argtypes = [C.POINTER(QoParams), dp]
+        _lib.qo_max_violation.restype = C.c_double
+        _lib.qo_default_options.argtypes = [C.POINTER(QoOptions)]
+        _lib.qo_solve.argtypes = [C.POINTER(QoParams), C.POINTER(QoProblem),
+                                  C.POINTER(QoOptions), dp, C.POINTER(QoInfo)]
+        _lib.qo_ldlt_solve_dense.argtypes = [C.c_int, dp, dp]
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Oracle:
+    """Thin object wrapper: Oracle(cfg_dict).  cfg keys mirror qo_params."""
+
+    def __init__(self, cfg, height=None, hcell=0.1, hx0=-1.0, hy0=-1.0):
+        self.p = QoParams()
+        p = self.p
+        for e in range(NEE):
+            d = cfg["phase_durations"][e]
+            p.n_phases[e] = len(d)
+            for k, v in enumerate(d):
+                p.phase_dur[e][k] = float(v)
+            for k in range(3):
+                p.nominal_stance[e][k] = float(cfg["nominal_stance"][e][k])
+        p.dt_base, p.dt_dyn, p.dt_rom = cfg["dt_base"], cfg["dt_dyn"], cfg["dt_rom"]
+        p.force_polys_per_stance = cfg.get("force_polys_per_stance", 3)
+        p.mass, p.gravity = cfg["mass"], cfg["gravity"]
+        for k, v in enumerate(np.asarray(cfg["inertia_b"], float).reshape(9)):
+            p.Ib[k] = v
+        for k in range(3):
+            p.max_dev[k] = cfg["max_dev"][k]
+        p.mu, p.f_max, p.t_swing_avg = cfg["mu"], cfg["f_max"], cfg["t_swing_avg"]
+        self._height = None
+        if height is not None:
+            self._height = np.ascontiguousarray(height, dtype=np.float64)
+            p.height = _dp(self._height)
+            p.hnx, p.hny = self._height.shape
+            p.hcell, p.hx0, p.hy0 = hcell, hx0, hy0
+        self.L = QoLayout()
+        rc = lib().qo_get_layout(C.byref(p), C.byref(self.L))
+        if rc:
+            raise ValueError("qo_get_layout failed rc=%d" % rc)
+        self.n, self.m = self.L.n_vars, self.L.n_cons
+
+    @staticmethod
+    def problem(s, s_ang, ee, g, s_vel=(0, 0, 0), s_ang_vel=(0, 0, 0), t0=0.0):
+        q = QoProblem()
+        for k in range(3):
+            q.s[k], q.s_ang[k], q.g[k] = s[k], s_ang[k], g[k]
+            q.s_vel[k], q.s_ang_vel[k] = s_vel[k], s_ang_vel[k]
+            for e in range(NEE):
+                q.ee[e][k] = ee[e][k]
+        q.t0 = t0
+        return q
+
+    def var_bounds(self, q):
+        lo, hi = np.empty(self.n), np.empty(self.n)
+        lib().qo_var_bounds(C.byref(self.p), C.byref(q), _dp(lo), _dp(hi))
+        return lo, hi
+
+    def con_bounds(self):
+        lo, hi = np.empty(self.m), np.empty(self.m)
+        lib().qo_con_bounds(C.byref(self.p), _dp(lo), _dp(hi))
+        return lo, hi
+
+    def initial_guess(self, q):
+        x = np.empty(self.n)
+        lib().qo_initial_guess(C.byref(self.p), C.byref(q), _dp(x))
+        return x
+
+    def constraints(self, x):
+        x = np.ascontiguousarray(x, float)
+        g = np.empty(self.m)
+        lib().qo_constraints(C.byref(self.p), _dp(x), _dp(g))
+        return g
+
+    def jacobian(self, x):
+        x = np.ascontiguousarray(x, float)
+        J = np.empty((self.m, self.n))
+        lib().qo_jacobian(C.byref(self.p), _dp(x), _dp(J))
+        return J
+
+    def sample(self, x, t0=0.0, hz=1000.0, n_rows=None):
+        x = np.ascontiguousarray(x, float)
+        if n_rows is None:
+            n_rows = int(round(self.L.T * hz)) + 1
+        rows = np.empty((n_rows, 37))
+        lib().qo_sample(C.byref(self.p), _dp(x), t0, hz, n_rows, _dp(rows))
+        return rows
+
+    def max_violation(self, x):
+        x = np.ascontiguousarray(x, float)
+        return lib().qo_max_violation(C.byref(self.p), _dp(x))
+
+    def terrain_height(self, x, y):
+        return lib().qo_terrain_height(C.byref(self.p), x, y)
+
+    def default_options(self):
+        o = QoOptions()
+        lib().qo_default_options(C.byref(o))
+        return o
+
+    def solve(self, q, x0=None, opts=None):
+        o = opts or self.default_options()
+        x = np.empty(self.n)
+        if x0 is not None:
+            x[:] = x0
+            o.warm_start = 1
+        info = QoInfo()
+        lib().qo_solve(C.byref(self.p), C.byref(q), C.byref(o), _dp(x), C.byref(info))
+        return x, info

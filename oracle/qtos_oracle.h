@@ -1,0 +1,123 @@
+/*
+ * qtos_oracle.h -- CPU restatement (plain C99, double precision) of the NLP that QTOS's
+ * Docker-backed TOWR/Ipopt local planner solves.
+ *
+ * THIS IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product path (the HIP library under
+ * quadruped-trajectory-optimization-stack_amd/csrc) never links, imports or calls it.
+ *
+ * PARITY STATUS: the reference's solver source is absent from /root/reference (solver/ is an
+ * empty submodule: github.com/Alexyskoutnev/towr_solo12, fork of ethz-adrl/towr v1.4, unpinned
+ * HEAD; ifopt v2.0; Ipopt 3.11.9 + MUMPS -- Dockerfile:12-45, logs/towr_log.out:3,37,88).  The
+ * restatement follows the published TOWR v1.4 formulation and is pinned against the artefacts the
+ * reference commits for this path:
+ *   - NLP dimensions / bound split / set order        logs/towr_log.out:40-52,99-129
+ *   - GV1 test/data/traj/gait.csv, GV2 data/traj/towr.csv rows 1254.. (constraint residuals vanish
+ *     on the golden trajectories; see tests/test_oracle_golden.py and SURVEY.md 8c P1)
+ * The solver *iterates* of Ipopt are not reproducible (no objective, L-BFGS Hessian, unpinned
+ * code), so solution parity follows protocol P1-P4 of SURVEY.md 8c, not digit-for-digit equality.
+ */
+#ifndef QTOS_ORACLE_H
+#define QTOS_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QO_NEE 4
+#define QO_MAX_PHASES 16
+#define QO_MAX_POLYS 260
+#define QO_MAX_NODES (QO_MAX_POLYS + 1)
+
+/* Model + transcription parameters (upstream towr Parameters / RobotModel, plus the fork's
+ * data-derived SOLO12 constants: SURVEY.md 0.5, 8a-7, 8a-8). */
+typedef struct {
+  int n_phases[QO_NEE];                     /* odd; every foot starts and ends in stance      */
+  double phase_dur[QO_NEE][QO_MAX_PHASES];  /* seconds, sums to T for every foot              */
+  double dt_base;                           /* duration_base_polynomial_ (0.1)                */
+  double dt_dyn;                            /* dt_constraint_dynamic_ (0.1)                   */
+  double dt_rom;                            /* dt_constraint_range_of_motion_ (0.08)          */
+  int force_polys_per_stance;               /* 3                                              */
+  double mass, gravity, Ib[9];              /* single rigid body                              */
+  double nominal_stance[QO_NEE][3];         /* in base frame                                  */
+  double max_dev[3];                        /* range-of-motion box half-widths                */
+  double mu, f_max, t_swing_avg;            /* friction, normal-force limit, swing ref time   */
+  /* terrain: height[ix*hny+iy] at x = hx0 + ix*hcell, y = hy0 + iy*hcell, bilinear, clamped;
+   * NULL = flat ground at z = 0 */
+  const double *height;
+  int hnx, hny;
+  double hcell, hx0, hy0;
+} qo_params;
+
+/* One planning problem = the reference's solver flags (QTOS/utils.py:26 _flags). */
+typedef struct {
+  double s[3];         /* -s      CoM start                       */
+  double s_ang[3];     /* -s_ang  Euler roll,pitch,yaw            */
+  double ee[QO_NEE][3];/* -e1..-e4 world foot positions FL,FR,HL,HR */
+  double s_vel[3];     /* s_vel                                   */
+  double s_ang_vel[3]; /* s_ang_vel (Euler rates)                 */
+  double g[3];         /* -g      goal (x,y used; z only seeds)   */
+  double t0;           /* -t      time stamp of first CSV row     */
+} qo_problem;
+
+typedef struct {
+  int n_base_nodes;
+  int off_lin, off_ang, off_eem[QO_NEE], off_eef[QO_NEE], n_vars;
+  int n_eem[QO_NEE], n_eef[QO_NEE];
+  int off_terrain[QO_NEE], off_dyn, off_acc_lin, off_acc_ang, off_rom[QO_NEE], off_force[QO_NEE],
+      off_swing[QO_NEE], n_cons;
+  int n_dyn_times, n_rom_times;
+  double T;
+} qo_layout;
+
+/* ---- structure ------------------------------------------------------------------------------ */
+int qo_get_layout(const qo_params *p, qo_layout *L);
+/* variable bounds; fixed variables have lo == hi (logs/towr_log.out:44: 1040 -> 1005) */
+int qo_var_bounds(const qo_params *p, const qo_problem *q, double *lo, double *hi);
+/* constraint bounds, +-1e20 = infinite */
+int qo_con_bounds(const qo_params *p, double *lo, double *hi);
+/* upstream-style initial guess (linear interpolation by node index, fz = m g / 4) */
+int qo_initial_guess(const qo_params *p, const qo_problem *q, double *x);
+
+/* ---- functions ------------------------------------------------------------------------------ */
+int qo_constraints(const qo_params *p, const double *x, double *g);
+/* dense row-major Jacobian n_cons x n_vars */
+int qo_jacobian(const qo_params *p, const double *x, double *J);
+/* 1 kHz-style sampling: rows[n_rows][37], row k at t = k/hz, time column = t0 + k/hz */
+int qo_sample(const qo_params *p, const double *x, double t0, double hz, int n_rows, double *rows);
+double qo_terrain_height(const qo_params *p, double x, double y);
+
+/* ---- solver --------------------------------------------------------------------------------- */
+typedef struct {
+  int max_iter;        /* 40                                                   */
+  double tol;          /* primal feasibility (inf-norm) to declare status 0    */
+  double mu_init, mu_min;
+  double delta_x;      /* proximal weight (W = delta I)                        */
+  double eps_dual;     /* quasi-definite regularisation on the equality block  */
+  int warm_start;      /* 1: x_io holds the starting point                     */
+  int verbose;
+} qo_options;
+
+typedef struct {
+  int status;          /* 0 converged, 1 max-iter, 2 numerical failure         */
+  int iters;
+  double inf_pr;       /* final max constraint violation (unscaled)            */
+  double inf_pr0;      /* violation at the starting point                      */
+  double mu;
+  double factor_secs, eval_secs;
+} qo_info;
+
+void qo_default_options(qo_options *o);
+int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, double *x_io,
+             qo_info *info);
+/* max violation of all 1730 rows (equalities and two-sided bounds) + violated fixed vars */
+double qo_max_violation(const qo_params *p, const double *x);
+
+/* Linear-algebra building block exposed for KKT parity tests: skyline LDL^T of a symmetric
+ * quasi-definite matrix given as dense lower triangle (n x n row-major), solve in place. */
+int qo_ldlt_solve_dense(int n, const double *A, double *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference's committed artefacts.
+
+Runs ONLY in the build container (reads /root/reference); the GPU box and the test-suite use the
+committed outputs.  Inputs:
+  GV1  /root/reference/test/data/traj/gait.csv               (5001 x 37, one full 5 s plan)
+  GV2  /root/reference/data/traj/towr.csv rows 1254..6254    (second full plan, t0 = 3.756)
+  GV3  /root/reference/data/traj/towr.csv rows 0..1253       (partial first plan)
+  log  /root/reference/logs/towr_log.out                     (solver inputs, NLP dimensions)
+Outputs: gv1.npz, gv2.npz (TOWR-ordered node vector fitted to the 1 kHz samples, the samples
+themselves on a 10 ms grid + phase boundary rows, solver inputs), nlp_dims.json.
+
+The node vector is obtained by *reading* base nodes off the CSV (rows k*100) and by linear
+least-squares of the cubic-Hermite phase splines to the foot / force samples (the CSV holds neither
+foot velocities nor force derivatives).  No reference source text is copied: only data.
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# phase schedule (verified against the force columns at 1 ms resolution)
+UNNORM = {
+    0: [0.8, 0.3, 1.7, 0.3, 1.7, 0.3, 1.45, 0.51, 1.06],   # FL  (-e1)
+    1: [1.8, 0.3, 1.7, 0.3, 1.7, 0.3, 1.21, 0.51, 0.30],   # FR  (-e2)
+    2: [0.3, 0.3, 1.7, 0.3, 1.7, 0.3, 1.70, 0.38, 1.44],   # HL  (-e3)
+    3: [1.3, 0.3, 1.7, 0.3, 1.7, 0.3, 1.33, 0.51, 0.68],   # HR  (-e4)
+}
+T_TOTAL = 5.0
+
+
+def phase_durations():
+    s = T_TOTAL / 8.12
+    return [[d * s for d in UNNORM[e]] for e in range(4)]
+
+
+def hermite_w(T, t, deriv=0):
+    t = np.asarray(t, float)
+    if deriv == 0:
+        return np.stack([1 - 3 * t**2 / T**2 + 2 * t**3 / T**3, t - 2 * t**2 / T + t**3 / T**2,
+                         3 * t**2 / T**2 - 2 * t**3 / T**3, -t**2 / T + t**3 / T**2], -1)
+    raise NotImplementedError
+
+
+def fit_plan(rows, first_row_forces_valid=True):
+    """rows: (5001, 37) with local time k/1000.  Returns x (1040,) in TOWR variable order.
+
+    GV2's first row (towr.csv row 1254) is the hand-over row of the PREVIOUS plan (the stitcher
+    drops the new plan's first row, QTOS/combiner.py:131,305): its state columns equal the new
+    plan's start state but its force columns belong to the old plan, so they are excluded."""
+    assert rows.shape == (5001, 37)
+    t = np.arange(5001) / 1000.0
+    ph = phase_durations()
+    x = np.zeros(1040)
+    # base nodes: rows k*100
+    for k in range(51):
+        r = rows[k * 100]
+        x[6 * k:6 * k + 3] = r[1:4]
+        x[6 * k + 3:6 * k + 6] = r[19:22]
+        x[306 + 6 * k:306 + 6 * k + 3] = r[4:7]
+        x[306 + 6 * k + 3:306 + 6 * k + 6] = r[22:25]
+    if not first_row_forces_valid:
+        # the new plan itself starts at rest: towr.csv rows 1255.. ramp up from zero velocity, i.e.
+        # the reference solver did not apply the s_vel / s_ang_vel flags (the flags carry no dash,
+        # QTOS/utils.py:26; logs/towr_log.out:161-166 shows them mis-parsed)
+        x[3:6] = 0.0
+        x[306 + 3:306 + 6] = 0.0
+    resid = {}
+    for e in range(4):
+        bounds = np.concatenate([[0.0], np.cumsum(ph[e])])
+        pos = rows[:, 7 + 3 * e:10 + 3 * e]
+        frc = rows[:, 25 + 3 * e:28 + 3 * e]
+        off_m, off_f = 612 + 35 * e, 752 + 72 * e
+        stance_pos = []
+        for s in range(5):
+            a, b = bounds[2 * s], bounds[2 * s + 1]
+            sel = (t > a + 2e-3) & (t < b - 2e-3)
+            p = np.median(pos[sel], axis=0)
+            stance_pos.append(p)
+            x[off_m + 8 * s:off_m + 8 * s + 3] = p
+        # swing mid nodes: LSQ of (px,vx,py,vy,pz) with known end points and vz = 0
+        worst = 0.0
+        for s in range(4):
+            a, b = bounds[2 * s + 1], bounds[2 * s + 2]
+            Th = (b - a) / 2
+            p0, p1 = stance_pos[s], stance_pos[s + 1]
+            sel1 = (t >= a) & (t <= a + Th)
+            sel2 = (t > a + Th) & (t <= b)
+            for d in range(3):
+                w1 = hermite_w(Th, t[sel1] - a)        # nodes: stance(p0,0) -> mid(pm,vm)
+                w2 = hermite_w(Th, t[sel2] - a - Th)   # nodes: mid(pm,vm) -> stance(p1,0)
+                A = np.concatenate([w1[:, 2:4], w2[:, 0:2]], 0)
+                rhs = np.concatenate([pos[sel1, d] - w1[:, 0] * p0[d], pos[sel2, d] - w2[:, 2] * p1[d]])
+                if d == 2:
+                    A = A[:, :1]
+                sol, *_ = np.linalg.lstsq(A, rhs, rcond=None)
+                worst = max(worst, np.abs(A @ sol - rhs).max())
+                base = off_m + 8 * s + 3
+                if d < 2:
+                    x[base + 2 * d], x[base + 2 * d + 1] = sol
+                else:
+                    x[base + 4] = sol[0]
+        resid["ee%d_swing_fit" % e] = worst
+        # force nodes: per stance 3 polys / 4 nodes; nodes adjacent to a swing are zero
+        worst = 0.0
+        c = 0
+        for s in range(5):
+            a, b = bounds[2 * s], bounds[2 * s + 1]
+            Tp = (b - a) / 3
+            free = [j for j in range(4) if not ((j == 0 and s > 0) or (j == 3 and s < 4))]
+            for d in range(3):
+                Arows, rhs = [], []
+                for j in range(3):
+                    lo, hi = a + j * Tp, a + (j + 1) * Tp
+                    sel = (t >= lo - 1e-12) & (t <= hi + 1e-12) & (t > a + 1e-9) & (t < b - 1e-9)
+                    if s == 0 and j == 0 and first_row_forces_valid:
+                        sel |= (t == 0.0)
+                    if s == 4 and j == 2:
+                        sel |= (t == 5.0)
+                    w = hermite_w(Tp, np.clip(t[sel] - lo, 0, Tp))
+                    blk = np.zeros((sel.sum(), 8))
+                    blk[:, 2 * j:2 * j + 2] = w[:, 0:2]
+                    blk[:, 2 * j + 2:2 * j + 4] = w[:, 2:4]
+                    Arows.append(blk)
+                    rhs.append(frc[sel, d])
+                A = np.concatenate(Arows, 0)
+                rhs = np.concatenate(rhs)
+                cols = [2 * j + q for j in free for q in range(2)]
+                sol, *_ = np.linalg.lstsq(A[:, cols], rhs, rcond=None)
+                worst = max(worst, np.abs(A[:, cols] @ sol - rhs).max())
+                for jj, j in enumerate(free):
+                    x[off_f + 6 * (c + jj) + 2 * d] = sol[2 * jj]
+                    x[off_f + 6 * (c + jj) + 2 * d + 1] = sol[2 * jj + 1]
+            c += len(free)
+        assert c == 12
+        resid["ee%d_force_fit" % e] = worst
+    return x, resid
+
+
+def parse_log(path):
+    txt = open(path).read()
+    dims = {
+        "n_vars_free": int(re.search(r"Total number of variables\.+:\s+(\d+)", txt).group(1)),
+        "n_eq": int(re.search(r"Total number of equality constraints\.+:\s+(\d+)", txt).group(1)),
+        "n_ineq": int(re.search(r"Total number of inequality constraints\.+:\s+(\d+)", txt).group(1)),
+        "ineq_lower_only": int(re.search(r"only lower bounds:\s+(\d+)\n\s+inequality constraints with lower and", txt).group(1)),
+        "ineq_both": int(re.search(r"inequality constraints with lower and upper bounds:\s+(\d+)", txt).group(1)),
+        "ineq_upper_only": int(re.findall(r"inequality constraints with only upper bounds:\s+(\d+)", txt)[0]),
+        "jac_nnz_eq": int(re.search(r"equality constraint Jacobian\.+:\s+(\d+)", txt).group(1)),
+        "jac_nnz_ineq": int(re.search(r"inequality constraint Jacobian\.:\s+(\d+)", txt).group(1)),
+    }
+    sets = re.findall(r"^\s+([a-z\-_0-9]+)\s+(\d+)\s+(\d+)\.+(\d+)", txt, re.M)
+    seen, var_sets, con_sets = set(), [], []
+    for name, c, a, b in sets:
+        if name in seen:
+            continue
+        seen.add(name)
+        (var_sets if name.startswith(("base", "ee-")) else con_sets).append([name, int(c), int(a), int(b)])
+    dims["variable_sets"] = var_sets
+    dims["constraint_sets"] = con_sets
+    dims["inf_pr_iter0"] = [float(v) for v in re.findall(r"^\s+0\s+0\.0000000e\+00\s+(\S+)", txt, re.M)]
+    dims["iterations"] = [int(v) for v in re.findall(r"Number of Iterations\.+:\s+(\d+)", txt)]
+    return dims
+
+
+def main():
+    gait = np.loadtxt(os.path.join(REF, "test/data/traj/gait.csv"), delimiter=",")
+    towr = np.loadtxt(os.path.join(REF, "data/traj/towr.csv"), delimiter=",")
+    gv2 = towr[1254:6255].copy()
+    gv3 = towr[:1254].copy()
+    keep = sorted(set(range(0, 5001, 10)))
+    nominal_feet = [[0.21, 0.19, 0.0], [0.21, -0.19, 0.0], [-0.21, 0.19, 0.0], [-0.21, -0.19, 0.0]]
+    inputs = {
+        "gv1": dict(s=[0, 0, 0.24], s_ang=[0, 0, 0], ee=nominal_feet,
+                    g=[float(gait[-1, 1]), 0.0, 0.24], s_vel=[0, 0, 0], s_ang_vel=[0, 0, 0], t0=0.0),
+        # logs/towr_log.out:140-166 (flags), velocities = towr.csv row 1254 cols 19-24
+        "gv2": dict(s=[0.335266, -0.0123145, 0.221551], s_ang=[-0.0422299, -0.0416417, 0.00880732],
+                    ee=[[0.548758, 0.14327, 0], [0.606166, -0.175889, 0], [0.105142, 0.175699, 0],
+                        [0.141849, -0.176012, 0]],
+                    g=[0.9100042764299588, 0.0, 0.24], s_vel=[0, 0, 0], s_ang_vel=[0, 0, 0], t0=3.756,
+                    s_vel_flag=gv2[0, 19:22].tolist(), s_ang_vel_flag=gv2[0, 22:25].tolist()),
+    }
+    for name, rows in (("gv1", gait), ("gv2", gv2)):
+        x, resid = fit_plan(rows, first_row_forces_valid=(name == "gv1"))
+        print(name, {k: "%.2e" % v for k, v in resid.items()})
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), x=x, row_idx=np.array(keep),
+                            rows=rows[keep], inputs=json.dumps(inputs[name]),
+                            phase_durations=np.array(phase_durations()))
+    np.savez_compressed(os.path.join(OUT, "gv3_partial.npz"), rows=gv3[::10], row_idx=np.arange(0, 1254, 10))
+    dims = parse_log(os.path.join(REF, "logs/towr_log.out"))
+    json.dump(dims, open(os.path.join(OUT, "nlp_dims.json"), "w"), indent=1)
+    print(json.dumps({k: v for k, v in dims.items() if not k.endswith("_sets")}))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
