@@ -791,8 +791,439 @@ double qo_max_violation(const qo_params *p, const double *x) {
   return v;
 }
 
-/* solver appended below */
-void qo_default_options(qo_options *o) { memset(o, 0, sizeof(*o)); }
-int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, double *x_io,
-             qo_info *info) { return -1; }
-int qo_ldlt_solve_dense(int n, const double *A, double *b) { return -1; }
+
+/* ============================================================================================ */
+/* Solver: primal-dual interior point on the feasibility NLP with a proximal Hessian W = delta I */
+/* (the reference runs Ipopt with an L-BFGS Hessian on a problem without cost terms,            */
+/*  logs/towr_log.out:42,131; each step is therefore a damped least-norm Newton step on the     */
+/*  constraints).  Condensed KKT  [W + Ji' S Ji, Je'; Je, -eps I]  factorised by a skyline LDL'.  */
+/* ============================================================================================ */
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+typedef struct {
+  int n;
+  int *first;    /* first stored column of row i */
+  size_t *start; /* offset of row i (entry for column first[i]) */
+  double *a;     /* row-wise skyline, diagonal is the last entry of each row */
+} skyline;
+
+static void sky_alloc(skyline *S, int n, const int *first) {
+  S->n = n;
+  S->first = (int *)malloc(sizeof(int) * n);
+  S->start = (size_t *)malloc(sizeof(size_t) * (n + 1));
+  size_t tot = 0;
+  for (int i = 0; i < n; ++i) {
+    S->first[i] = first[i];
+    S->start[i] = tot;
+    tot += (size_t)(i - first[i] + 1);
+  }
+  S->start[n] = tot;
+  S->a = (double *)calloc(tot, sizeof(double));
+}
+static void sky_free(skyline *S) { free(S->first); free(S->start); free(S->a); }
+static inline double *sky_at(skyline *S, int i, int j) { /* j <= i, j >= first[i] */
+  return S->a + S->start[i] + (j - S->first[i]);
+}
+
+/* in-place LDL^T (no pivoting; the matrix is quasi-definite).  Returns 0 or -1 on a zero pivot */
+static int sky_factor(skyline *S) {
+  int n = S->n;
+  for (int i = 0; i < n; ++i) {
+    double *ri = S->a + S->start[i];
+    int fi = S->first[i];
+    /* u[i][j] for j = fi..i-1 */
+    for (int j = fi; j < i; ++j) {
+      int fj = S->first[j];
+      const double *rj = S->a + S->start[j];
+      int k0 = fi > fj ? fi : fj;
+      double acc = ri[j - fi];
+      for (int k = k0; k < j; ++k) acc -= ri[k - fi] * rj[k - fj];
+      ri[j - fi] = acc; /* holds u = L*D for now */
+    }
+    double d = ri[i - fi];
+    for (int j = fi; j < i; ++j) {
+      double dj = *(S->a + S->start[j] + (j - S->first[j]));
+      double l = ri[j - fi] / dj;
+      d -= ri[j - fi] * l;
+      ri[j - fi] = l;
+    }
+    if (d == 0.0 || d != d) return -1;
+    ri[i - fi] = d;
+  }
+  return 0;
+}
+static void sky_solve(const skyline *S, double *b) {
+  int n = S->n;
+  for (int i = 0; i < n; ++i) {
+    const double *ri = S->a + S->start[i];
+    int fi = S->first[i];
+    double acc = b[i];
+    for (int j = fi; j < i; ++j) acc -= ri[j - fi] * b[j];
+    b[i] = acc;
+  }
+  for (int i = 0; i < n; ++i) b[i] /= S->a[S->start[i] + (i - S->first[i])];
+  for (int i = n - 1; i >= 0; --i) {
+    const double *ri = S->a + S->start[i];
+    int fi = S->first[i];
+    double bi = b[i];
+    for (int j = fi; j < i; ++j) b[j] -= ri[j - fi] * bi;
+  }
+}
+
+int qo_ldlt_solve_dense(int n, const double *A, double *b) {
+  int *first = (int *)malloc(sizeof(int) * n);
+  for (int i = 0; i < n; ++i) {
+    int f = i;
+    for (int j = 0; j < i; ++j)
+      if (A[(size_t)i * n + j] != 0.0) { f = j; break; }
+    first[i] = f;
+  }
+  skyline S;
+  sky_alloc(&S, n, first);
+  for (int i = 0; i < n; ++i)
+    for (int j = first[i]; j <= i; ++j) *sky_at(&S, i, j) = A[(size_t)i * n + j];
+  int rc = sky_factor(&S);
+  if (rc == 0) sky_solve(&S, b);
+  sky_free(&S);
+  free(first);
+  return rc;
+}
+
+void qo_default_options(qo_options *o) {
+  o->max_iter = 40;
+  o->tol = 1e-4;
+  o->mu_init = 0.1;
+  o->mu_min = 1e-9;
+  o->delta_x = 1e-2;
+  o->eps_dual = 1e-8;
+  o->warm_start = 0;
+  o->verbose = 0;
+}
+
+/* time stamp of every variable / constraint row: used only to order the KKT unknowns */
+static void unknown_times(const qo_params *p, const qo_model *M, double *tv, double *tc) {
+  const qo_layout *L = &M->L;
+  const qo_spline *sp[2 + 2 * QO_NEE];
+  int ns = 0;
+  sp[ns++] = &M->lin;
+  sp[ns++] = &M->ang;
+  for (int e = 0; e < QO_NEE; ++e) sp[ns++] = &M->eem[e];
+  for (int e = 0; e < QO_NEE; ++e) sp[ns++] = &M->eef[e];
+  for (int s = 0; s < ns; ++s) {
+    double t = 0;
+    for (int node = 0; node <= sp[s]->n_polys; ++node) {
+      for (int q = 0; q < 2; ++q)
+        for (int d = 0; d < 3; ++d) {
+          int v = sp[s]->idx[node][q][d];
+          if (v >= 0) tv[v] = t; /* later node sharing the variable wins (end of stance) */
+        }
+      if (node < sp[s]->n_polys) t += sp[s]->dur[node];
+    }
+  }
+  for (int e = 0; e < QO_NEE; ++e) {
+    const qo_spline *S = &M->eem[e];
+    double t = 0;
+    int sw = 0;
+    for (int node = 1; node <= S->n_polys; ++node) {
+      t += S->dur[node - 1];
+      tc[L->off_terrain[e] + node - 1] = t;
+      if (node < S->n_polys && S->idx[node][1][0] >= 0) {
+        for (int r = 0; r < 4; ++r) tc[L->off_swing[e] + 4 * sw + r] = t;
+        sw++;
+      }
+    }
+    for (int k = 0; k < M->n_rom; ++k)
+      for (int d = 0; d < 3; ++d) tc[L->off_rom[e] + 3 * k + d] = M->t_rom[k];
+    for (int j = 0; j < M->n_fnodes[e]; ++j) {
+      double tt = 0;
+      for (int i = 0; i < M->fnode_id[e][j]; ++i) tt += M->eef[e].dur[i];
+      for (int r = 0; r < 5; ++r) tc[L->off_force[e] + 5 * j + r] = tt;
+    }
+  }
+  for (int k = 0; k < M->n_dyn; ++k)
+    for (int d = 0; d < 6; ++d) tc[L->off_dyn + 6 * k + d] = M->t_dyn[k];
+  for (int j = 0; j + 1 < M->lin.n_polys; ++j)
+    for (int d = 0; d < 3; ++d) {
+      tc[L->off_acc_lin + 3 * j + d] = (j + 1) * p->dt_base;
+      tc[L->off_acc_ang + 3 * j + d] = (j + 1) * p->dt_base;
+    }
+}
+
+typedef struct { double key; int id; } keyed;
+static int cmp_keyed(const void *a, const void *b) {
+  const keyed *x = (const keyed *)a, *y = (const keyed *)b;
+  if (x->key < y->key) return -1;
+  if (x->key > y->key) return 1;
+  return x->id - y->id;
+}
+
+int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, double *x, qo_info *info) {
+  qo_model *M = (qo_model *)malloc(sizeof(qo_model));
+  if (build_model(p, M)) { free(M); return -1; }
+  const qo_layout *L = &M->L;
+  const int n = L->n_vars, m = L->n_cons;
+  double t_eval = 0, t_fac = 0, t0;
+  memset(info, 0, sizeof(*info));
+
+  double *xl = (double *)malloc(sizeof(double) * 2 * n), *xh = xl + n;
+  double *cl = (double *)malloc(sizeof(double) * 2 * m), *ch = cl + m;
+  qo_var_bounds(p, q, xl, xh);
+  qo_con_bounds(p, cl, ch);
+  if (!o->warm_start) qo_initial_guess(p, q, x);
+  for (int i = 0; i < n; ++i)
+    if (xl[i] == xh[i]) x[i] = xl[i];
+
+  double *g = (double *)malloc(sizeof(double) * m), *gt = (double *)malloc(sizeof(double) * m);
+  double *J = (double *)malloc(sizeof(double) * (size_t)m * n);
+  double *xt = (double *)malloc(sizeof(double) * n);
+
+  /* ---- working sets: free variables, de-duplicated equality rows, inequality rows ---------- */
+  int *vpos = (int *)malloc(sizeof(int) * n); /* var -> KKT position or -1 */
+  int nf = 0;
+  for (int i = 0; i < n; ++i) nf += (xl[i] != xh[i]);
+  /* row structure from one Jacobian evaluation at a perturbed point */
+  {
+    unsigned s = 12345u;
+    for (int i = 0; i < n; ++i) {
+      s = s * 1664525u + 1013904223u;
+      xt[i] = x[i] + 1e-2 * ((double)(s >> 8) / 16777216.0 - 0.5);
+    }
+    eval_all(p, M, xt, NULL, J);
+  }
+  int *rowtype = (int *)calloc(m, sizeof(int)); /* 0 dropped, 1 equality, 2 inequality */
+  int nE = 0, nI = 0;
+  /* CSR of the structural pattern restricted to free variables */
+  int *rp = (int *)malloc(sizeof(int) * (m + 1));
+  int nnz = 0;
+  for (int r = 0; r < m; ++r)
+    for (int c = 0; c < n; ++c)
+      if (xl[c] != xh[c] && J[(size_t)r * n + c] != 0.0) nnz++;
+  int *ci = (int *)malloc(sizeof(int) * (nnz + 1));
+  nnz = 0;
+  for (int r = 0; r < m; ++r) {
+    rp[r] = nnz;
+    for (int c = 0; c < n; ++c)
+      if (xl[c] != xh[c] && J[(size_t)r * n + c] != 0.0) ci[nnz++] = c;
+  }
+  rp[m] = nnz;
+  for (int r = 0; r < m; ++r) {
+    int len = rp[r + 1] - rp[r];
+    if (cl[r] != ch[r]) { rowtype[r] = 2; nI++; continue; }
+    if (len == 0) continue; /* constant row: nothing can change it */
+    /* the time grid repeats T (floor(T/dt)*dt == T): the second copy of the dynamics block is
+     * the same six equations and is left out of the working set */
+    if (M->n_dyn >= 2 && fabs(M->t_dyn[M->n_dyn - 1] - M->t_dyn[M->n_dyn - 2]) < 1e-9 &&
+        r >= L->off_dyn + 6 * (M->n_dyn - 1) && r < L->off_dyn + 6 * M->n_dyn)
+      continue;
+    int dup = 0;
+    for (int r2 = 0; r2 < r && !dup; ++r2) {
+      if (rowtype[r2] != 1 || rp[r2 + 1] - rp[r2] != len) continue;
+      int same = 1;
+      for (int k = 0; k < len && same; ++k) {
+        int c = ci[rp[r] + k];
+        if (ci[rp[r2] + k] != c ||
+            fabs(J[(size_t)r * n + c] - J[(size_t)r2 * n + c]) > 1e-9 * (1 + fabs(J[(size_t)r * n + c])))
+          same = 0;
+      }
+      dup = same;
+    }
+    if (!dup) { rowtype[r] = 1; nE++; }
+  }
+  int *Er = (int *)malloc(sizeof(int) * (nE + 1)), *Ir = (int *)malloc(sizeof(int) * (nI + 1));
+  nE = nI = 0;
+  for (int r = 0; r < m; ++r) {
+    if (rowtype[r] == 1) Er[nE++] = r;
+    if (rowtype[r] == 2) Ir[nI++] = r;
+  }
+  /* ---- ordering of the nf + nE unknowns by time ------------------------------------------- */
+  const int N = nf + nE;
+  double *tv = (double *)calloc(n, sizeof(double)), *tc = (double *)calloc(m, sizeof(double));
+  unknown_times(p, M, tv, tc);
+  keyed *ks = (keyed *)malloc(sizeof(keyed) * N);
+  {
+    int k = 0;
+    for (int i = 0; i < n; ++i)
+      if (xl[i] != xh[i]) { ks[k].key = tv[i]; ks[k].id = i; k++; }
+    for (int e = 0; e < nE; ++e) { ks[k].key = tc[Er[e]] + 1e-7; ks[k].id = n + e; k++; }
+  }
+  qsort(ks, N, sizeof(keyed), cmp_keyed);
+  int *epos = (int *)malloc(sizeof(int) * (nE + 1));
+  for (int i = 0; i < n; ++i) vpos[i] = -1;
+  for (int k = 0; k < N; ++k) {
+    if (ks[k].id < n) vpos[ks[k].id] = k;
+    else epos[ks[k].id - n] = k;
+  }
+  int *first = (int *)malloc(sizeof(int) * N);
+  for (int i = 0; i < N; ++i) first[i] = i;
+  for (int r = 0; r < m; ++r) {
+    if (rowtype[r] != 2) continue;
+    int mn = N;
+    for (int k = rp[r]; k < rp[r + 1]; ++k) if (vpos[ci[k]] < mn) mn = vpos[ci[k]];
+    for (int k = rp[r]; k < rp[r + 1]; ++k) if (mn < first[vpos[ci[k]]]) first[vpos[ci[k]]] = mn;
+  }
+  for (int e = 0; e < nE; ++e) {
+    int r = Er[e], pe = epos[e];
+    for (int k = rp[r]; k < rp[r + 1]; ++k) {
+      int pv = vpos[ci[k]];
+      int a = pv < pe ? pv : pe, b = pv < pe ? pe : pv;
+      if (a < first[b]) first[b] = a;
+    }
+  }
+  skyline K;
+  sky_alloc(&K, N, first);
+  if (o->verbose) fprintf(stderr, "oracle: N=%d (free %d, eq %d), ineq %d, skyline %zu\n", N, nf, nE, nI, K.start[N]);
+
+  /* ---- interior-point state ---------------------------------------------------------------- */
+  double *s = (double *)malloc(sizeof(double) * 8 * (nI + 1));
+  double *zl = s + nI, *zu = zl + nI, *ds = zu + nI, *dzl = ds + nI, *dzu = dzl + nI, *Sig = dzu + nI, *wv = Sig + nI;
+  double *rhs = (double *)malloc(sizeof(double) * N);
+  double *dx = (double *)calloc(n, sizeof(double));
+  t0 = now_s();
+  eval_all(p, M, x, g, NULL);
+  t_eval += now_s() - t0;
+  double theta0 = 0;
+  for (int i = 0; i < nI; ++i) {
+    int r = Ir[i];
+    double l = cl[r], u = ch[r];
+    int hl = l > -1e19, hu = u < 1e19;
+    double pl = hl ? 0.01 * fmax(1.0, fabs(l)) : 0, pu = hu ? 0.01 * fmax(1.0, fabs(u)) : 0;
+    if (hl && hu) { pl = fmin(pl, 0.01 * (u - l)); pu = fmin(pu, 0.01 * (u - l)); }
+    double si = g[r];
+    if (hl) si = fmax(si, l + pl);
+    if (hu) si = fmin(si, u - pu);
+    s[i] = si;
+    theta0 = fmax(theta0, fabs(g[r] - si));
+  }
+  for (int e = 0; e < nE; ++e) theta0 = fmax(theta0, fabs(g[Er[e]]));
+  double mu = fmax(o->mu_min, fmin(o->mu_init, 0.01 * theta0 * theta0));
+  for (int i = 0; i < nI; ++i) {
+    int r = Ir[i];
+    zl[i] = cl[r] > -1e19 ? mu / (s[i] - cl[r]) : 0.0;
+    zu[i] = ch[r] < 1e19 ? mu / (ch[r] - s[i]) : 0.0;
+  }
+  info->inf_pr0 = max_violation(M, g, cl, ch);
+  int status = 1, it;
+  double viol = 0;
+  for (it = 0; it < o->max_iter; ++it) {
+    double theta = 0;
+    viol = 0;
+    for (int e = 0; e < nE; ++e) theta = fmax(theta, fabs(g[Er[e]]));
+    viol = theta;
+    for (int i = 0; i < nI; ++i) {
+      int r = Ir[i];
+      theta = fmax(theta, fabs(g[r] - s[i]));
+      viol = fmax(viol, fmax(cl[r] - g[r], g[r] - ch[r]));
+    }
+    if (o->verbose) fprintf(stderr, "oracle: it %2d viol %.3e theta %.3e mu %.1e\n", it, viol, theta, mu);
+    if (viol <= o->tol && theta <= o->tol) { status = 0; break; }
+    t0 = now_s();
+    eval_all(p, M, x, NULL, J);
+    t_eval += now_s() - t0;
+    t0 = now_s();
+    memset(K.a, 0, sizeof(double) * K.start[N]);
+    memset(rhs, 0, sizeof(double) * N);
+    for (int i = 0; i < n; ++i)
+      if (vpos[i] >= 0) *sky_at(&K, vpos[i], vpos[i]) = o->delta_x;
+    for (int i = 0; i < nI; ++i) {
+      int r = Ir[i];
+      double l = cl[r], u = ch[r];
+      int hl = l > -1e19, hu = u < 1e19;
+      double dl = hl ? s[i] - l : 1, du = hu ? u - s[i] : 1;
+      double sg = (hl ? zl[i] / dl : 0) + (hu ? zu[i] / du : 0);
+      double gmu = -(hl ? mu / dl : 0) + (hu ? mu / du : 0);
+      double rI = g[r] - s[i];
+      Sig[i] = sg;
+      double w = sg * rI + gmu;
+      const double *Jr = J + (size_t)r * n;
+      for (int a = rp[r]; a < rp[r + 1]; ++a) {
+        int ca = ci[a], pa = vpos[ca];
+        double ja = Jr[ca];
+        rhs[pa] -= ja * w;
+        for (int b = rp[r]; b < rp[r + 1]; ++b) {
+          int pb = vpos[ci[b]];
+          if (pb <= pa) *sky_at(&K, pa, pb) += sg * ja * Jr[ci[b]];
+        }
+      }
+    }
+    for (int e = 0; e < nE; ++e) {
+      int r = Er[e], pe = epos[e];
+      const double *Jr = J + (size_t)r * n;
+      *sky_at(&K, pe, pe) = -o->eps_dual;
+      rhs[pe] = -g[r];
+      for (int a = rp[r]; a < rp[r + 1]; ++a) {
+        int pv = vpos[ci[a]];
+        if (pv < pe) *sky_at(&K, pe, pv) += Jr[ci[a]];
+        else *sky_at(&K, pv, pe) += Jr[ci[a]];
+      }
+    }
+    if (sky_factor(&K)) { status = 2; break; }
+    sky_solve(&K, rhs);
+    t_fac += now_s() - t0;
+    for (int i = 0; i < n; ++i) dx[i] = vpos[i] >= 0 ? rhs[vpos[i]] : 0.0;
+    /* slack / dual steps and fraction to the boundary */
+    double tau = fmax(0.99, 1 - mu), amax = 1.0, az = 1.0, th0 = 0;
+    for (int e = 0; e < nE; ++e) th0 += fabs(g[Er[e]]);
+    for (int i = 0; i < nI; ++i) {
+      int r = Ir[i];
+      double l = cl[r], u = ch[r];
+      int hl = l > -1e19, hu = u < 1e19;
+      double dl = hl ? s[i] - l : 1, du = hu ? u - s[i] : 1;
+      double rI = g[r] - s[i], jd = 0;
+      const double *Jr = J + (size_t)r * n;
+      for (int a = rp[r]; a < rp[r + 1]; ++a) jd += Jr[ci[a]] * dx[ci[a]];
+      ds[i] = jd + rI;
+      dzl[i] = hl ? mu / dl - zl[i] - zl[i] / dl * ds[i] : 0;
+      dzu[i] = hu ? mu / du - zu[i] + zu[i] / du * ds[i] : 0;
+      if (hl && ds[i] < 0) amax = fmin(amax, tau * dl / -ds[i]);
+      if (hu && ds[i] > 0) amax = fmin(amax, tau * du / ds[i]);
+      if (hl && dzl[i] < 0) az = fmin(az, tau * zl[i] / -dzl[i]);
+      if (hu && dzu[i] < 0) az = fmin(az, tau * zu[i] / -dzu[i]);
+      th0 += fabs(rI);
+    }
+    /* backtracking on the l1 infeasibility */
+    double al = amax, th = 0;
+    int ls;
+    for (ls = 0; ls < 6; ++ls) {
+      for (int i = 0; i < n; ++i) xt[i] = x[i] + al * dx[i];
+      t0 = now_s();
+      eval_all(p, M, xt, gt, NULL);
+      t_eval += now_s() - t0;
+      th = 0;
+      for (int e = 0; e < nE; ++e) th += fabs(gt[Er[e]]);
+      for (int i = 0; i < nI; ++i) th += fabs(gt[Ir[i]] - (s[i] + al * ds[i]));
+      if (th <= (1 - 1e-4 * al) * th0 || th < 1e-9) break;
+      if (ls < 5) al *= 0.5;
+    }
+    if (o->verbose) fprintf(stderr, "oracle:    amax %.3f alpha %.4f az %.3f ls %d th %.3e -> %.3e\n", amax, al, az, ls, th0, th);
+    memcpy(x, xt, sizeof(double) * n);
+    memcpy(g, gt, sizeof(double) * m);
+    for (int i = 0; i < nI; ++i) {
+      int r = Ir[i];
+      double l = cl[r], u = ch[r];
+      int hl = l > -1e19, hu = u < 1e19;
+      s[i] += al * ds[i];
+      zl[i] += az * dzl[i];
+      zu[i] += az * dzu[i];
+      const double kap = 1e10;
+      if (hl) zl[i] = fmin(fmax(zl[i], mu / (kap * (s[i] - l))), kap * mu / (s[i] - l));
+      if (hu) zu[i] = fmin(fmax(zu[i], mu / (kap * (u - s[i]))), kap * mu / (u - s[i]));
+    }
+    if (al > 0.3) mu = fmax(o->mu_min, 0.2 * mu);
+  }
+  info->status = status;
+  info->iters = it;
+  info->inf_pr = max_violation(M, g, cl, ch);
+  info->mu = mu;
+  info->eval_secs = t_eval;
+  info->factor_secs = t_fac;
+  (void)wv;
+  sky_free(&K);
+  free(first); free(epos); free(ks); free(tv); free(tc); free(Er); free(Ir); free(ci); free(rp);
+  free(rowtype); free(vpos); free(xt); free(J); free(gt); free(g); free(cl); free(xl); free(s);
+  free(rhs); free(dx); free(M);
+  return status;
+}
