@@ -1,0 +1,138 @@
+/*
+ * qtos_planner.h -- C ABI of the MI355X-native batched local planner.
+ *
+ * Drop-in boundary.  In the reference the local planner is a process:
+ *     subprocess.run("docker exec <id> ./main " + cmd_args(args))
+ *         scripts/main.py:49-50, 90-91, 125-126; scripts/run.py:294-295;
+ *         QTOS/generateHeightField.py:385-386   (one NLP per call, 32 callers at once)
+ * with the flag set of QTOS/utils.py:26 (_flags), the terrain pushed beforehand as a text file
+ * (QTOS/utils.py:21-22) and the result fetched as build/traj.csv (QTOS/utils.py:16,19).
+ * Every entry point below names the piece of that process ABI it replaces.  Plain pointers and
+ * sizes only; no C++ or torch types; no global state; one planner handle is used by one thread
+ * at a time (use one handle per (device, stream)).
+ *
+ * All floating point is IEEE double (the reference solver is double precision throughout).
+ */
+#ifndef QTOS_PLANNER_H
+#define QTOS_PLANNER_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QTOS_NEE 4
+#define QTOS_MAX_PHASES 16
+#define QTOS_START_DOUBLES 24 /* CoM 3, Euler 3, feet FL FR HL HR 12, lin vel 3, Euler rates 3 */
+#define QTOS_CSV_COLS 37
+
+/* Model + transcription + solver parameters.  Replaces the constants compiled into the
+ * reference's ./main (towr Parameters / RobotModel of the towr_solo12 fork; values recovered from
+ * the committed artefacts) and the Ipopt options. */
+typedef struct QtosParams {
+  int n_phases[QTOS_NEE];                       /* odd: stance, swing, ..., stance            */
+  double phase_dur[QTOS_NEE][QTOS_MAX_PHASES];  /* [s]; each foot sums to the plan duration   */
+  double dt_base, dt_dyn, dt_rom;               /* base poly / dynamics / range-of-motion dt  */
+  int force_polys_per_stance;
+  double mass, gravity, inertia_b[9];
+  double nominal_stance[QTOS_NEE][3], max_dev[3];
+  double mu, f_max, t_swing_avg;
+  int honor_start_velocity; /* 0 = reference behaviour (plans start at rest), 1 = use s_vel */
+  int max_iter;
+  double tol, mu_init, mu_min, delta_x, eps_dual;
+} QtosParams;
+
+typedef struct QtosDims {
+  int n_vars, n_cons;               /* 1040 / 1730 for the reference transcription           */
+  int n_free, n_eq, n_ineq;         /* 1005 / 706 / 1024 (logs/towr_log.out:44-52)            */
+  int n_ineq_lower, n_ineq_both, n_ineq_upper; /* 112 / 816 / 96                              */
+  int n_eq_work;                    /* equality rows after dropping constant/duplicate rows   */
+  int n_unknowns;                   /* n_free + n_eq_work = KKT dimension                     */
+  int n_stages, pivots, front;      /* chain of n_stages fronts, `pivots` eliminated per stage */
+  int n_base_nodes, n_dyn_times, n_rom_times, n_rows_csv;
+  long long panel_doubles;          /* factor panel storage per problem                       */
+  long long g_doubles;              /* Jacobian block storage per problem                     */
+  long long kkt_algorithmic_bytes;  /* w*[sum_k (p+c_k)*p + 2M], SURVEY.md 8d formula          */
+  long long kkt_flops;              /* 2*sum_k p*(p+c_k)^2                                     */
+  long long envelope;               /* skyline size of K in the elimination order             */
+  int max_active, pad;              /* largest front actually populated                       */
+  double duration;
+} QtosDims;
+
+typedef struct QtosPlanner QtosPlanner;
+
+/* Build the planner for one transcription (symbolic KKT analysis + device workspaces for up to
+ * max_batch problems on HIP device `device`).  Replaces starting the `towr` container
+ * (QTOS/utils.py:686-692 DockerInfo).  Returns 0, or <0: -1 bad parameters, -2 no HIP device /
+ * HIP error, -3 out of memory, -4 front too large for LDS. */
+int qtos_planner_create(const QtosParams *params, int max_batch, int device, QtosPlanner **out);
+void qtos_planner_destroy(QtosPlanner *p);
+int qtos_planner_dims(const QtosPlanner *p, QtosDims *dims);
+const char *qtos_last_error(const QtosPlanner *p);
+
+/* Terrain side channel.  Replaces `docker cp towr_heightfield.txt <id>:...`
+ * (QTOS/utils.py:21-22; scripts/main.py:77-78; QTOS/generateHeightField.py:276-279).
+ * n_maps height grids of identical shape, height[map][ix*hny+iy] at x = x0+ix*cell,
+ * y = y0+iy*cell (the file's row = x index, column = y index: QTOS/generateHeightField.py:568,
+ * 598-605).  n_maps = 0 restores flat ground. */
+int qtos_set_heightfields(QtosPlanner *p, int n_maps, const double *height, int hnx, int hny,
+                          double cell, double x0, double y0);
+
+/* One batched solve = B invocations of `./main -g .. -s .. -s_ang .. -e1..-e4 .. [s_vel ..]
+ * [s_ang_vel ..]`.  Host-pointer form: copies in, solves on the GPU, copies out.
+ *   start   B x 24   CoM, Euler, feet FL FR HL HR (world), CoM velocity, Euler rates
+ *                    (exactly columns 1..24 of a CSV row, QTOS/combiner.py:267-274)
+ *   goal    B x 3    -g
+ *   map_id  B        heightfield index per problem, NULL = map 0
+ *   warm    B x n_vars or NULL: starting nodes (receding-horizon warm start)
+ *   nodes_out  B x n_vars  solution in the reference NLP's variable order
+ *                          (logs/towr_log.out:99-110)
+ *   status_out B   0 = solved (the reference's exit code / "status -> 0"), 1 = iteration limit,
+ *                  2 = numerical failure
+ *   iters_out B, viol_out B (max constraint violation), either may be NULL
+ * Returns 0 or a negative error code; never throws. */
+int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *goal,
+                    const int *map_id, const double *warm, double *nodes_out, int *status_out,
+                    int *iters_out, double *viol_out);
+
+/* Same, all pointers in device memory of the planner's device, asynchronous on `stream`
+ * (a hipStream_t passed as void*, NULL = default stream).  This is the form bench.py times. */
+int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
+                           const int *d_map_id, const double *d_warm, double *d_nodes_out,
+                           int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream);
+
+/* 1 kHz sampling of solution nodes into the reference's CSV row layout (37 columns,
+ * QTOS/utils.py:107-148; producer build/traj.csv).  rows_out is B x n_rows x 37, row k is at
+ * local time k/hz and carries time stamp t0[b] + k/hz.  Host pointers. */
+int qtos_sample_csv(QtosPlanner *p, int B, const double *nodes, const double *t0, double hz,
+                    int n_rows, double *rows_out);
+int qtos_sample_csv_device(QtosPlanner *p, int B, const double *d_nodes, const double *d_t0,
+                           double hz, int n_rows, double *d_rows_out, void *stream);
+
+/* Seconds spent in the KKT kernels / all kernels during the last qtos_plan_batch* call, from HIP
+ * events on the launch stream (valid after the stream has been synchronised), and the number of
+ * KKT launches.  Used by bench.py for the roofline figure. */
+int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, double *total_seconds,
+                     int *iterations);
+
+/* ---- introspection for the parity tests (host pointers) ------------------------------------ */
+/* constraint values (B x n_cons) and, if J_out != NULL, the dense Jacobian (B x n_cons x n_vars,
+ * columns of fixed variables zero, dropped rows zero) at the given nodes */
+int qtos_debug_eval(QtosPlanner *p, int B, const double *start, const double *goal,
+                    const int *map_id, const double *nodes, double *g_out, double *J_out);
+/* one condensed KKT solve per problem with caller-supplied barrier weights:
+ *   [delta I + Ji' diag(sig) Ji, Je'; Je, -eps I] [dx; y] = [-Ji' w; -g_e]
+ * sig, w: B x n_cons (entries of inequality rows are used); dx_out: B x n_vars */
+int qtos_debug_newton(QtosPlanner *p, int B, const double *start, const double *goal,
+                      const int *map_id, const double *nodes, const double *sig, const double *w,
+                      double *dx_out);
+/* working-set description: row_kind[n_cons] (0 dropped, 1 equality, 2 inequality),
+ * var_free[n_vars] (0/1), unknown order[n_unknowns] (var index, or n_vars + row for multipliers) */
+int qtos_debug_structure(const QtosPlanner *p, int *row_kind, int *var_free, int *order);
+/* per-iteration trace of the last plan call for problem b: rows of (viol, theta, alpha, mu),
+ * at most max_iter rows; returns the number of rows */
+int qtos_debug_trace(QtosPlanner *p, int b, double *trace_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,229 @@
+"""ctypes binding of the HIP planner library (csrc/libqtos_planner.so, ABI in include/qtos_planner.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible, loading / creating a
+planner raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C quadruped-trajectory-optimization-stack_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libqtos_planner.so")
+NEE, MAX_PHASES, START_DOUBLES, CSV_COLS = 4, 16, 24, 37
+
+
+class QtosParams(C.Structure):
+    _fields_ = [
+        ("n_phases", C.c_int * NEE),
+        ("phase_dur", (C.c_double * MAX_PHASES) * NEE),
+        ("dt_base", C.c_double), ("dt_dyn", C.c_double), ("dt_rom", C.c_double),
+        ("force_polys_per_stance", C.c_int),
+        ("mass", C.c_double), ("gravity", C.c_double), ("inertia_b", C.c_double * 9),
+        ("nominal_stance", (C.c_double * 3) * NEE), ("max_dev", C.c_double * 3),
+        ("mu", C.c_double), ("f_max", C.c_double), ("t_swing_avg", C.c_double),
+        ("honor_start_velocity", C.c_int),
+        ("max_iter", C.c_int),
+        ("tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
+        ("delta_x", C.c_double), ("eps_dual", C.c_double),
+    ]
+
+
+class QtosDims(C.Structure):
+    _fields_ = [
+        ("n_vars", C.c_int), ("n_cons", C.c_int),
+        ("n_free", C.c_int), ("n_eq", C.c_int), ("n_ineq", C.c_int),
+        ("n_ineq_lower", C.c_int), ("n_ineq_both", C.c_int), ("n_ineq_upper", C.c_int),
+        ("n_eq_work", C.c_int), ("n_unknowns", C.c_int),
+        ("n_stages", C.c_int), ("pivots", C.c_int), ("front", C.c_int),
+        ("n_base_nodes", C.c_int), ("n_dyn_times", C.c_int), ("n_rom_times", C.c_int),
+        ("n_rows_csv", C.c_int),
+        ("panel_doubles", C.c_longlong), ("g_doubles", C.c_longlong),
+        ("kkt_algorithmic_bytes", C.c_longlong), ("kkt_flops", C.c_longlong),
+        ("envelope", C.c_longlong), ("max_active", C.c_int), ("pad", C.c_int),
+        ("duration", C.c_double),
+    ]
+
+
+EXPORTS = [
+    "qtos_planner_create", "qtos_planner_destroy", "qtos_planner_dims", "qtos_last_error",
+    "qtos_set_heightfields", "qtos_plan_batch", "qtos_plan_batch_device", "qtos_sample_csv",
+    "qtos_sample_csv_device", "qtos_last_timing", "qtos_debug_eval", "qtos_debug_newton",
+    "qtos_debug_structure", "qtos_debug_trace",
+]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises OSError with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("HIP planner library not built: %s (run __graft_entry__.build()); "
+                      "this package has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    lib.qtos_planner_create.argtypes = [C.POINTER(QtosParams), C.c_int, C.c_int, C.POINTER(vp)]
+    lib.qtos_planner_destroy.argtypes = [vp]
+    lib.qtos_planner_destroy.restype = None
+    lib.qtos_planner_dims.argtypes = [vp, C.POINTER(QtosDims)]
+    lib.qtos_last_error.argtypes = [vp]
+    lib.qtos_last_error.restype = C.c_char_p
+    lib.qtos_set_heightfields.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+    lib.qtos_plan_batch.argtypes = [vp, C.c_int, dp, dp, ip, dp, dp, ip, ip, dp]
+    lib.qtos_plan_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.qtos_sample_csv.argtypes = [vp, C.c_int, dp, dp, C.c_double, C.c_int, dp]
+    lib.qtos_sample_csv_device.argtypes = [vp, C.c_int, vp, vp, C.c_double, C.c_int, vp, vp]
+    lib.qtos_last_timing.argtypes = [vp, dp, ip, dp, ip]
+    lib.qtos_debug_eval.argtypes = [vp, C.c_int, dp, dp, ip, dp, dp, dp]
+    lib.qtos_debug_newton.argtypes = [vp, C.c_int, dp, dp, ip, dp, dp, dp, dp]
+    lib.qtos_debug_structure.argtypes = [vp, ip, ip, ip]
+    lib.qtos_debug_trace.argtypes = [vp, C.c_int, dp]
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def params_from_config(cfg):
+    p = QtosParams()
+    for e in range(NEE):
+        d = cfg.phase_durations[e]
+        if len(d) > MAX_PHASES:
+            raise ValueError("at most %d phases per foot" % MAX_PHASES)
+        p.n_phases[e] = len(d)
+        for k, v in enumerate(d):
+            p.phase_dur[e][k] = float(v)
+        for k in range(3):
+            p.nominal_stance[e][k] = float(cfg.nominal_stance[e][k])
+    p.dt_base, p.dt_dyn, p.dt_rom = cfg.dt_base, cfg.dt_dynamic, cfg.dt_range_of_motion
+    p.force_polys_per_stance = cfg.force_polys_per_stance
+    p.mass, p.gravity = cfg.mass, cfg.gravity
+    for k, v in enumerate(np.asarray(cfg.inertia_b, float).reshape(9)):
+        p.inertia_b[k] = v
+    for k in range(3):
+        p.max_dev[k] = cfg.max_deviation[k]
+    p.mu, p.f_max, p.t_swing_avg = cfg.friction, cfg.force_limit, cfg.t_swing_avg
+    p.honor_start_velocity = int(cfg.honor_start_velocity)
+    p.max_iter, p.tol = cfg.max_iter, cfg.tol
+    p.mu_init, p.mu_min, p.delta_x, p.eps_dual = cfg.mu_init, cfg.mu_min, cfg.delta_x, cfg.eps_dual
+    return p
+
+
+class Planner:
+    """Owning wrapper of a QtosPlanner handle."""
+
+    def __init__(self, cfg, max_batch=256, device=0):
+        self.lib = load()
+        self.cfg = cfg
+        self.params = params_from_config(cfg)
+        self.h = C.c_void_p()
+        rc = self.lib.qtos_planner_create(C.byref(self.params), max_batch, device, C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("qtos_planner_create failed (%d): -2 = no HIP device, -3 = out of "
+                               "memory, -4 = front too large" % rc)
+        self.max_batch, self.device = max_batch, device
+        self.dims = QtosDims()
+        self.lib.qtos_planner_dims(self.h, C.byref(self.dims))
+        self.n, self.m = self.dims.n_vars, self.dims.n_cons
+
+    def close(self):
+        if self.h:
+            self.lib.qtos_planner_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.qtos_last_error(self.h).decode()))
+
+    def set_heightfields(self, maps, cell, x0=-1.0, y0=-1.0):
+        """maps: (n_maps, nx, ny) heights, maps[k][ix][iy] at x = x0 + ix*cell, y = y0 + iy*cell."""
+        if maps is None:
+            self._chk(self.lib.qtos_set_heightfields(self.h, 0, None, 0, 0, 1.0, 0.0, 0.0), "set_heightfields")
+            return
+        a = np.ascontiguousarray(maps, dtype=np.float64)
+        if a.ndim == 2:
+            a = a[None]
+        self._chk(self.lib.qtos_set_heightfields(self.h, a.shape[0], _dp(a), a.shape[1], a.shape[2],
+                                                 cell, x0, y0), "set_heightfields")
+
+    def plan(self, start, goal, map_id=None, warm=None):
+        start = np.ascontiguousarray(start, np.float64).reshape(-1, START_DOUBLES)
+        goal = np.ascontiguousarray(goal, np.float64).reshape(-1, 3)
+        B = start.shape[0]
+        nodes = np.empty((B, self.n))
+        status = np.empty(B, np.int32)
+        iters = np.empty(B, np.int32)
+        viol = np.empty(B)
+        mid = None if map_id is None else np.ascontiguousarray(map_id, np.int32)
+        wm = None if warm is None else np.ascontiguousarray(warm, np.float64).reshape(B, self.n)
+        self._chk(self.lib.qtos_plan_batch(self.h, B, _dp(start), _dp(goal), _ip(mid), _dp(wm),
+                                           _dp(nodes), _ip(status), _ip(iters), _dp(viol)), "plan_batch")
+        return nodes, status, iters, viol
+
+    def sample(self, nodes, t0, hz=1000.0, n_rows=None):
+        nodes = np.ascontiguousarray(nodes, np.float64).reshape(-1, self.n)
+        B = nodes.shape[0]
+        t0 = np.ascontiguousarray(np.broadcast_to(np.asarray(t0, np.float64), (B,)))
+        if n_rows is None:
+            n_rows = int(round(self.dims.duration * hz)) + 1
+        rows = np.empty((B, n_rows, CSV_COLS))
+        self._chk(self.lib.qtos_sample_csv(self.h, B, _dp(nodes), _dp(t0), hz, n_rows, _dp(rows)), "sample_csv")
+        return rows
+
+    def timing(self):
+        k, t = C.c_double(), C.c_double()
+        nl, it = C.c_int(), C.c_int()
+        self._chk(self.lib.qtos_last_timing(self.h, C.byref(k), C.byref(nl), C.byref(t), C.byref(it)), "last_timing")
+        return dict(kkt_seconds=k.value, kkt_launches=nl.value, total_seconds=t.value, iterations=it.value)
+
+    # ---- introspection (parity tests) ----
+    def debug_eval(self, start, goal, nodes, map_id=None, jac=True):
+        start = np.ascontiguousarray(start, np.float64).reshape(-1, START_DOUBLES)
+        goal = np.ascontiguousarray(goal, np.float64).reshape(-1, 3)
+        nodes = np.ascontiguousarray(nodes, np.float64).reshape(-1, self.n)
+        B = start.shape[0]
+        g = np.empty((B, self.m))
+        J = np.empty((B, self.m, self.n)) if jac else None
+        mid = None if map_id is None else np.ascontiguousarray(map_id, np.int32)
+        self._chk(self.lib.qtos_debug_eval(self.h, B, _dp(start), _dp(goal), _ip(mid), _dp(nodes), _dp(g), _dp(J)), "debug_eval")
+        return g, J
+
+    def debug_newton(self, start, goal, nodes, sig, w, map_id=None):
+        start = np.ascontiguousarray(start, np.float64).reshape(-1, START_DOUBLES)
+        goal = np.ascontiguousarray(goal, np.float64).reshape(-1, 3)
+        nodes = np.ascontiguousarray(nodes, np.float64).reshape(-1, self.n)
+        B = start.shape[0]
+        sig = np.ascontiguousarray(sig, np.float64).reshape(B, self.m)
+        w = np.ascontiguousarray(w, np.float64).reshape(B, self.m)
+        dx = np.empty((B, self.n))
+        mid = None if map_id is None else np.ascontiguousarray(map_id, np.int32)
+        self._chk(self.lib.qtos_debug_newton(self.h, B, _dp(start), _dp(goal), _ip(mid), _dp(nodes), _dp(sig), _dp(w), _dp(dx)), "debug_newton")
+        return dx
+
+    def structure(self):
+        rk = np.empty(self.m, np.int32)
+        vf = np.empty(self.n, np.int32)
+        order = np.empty(self.dims.n_unknowns, np.int32)
+        self.lib.qtos_debug_structure(self.h, _ip(rk), _ip(vf), _ip(order))
+        return rk, vf, order
+
+    def trace(self, b):
+        t = np.zeros((self.cfg.max_iter + 1, 4))
+        rows = self.lib.qtos_debug_trace(self.h, b, _dp(t))
+        return t[:max(rows, 0)]

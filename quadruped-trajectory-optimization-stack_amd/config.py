@@ -1,0 +1,103 @@
+"""Planner configuration: SOLO12 single-rigid-body model, gait schedule, transcription.
+
+Defaults are the ``reference_compat`` set: the constants that make the reference's committed
+trajectories (test/data/traj/gait.csv, data/traj/towr.csv) satisfy the NLP's constraints
+(checked in tests/test_oracle_golden.py).  The solver that produced
+them is not in the reference tree, so values that no artefact pins are named and flagged below.
+"""
+from dataclasses import dataclass, field
+from typing import List
+
+EE_NAMES = ("FL_FOOT", "FR_FOOT", "HL_FOOT", "HR_FOOT")  # QTOS/utils.py:13, flag order -e1..-e4
+
+# Un-normalised per-foot phase durations (stance, swing, ..., stance); every list sums to 8.12 and
+# is scaled to the plan duration.  Reproduces all 32 contact switch times of both golden plans at
+# 1 ms resolution.  Order FL, FR, HL, HR.
+REFERENCE_WALK_UNNORMALISED = (
+    (0.8, 0.3, 1.7, 0.3, 1.7, 0.3, 1.45, 0.51, 1.06),
+    (1.8, 0.3, 1.7, 0.3, 1.7, 0.3, 1.21, 0.51, 0.30),
+    (0.3, 0.3, 1.7, 0.3, 1.7, 0.3, 1.70, 0.38, 1.44),
+    (1.3, 0.3, 1.7, 0.3, 1.7, 0.3, 1.33, 0.51, 0.68),
+)
+
+# Diagonal-pair trot (FL+HR, FR+HL), same stand / swing / stance proportions as the walk above.
+# Not pinned by any reference artefact (the committed gait is the walk); provided because
+# BASELINE.json names a trot.
+TROT_UNNORMALISED = (
+    (0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.6),
+    (0.6, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3),
+    (0.6, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3),
+    (0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.6),
+)
+
+# Inertia tensor as the reference solver evidently used it: data/config/solo12.yml:13-18 lists
+# (ixx, ixy, ixz, iyy, iyz, izz) and the values went into an (Ixx, Iyy, Izz, Ixy, Ixz, Iyz)
+# constructor.  With this tensor the angular dynamics residual on gait.csv is 5e-5 N m; with the
+# physical diagonal tensor it is 0.48 N m.
+INERTIA_REFERENCE_COMPAT = ((0.00578574, -0.01938108, 0.0),
+                            (-0.01938108, 0.0, -0.02476124),
+                            (0.0, -0.02476124, 0.0))
+INERTIA_PHYSICAL = ((0.00578574, 0.0, 0.0), (0.0, 0.01938108, 0.0), (0.0, 0.0, 0.02476124))
+
+
+def scaled_phases(unnormalised, duration):
+    total = sum(unnormalised[0])
+    return [[d * duration / total for d in foot] for foot in unnormalised]
+
+
+@dataclass
+class PlannerConfig:
+    duration: float = 5.0                  # plan horizon [s]
+    gait: str = "walk"                     # "walk" (reference) or "trot"
+    dt_base: float = 0.1                   # base polynomial duration (upstream towr default)
+    dt_dynamic: float = 0.1                # dynamics collocation spacing
+    dt_range_of_motion: float = 0.08       # range-of-motion spacing
+    force_polys_per_stance: int = 3
+    mass: float = 3.0                      # pinned by gait.csv: 2.99994 +- 0.0012 kg
+    gravity: float = 9.80665
+    inertia_b: tuple = INERTIA_REFERENCE_COMPAT
+    # Range-of-motion box: NOT pinned (no bound is active in the golden plans); this is the
+    # smallest round box containing the golden envelope.
+    nominal_stance: tuple = ((0.20, 0.17, -0.26), (0.20, -0.17, -0.26),
+                             (-0.20, 0.17, -0.26), (-0.20, -0.17, -0.26))
+    max_deviation: tuple = (0.07, 0.07, 0.09)
+    friction: float = 0.5                  # upstream default; golden max |ft|/fn = 0.367
+    force_limit: float = 1000.0            # upstream default; golden max fz = 18.3 N
+    t_swing_avg: float = 0.3               # pinned: golden swing mid-node velocity ratio
+    # The reference solver ignores s_vel / s_ang_vel (towr.csv rows 1255.. restart from rest);
+    # set True to start from the hand-over velocities instead.
+    honor_start_velocity: bool = False
+    hz: float = 1000.0                     # CSV sampling rate (scripts/run.py consumes 1 kHz rows)
+    # solver
+    max_iter: int = 40
+    tol: float = 1e-4
+    mu_init: float = 0.1
+    mu_min: float = 1e-9
+    delta_x: float = 1e-2
+    eps_dual: float = 1e-8
+    phase_durations: List[List[float]] = field(default=None)
+
+    def __post_init__(self):
+        if self.phase_durations is None:
+            table = REFERENCE_WALK_UNNORMALISED if self.gait == "walk" else TROT_UNNORMALISED
+            self.phase_durations = scaled_phases(table, self.duration)
+
+    @classmethod
+    def reference_compat(cls, **kw):
+        """51 base nodes, dynamics every 0.1 s: the NLP of logs/towr_log.out (1040 vars, 1730 rows)."""
+        return cls(**kw)
+
+    @classmethod
+    def knots100(cls, **kw):
+        """BASELINE.json configs[1..3]: 100 base polynomials / dynamics knots over the 5 s horizon."""
+        kw.setdefault("dt_base", 0.05)
+        kw.setdefault("dt_dynamic", 0.05)
+        return cls(**kw)
+
+    def oracle_dict(self):
+        """The same numbers in the key names oracle/oracle.py expects (tests only)."""
+        return dict(phase_durations=self.phase_durations, nominal_stance=self.nominal_stance,
+                    dt_base=self.dt_base, dt_dyn=self.dt_dynamic, dt_rom=self.dt_range_of_motion,
+                    force_polys_per_stance=self.force_polys_per_stance, mass=self.mass,
+                    gravity=self.gravity, inertia_b=self.inertia_b, max_dev=self.max_deviation,
+                    mu=self.friction, f_max=self.force_limit, t_swing_avg=self.t_swing_avg)

@@ -1,0 +1,863 @@
+// kernels.hpp -- gfx950 device code of the batched planner.  One workgroup per planning problem.
+//
+//   k_start : initial guess (or warm start), constraint values, slack / barrier initialisation,
+//             first linearisation (per-instance dense Jacobian blocks G, barrier weights)
+//   k_kkt   : fused front assembly + block LDL^T (Schur-complement chain, 16 pivots per stage,
+//             front resident in LDS) + forward/backward substitution  -> Newton step dx
+//   k_step  : slack/dual steps, fraction-to-the-boundary, backtracking on the l1 infeasibility,
+//             state update, convergence test, next linearisation
+//   k_sample: 1 kHz spline sampling into the 37-column CSV row layout
+//
+// Formulas: towr v1.4 (the reference's solver is a fork of it, Dockerfile:45):
+//   euler_converter.cc (R, M, Mdot), single_rigid_body_dynamics.cc (Newton-Euler violation),
+//   range_of_motion_constraint.cc, terrain_constraint.cc, force_constraint.cc, height_map.cc.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "model.hpp"
+#include "symbolic.hpp"
+
+namespace qtos {
+
+struct DevPlan {
+  int n_vars, n_cons, n_stages, front;
+  int n_dyn, n_rom, n_terr, n_force, n_lin, n_blocks;
+  const DynInst *dyn;
+  const RomInst *rom;
+  const TerrInst *terr;
+  const ForceInst *force;
+  const LinRow *lin;
+  const Block *blocks;
+  const int *block_cols;
+  const double *g_static;
+  const int *piv_slot, *piv_unknown;
+  const double *piv_diag;
+  const StageDesc *stages;
+  const EqEntry *eq_entries;
+  const EqRhs *eq_rhs;
+  const IqBlock *iq_blocks;
+  const short *iq_slots;
+  int max_stage_g;
+  const double *con_lo, *con_hi;
+  const int *row_kind;
+  const InitDesc *init;
+  double mass, gravity, Ib[9], mu_fric, f_max, T;
+  double nominal[NEE][3];
+  double tol, mu_init, mu_min, delta_x, eps_dual;
+  int max_iter;
+  const double *height;
+  int n_maps, hnx, hny;
+  double hcell, hx0, hy0;
+  long long g_doubles, panel_stride;  // per problem
+};
+
+struct DevWork {
+  const double *start, *goal, *warm;
+  const int *map_id;
+  double *x, *xt, *g, *gt, *s, *zl, *zu, *ds, *dzl, *dzu, *sig, *w, *G, *panel, *dx;
+  double *mu, *viol, *trace;
+  int *status, *iters, *done, *n_active;
+};
+
+// ---- tiny forward-mode dual (one tangent) for the rotation-dependent Jacobians ---------------
+struct D1 {
+  double v, d;
+};
+__device__ inline D1 operator+(D1 a, D1 b) { return {a.v + b.v, a.d + b.d}; }
+__device__ inline D1 operator-(D1 a, D1 b) { return {a.v - b.v, a.d - b.d}; }
+__device__ inline D1 operator-(D1 a) { return {-a.v, -a.d}; }
+__device__ inline D1 operator*(D1 a, D1 b) { return {a.v * b.v, a.v * b.d + a.d * b.v}; }
+__device__ inline D1 operator*(double a, D1 b) { return {a * b.v, a * b.d}; }
+__device__ inline D1 operator*(D1 a, double b) { return {a.v * b, a.d * b}; }
+__device__ inline void sincos_t(double x, double &s, double &c) { sincos(x, &s, &c); }
+__device__ inline void sincos_t(D1 x, D1 &s, D1 &c) {
+  double sv, cv;
+  sincos(x.v, &sv, &cv);
+  s = {sv, cv * x.d};
+  c = {cv, -sv * x.d};
+}
+__device__ inline double mk(double, double v) { return v; }
+__device__ inline D1 mk(D1, double v) { return {v, 0.0}; }
+
+// R = Rz(yaw) Ry(pitch) Rx(roll), th = (roll, pitch, yaw)
+template <class T>
+__device__ inline void rotation(const T th[3], T R[9]) {
+  T sx, cx, sy, cy, sz, cz;
+  sincos_t(th[0], sx, cx);
+  sincos_t(th[1], sy, cy);
+  sincos_t(th[2], sz, cz);
+  R[0] = cy * cz; R[1] = cz * sx * sy - cx * sz; R[2] = sx * sz + cx * cz * sy;
+  R[3] = cy * sz; R[4] = cx * cz + sx * sy * sz; R[5] = cx * sy * sz - cz * sx;
+  R[6] = -sy;     R[7] = cy * sx;                R[8] = cx * cy;
+}
+
+// I_w wd + w x (I_w w) with I_w = R Ib R^T, w = M(th) thd, wd = Mdot thd + M thdd
+template <class T>
+__device__ inline void dyn_angular(const double *Ib, const T th[3], const T thd[3], const T thdd[3],
+                                   T out[3]) {
+  T sy, cy, sz, cz;
+  sincos_t(th[1], sy, cy);
+  sincos_t(th[2], sz, cz);
+  const T yd = thd[1], zd = thd[2];
+  // w = M thd
+  T w[3], wd[3];
+  w[0] = cy * cz * thd[0] - sz * thd[1];
+  w[1] = cy * sz * thd[0] + cz * thd[1];
+  w[2] = thd[2] - sy * thd[0];
+  // wd = Mdot thd + M thdd
+  T m00 = -(cz * sy * yd) - cy * sz * zd, m01 = -(cz * zd);
+  T m10 = cy * cz * zd - sy * sz * yd, m11 = -(sz * zd);
+  T m20 = -(cy * yd);
+  wd[0] = m00 * thd[0] + m01 * thd[1] + cy * cz * thdd[0] - sz * thdd[1];
+  wd[1] = m10 * thd[0] + m11 * thd[1] + cy * sz * thdd[0] + cz * thdd[1];
+  wd[2] = m20 * thd[0] + thdd[2] - sy * thdd[0];
+  T R[9];
+  rotation(th, R);
+  // body-frame vectors u = R^T w, ud = R^T wd ; I_w v = R (Ib (R^T v))
+  T u[3], ud[3];
+  for (int i = 0; i < 3; ++i) {
+    u[i] = R[i] * w[0] + R[3 + i] * w[1] + R[6 + i] * w[2];
+    ud[i] = R[i] * wd[0] + R[3 + i] * wd[1] + R[6 + i] * wd[2];
+  }
+  T Iu[3], Iud[3];
+  for (int i = 0; i < 3; ++i) {
+    Iu[i] = Ib[3 * i] * u[0] + Ib[3 * i + 1] * u[1] + Ib[3 * i + 2] * u[2];
+    Iud[i] = Ib[3 * i] * ud[0] + Ib[3 * i + 1] * ud[1] + Ib[3 * i + 2] * ud[2];
+  }
+  T Iww[3], Iwd[3];
+  for (int i = 0; i < 3; ++i) {
+    Iww[i] = R[3 * i] * Iu[0] + R[3 * i + 1] * Iu[1] + R[3 * i + 2] * Iu[2];
+    Iwd[i] = R[3 * i] * Iud[0] + R[3 * i + 1] * Iud[1] + R[3 * i + 2] * Iud[2];
+  }
+  out[0] = Iwd[0] + w[1] * Iww[2] - w[2] * Iww[1];
+  out[1] = Iwd[1] + w[2] * Iww[0] - w[0] * Iww[2];
+  out[2] = Iwd[2] + w[0] * Iww[1] - w[1] * Iww[0];
+}
+
+__device__ inline void vec_eval(const VecIn &in, const double *x, double out[3]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    double acc = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int v = in.var[3 * a + d];
+      if (v >= 0) acc += in.w[a] * x[v];
+    }
+    out[d] = acc;
+  }
+}
+
+struct Terr {
+  double h, hx, hy, hxy;
+};
+// bilinear height, clamped at the border (zero slope outside the map)
+__device__ inline Terr terrain_at(const DevPlan &P, int map, double x, double y) {
+  Terr t = {0, 0, 0, 0};
+  if (!P.height || P.n_maps <= 0) return t;
+  const double *H = P.height + (size_t)map * P.hnx * P.hny;
+  double fx = (x - P.hx0) / P.hcell, fy = (y - P.hy0) / P.hcell;
+  const double mx = P.hnx - 1, my = P.hny - 1;
+  bool cx = false, cy = false;
+  if (fx <= 0) { fx = 0; cx = true; }
+  if (fx >= mx) { fx = mx; cx = true; }
+  if (fy <= 0) { fy = 0; cy = true; }
+  if (fy >= my) { fy = my; cy = true; }
+  int ix = (int)floor(fx), iy = (int)floor(fy);
+  ix = min(ix, P.hnx - 2); iy = min(iy, P.hny - 2);
+  ix = max(ix, 0); iy = max(iy, 0);
+  const double u = fx - ix, v = fy - iy;
+  const int ix1 = P.hnx > 1 ? ix + 1 : ix, iy1 = P.hny > 1 ? iy + 1 : iy;
+  const double h00 = H[ix * P.hny + iy], h10 = H[ix1 * P.hny + iy], h01 = H[ix * P.hny + iy1],
+               h11 = H[ix1 * P.hny + iy1];
+  t.h = h00 * (1 - u) * (1 - v) + h10 * u * (1 - v) + h01 * (1 - u) * v + h11 * u * v;
+  const double c = P.hcell;
+  t.hx = cx ? 0 : ((h10 - h00) * (1 - v) + (h11 - h01) * v) / c;
+  t.hy = cy ? 0 : ((h01 - h00) * (1 - u) + (h11 - h10) * u) / c;
+  t.hxy = (cx || cy) ? 0 : (h11 - h10 - h01 + h00) / (c * c);
+  return t;
+}
+// normalised normal / tangent1 / tangent2 and their x, y derivatives (height_map.cc)
+__device__ inline void terrain_basis(const Terr &t, int which, double b[3], double bx[3], double by[3]) {
+  double v[3], vx[3] = {0, 0, 0}, vy[3] = {0, 0, 0};
+  if (which == 0) { v[0] = -t.hx; v[1] = -t.hy; v[2] = 1; vx[1] = -t.hxy; vy[0] = -t.hxy; }
+  else if (which == 1) { v[0] = 1; v[1] = 0; v[2] = t.hx; vy[2] = t.hxy; }
+  else { v[0] = 0; v[1] = 1; v[2] = t.hy; vx[2] = t.hxy; }
+  const double nn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  for (int i = 0; i < 3; ++i) b[i] = v[i] / nn;
+  const double px = b[0] * vx[0] + b[1] * vx[1] + b[2] * vx[2];
+  const double py = b[0] * vy[0] + b[1] * vy[1] + b[2] * vy[2];
+  for (int i = 0; i < 3; ++i) { bx[i] = (vx[i] - b[i] * px) / nn; by[i] = (vy[i] - b[i] * py) / nn; }
+}
+
+// ---- per-instance evaluation ------------------------------------------------------------------
+// JAC = false: constraint values only;  JAC = true: values + dense block G (row-major m x ncol)
+template <bool JAC>
+__device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double *x, double *g, double *Gp) {
+  double r[3], a[3], th[3], thd[3], thdd[3];
+  vec_eval(I.r, x, r); vec_eval(I.a, x, a);
+  vec_eval(I.th, x, th); vec_eval(I.thd, x, thd); vec_eval(I.thdd, x, thdd);
+  double ga[3], gl[3];
+  dyn_angular<double>(P.Ib, th, thd, thdd, ga);
+  gl[0] = P.mass * a[0]; gl[1] = P.mass * a[1]; gl[2] = P.mass * a[2] + P.mass * P.gravity;
+  double *G = nullptr;
+  const int nc = I.ncol;
+  const bool jac = JAC && I.in_kkt;
+  if (jac) {
+    G = Gp + I.goff;
+    for (int i = 0; i < 6 * nc; ++i) G[i] = 0.0;
+    // angular rows wrt Euler angles / rates / accelerations: 9 forward-mode passes
+    for (int what = 0; what < 3; ++what)
+      for (int j = 0; j < 3; ++j) {
+        D1 t0[3], t1[3], t2[3], o[3];
+        for (int i = 0; i < 3; ++i) { t0[i] = {th[i], 0.0}; t1[i] = {thd[i], 0.0}; t2[i] = {thdd[i], 0.0}; }
+        if (what == 0) t0[j].d = 1.0;
+        if (what == 1) t1[j].d = 1.0;
+        if (what == 2) t2[j].d = 1.0;
+        dyn_angular<D1>(P.Ib, t0, t1, t2, o);
+        const VecIn &in = what == 0 ? I.th : (what == 1 ? I.thd : I.thdd);
+        for (int s = 0; s < 4; ++s) {
+          int c = I.c_ang[3 * s + j];
+          if (c < 0) continue;
+          for (int i = 0; i < 3; ++i) G[i * nc + c] += o[i].d * in.w[s];
+        }
+      }
+    for (int s = 0; s < 4; ++s)
+      for (int d = 0; d < 3; ++d) {
+        int c = I.c_lin[3 * s + d];
+        if (c >= 0) G[(3 + d) * nc + c] += P.mass * I.a.w[s];
+      }
+  }
+  double sf[3] = {0, 0, 0};
+  for (int e = 0; e < NEE; ++e) {
+    double pe[3], f[3];
+    vec_eval(I.p[e], x, pe);
+    vec_eval(I.f[e], x, f);
+    const double d[3] = {r[0] - pe[0], r[1] - pe[1], r[2] - pe[2]};
+    // tau_sum += f x (r - p)
+    ga[0] -= f[1] * d[2] - f[2] * d[1];
+    ga[1] -= f[2] * d[0] - f[0] * d[2];
+    ga[2] -= f[0] * d[1] - f[1] * d[0];
+    gl[0] -= f[0]; gl[1] -= f[1]; gl[2] -= f[2];
+    if (jac) {
+      sf[0] += f[0]; sf[1] += f[1]; sf[2] += f[2];
+      // d g_ang / d p = [f]x ; d g_ang / d f = [d]x ; d g_lin / d f = -I
+      const double Fx[9] = {0, -f[2], f[1], f[2], 0, -f[0], -f[1], f[0], 0};
+      const double Dx[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
+      for (int s = 0; s < 4; ++s)
+        for (int dd = 0; dd < 3; ++dd) {
+          int cp = I.c_p[e][3 * s + dd], cf = I.c_f[e][3 * s + dd];
+          if (cp >= 0)
+            for (int i = 0; i < 3; ++i) G[i * nc + cp] += Fx[3 * i + dd] * I.p[e].w[s];
+          if (cf >= 0) {
+            for (int i = 0; i < 3; ++i) G[i * nc + cf] += Dx[3 * i + dd] * I.f[e].w[s];
+            G[(3 + dd) * nc + cf] -= I.f[e].w[s];
+          }
+        }
+    }
+  }
+  if (jac) {
+    const double Sx[9] = {0, sf[2], -sf[1], -sf[2], 0, sf[0], sf[1], -sf[0], 0};  // -[sum f]x
+    for (int s = 0; s < 4; ++s)
+      for (int dd = 0; dd < 3; ++dd) {
+        int c = I.c_lin[3 * s + dd];
+        if (c >= 0)
+          for (int i = 0; i < 3; ++i) G[i * nc + c] += Sx[3 * i + dd] * I.r.w[s];
+      }
+  }
+  for (int i = 0; i < 3; ++i) { g[I.row0 + i] = ga[i]; g[I.row0 + 3 + i] = gl[i]; }
+}
+
+template <bool JAC>
+__device__ inline void eval_rom(const DevPlan &P, const RomInst &I, const double *x, double *g, double *Gp) {
+  double r[3], th[3], pe[3];
+  vec_eval(I.r, x, r); vec_eval(I.th, x, th); vec_eval(I.p, x, pe);
+  const double d[3] = {pe[0] - r[0], pe[1] - r[1], pe[2] - r[2]};
+  double R[9];
+  rotation<double>(th, R);
+  for (int i = 0; i < 3; ++i) g[I.row0 + i] = R[i] * d[0] + R[3 + i] * d[1] + R[6 + i] * d[2];
+  if (JAC) {
+    const int nc = I.ncol;
+    double *G = Gp + I.goff;
+    for (int i = 0; i < 3 * nc; ++i) G[i] = 0.0;
+    for (int s = 0; s < 4; ++s)
+      for (int dd = 0; dd < 3; ++dd) {
+        int cp = I.c_p[3 * s + dd], cl = I.c_lin[3 * s + dd];
+        for (int i = 0; i < 3; ++i) {
+          const double rt = R[3 * dd + i];  // (R^T)[i][dd]
+          if (cp >= 0) G[i * nc + cp] += rt * I.p.w[s];
+          if (cl >= 0) G[i * nc + cl] -= rt * I.r.w[s];
+        }
+      }
+    for (int j = 0; j < 3; ++j) {
+      D1 t0[3] = {{th[0], 0.0}, {th[1], 0.0}, {th[2], 0.0}};
+      t0[j].d = 1.0;
+      D1 Rd[9];
+      rotation<D1>(t0, Rd);
+      for (int s = 0; s < 4; ++s) {
+        int c = I.c_ang[3 * s + j];
+        if (c < 0) continue;
+        for (int i = 0; i < 3; ++i)
+          G[i * nc + c] += (Rd[i].d * d[0] + Rd[3 + i].d * d[1] + Rd[6 + i].d * d[2]) * I.th.w[s];
+      }
+    }
+  }
+}
+
+template <bool JAC>
+__device__ inline void eval_terr(const DevPlan &P, const TerrInst &I, int map, const double *x, double *g, double *Gp) {
+  const Terr t = terrain_at(P, map, x[I.vx], x[I.vy]);
+  g[I.row] = x[I.vz] - t.h;
+  if (JAC && I.in_kkt) {
+    double *G = Gp + I.goff;
+    if (I.cx >= 0) G[I.cx] = -t.hx;
+    if (I.cy >= 0) G[I.cy] = -t.hy;
+    if (I.cz >= 0) G[I.cz] = 1.0;
+  }
+}
+
+template <bool JAC>
+__device__ inline void eval_force(const DevPlan &P, const ForceInst &I, int map, const double *x, double *g, double *Gp) {
+  const double f[3] = {x[I.vf[0]], x[I.vf[1]], x[I.vf[2]]};
+  const Terr t = terrain_at(P, map, x[I.vsx], x[I.vsy]);
+  double b[3][3], bx[3][3], by[3][3];
+  for (int w = 0; w < 3; ++w) terrain_basis(t, w, b[w], bx[w], by[w]);
+  const double mu = P.mu_fric;
+  const double ct[5][3] = {{1, 0, 0}, {-mu, 1, 0}, {mu, 1, 0}, {-mu, 0, 1}, {mu, 0, 1}};
+  const int nc = I.ncol;
+  double *G = JAC ? Gp + I.goff : nullptr;
+  for (int row = 0; row < 5; ++row) {
+    double v[3], vx[3], vy[3];
+    for (int i = 0; i < 3; ++i) {
+      v[i] = ct[row][0] * b[0][i] + ct[row][1] * b[1][i] + ct[row][2] * b[2][i];
+      vx[i] = ct[row][0] * bx[0][i] + ct[row][1] * bx[1][i] + ct[row][2] * bx[2][i];
+      vy[i] = ct[row][0] * by[0][i] + ct[row][1] * by[1][i] + ct[row][2] * by[2][i];
+    }
+    g[I.row0 + row] = f[0] * v[0] + f[1] * v[1] + f[2] * v[2];
+    if (JAC) {
+      for (int i = 0; i < 3; ++i)
+        if (I.cf[i] >= 0) G[row * nc + I.cf[i]] = v[i];
+      if (I.csx >= 0) G[row * nc + I.csx] = f[0] * vx[0] + f[1] * vx[1] + f[2] * vx[2];
+      if (I.csy >= 0) G[row * nc + I.csy] = f[0] * vy[0] + f[1] * vy[1] + f[2] * vy[2];
+    }
+  }
+}
+
+// all constraint rows of one problem, by the whole workgroup
+template <bool JAC>
+__device__ inline void eval_all(const DevPlan &P, int map, const double *x, double *g, double *G) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // heavy instances first so that the tail is short
+  for (int i = tid; i < P.n_dyn; i += nt) eval_dyn<JAC>(P, P.dyn[i], x, g, G);
+  for (int i = tid; i < P.n_rom; i += nt) eval_rom<JAC>(P, P.rom[i], x, g, G);
+  for (int i = tid; i < P.n_force; i += nt) eval_force<JAC>(P, P.force[i], map, x, g, G);
+  for (int i = tid; i < P.n_terr; i += nt) eval_terr<JAC>(P, P.terr[i], map, x, g, G);
+  for (int i = tid; i < P.n_lin; i += nt) {
+    const LinRow &L = P.lin[i];
+    double acc = 0;
+    for (int k = 0; k < L.n; ++k) acc += L.coef[k] * x[L.var[k]];
+    g[L.row] = acc;
+  }
+}
+
+// ---- workgroup reductions (fixed tree => bitwise reproducible) --------------------------------
+template <int OP>  // 0 sum, 1 max, 2 min
+__device__ inline double wg_reduce(double v, double *scratch) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  __syncthreads();
+  scratch[tid] = v;
+  __syncthreads();
+  for (int s = nt >> 1; s > 0; s >>= 1) {
+    if (tid < s) {
+      double a = scratch[tid], b = scratch[tid + s];
+      scratch[tid] = OP == 0 ? a + b : (OP == 1 ? fmax(a, b) : fmin(a, b));
+    }
+    __syncthreads();
+  }
+  double r = scratch[0];
+  __syncthreads();
+  return r;
+}
+
+// barrier weights of every inequality row: sig = zl/(s-l) + zu/(u-s), w = sig (g - s) - mu/(s-l) + mu/(u-s)
+__device__ inline void barrier_terms(const DevPlan &P, const double *g, const double *s, const double *zl,
+                                     const double *zu, double mu, double *sig, double *w) {
+  for (int r = threadIdx.x; r < P.n_cons; r += blockDim.x) {
+    if (P.row_kind[r] != 2) continue;
+    const double l = P.con_lo[r], u = P.con_hi[r];
+    const bool hl = l > -1e19, hu = u < 1e19;
+    const double dl = hl ? s[r] - l : 1.0, du = hu ? u - s[r] : 1.0;
+    const double sg = (hl ? zl[r] / dl : 0.0) + (hu ? zu[r] / du : 0.0);
+    const double gmu = -(hl ? mu / dl : 0.0) + (hu ? mu / du : 0.0);
+    sig[r] = sg;
+    w[r] = sg * (g[r] - s[r]) + gmu;
+  }
+}
+
+// max violation of the working rows (viol) and of the slack form (theta)
+__device__ inline void infeasibility(const DevPlan &P, const double *g, const double *s, double *scratch,
+                                     double &viol, double &theta) {
+  double v = 0, t = 0;
+  for (int r = threadIdx.x; r < P.n_cons; r += blockDim.x) {
+    const int k = P.row_kind[r];
+    if (k == 1) { v = fmax(v, fabs(g[r])); t = fmax(t, fabs(g[r])); }
+    else if (k == 2) {
+      v = fmax(v, fmax(P.con_lo[r] - g[r], g[r] - P.con_hi[r]));
+      t = fmax(t, fabs(g[r] - s[r]));
+    }
+  }
+  viol = wg_reduce<1>(v, scratch);
+  theta = wg_reduce<1>(t, scratch);
+}
+
+__device__ inline double l1_infeasibility(const DevPlan &P, const double *g, const double *s, const double *ds,
+                                          double al, double *scratch) {
+  double t = 0;
+  for (int r = threadIdx.x; r < P.n_cons; r += blockDim.x) {
+    const int k = P.row_kind[r];
+    if (k == 1) t += fabs(g[r]);
+    else if (k == 2) t += fabs(g[r] - (s[r] + al * ds[r]));
+  }
+  return wg_reduce<0>(t, scratch);
+}
+
+__device__ inline void record_trace(const DevPlan &P, const DevWork &W, int b, int it, double viol,
+                                    double theta, double al, double mu) {
+  if (W.trace && it < P.max_iter + 1) {
+    double *t = W.trace + ((size_t)b * (P.max_iter + 1) + it) * 4;
+    t[0] = viol; t[1] = theta; t[2] = al; t[3] = mu;
+  }
+}
+
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  __shared__ double scratch[256];
+  const int n = P.n_vars, m = P.n_cons, tid = threadIdx.x;
+  double *x = W.x + (size_t)b * n, *g = W.g + (size_t)b * m;
+  double *s = W.s + (size_t)b * m, *zl = W.zl + (size_t)b * m, *zu = W.zu + (size_t)b * m;
+  const double *st = W.start + (size_t)b * QTOS_START_DOUBLES, *gl = W.goal + (size_t)b * 3;
+  const int map = W.map_id ? W.map_id[b] : 0;
+  // end points of the linear-interpolation guess (towr nlp_formulation.cc Make*Variables)
+  const double fin[3] = {gl[0], gl[1], terrain_at(P, map, gl[0], gl[1]).h - P.nominal[0][2]};
+  for (int v = tid; v < n; v += blockDim.x) {
+    const InitDesc I = P.init[v];
+    double val;
+    if (I.fix_src >= 0) {
+      val = I.fix_src < 24 ? st[I.fix_src] : (I.fix_src < 26 ? gl[I.fix_src - 24] : 0.0);
+    } else if (W.warm) {
+      val = W.warm[(size_t)b * n + v];
+    } else {
+      double a, e;
+      if (I.set == 0) { a = st[I.dim]; e = fin[I.dim]; }
+      else if (I.set == 1) { a = st[3 + I.dim]; e = 0.0; }
+      else if (I.set < 6) {
+        const int ee = I.set - 2;
+        a = st[6 + 3 * ee + I.dim];
+        const double fx = fin[0] + P.nominal[ee][0], fy = fin[1] + P.nominal[ee][1];
+        e = I.dim == 0 ? fx : (I.dim == 1 ? fy : terrain_at(P, map, fx, fy).h);
+      } else { a = e = I.dim == 2 ? P.mass * P.gravity / NEE : 0.0; }
+      val = I.is_vel ? (e - a) / P.T : a + I.frac * (e - a);
+    }
+    x[v] = val;
+  }
+  __syncthreads();
+  eval_all<false>(P, map, x, g, nullptr);
+  __syncthreads();
+  // slack initialisation: push strictly inside the bounds (Ipopt bound_push / bound_frac = 0.01)
+  for (int r = tid; r < m; r += blockDim.x) {
+    if (P.row_kind[r] != 2) { s[r] = 0; zl[r] = 0; zu[r] = 0; continue; }
+    const double l = P.con_lo[r], u = P.con_hi[r];
+    const bool hl = l > -1e19, hu = u < 1e19;
+    double pl = hl ? 0.01 * fmax(1.0, fabs(l)) : 0.0, pu = hu ? 0.01 * fmax(1.0, fabs(u)) : 0.0;
+    if (hl && hu) { pl = fmin(pl, 0.01 * (u - l)); pu = fmin(pu, 0.01 * (u - l)); }
+    double si = g[r];
+    if (hl) si = fmax(si, l + pl);
+    if (hu) si = fmin(si, u - pu);
+    s[r] = si;
+  }
+  double viol, theta;
+  infeasibility(P, g, s, scratch, viol, theta);
+  const double mu = fmax(P.mu_min, fmin(P.mu_init, 0.01 * theta * theta));
+  for (int r = tid; r < m; r += blockDim.x) {
+    if (P.row_kind[r] != 2) continue;
+    const double l = P.con_lo[r], u = P.con_hi[r];
+    zl[r] = l > -1e19 ? mu / (s[r] - l) : 0.0;
+    zu[r] = u < 1e19 ? mu / (u - s[r]) : 0.0;
+  }
+  const bool conv = viol <= P.tol && theta <= P.tol;
+  if (tid == 0) {
+    W.mu[b] = mu;
+    W.viol[b] = viol;
+    W.iters[b] = 0;
+    W.status[b] = conv ? 0 : 1;
+    W.done[b] = conv ? 1 : 0;
+    if (!conv) atomicAdd(W.n_active, 1);
+    record_trace(P, W, b, 0, viol, theta, 0.0, mu);
+  }
+  if (conv) return;
+  __syncthreads();
+  eval_all<true>(P, map, x, g, W.G + (size_t)b * P.g_doubles);
+  barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m);
+}
+
+// =================================================================================================
+// k_kkt: one workgroup (KT threads) per problem.
+//   LDS: A   lower triangle of the symmetric front, rows 0..F; row F is the right-hand side
+//        Pn[(F+1) x 17] pivot columns (border panel C; pivot rows zeroed), Wn = Pn * Binv
+constexpr int KT = 512;
+constexpr int PLD = PIV + 1;
+__device__ __forceinline__ int tri(int r, int c) { return ((r * (r + 1)) >> 1) + c; }  // c <= r
+__device__ __forceinline__ int trs(int a, int b) { return a >= b ? tri(a, b) : tri(b, a); }
+
+__device__ inline void invert16(double *Bm /* 16 x PLD in LDS, symmetric */, int lane) {
+  // in-place Gauss-Jordan without pivoting (quasi-definite block, fixed order); one wave.
+  // lane (i, c) = (lane >> 2, lane & 3) owns B[i][4c .. 4c+3]
+  const int i = lane >> 2, c = lane & 3;
+  double a[4];
+  for (int j = 0; j < 4; ++j) a[j] = Bm[i * PLD + 4 * c + j];
+#pragma unroll
+  for (int k = 0; k < PIV; ++k) {
+    const int kc = k >> 2, ke = k & 3;
+    // pivot row segment for my columns, pivot value, my row's k-th entry
+    double rk[4];
+    for (int j = 0; j < 4; ++j) rk[j] = __shfl(a[j], 4 * k + c);
+    const double p = __shfl(a[ke], 4 * k + kc);
+    double f = __shfl(a[ke], 4 * i + kc);
+    const double ip = 1.0 / p;
+    if (c == kc) rk[ke] = 1.0;  // the pivot column of the pivot row becomes 1 before scaling
+    if (i == k) {
+      for (int j = 0; j < 4; ++j) a[j] = rk[j] * ip;
+    } else {
+      if (c == kc) a[ke] = 0.0;
+      for (int j = 0; j < 4; ++j) a[j] -= f * rk[j] * ip;
+    }
+  }
+  for (int j = 0; j < 4; ++j) Bm[i * PLD + 4 * c + j] = a[j];
+}
+
+__global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
+  const int b = blockIdx.x;
+  if (b >= B || W.done[b]) return;
+  extern __shared__ double lds[];
+  const int F = P.front, tid = threadIdx.x;
+  const int ntri = ((F + 1) * (F + 2)) >> 1;
+  double *A = lds;                    // lower triangle incl. rhs row F
+  double *Pn = A + ntri;              // (F+1) * PLD
+  double *Wn = Pn + (F + 1) * PLD;    // (F+1) * PLD
+  double *Bm = Wn + (F + 1) * PLD;    // PIV * PLD
+  double *xs = Bm + PIV * PLD;        // F
+  double *Gs = xs + F;                // max_stage_g: this stage's slice of G
+  __shared__ int ps[PIV];
+  const int m = P.n_cons, n = P.n_vars;
+  const double *G = W.G + (size_t)b * P.g_doubles;
+  const double *g = W.g + (size_t)b * m, *sig = W.sig + (size_t)b * m, *wv = W.w + (size_t)b * m;
+  double *panel = W.panel + (size_t)b * P.panel_stride;
+  double *dx = W.dx + (size_t)b * n;
+  const int pstride = (F + PIV + 1) * PIV;  // doubles per stage: C (F x 16), Binv (16 x 16), b1 (16)
+
+  for (int i = tid; i < ntri; i += KT) A[i] = 0.0;
+  for (int v = tid; v < n; v += KT) dx[v] = 0.0;
+
+  for (int k = 0; k < P.n_stages; ++k) {
+    const StageDesc S = P.stages[k];
+    // ---- stage's slice of G: one contiguous, coalesced read into LDS --------------------------
+    for (int i = tid; i < S.g_len; i += KT) Gs[i] = G[S.g_begin + i];
+    if (tid < PIV) ps[tid] = P.piv_slot[k * PIV + tid];
+    __syncthreads();
+    // ---- assembly --------------------------------------------------------------------------------
+    if (tid < PIV) A[tri(ps[tid], ps[tid])] += P.piv_diag[k * PIV + tid];
+    for (int i = S.ent_begin + tid; i < S.ent_end; i += KT) {
+      const EqEntry e = P.eq_entries[i];
+      A[trs(e.slot_r, e.slot_c)] = e.src >= 0 ? Gs[e.src] : P.g_static[-e.src - 1];
+    }
+    for (int i = S.rhs_begin + tid; i < S.rhs_end; i += KT) {
+      const EqRhs e = P.eq_rhs[i];
+      A[tri(F, e.slot)] = -g[e.row];
+    }
+    for (int q = S.iq_begin; q < S.iq_end; ++q) {
+      const IqBlock Q = P.iq_blocks[q];
+      const short *sl = P.iq_slots + Q.slot_off;
+      const double *Gb = Gs + Q.gloc;
+      __syncthreads();
+      const int npair = (Q.n * (Q.n + 1)) >> 1;
+      for (int i = tid; i < npair + Q.n; i += KT) {
+        if (i < npair) {
+          // (a, c) with c <= a from the linear index
+          int a = (int)((sqrt(8.0 * i + 1.0) - 1.0) * 0.5);
+          while (((a + 1) * (a + 2)) >> 1 <= i) ++a;
+          while ((a * (a + 1)) >> 1 > i) --a;
+          const int c = i - ((a * (a + 1)) >> 1);
+          double acc = 0;
+          for (int r = 0; r < Q.m; ++r) acc += sig[Q.row0 + r] * Gb[r * Q.n + a] * Gb[r * Q.n + c];
+          A[trs(sl[a], sl[c])] += acc;
+        } else {
+          const int a = i - npair;
+          double acc = 0;
+          for (int r = 0; r < Q.m; ++r) acc += Gb[r * Q.n + a] * wv[Q.row0 + r];
+          A[tri(F, sl[a])] -= acc;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- pivot columns -> panel; pivot block -> Bm ------------------------------------------
+    for (int i = tid; i < (F + 1) * PIV; i += KT) {
+      const int r = i / PIV, j = i - r * PIV;
+      Pn[r * PLD + j] = A[trs(r, ps[j])];
+    }
+    __syncthreads();
+    if (tid < PIV * PIV) {
+      const int i = tid / PIV, j = tid - i * PIV;
+      Bm[i * PLD + j] = Pn[ps[i] * PLD + j];
+    }
+    __syncthreads();
+    if (tid >= 256 && tid < 256 + PIV * PIV) {  // pivot rows leave the panel (not part of the border)
+      const int t = tid - 256, i = t / PIV, j = t - i * PIV;
+      Pn[ps[i] * PLD + j] = 0.0;
+    }
+    if (tid < 64) invert16(Bm, tid);
+    __syncthreads();
+    // ---- Wn = Pn * Binv -------------------------------------------------------------------------
+    for (int i = tid; i < (F + 1) * PIV; i += KT) {
+      const int r = i / PIV, j = i - r * PIV;
+      double acc = 0;
+#pragma unroll
+      for (int q = 0; q < PIV; ++q) acc += Pn[r * PLD + q] * Bm[q * PLD + j];
+      Wn[r * PLD + j] = acc;
+    }
+    __syncthreads();
+    // ---- Schur complement on the lower triangle: A[r][c] -= Wn[r][:] . Pn[c][:], c <= r <= F ---
+    {
+      const int nt4 = (F + 4) / 4;  // 4-row tiles covering rows 0..F
+      const int ntile = (nt4 * (nt4 + 1)) >> 1;
+      for (int t = tid; t < ntile; t += KT) {
+        int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while (((tr + 1) * (tr + 2)) >> 1 <= t) ++tr;
+        while ((tr * (tr + 1)) >> 1 > t) --tr;
+        const int tc = t - ((tr * (tr + 1)) >> 1);
+        const int r0 = tr * 4, c0 = tc * 4;
+        double acc[4][4] = {{0}};
+#pragma unroll
+        for (int q = 0; q < PIV; ++q) {
+          double wr[4], pc[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wr[i] = (r0 + i <= F) ? Wn[(r0 + i) * PLD + q] : 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pc[j] = (c0 + j <= F) ? Pn[(c0 + j) * PLD + q] : 0.0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] += wr[i] * pc[j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = r0 + i, c = c0 + j;
+            if (r <= F && c <= r && c < F) A[tri(r, c)] -= acc[i][j];
+          }
+      }
+    }
+    // ---- factor panel to HBM: C (F x 16), Binv (16 x 16), b1 (16) -----------------------------
+    {
+      double *pk = panel + (size_t)k * pstride;
+      for (int i = tid; i < F * PIV; i += KT) pk[i] = Pn[(i / PIV) * PLD + (i % PIV)];
+      if (tid < PIV * PIV) pk[F * PIV + tid] = Bm[(tid / PIV) * PLD + (tid % PIV)];
+      if (tid < PIV) pk[(F + PIV) * PIV + tid] = Pn[F * PLD + tid];
+    }
+    __syncthreads();
+    // ---- retire the pivots: their rows / columns are recycled by later unknowns ---------------
+    for (int i = tid; i < PIV * (F + 1); i += KT) {
+      const int j = i / (F + 1), r = i - j * (F + 1);
+      A[trs(r, ps[j])] = 0.0;
+    }
+    __syncthreads();
+  }
+  // ---- backward substitution: x1 = Binv (b1 - C^T x2) -------------------------------------------
+  for (int i = tid; i < F; i += KT) xs[i] = 0.0;
+  __syncthreads();
+  for (int k = P.n_stages - 1; k >= 0; --k) {
+    const double *pk = panel + (size_t)k * pstride;
+    // partial sums: thread (j, q) accumulates rows r = q, q+32, ... of column j
+    const int j = tid & (PIV - 1), q = tid >> 4;  // q in 0..31
+    double acc = 0;
+    for (int r = q; r < F; r += KT / PIV) acc += pk[r * PIV + j] * xs[r];
+    Wn[q * PLD + j] = acc;
+    if (tid < PIV * PIV) Bm[(tid / PIV) * PLD + (tid % PIV)] = pk[F * PIV + tid];
+    if (tid < PIV) ps[tid] = P.piv_slot[k * PIV + tid];
+    __syncthreads();
+    if (tid < PIV) {
+      double t = pk[(F + PIV) * PIV + tid];
+      for (int qq = 0; qq < KT / PIV; ++qq) t -= Wn[qq * PLD + tid];
+      Pn[tid] = t;
+    }
+    __syncthreads();
+    if (tid < PIV) {
+      double v = 0;
+      for (int i = 0; i < PIV; ++i) v += Bm[tid * PLD + i] * Pn[i];
+      xs[ps[tid]] = v;
+      const int u = P.piv_unknown[k * PIV + tid];
+      if (u >= 0 && u < n) dx[u] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int it) {
+  const int b = blockIdx.x;
+  if (b >= B || W.done[b]) return;
+  __shared__ double scratch[256];
+  const int n = P.n_vars, m = P.n_cons, tid = threadIdx.x;
+  double *x = W.x + (size_t)b * n, *xt = W.xt + (size_t)b * n, *dx = W.dx + (size_t)b * n;
+  double *g = W.g + (size_t)b * m, *gt = W.gt + (size_t)b * m;
+  double *s = W.s + (size_t)b * m, *zl = W.zl + (size_t)b * m, *zu = W.zu + (size_t)b * m;
+  double *ds = W.ds + (size_t)b * m, *dzl = W.dzl + (size_t)b * m, *dzu = W.dzu + (size_t)b * m;
+  const double *G = W.G + (size_t)b * P.g_doubles;
+  const int map = W.map_id ? W.map_id[b] : 0;
+  double mu = W.mu[b];
+  // ds = Ji dx + (g - s) through the inequality blocks
+  for (int bi = tid; bi < P.n_blocks; bi += blockDim.x) {
+    const Block blk = P.blocks[bi];
+    if (blk.kind != 1) continue;
+    const double *Gb = G + blk.goff;
+    for (int r = 0; r < blk.m; ++r) {
+      double acc = 0;
+      for (int a = 0; a < blk.n; ++a) acc += Gb[r * blk.n + a] * dx[P.block_cols[blk.col_off + a]];
+      const int row = blk.row0 + r;
+      ds[row] = acc + (g[row] - s[row]);
+    }
+  }
+  __syncthreads();
+  const double tau = fmax(0.99, 1.0 - mu);
+  double amax = 1.0, az = 1.0;
+  for (int r = tid; r < m; r += blockDim.x) {
+    if (P.row_kind[r] != 2) continue;
+    const double l = P.con_lo[r], u = P.con_hi[r];
+    const bool hl = l > -1e19, hu = u < 1e19;
+    const double dl = hl ? s[r] - l : 1.0, du = hu ? u - s[r] : 1.0;
+    const double d = ds[r];
+    const double a = hl ? mu / dl - zl[r] - zl[r] / dl * d : 0.0;
+    const double c = hu ? mu / du - zu[r] + zu[r] / du * d : 0.0;
+    dzl[r] = a;
+    dzu[r] = c;
+    if (hl && d < 0) amax = fmin(amax, tau * dl / -d);
+    if (hu && d > 0) amax = fmin(amax, tau * du / d);
+    if (hl && a < 0) az = fmin(az, tau * zl[r] / -a);
+    if (hu && c < 0) az = fmin(az, tau * zu[r] / -c);
+  }
+  amax = wg_reduce<2>(amax, scratch);
+  az = wg_reduce<2>(az, scratch);
+  const double th0 = l1_infeasibility(P, g, s, ds, 0.0, scratch);
+  // backtracking on the l1 infeasibility of (c_E, c_I - s)
+  double al = amax, th = 0;
+  for (int ls = 0; ls < 6; ++ls) {
+    for (int v = tid; v < n; v += blockDim.x) xt[v] = x[v] + al * dx[v];
+    __syncthreads();
+    eval_all<false>(P, map, xt, gt, nullptr);
+    __syncthreads();
+    th = l1_infeasibility(P, gt, s, ds, al, scratch);
+    if (th <= (1.0 - 1e-4 * al) * th0 || th < 1e-9) break;
+    if (ls < 5) al *= 0.5;
+  }
+  for (int v = tid; v < n; v += blockDim.x) x[v] = xt[v];
+  for (int r = tid; r < m; r += blockDim.x) {
+    g[r] = gt[r];
+    if (P.row_kind[r] != 2) continue;
+    const double l = P.con_lo[r], u = P.con_hi[r];
+    const bool hl = l > -1e19, hu = u < 1e19;
+    const double sn = s[r] + al * ds[r];
+    s[r] = sn;
+    double a = zl[r] + az * dzl[r], c = zu[r] + az * dzu[r];
+    const double kap = 1e10;
+    if (hl) a = fmin(fmax(a, mu / (kap * (sn - l))), kap * mu / (sn - l));
+    if (hu) c = fmin(fmax(c, mu / (kap * (u - sn))), kap * mu / (u - sn));
+    zl[r] = a;
+    zu[r] = c;
+  }
+  if (al > 0.3) mu = fmax(P.mu_min, 0.2 * mu);
+  __syncthreads();
+  double viol, theta;
+  infeasibility(P, g, s, scratch, viol, theta);
+  const bool conv = viol <= P.tol && theta <= P.tol;
+  const bool bad = !(viol == viol) || !(th == th);
+  if (tid == 0) {
+    W.mu[b] = mu;
+    W.viol[b] = viol;
+    W.iters[b] = it + 1;
+    record_trace(P, W, b, it + 1, viol, theta, al, mu);
+    if (conv || bad) {
+      W.status[b] = conv ? 0 : 2;
+      W.done[b] = 1;
+      atomicAdd(W.n_active, -1);
+    }
+  }
+  if (conv || bad) return;
+  __syncthreads();
+  eval_all<true>(P, map, x, g, W.G + (size_t)b * P.g_doubles);
+  barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m);
+}
+
+// =================================================================================================
+// CSV sampling: row layout of QTOS/utils.py:107-148.  Spline lookup tables are built on the host.
+struct SampleSpline {
+  int n_polys;
+  const double *tend;  // cumulative end time of each polynomial
+  const double *dur;
+  const int *idx;      // (n_polys+1) x 6
+};
+struct SamplePlan {
+  SampleSpline lin, ang, eem[NEE], eef[NEE];
+  int n_vars;
+  double T;
+};
+
+__device__ inline void sample_spline(const SampleSpline &S, const double *x, double t, int deriv, double out[3]) {
+  // first polynomial whose end time >= t - eps (towr spline.cc GetSegmentID)
+  int lo = 0, hi = S.n_polys - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (S.tend[mid] >= t - 1e-10) hi = mid; else lo = mid + 1;
+  }
+  const int k = lo;
+  const double T = S.dur[k], tau = t - (S.tend[k] - T);
+  double w[4];
+  const double T2 = T * T, T3 = T2 * T, t2 = tau * tau, t3 = t2 * tau;
+  if (deriv == 0) {
+    w[0] = 1 - 3 * t2 / T2 + 2 * t3 / T3; w[1] = tau - 2 * t2 / T + t3 / T2;
+    w[2] = 3 * t2 / T2 - 2 * t3 / T3; w[3] = -t2 / T + t3 / T2;
+  } else {
+    w[0] = -6 * tau / T2 + 6 * t2 / T3; w[1] = 1 - 4 * tau / T + 3 * t2 / T2;
+    w[2] = 6 * tau / T2 - 6 * t2 / T3; w[3] = -2 * tau / T + 3 * t2 / T2;
+  }
+  for (int d = 0; d < 3; ++d) {
+    double acc = 0;
+    for (int a = 0; a < 4; ++a) {
+      const int v = S.idx[(k + (a >> 1)) * 6 + (a & 1) * 3 + d];
+      if (v >= 0) acc += w[a] * x[v];
+    }
+    out[d] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sample(SamplePlan S, const double *nodes, const double *t0, double hz,
+                                                int n_rows, double *rows, int B) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B || k >= n_rows) return;
+  const double *x = nodes + (size_t)b * S.n_vars;
+  double t = k / hz;
+  if (t > S.T) t = S.T;
+  double row[QTOS_CSV_COLS];
+  row[0] = t0[b] + k / hz;
+  sample_spline(S.lin, x, t, 0, row + 1);
+  sample_spline(S.ang, x, t, 0, row + 4);
+  for (int e = 0; e < NEE; ++e) sample_spline(S.eem[e], x, t, 0, row + 7 + 3 * e);
+  sample_spline(S.lin, x, t, 1, row + 19);
+  sample_spline(S.ang, x, t, 1, row + 22);
+  for (int e = 0; e < NEE; ++e) sample_spline(S.eef[e], x, t, 0, row + 25 + 3 * e);
+  double *out = rows + ((size_t)b * n_rows + k) * QTOS_CSV_COLS;
+  for (int i = 0; i < QTOS_CSV_COLS; ++i) out[i] = row[i];
+}
+
+}  // namespace qtos

@@ -1,0 +1,532 @@
+// model.hpp -- host-side description of the planning NLP and the POD descriptors the device
+// kernels consume.
+//
+// The NLP is the one the reference hands to Ipopt (sets, sizes and order: logs/towr_log.out:99-129;
+// formulation: towr v1.4, of which the reference's solver is a fork -- Dockerfile:45).  Everything
+// time-dependent is resolved here, on the host, once per planner: every constraint instance is
+// reduced to "local inputs are fixed sparse linear combinations of node variables"
+// (cubic-Hermite weights at a fixed time), so the device code never walks a spline.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qtos_planner.h"
+
+namespace qtos {
+
+constexpr int NEE = QTOS_NEE;
+constexpr double BIG = 1e20;
+
+// ---- descriptors shared with the device ------------------------------------------------------
+// 3-vector input: value[d] = sum_a w[a] * x[var[3a+d]]  (var < 0 contributes 0);
+// a = (node k pos, node k vel, node k+1 pos, node k+1 vel) of the polynomial containing the time.
+struct VecIn {
+  double w[4];
+  int var[12];
+};
+
+struct DynInst {  // 6 rows: angular (3) then linear (3) momentum balance at one time
+  VecIn r, a, th, thd, thdd, p[NEE], f[NEE];
+  int row0, goff, ncol, in_kkt;
+  short c_lin[12], c_ang[12], c_p[NEE][12], c_f[NEE][12];  // block column of input slot, or -1
+};
+struct RomInst {  // 3 rows: R(th)^T (p - r) for one foot at one time
+  VecIn r, th, p;
+  int row0, goff, ncol, ee;
+  short c_lin[12], c_ang[12], c_p[12];
+};
+struct TerrInst {  // 1 row: z - h(x,y) at a foot node
+  int vx, vy, vz, row, goff, ncol, in_kkt;
+  short cx, cy, cz, pad;
+};
+struct ForceInst {  // 5 rows: normal force + friction pyramid at a force node
+  int vf[3], vsx, vsy, row0, goff, ncol;
+  short cf[3], csx, csy, pad;
+};
+struct LinRow {  // 1 row with constant coefficients (acceleration continuity, swing)
+  int row, n;
+  int var[8];
+  double coef[8];
+};
+// K2 assembly block: m consecutive constraint rows sharing one dense column list
+struct Block {
+  int kind;  // 0 equality, 1 inequality
+  int m, n, row0, goff, gstatic, col_off, pad;
+};
+// initial guess per variable (towr SetByLinearInterpolation): x = a + frac*(b-a) or (b-a)/T
+struct InitDesc {
+  int set;  // 0 base-lin, 1 base-ang, 2+e ee-motion, 6+e ee-force
+  int dim;
+  int is_vel;
+  int fix_src;  // -1 free; 0..23 start[k]; 24,25 goal x,y; 26 zero
+  double frac;
+};
+
+struct Spline {
+  int n_polys = 0;
+  std::vector<double> dur;
+  std::vector<std::array<int, 6>> idx;  // [node][q*3+d] -> variable or -1 (constant zero)
+
+  void locate(double t, int &k, double &tau) const {
+    // at junctions the previous polynomial is used (towr spline.cc GetSegmentID, eps 1e-10)
+    const double eps = 1e-10;
+    double acc = 0;
+    int id = n_polys - 1;
+    for (int i = 0; i < n_polys; ++i) {
+      acc += dur[i];
+      if (acc >= t - eps) { id = i; break; }
+    }
+    double tl = t;
+    for (int i = 0; i < id; ++i) tl -= dur[i];
+    k = id;
+    tau = tl;
+  }
+  double node_time(int node) const {
+    double t = 0;
+    for (int i = 0; i < node; ++i) t += dur[i];
+    return t;
+  }
+};
+
+inline void hermite_weights(double T, double t, int deriv, double w[4]) {
+  const double T2 = T * T, T3 = T2 * T, t2 = t * t, t3 = t2 * t;
+  if (deriv == 0) {
+    w[0] = 1 - 3 * t2 / T2 + 2 * t3 / T3;
+    w[1] = t - 2 * t2 / T + t3 / T2;
+    w[2] = 3 * t2 / T2 - 2 * t3 / T3;
+    w[3] = -t2 / T + t3 / T2;
+  } else if (deriv == 1) {
+    w[0] = -6 * t / T2 + 6 * t2 / T3;
+    w[1] = 1 - 4 * t / T + 3 * t2 / T2;
+    w[2] = 6 * t / T2 - 6 * t2 / T3;
+    w[3] = -2 * t / T + 3 * t2 / T2;
+  } else {
+    w[0] = -6 / T2 + 12 * t / T3;
+    w[1] = -4 / T + 6 * t / T2;
+    w[2] = 6 / T2 - 12 * t / T3;
+    w[3] = -2 / T + 6 * t / T2;
+  }
+}
+
+inline VecIn make_in_poly(const Spline &S, int k, double tau, int deriv) {
+  VecIn v;
+  hermite_weights(S.dur[k], tau, deriv, v.w);
+  for (int a = 0; a < 4; ++a)
+    for (int d = 0; d < 3; ++d) v.var[3 * a + d] = S.idx[k + (a >> 1)][(a & 1) * 3 + d];
+  return v;
+}
+inline VecIn make_in(const Spline &S, double t, int deriv) {
+  int k;
+  double tau;
+  S.locate(t, k, tau);
+  return make_in_poly(S, k, tau, deriv);
+}
+
+struct HostModel {
+  QtosParams P;
+  double T = 0;
+  int n_vars = 0, n_cons = 0, n_base_nodes = 0;
+  Spline lin, ang, eem[NEE], eef[NEE];
+  int off_lin = 0, off_ang = 0, off_eem[NEE], off_eef[NEE];
+  int off_terrain[NEE], off_dyn = 0, off_acc_lin = 0, off_acc_ang = 0, off_rom[NEE],
+      off_force[NEE], off_swing[NEE];
+  std::vector<double> t_dyn, t_rom;
+  std::vector<double> var_time, con_time, con_lo, con_hi;
+  std::vector<int> row_kind;  // 0 dropped from the working set, 1 equality, 2 inequality
+  std::vector<InitDesc> init;
+  // instances
+  std::vector<DynInst> dyn;
+  std::vector<RomInst> rom;
+  std::vector<TerrInst> terr;
+  std::vector<ForceInst> force;
+  std::vector<LinRow> linrow;
+  // assembly blocks (+ shared column list, static G for constant-coefficient rows)
+  std::vector<Block> blocks;
+  std::vector<int> block_cols;
+  std::vector<double> g_static;
+  long long g_doubles = 0;
+  std::string err;
+
+  bool is_free(int v) const { return init[v].fix_src < 0; }
+
+  static std::vector<double> time_grid(double T, double dt) {
+    // towr time_discretization_constraint.cc: 0, dt, ..., floor(T/dt)*dt (accumulated), T
+    std::vector<double> out;
+    double t = 0;
+    out.push_back(t);
+    int steps = (int)std::floor(T / dt);
+    for (int i = 0; i < steps; ++i) {
+      t += dt;
+      out.push_back(t);
+    }
+    out.push_back(T);
+    return out;
+  }
+
+  // column list helper: assigns block columns to the free variables of an input group
+  struct ColBuilder {
+    std::vector<int> cols;
+    const HostModel *M;
+    short add(int var) {
+      if (var < 0 || !M->is_free(var)) return -1;
+      for (size_t i = 0; i < cols.size(); ++i)
+        if (cols[i] == var) return (short)i;
+      cols.push_back(var);
+      return (short)(cols.size() - 1);
+    }
+    void group(const VecIn &in, short out[12]) {
+      for (int i = 0; i < 12; ++i) out[i] = add(in.var[i]);
+    }
+  };
+
+  // returns the block id; dynamic G offsets are assigned later, in stage order (Symbolic::build)
+  int add_block(int kind, int m, int row0, const std::vector<int> &cols, bool gstatic,
+                const double *gvals) {
+    Block b;
+    std::memset(&b, 0, sizeof(b));
+    b.kind = kind;
+    b.m = m;
+    b.n = (int)cols.size();
+    b.row0 = row0;
+    b.col_off = (int)block_cols.size();
+    b.gstatic = gstatic ? 1 : 0;
+    b.goff = -1;
+    if (gstatic) {
+      b.goff = (int)g_static.size();
+      g_static.insert(g_static.end(), gvals, gvals + (size_t)m * cols.size());
+    }
+    block_cols.insert(block_cols.end(), cols.begin(), cols.end());
+    blocks.push_back(b);
+    return (int)blocks.size() - 1;
+  }
+  // instances hold a block id in .goff until the offsets are final
+  void finalize_goff() {
+    auto fix = [&](int &goff) { if (goff >= 0) goff = blocks[goff].goff; };
+    for (auto &i : dyn) fix(i.goff);
+    for (auto &i : rom) fix(i.goff);
+    for (auto &i : terr) fix(i.goff);
+    for (auto &i : force) fix(i.goff);
+  }
+
+  int build(const QtosParams &params) {
+    P = params;
+    T = 0;
+    for (int k = 0; k < P.n_phases[0]; ++k) T += P.phase_dur[0][k];
+    if (!(T > 0) || !(P.dt_base > 0) || !(P.dt_dyn > 0) || !(P.dt_rom > 0) ||
+        P.force_polys_per_stance < 1) {
+      err = "bad durations";
+      return -1;
+    }
+    for (int e = 0; e < NEE; ++e) {
+      int n = P.n_phases[e];
+      if (n < 1 || n > QTOS_MAX_PHASES || n % 2 == 0) { err = "n_phases must be odd, <= 16"; return -1; }
+      double s = 0;
+      for (int k = 0; k < n; ++k) s += P.phase_dur[e][k];
+      if (std::fabs(s - T) > 1e-6) { err = "phase durations of all feet must sum to T"; return -1; }
+    }
+    // ---- base splines (towr parameters.cc GetBasePolyDurations) ----
+    {
+      double t_left = T;
+      const double eps = 1e-10;
+      while (t_left > eps) {
+        lin.dur.push_back(t_left > P.dt_base ? P.dt_base : t_left);
+        t_left -= P.dt_base;
+      }
+      lin.n_polys = (int)lin.dur.size();
+      ang = lin;
+    }
+    const int nb = lin.n_polys;
+    n_base_nodes = nb + 1;
+    off_lin = 0;
+    off_ang = 6 * (nb + 1);
+    lin.idx.resize(nb + 1);
+    ang.idx.resize(nb + 1);
+    for (int k = 0; k <= nb; ++k)
+      for (int q = 0; q < 2; ++q)
+        for (int d = 0; d < 3; ++d) {
+          lin.idx[k][q * 3 + d] = off_lin + 6 * k + 3 * q + d;
+          ang.idx[k][q * 3 + d] = off_ang + 6 * k + 3 * q + d;
+        }
+    int off = 12 * (nb + 1);
+    // ---- foot motion: stance = one constant polynomial, swing = two polynomials, free mid node
+    //      with (px, vx, py, vy, pz); towr NodesVariablesEEMotion ----
+    std::vector<int> stance_var[NEE];
+    for (int e = 0; e < NEE; ++e) {
+      Spline &S = eem[e];
+      off_eem[e] = off;
+      int v = off;
+      std::array<int, 6> none;
+      none.fill(-1);
+      S.idx.push_back(none);
+      for (int ph = 0; ph < P.n_phases[e]; ++ph) {
+        double d = P.phase_dur[e][ph];
+        if (ph % 2 == 0) {
+          std::array<int, 6> nd = none;
+          for (int dd = 0; dd < 3; ++dd) nd[dd] = v + dd;
+          S.idx.back() = nd;
+          S.idx.push_back(nd);
+          S.dur.push_back(d);
+          stance_var[e].push_back(v);
+          v += 3;
+        } else {
+          std::array<int, 6> mid = none;
+          mid[0] = v + 0; mid[3] = v + 1; mid[1] = v + 2; mid[4] = v + 3; mid[2] = v + 4;
+          S.idx.push_back(mid);
+          S.idx.push_back(none);  // start of the next stance, filled by that stance
+          S.dur.push_back(d / 2);
+          S.dur.push_back(d / 2);
+          v += 5;
+        }
+      }
+      S.n_polys = (int)S.dur.size();
+      off = v;
+    }
+    // ---- foot force: stance = force_polys polynomials, swing = zero; nodes touching a swing
+    //      polynomial are constant zero; towr NodesVariablesEEForce ----
+    std::vector<int> fnode[NEE], fnode_stance[NEE];
+    for (int e = 0; e < NEE; ++e) {
+      Spline &S = eef[e];
+      off_eef[e] = off;
+      std::vector<int> swing_poly, stance_of;
+      for (int ph = 0; ph < P.n_phases[e]; ++ph) {
+        double d = P.phase_dur[e][ph];
+        if (ph % 2 == 0)
+          for (int j = 0; j < P.force_polys_per_stance; ++j) {
+            S.dur.push_back(d / P.force_polys_per_stance);
+            swing_poly.push_back(0);
+            stance_of.push_back(ph / 2);
+          }
+        else {
+          S.dur.push_back(d);
+          swing_poly.push_back(1);
+          stance_of.push_back(-1);
+        }
+      }
+      S.n_polys = (int)S.dur.size();
+      int v = off;
+      for (int node = 0; node <= S.n_polys; ++node) {
+        bool constant = (node > 0 && swing_poly[node - 1]) || (node < S.n_polys && swing_poly[node]);
+        std::array<int, 6> nd;
+        nd.fill(-1);
+        if (!constant) {
+          for (int dd = 0; dd < 3; ++dd) { nd[dd] = v + 2 * dd; nd[3 + dd] = v + 2 * dd + 1; }
+          fnode[e].push_back(node);
+          fnode_stance[e].push_back(node < S.n_polys ? stance_of[node] : stance_of[node - 1]);
+          v += 6;
+        }
+        S.idx.push_back(nd);
+      }
+      off = v;
+    }
+    n_vars = off;
+
+    // ---- variable bookkeeping: node time (the later node sharing a variable wins), initial
+    //      guess rule, fixed variables (towr nlp_formulation.cc Add*Bound; parameters.cc
+    //      bounds_final_*: final lin pos {X,Y}, final lin vel / ang pos / ang vel {X,Y,Z}) ----
+    var_time.assign(n_vars, 0.0);
+    init.assign(n_vars, InitDesc{0, 0, 0, -1, 0.0});
+    auto book = [&](const Spline &S, int set) {
+      for (int node = 0; node <= S.n_polys; ++node) {
+        double t = S.node_time(node);
+        for (int q = 0; q < 2; ++q)
+          for (int d = 0; d < 3; ++d) {
+            int v = S.idx[node][q * 3 + d];
+            if (v < 0) continue;
+            var_time[v] = t;
+            init[v].set = set;
+            init[v].dim = d;
+            init[v].is_vel = q;
+            init[v].frac = (double)node / (double)S.n_polys;
+          }
+      }
+    };
+    book(lin, 0);
+    book(ang, 1);
+    for (int e = 0; e < NEE; ++e) book(eem[e], 2 + e);
+    for (int e = 0; e < NEE; ++e) book(eef[e], 6 + e);
+    for (int d = 0; d < 3; ++d) {
+      init[off_lin + d].fix_src = d;                                   // start CoM
+      init[off_lin + 3 + d].fix_src = P.honor_start_velocity ? 18 + d : 26;
+      init[off_ang + d].fix_src = 3 + d;                               // start Euler
+      init[off_ang + 3 + d].fix_src = P.honor_start_velocity ? 21 + d : 26;
+      if (d < 2) init[off_lin + 6 * nb + d].fix_src = 24 + d;          // goal x, y
+      init[off_lin + 6 * nb + 3 + d].fix_src = 26;
+      init[off_ang + 6 * nb + d].fix_src = 26;
+      init[off_ang + 6 * nb + 3 + d].fix_src = 26;
+      for (int e = 0; e < NEE; ++e) init[off_eem[e] + d].fix_src = 6 + 3 * e + d;  // start feet
+    }
+
+    // ---- constraint layout (logs/towr_log.out:112-129) ----
+    t_dyn = time_grid(T, P.dt_dyn);
+    t_rom = time_grid(T, P.dt_rom);
+    int c = 0;
+    for (int e = 0; e < NEE; ++e) { off_terrain[e] = c; c += eem[e].n_polys; }
+    off_dyn = c; c += 6 * (int)t_dyn.size();
+    off_acc_lin = c; c += 3 * (nb - 1);
+    off_acc_ang = c; c += 3 * (nb - 1);
+    for (int e = 0; e < NEE; ++e) { off_rom[e] = c; c += 3 * (int)t_rom.size(); }
+    for (int e = 0; e < NEE; ++e) { off_force[e] = c; c += 5 * (int)fnode[e].size(); }
+    for (int e = 0; e < NEE; ++e) { off_swing[e] = c; c += 4 * (P.n_phases[e] - 1) / 2; }
+    n_cons = c;
+    con_lo.assign(n_cons, 0.0);
+    con_hi.assign(n_cons, 0.0);
+    con_time.assign(n_cons, 0.0);
+    row_kind.assign(n_cons, 1);
+
+    // ---- terrain rows: nodes 1..N of each foot; stance rows are equalities, swing rows z >= h.
+    //      Working set: the row of the fixed first stance is constant and the second node of a
+    //      stance repeats the first, so one row per later stance is kept. ----
+    for (int e = 0; e < NEE; ++e) {
+      const Spline &S = eem[e];
+      for (int node = 1; node <= S.n_polys; ++node) {
+        int row = off_terrain[e] + node - 1;
+        bool swing = S.idx[node][3] >= 0;
+        con_time[row] = S.node_time(node);
+        TerrInst ti;
+        std::memset(&ti, 0, sizeof(ti));
+        ti.vx = S.idx[node][0]; ti.vy = S.idx[node][1]; ti.vz = S.idx[node][2];
+        ti.row = row;
+        ColBuilder cb{{}, this};
+        ti.cx = cb.add(ti.vx); ti.cy = cb.add(ti.vy); ti.cz = cb.add(ti.vz);
+        ti.ncol = (int)cb.cols.size();
+        bool dup = !swing && node >= 1 && S.idx[node - 1][0] == ti.vx;  // second node of a stance
+        if (swing) { con_hi[row] = BIG; row_kind[row] = 2; }
+        if (ti.ncol == 0 || dup) row_kind[row] = 0;
+        ti.in_kkt = row_kind[row] != 0;
+        ti.goff = -1;
+        if (ti.in_kkt) ti.goff = add_block(swing ? 1 : 0, 1, row, cb.cols, false, nullptr);
+        terr.push_back(ti);
+      }
+    }
+    // ---- dynamics ----
+    for (size_t k = 0; k < t_dyn.size(); ++k) {
+      double t = t_dyn[k];
+      DynInst di;
+      std::memset(&di, 0, sizeof(di));
+      di.r = make_in(lin, t, 0); di.a = make_in(lin, t, 2);
+      di.th = make_in(ang, t, 0); di.thd = make_in(ang, t, 1); di.thdd = make_in(ang, t, 2);
+      for (int e = 0; e < NEE; ++e) { di.p[e] = make_in(eem[e], t, 0); di.f[e] = make_in(eef[e], t, 0); }
+      di.row0 = off_dyn + 6 * (int)k;
+      ColBuilder cb{{}, this};
+      cb.group(di.r, di.c_lin);
+      cb.group(di.th, di.c_ang);
+      for (int e = 0; e < NEE; ++e) { cb.group(di.p[e], di.c_p[e]); cb.group(di.f[e], di.c_f[e]); }
+      di.ncol = (int)cb.cols.size();
+      // the grid repeats T when floor(T/dt)*dt == T: the repeated block is the same six equations
+      bool dup = k > 0 && std::fabs(t - t_dyn[k - 1]) < 1e-9;
+      di.in_kkt = !dup;
+      for (int i = 0; i < 6; ++i) {
+        con_time[di.row0 + i] = t;
+        if (dup) row_kind[di.row0 + i] = 0;
+      }
+      di.goff = -1;
+      if (di.in_kkt) di.goff = add_block(0, 6, di.row0, cb.cols, false, nullptr);
+      dyn.push_back(di);
+    }
+    // ---- acceleration continuity at the interior junctions (constant coefficients) ----
+    for (int which = 0; which < 2; ++which) {
+      const Spline &S = which ? ang : lin;
+      int r0 = which ? off_acc_ang : off_acc_lin;
+      for (int j = 0; j + 1 < nb; ++j) {
+        VecIn prev = make_in_poly(S, j, S.dur[j], 2), next = make_in_poly(S, j + 1, 0.0, 2);
+        for (int d = 0; d < 3; ++d) {
+          LinRow lr;
+          std::memset(&lr, 0, sizeof(lr));
+          lr.row = r0 + 3 * j + d;
+          auto addterm = [&](int var, double cf) {
+            if (var < 0 || cf == 0.0) return;
+            for (int i = 0; i < lr.n; ++i)
+              if (lr.var[i] == var) { lr.coef[i] += cf; return; }
+            lr.var[lr.n] = var; lr.coef[lr.n] = cf; lr.n++;
+          };
+          for (int a = 0; a < 4; ++a) { addterm(prev.var[3 * a + d], prev.w[a]); addterm(next.var[3 * a + d], -next.w[a]); }
+          con_time[lr.row] = S.node_time(j + 1);
+          linrow.push_back(lr);
+        }
+      }
+    }
+    // ---- range of motion ----
+    for (int e = 0; e < NEE; ++e)
+      for (size_t k = 0; k < t_rom.size(); ++k) {
+        double t = t_rom[k];
+        RomInst ri;
+        std::memset(&ri, 0, sizeof(ri));
+        ri.r = make_in(lin, t, 0); ri.th = make_in(ang, t, 0); ri.p = make_in(eem[e], t, 0);
+        ri.ee = e;
+        ri.row0 = off_rom[e] + 3 * (int)k;
+        ColBuilder cb{{}, this};
+        cb.group(ri.r, ri.c_lin); cb.group(ri.th, ri.c_ang); cb.group(ri.p, ri.c_p);
+        ri.ncol = (int)cb.cols.size();
+        for (int d = 0; d < 3; ++d) {
+          con_lo[ri.row0 + d] = P.nominal_stance[e][d] - P.max_dev[d];
+          con_hi[ri.row0 + d] = P.nominal_stance[e][d] + P.max_dev[d];
+          con_time[ri.row0 + d] = t;
+          row_kind[ri.row0 + d] = 2;
+        }
+        ri.goff = add_block(1, 3, ri.row0, cb.cols, false, nullptr);
+        rom.push_back(ri);
+      }
+    // ---- force: unilateral + friction pyramid at every optimised force node ----
+    for (int e = 0; e < NEE; ++e)
+      for (size_t j = 0; j < fnode[e].size(); ++j) {
+        int node = fnode[e][j], sv = stance_var[e][fnode_stance[e][j]];
+        ForceInst fi;
+        std::memset(&fi, 0, sizeof(fi));
+        for (int d = 0; d < 3; ++d) fi.vf[d] = eef[e].idx[node][d];
+        fi.vsx = sv; fi.vsy = sv + 1;
+        fi.row0 = off_force[e] + 5 * (int)j;
+        ColBuilder cb{{}, this};
+        for (int d = 0; d < 3; ++d) fi.cf[d] = cb.add(fi.vf[d]);
+        fi.csx = cb.add(fi.vsx); fi.csy = cb.add(fi.vsy);
+        fi.ncol = (int)cb.cols.size();
+        double tt = eef[e].node_time(node);
+        for (int r = 0; r < 5; ++r) { con_time[fi.row0 + r] = tt; row_kind[fi.row0 + r] = 2; }
+        con_lo[fi.row0] = 0; con_hi[fi.row0] = P.f_max;
+        con_lo[fi.row0 + 1] = -BIG; con_hi[fi.row0 + 1] = 0;
+        con_lo[fi.row0 + 2] = 0; con_hi[fi.row0 + 2] = BIG;
+        con_lo[fi.row0 + 3] = -BIG; con_hi[fi.row0 + 3] = 0;
+        con_lo[fi.row0 + 4] = 0; con_hi[fi.row0 + 4] = BIG;
+        fi.goff = add_block(1, 5, fi.row0, cb.cols, false, nullptr);
+        force.push_back(fi);
+      }
+    // ---- swing: mid node xy = centre of the neighbouring stances, v_xy = distance / t_swing_avg
+    for (int e = 0; e < NEE; ++e) {
+      const Spline &S = eem[e];
+      int row = off_swing[e];
+      for (int node = 1; node < S.n_polys; ++node) {
+        if (S.idx[node][3] < 0) continue;
+        for (int d = 0; d < 2; ++d) {
+          int ip = S.idx[node - 1][d], in = S.idx[node + 1][d], ic = S.idx[node][d], iv = S.idx[node][3 + d];
+          LinRow a, b;
+          std::memset(&a, 0, sizeof(a));
+          std::memset(&b, 0, sizeof(b));
+          a.row = row; a.n = 3;
+          a.var[0] = ic; a.coef[0] = 1; a.var[1] = ip; a.coef[1] = -0.5; a.var[2] = in; a.coef[2] = -0.5;
+          b.row = row + 1; b.n = 3;
+          b.var[0] = iv; b.coef[0] = 1; b.var[1] = ip; b.coef[1] = 1 / P.t_swing_avg; b.var[2] = in; b.coef[2] = -1 / P.t_swing_avg;
+          con_time[row] = con_time[row + 1] = S.node_time(node);
+          linrow.push_back(a);
+          linrow.push_back(b);
+          row += 2;
+        }
+      }
+    }
+    // constant-coefficient rows become equality blocks with a shared (static) G
+    for (const LinRow &lr : linrow) {
+      std::vector<int> cols;
+      std::vector<double> vals;
+      for (int i = 0; i < lr.n; ++i)
+        if (is_free(lr.var[i])) { cols.push_back(lr.var[i]); vals.push_back(lr.coef[i]); }
+      if (cols.empty()) { row_kind[lr.row] = 0; continue; }
+      add_block(0, 1, lr.row, cols, true, vals.data());
+    }
+    return 0;
+  }
+};
+
+}  // namespace qtos

@@ -1,0 +1,421 @@
+// qtos_planner.hip -- C ABI (include/qtos_planner.h) over the gfx950 kernels in kernels.hpp.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared qtos_planner.hip -o libqtos_planner.so
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace qtos;
+
+#define HIPCHK(p, call)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (p)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+      return e_ == hipErrorOutOfMemory ? -3 : -2;                                             \
+    }                                                                                         \
+  } while (0)
+
+struct QtosPlanner {
+  HostModel M;
+  Symbolic S;
+  DevPlan dp;
+  SamplePlan sp;
+  int device = 0, max_batch = 0;
+  std::vector<void *> allocs;  // everything to free
+  // workspace
+  DevWork wk;
+  double *d_start = nullptr, *d_goal = nullptr, *d_nodes = nullptr, *d_warm = nullptr;
+  int *d_map = nullptr;
+  double *d_height = nullptr;
+  int *h_active = nullptr;  // pinned
+  std::vector<hipEvent_t> ev;  // 2 per iteration (kkt begin/end) + 2 (total)
+  int last_launches = 0, last_iters = 0;
+  size_t kkt_lds = 0;
+  std::string err;
+
+  template <class T>
+  int upload(const std::vector<T> &v, const T **out) {
+    T *d = nullptr;
+    size_t bytes = std::max<size_t>(1, v.size()) * sizeof(T);
+    HIPCHK(this, hipMalloc((void **)&d, bytes));
+    allocs.push_back(d);
+    if (!v.empty()) HIPCHK(this, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = d;
+    return 0;
+  }
+  template <class T>
+  int alloc(T **out, size_t count) {
+    T *d = nullptr;
+    HIPCHK(this, hipMalloc((void **)&d, std::max<size_t>(1, count) * sizeof(T)));
+    HIPCHK(this, hipMemset(d, 0, std::max<size_t>(1, count) * sizeof(T)));
+    allocs.push_back(d);
+    *out = d;
+    return 0;
+  }
+};
+
+static int upload_spline(QtosPlanner *p, const Spline &S, SampleSpline *out) {
+  std::vector<double> tend(S.n_polys), dur(S.dur);
+  double t = 0;
+  for (int i = 0; i < S.n_polys; ++i) { t += S.dur[i]; tend[i] = t; }
+  std::vector<int> idx;
+  for (auto &nd : S.idx)
+    for (int i = 0; i < 6; ++i) idx.push_back(nd[i]);
+  out->n_polys = S.n_polys;
+  int rc;
+  if ((rc = p->upload(tend, &out->tend))) return rc;
+  if ((rc = p->upload(dur, &out->dur))) return rc;
+  if ((rc = p->upload(idx, &out->idx))) return rc;
+  return 0;
+}
+
+extern "C" {
+
+const char *qtos_last_error(const QtosPlanner *p) { return p ? p->err.c_str() : "null planner"; }
+
+void qtos_planner_destroy(QtosPlanner *p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  for (void *a : p->allocs) (void)hipFree(a);
+  for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+  if (p->h_active) (void)hipHostFree(p->h_active);
+  delete p;
+}
+
+int qtos_planner_create(const QtosParams *params, int max_batch, int device, QtosPlanner **out) {
+  if (!params || !out || max_batch < 1) return -1;
+  *out = nullptr;
+  QtosPlanner *p = new QtosPlanner();
+  p->device = device;
+  p->max_batch = max_batch;
+  if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
+  if (p->S.build(p->M)) { delete p; return -1; }
+  const HostModel &M = p->M;
+  const Symbolic &S = p->S;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) {
+    fprintf(stderr, "qtos: no HIP device %d (found %d) -- the planner has no CPU fallback\n", device, ndev);
+    delete p;
+    return -2;
+  }
+  int rc = 0;
+#define TRY(x) do { if ((rc = (x))) { fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return rc; } } while (0)
+  {
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { delete p; return -2; }
+  }
+  DevPlan &D = p->dp;
+  std::memset(&D, 0, sizeof(D));
+  D.n_vars = M.n_vars; D.n_cons = M.n_cons; D.n_stages = S.n_stages; D.front = S.front;
+  D.n_dyn = (int)M.dyn.size(); D.n_rom = (int)M.rom.size(); D.n_terr = (int)M.terr.size();
+  D.n_force = (int)M.force.size(); D.n_lin = (int)M.linrow.size(); D.n_blocks = (int)M.blocks.size();
+  TRY(p->upload(M.dyn, &D.dyn)); TRY(p->upload(M.rom, &D.rom)); TRY(p->upload(M.terr, &D.terr));
+  TRY(p->upload(M.force, &D.force)); TRY(p->upload(M.linrow, &D.lin));
+  TRY(p->upload(M.blocks, &D.blocks)); TRY(p->upload(M.block_cols, &D.block_cols));
+  TRY(p->upload(M.g_static, &D.g_static));
+  TRY(p->upload(S.piv_slot, &D.piv_slot)); TRY(p->upload(S.piv_unknown, &D.piv_unknown));
+  TRY(p->upload(S.piv_diag, &D.piv_diag)); TRY(p->upload(S.stages, &D.stages));
+  TRY(p->upload(S.eq_entries, &D.eq_entries)); TRY(p->upload(S.eq_rhs, &D.eq_rhs));
+  TRY(p->upload(S.iq_blocks, &D.iq_blocks)); TRY(p->upload(S.iq_slots, &D.iq_slots));
+  TRY(p->upload(M.con_lo, &D.con_lo)); TRY(p->upload(M.con_hi, &D.con_hi));
+  TRY(p->upload(M.row_kind, &D.row_kind)); TRY(p->upload(M.init, &D.init));
+  D.max_stage_g = S.max_stage_g;
+  D.mass = M.P.mass; D.gravity = M.P.gravity; D.mu_fric = M.P.mu; D.f_max = M.P.f_max; D.T = M.T;
+  for (int i = 0; i < 9; ++i) D.Ib[i] = M.P.inertia_b[i];
+  for (int e = 0; e < NEE; ++e)
+    for (int d = 0; d < 3; ++d) D.nominal[e][d] = M.P.nominal_stance[e][d];
+  D.tol = M.P.tol; D.mu_init = M.P.mu_init; D.mu_min = M.P.mu_min; D.delta_x = M.P.delta_x;
+  D.eps_dual = M.P.eps_dual; D.max_iter = M.P.max_iter;
+  D.g_doubles = S.g_doubles;
+  D.panel_stride = (long long)S.n_stages * (S.front + PIV + 1) * PIV;
+  // LDS budget of k_kkt
+  const int F = S.front;
+  size_t lds_d = (size_t)((F + 1) * (F + 2) / 2) + 2 * (size_t)(F + 1) * PLD + PIV * PLD + F + S.max_stage_g + 8;
+  p->kkt_lds = lds_d * sizeof(double);
+  if (p->kkt_lds > 160 * 1024 - 256) {
+    p->err = "front too large for LDS";
+    fprintf(stderr, "qtos: front %d needs %zu B of LDS\n", F, p->kkt_lds);
+    qtos_planner_destroy(p);
+    return -4;
+  }
+  {
+    hipError_t e = hipFuncSetAttribute((const void *)k_kkt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
+    if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
+  }
+  // sampling tables
+  SamplePlan &SP = p->sp;
+  std::memset(&SP, 0, sizeof(SP));
+  SP.n_vars = M.n_vars; SP.T = M.T;
+  TRY(upload_spline(p, M.lin, &SP.lin)); TRY(upload_spline(p, M.ang, &SP.ang));
+  for (int e = 0; e < NEE; ++e) { TRY(upload_spline(p, M.eem[e], &SP.eem[e])); TRY(upload_spline(p, M.eef[e], &SP.eef[e])); }
+  // workspaces
+  DevWork &W = p->wk;
+  std::memset(&W, 0, sizeof(W));
+  const size_t Bm = (size_t)max_batch, n = M.n_vars, m = M.n_cons;
+  TRY(p->alloc(&W.x, Bm * n)); TRY(p->alloc(&W.xt, Bm * n)); TRY(p->alloc(&W.dx, Bm * n));
+  TRY(p->alloc(&W.g, Bm * m)); TRY(p->alloc(&W.gt, Bm * m)); TRY(p->alloc(&W.s, Bm * m));
+  TRY(p->alloc(&W.zl, Bm * m)); TRY(p->alloc(&W.zu, Bm * m)); TRY(p->alloc(&W.ds, Bm * m));
+  TRY(p->alloc(&W.dzl, Bm * m)); TRY(p->alloc(&W.dzu, Bm * m)); TRY(p->alloc(&W.sig, Bm * m));
+  TRY(p->alloc(&W.w, Bm * m)); TRY(p->alloc(&W.G, Bm * (size_t)S.g_doubles));
+  TRY(p->alloc(&W.panel, Bm * (size_t)D.panel_stride));
+  TRY(p->alloc(&W.mu, Bm)); TRY(p->alloc(&W.viol, Bm));
+  TRY(p->alloc(&W.trace, Bm * (size_t)(M.P.max_iter + 1) * 4));
+  TRY(p->alloc(&W.status, Bm)); TRY(p->alloc(&W.iters, Bm)); TRY(p->alloc(&W.done, Bm));
+  TRY(p->alloc(&W.n_active, 1));
+  TRY(p->alloc(&p->d_start, Bm * QTOS_START_DOUBLES)); TRY(p->alloc(&p->d_goal, Bm * 3));
+  TRY(p->alloc(&p->d_nodes, Bm * n)); TRY(p->alloc(&p->d_warm, Bm * n)); TRY(p->alloc(&p->d_map, Bm));
+  if (hipHostMalloc((void **)&p->h_active, sizeof(int)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
+  p->ev.resize(2 * (size_t)M.P.max_iter + 2);
+  for (auto &e : p->ev)
+    if (hipEventCreate(&e) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+#undef TRY
+  *out = p;
+  return 0;
+}
+
+int qtos_planner_dims(const QtosPlanner *p, QtosDims *d) {
+  if (!p || !d) return -1;
+  const HostModel &M = p->M;
+  const Symbolic &S = p->S;
+  std::memset(d, 0, sizeof(*d));
+  d->n_vars = M.n_vars; d->n_cons = M.n_cons; d->n_free = S.n_free;
+  for (int r = 0; r < M.n_cons; ++r) {
+    const bool eq = M.con_lo[r] == M.con_hi[r];
+    if (eq) d->n_eq++;
+    else {
+      d->n_ineq++;
+      const bool hl = M.con_lo[r] > -1e19, hu = M.con_hi[r] < 1e19;
+      if (hl && hu) d->n_ineq_both++;
+      else if (hl) d->n_ineq_lower++;
+      else d->n_ineq_upper++;
+    }
+  }
+  d->n_eq_work = S.n_eq; d->n_unknowns = S.n_unknowns; d->n_stages = S.n_stages;
+  d->pivots = PIV; d->front = S.front;
+  d->n_base_nodes = M.n_base_nodes; d->n_dyn_times = (int)M.t_dyn.size(); d->n_rom_times = (int)M.t_rom.size();
+  d->n_rows_csv = (int)std::llround(M.T * 1000.0) + 1;
+  d->panel_doubles = p->dp.panel_stride; d->g_doubles = S.g_doubles;
+  d->kkt_algorithmic_bytes = S.algorithmic_bytes; d->kkt_flops = S.flops;
+  d->envelope = S.envelope; d->max_active = S.max_active;
+  d->duration = M.T;
+  return 0;
+}
+
+int qtos_set_heightfields(QtosPlanner *p, int n_maps, const double *height, int hnx, int hny,
+                          double cell, double x0, double y0) {
+  if (!p) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  if (p->d_height) {
+    (void)hipFree(p->d_height);
+    p->d_height = nullptr;
+  }
+  p->dp.height = nullptr;
+  p->dp.n_maps = 0;
+  if (n_maps <= 0 || !height) return 0;
+  if (hnx < 1 || hny < 1 || !(cell > 0)) return -1;
+  const size_t cnt = (size_t)n_maps * hnx * hny;
+  HIPCHK(p, hipMalloc((void **)&p->d_height, cnt * sizeof(double)));
+  HIPCHK(p, hipMemcpy(p->d_height, height, cnt * sizeof(double), hipMemcpyHostToDevice));
+  p->dp.height = p->d_height;
+  p->dp.n_maps = n_maps; p->dp.hnx = hnx; p->dp.hny = hny;
+  p->dp.hcell = cell; p->dp.hx0 = x0; p->dp.hy0 = y0;
+  return 0;
+}
+
+int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
+                           const int *d_map_id, const double *d_warm, double *d_nodes_out,
+                           int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream_) {
+  if (!p || B < 1 || B > p->max_batch || !d_start || !d_goal || !d_nodes_out) return -1;
+  hipStream_t st = (hipStream_t)stream_;
+  HIPCHK(p, hipSetDevice(p->device));
+  DevWork W = p->wk;
+  W.start = d_start; W.goal = d_goal; W.map_id = d_map_id; W.warm = d_warm;
+  const DevPlan &D = p->dp;
+  HIPCHK(p, hipMemsetAsync(W.n_active, 0, sizeof(int), st));
+  HIPCHK(p, hipEventRecord(p->ev[0], st));
+  hipLaunchKernelGGL(k_start, dim3(B), dim3(256), 0, st, D, W, B);
+  int launches = 0, it = 0;
+  for (it = 0; it < D.max_iter; ++it) {
+    HIPCHK(p, hipMemcpyAsync(p->h_active, W.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(p, hipStreamSynchronize(st));
+    if (*p->h_active <= 0) break;
+    HIPCHK(p, hipEventRecord(p->ev[2 + 2 * launches], st));
+    hipLaunchKernelGGL(k_kkt, dim3(B), dim3(KT), p->kkt_lds, st, D, W, B);
+    HIPCHK(p, hipEventRecord(p->ev[3 + 2 * launches], st));
+    launches++;
+    hipLaunchKernelGGL(k_step, dim3(B), dim3(256), 0, st, D, W, B, it);
+  }
+  HIPCHK(p, hipMemcpyAsync(d_nodes_out, W.x, (size_t)B * D.n_vars * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (d_status_out) HIPCHK(p, hipMemcpyAsync(d_status_out, W.status, B * sizeof(int), hipMemcpyDeviceToDevice, st));
+  if (d_iters_out) HIPCHK(p, hipMemcpyAsync(d_iters_out, W.iters, B * sizeof(int), hipMemcpyDeviceToDevice, st));
+  if (d_viol_out) HIPCHK(p, hipMemcpyAsync(d_viol_out, W.viol, B * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HIPCHK(p, hipEventRecord(p->ev[1], st));
+  p->last_launches = launches;
+  p->last_iters = it;
+  HIPCHK(p, hipGetLastError());
+  return 0;
+}
+
+int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *goal, const int *map_id,
+                    const double *warm, double *nodes_out, int *status_out, int *iters_out, double *viol_out) {
+  if (!p || B < 1 || B > p->max_batch || !start || !goal || !nodes_out) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  const size_t n = p->M.n_vars;
+  HIPCHK(p, hipMemcpy(p->d_start, start, (size_t)B * QTOS_START_DOUBLES * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(p, hipMemcpy(p->d_goal, goal, (size_t)B * 3 * sizeof(double), hipMemcpyHostToDevice));
+  if (map_id) HIPCHK(p, hipMemcpy(p->d_map, map_id, B * sizeof(int), hipMemcpyHostToDevice));
+  if (warm) HIPCHK(p, hipMemcpy(p->d_warm, warm, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice));
+  int rc = qtos_plan_batch_device(p, B, p->d_start, p->d_goal, map_id ? p->d_map : nullptr,
+                                  warm ? p->d_warm : nullptr, p->d_nodes, nullptr, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  HIPCHK(p, hipDeviceSynchronize());
+  HIPCHK(p, hipMemcpy(nodes_out, p->d_nodes, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost));
+  if (status_out) HIPCHK(p, hipMemcpy(status_out, p->wk.status, B * sizeof(int), hipMemcpyDeviceToHost));
+  if (iters_out) HIPCHK(p, hipMemcpy(iters_out, p->wk.iters, B * sizeof(int), hipMemcpyDeviceToHost));
+  if (viol_out) HIPCHK(p, hipMemcpy(viol_out, p->wk.viol, B * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, double *total_seconds, int *iterations) {
+  if (!p) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  HIPCHK(p, hipEventSynchronize(p->ev[1]));
+  double kkt = 0;
+  for (int i = 0; i < p->last_launches; ++i) {
+    float ms = 0;
+    HIPCHK(p, hipEventElapsedTime(&ms, p->ev[2 + 2 * i], p->ev[3 + 2 * i]));
+    kkt += ms * 1e-3;
+  }
+  float tot = 0;
+  HIPCHK(p, hipEventElapsedTime(&tot, p->ev[0], p->ev[1]));
+  if (kkt_seconds) *kkt_seconds = kkt;
+  if (kkt_launches) *kkt_launches = p->last_launches;
+  if (total_seconds) *total_seconds = tot * 1e-3;
+  if (iterations) *iterations = p->last_iters;
+  return 0;
+}
+
+int qtos_sample_csv_device(QtosPlanner *p, int B, const double *d_nodes, const double *d_t0, double hz,
+                           int n_rows, double *d_rows_out, void *stream_) {
+  if (!p || B < 1 || !d_nodes || !d_t0 || !d_rows_out || n_rows < 1 || !(hz > 0)) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  dim3 grid((n_rows + 255) / 256, B);
+  hipLaunchKernelGGL(k_sample, grid, dim3(256), 0, (hipStream_t)stream_, p->sp, d_nodes, d_t0, hz, n_rows, d_rows_out, B);
+  HIPCHK(p, hipGetLastError());
+  return 0;
+}
+
+int qtos_sample_csv(QtosPlanner *p, int B, const double *nodes, const double *t0, double hz, int n_rows, double *rows_out) {
+  if (!p || B < 1 || !nodes || !t0 || !rows_out) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  double *d_nodes = nullptr, *d_t0 = nullptr, *d_rows = nullptr;
+  const size_t n = p->M.n_vars, rows_bytes = (size_t)B * n_rows * QTOS_CSV_COLS * sizeof(double);
+  HIPCHK(p, hipMalloc((void **)&d_nodes, (size_t)B * n * sizeof(double)));
+  HIPCHK(p, hipMalloc((void **)&d_t0, B * sizeof(double)));
+  HIPCHK(p, hipMalloc((void **)&d_rows, rows_bytes));
+  HIPCHK(p, hipMemcpy(d_nodes, nodes, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(p, hipMemcpy(d_t0, t0, B * sizeof(double), hipMemcpyHostToDevice));
+  int rc = qtos_sample_csv_device(p, B, d_nodes, d_t0, hz, n_rows, d_rows, nullptr);
+  if (!rc) {
+    hipError_t e = hipMemcpy(rows_out, d_rows, rows_bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = -2;
+  }
+  (void)hipFree(d_nodes); (void)hipFree(d_t0); (void)hipFree(d_rows);
+  return rc;
+}
+
+// ---- introspection -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_debug_eval(DevPlan P, DevWork W, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int n = P.n_vars, m = P.n_cons;
+  double *x = W.x + (size_t)b * n, *g = W.g + (size_t)b * m;
+  const double *st = W.start + (size_t)b * QTOS_START_DOUBLES, *gl = W.goal + (size_t)b * 3;
+  for (int v = threadIdx.x; v < n; v += blockDim.x) {
+    const InitDesc I = P.init[v];
+    x[v] = I.fix_src >= 0 ? (I.fix_src < 24 ? st[I.fix_src] : (I.fix_src < 26 ? gl[I.fix_src - 24] : 0.0))
+                          : W.warm[(size_t)b * n + v];
+  }
+  __syncthreads();
+  eval_all<true>(P, W.map_id ? W.map_id[b] : 0, x, g, W.G + (size_t)b * P.g_doubles);
+  if (threadIdx.x == 0) W.done[b] = 0;
+}
+
+static int debug_upload(QtosPlanner *p, int B, const double *start, const double *goal, const int *map_id, const double *nodes, DevWork *W) {
+  if (!p || B < 1 || B > p->max_batch || !start || !goal || !nodes) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  const size_t n = p->M.n_vars;
+  HIPCHK(p, hipMemcpy(p->d_start, start, (size_t)B * QTOS_START_DOUBLES * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(p, hipMemcpy(p->d_goal, goal, (size_t)B * 3 * sizeof(double), hipMemcpyHostToDevice));
+  if (map_id) HIPCHK(p, hipMemcpy(p->d_map, map_id, B * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(p, hipMemcpy(p->d_warm, nodes, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice));
+  *W = p->wk;
+  W->start = p->d_start; W->goal = p->d_goal; W->map_id = map_id ? p->d_map : nullptr; W->warm = p->d_warm;
+  hipLaunchKernelGGL(k_debug_eval, dim3(B), dim3(256), 0, 0, p->dp, *W, B);
+  HIPCHK(p, hipDeviceSynchronize());
+  return 0;
+}
+
+int qtos_debug_eval(QtosPlanner *p, int B, const double *start, const double *goal, const int *map_id,
+                    const double *nodes, double *g_out, double *J_out) {
+  DevWork W;
+  int rc = debug_upload(p, B, start, goal, map_id, nodes, &W);
+  if (rc) return rc;
+  const HostModel &M = p->M;
+  const size_t n = M.n_vars, m = M.n_cons;
+  if (g_out) HIPCHK(p, hipMemcpy(g_out, W.g, (size_t)B * m * sizeof(double), hipMemcpyDeviceToHost));
+  if (J_out) {
+    std::vector<double> G((size_t)B * p->S.g_doubles);
+    HIPCHK(p, hipMemcpy(G.data(), W.G, G.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::memset(J_out, 0, (size_t)B * m * n * sizeof(double));
+    for (int b = 0; b < B; ++b)
+      for (const Block &blk : M.blocks) {
+        const double *Gb = blk.gstatic ? M.g_static.data() + blk.goff : G.data() + (size_t)b * p->S.g_doubles + blk.goff;
+        for (int r = 0; r < blk.m; ++r)
+          for (int a = 0; a < blk.n; ++a)
+            J_out[((size_t)b * m + blk.row0 + r) * n + M.block_cols[blk.col_off + a]] = Gb[r * blk.n + a];
+      }
+  }
+  return 0;
+}
+
+int qtos_debug_newton(QtosPlanner *p, int B, const double *start, const double *goal, const int *map_id,
+                      const double *nodes, const double *sig, const double *w, double *dx_out) {
+  DevWork W;
+  int rc = debug_upload(p, B, start, goal, map_id, nodes, &W);
+  if (rc) return rc;
+  const size_t n = p->M.n_vars, m = p->M.n_cons;
+  HIPCHK(p, hipMemcpy(W.sig, sig, (size_t)B * m * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(p, hipMemcpy(W.w, w, (size_t)B * m * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_kkt, dim3(B), dim3(KT), p->kkt_lds, 0, p->dp, W, B);
+  HIPCHK(p, hipDeviceSynchronize());
+  HIPCHK(p, hipMemcpy(dx_out, W.dx, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int qtos_debug_structure(const QtosPlanner *p, int *row_kind, int *var_free, int *order) {
+  if (!p) return -1;
+  if (row_kind) std::memcpy(row_kind, p->M.row_kind.data(), p->M.n_cons * sizeof(int));
+  if (var_free)
+    for (int v = 0; v < p->M.n_vars; ++v) var_free[v] = p->M.is_free(v) ? 1 : 0;
+  if (order) std::memcpy(order, p->S.order.data(), p->S.n_unknowns * sizeof(int));
+  return 0;
+}
+
+int qtos_debug_trace(QtosPlanner *p, int b, double *trace_out) {
+  if (!p || b < 0 || b >= p->max_batch || !trace_out) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  int iters = 0;
+  HIPCHK(p, hipMemcpy(&iters, p->wk.iters + b, sizeof(int), hipMemcpyDeviceToHost));
+  const int rows = iters + 1, stride = p->M.P.max_iter + 1;
+  HIPCHK(p, hipMemcpy(trace_out, p->wk.trace + (size_t)b * stride * 4, (size_t)rows * 4 * sizeof(double), hipMemcpyDeviceToHost));
+  return rows;
+}
+
+}  // extern "C"

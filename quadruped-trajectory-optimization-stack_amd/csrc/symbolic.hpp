@@ -1,0 +1,235 @@
+// symbolic.hpp -- fixed-structure analysis of the condensed KKT system
+//
+//     K = [ delta I + Ji' S Ji   Je' ]        unknowns: free node variables + equality multipliers
+//         [ Je                  -eps I ]
+//
+// The unknowns are ordered by the time stamp of their node / constraint, which makes K a
+// variable-band ("skyline") matrix: long-lived unknowns (a stance foothold is coupled to every base
+// node of its stance) sit at the END of their life so they only lengthen their own row.  The chain
+// is cut into stages of PIV consecutive pivots; stage k's front = its pivots + every later unknown
+// whose row reaches back into the eliminated range.  Each unknown is given ONE slot of the
+// LDS-resident front for its whole life, so Schur complements are applied in place and nothing is
+// ever copied between stages (slots of eliminated pivots are recycled).
+#pragma once
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "model.hpp"
+
+namespace qtos {
+
+constexpr int PIV = 16;
+
+struct StageDesc {
+  int n_active;            // pivots + border (for the algorithmic byte / flop count)
+  int g_begin, g_len;      // this stage's slice of the per-problem Jacobian-block buffer G
+  int ent_begin, ent_end;  // equality entries  (EqEntry)
+  int rhs_begin, rhs_end;  // equality right-hand sides (EqRhs)
+  int iq_begin, iq_end;    // inequality blocks (IqBlock)
+};
+// K[slot_r][slot_c] = G value (equality Jacobian entry = coupling multiplier <-> variable)
+struct EqEntry {
+  int src;   // >= 0: index into the stage's G slice (LDS copy); < 0: -(index+1) into g_static
+  short slot_r, slot_c;
+};
+struct EqRhs {
+  int row, slot;  // rhs[slot] = -g[row]
+};
+// inequality block: K[slot_a][slot_c] += sum_r sig_r G[r][a] G[r][c]; rhs[slot_a] -= sum_r G[r][a] w_r
+struct IqBlock {
+  int m, n, row0, gloc /* offset inside the stage's G slice */, slot_off, pad0, pad1, pad2;
+};
+
+struct Symbolic {
+  int n_unknowns = 0, n_free = 0, n_eq = 0, n_stages = 0, front = 0;
+  std::vector<int> order;      // position -> var index, or n_vars + row for a multiplier
+  std::vector<int> var_pos;    // var -> position or -1
+  std::vector<int> row_pos;    // row -> position or -1
+  std::vector<int> var_slot;   // var -> front slot or -1 (fixed)
+  std::vector<int> row_slot;   // equality row -> front slot or -1
+  std::vector<int> piv_slot;   // n_stages*PIV: slot of each pivot (dummy pivots get free slots)
+  std::vector<int> piv_unknown;// n_stages*PIV: order[] entry or -1 for a dummy pivot
+  std::vector<double> piv_diag;// n_stages*PIV: delta_x, -eps_dual, or 1 (dummy)
+  std::vector<StageDesc> stages;
+  std::vector<EqEntry> eq_entries;
+  std::vector<EqRhs> eq_rhs;
+  std::vector<IqBlock> iq_blocks;
+  std::vector<short> iq_slots;    // front slot of every column of every inequality block
+  int max_stage_g = 0;            // longest G slice of a stage (LDS staging size)
+  long long g_doubles = 0;
+  long long algorithmic_bytes = 0, flops = 0, envelope = 0;
+  int max_active = 0;
+  std::string err;
+
+  int build(HostModel &M) {
+    const int n = M.n_vars, m = M.n_cons;
+    struct Key { double t; int id; };
+    std::vector<Key> keys;
+    for (int v = 0; v < n; ++v)
+      if (M.is_free(v)) keys.push_back({M.var_time[v], v});
+    n_free = (int)keys.size();
+    // only rows that ended up in an equality block are multipliers
+    std::vector<char> is_eq(m, 0);
+    for (const Block &b : M.blocks)
+      if (b.kind == 0)
+        for (int r = 0; r < b.m; ++r) is_eq[b.row0 + r] = 1;
+    for (int r = 0; r < m; ++r)
+      if (is_eq[r]) keys.push_back({M.con_time[r] + 1e-7, n + r});
+    n_unknowns = (int)keys.size();
+    n_eq = n_unknowns - n_free;
+    std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+      return a.t < b.t || (a.t == b.t && a.id < b.id);
+    });
+    order.resize(n_unknowns);
+    var_pos.assign(n, -1);
+    row_pos.assign(m, -1);
+    for (int i = 0; i < n_unknowns; ++i) {
+      order[i] = keys[i].id;
+      if (keys[i].id < n) var_pos[keys[i].id] = i;
+      else row_pos[keys[i].id - n] = i;
+    }
+    // envelope: first[j] = smallest position coupled with j
+    std::vector<int> first(n_unknowns);
+    std::iota(first.begin(), first.end(), 0);
+    std::vector<int> block_minpos(M.blocks.size());
+    for (size_t bi = 0; bi < M.blocks.size(); ++bi) {
+      const Block &b = M.blocks[bi];
+      int mn = n_unknowns;
+      for (int a = 0; a < b.n; ++a) mn = std::min(mn, var_pos[M.block_cols[b.col_off + a]]);
+      if (b.kind == 0)
+        for (int r = 0; r < b.m; ++r) mn = std::min(mn, row_pos[b.row0 + r]);
+      block_minpos[bi] = mn;
+      for (int a = 0; a < b.n; ++a) {
+        int p = var_pos[M.block_cols[b.col_off + a]];
+        first[p] = std::min(first[p], mn);
+      }
+      if (b.kind == 0)
+        for (int r = 0; r < b.m; ++r) {
+          int p = row_pos[b.row0 + r];
+          first[p] = std::min(first[p], mn);
+        }
+    }
+    n_stages = (n_unknowns + PIV - 1) / PIV;
+    // slot allocation
+    var_slot.assign(n, -1);
+    row_slot.assign(m, -1);
+    std::vector<int> slot_of(n_unknowns, -1);
+    piv_slot.assign((size_t)n_stages * PIV, -1);
+    piv_unknown.assign((size_t)n_stages * PIV, -1);
+    piv_diag.assign((size_t)n_stages * PIV, 1.0);
+    stages.resize(n_stages);
+    // unknowns sorted by entry stage: an unknown enters the front at stage first[j] / PIV
+    std::vector<std::vector<int>> enter(n_stages);
+    for (int j = 0; j < n_unknowns; ++j) enter[first[j] / PIV].push_back(j);
+    std::vector<int> free_slots;  // kept sorted descending so pop_back gives the smallest
+    int n_slots = 0;
+    max_active = 0;
+    envelope = 0;
+    for (int j = 0; j < n_unknowns; ++j) envelope += j - first[j] + 1;
+    std::vector<int> active_count(n_stages, 0);
+    int active = 0;
+    for (int k = 0; k < n_stages; ++k) {
+      for (int j : enter[k]) {
+        int s;
+        if (!free_slots.empty()) { s = free_slots.back(); free_slots.pop_back(); }
+        else s = n_slots++;
+        slot_of[j] = s;
+        active++;
+      }
+      // dummy pivots of the (short) last stage need distinct unused slots
+      int lo = k * PIV, hi = std::min(n_unknowns, lo + PIV);
+      std::vector<int> dummies;
+      for (int i = hi; i < lo + PIV; ++i) {
+        int s;
+        if (!free_slots.empty()) { s = free_slots.back(); free_slots.pop_back(); }
+        else s = n_slots++;
+        dummies.push_back(s);
+      }
+      active_count[k] = active + (int)dummies.size();
+      max_active = std::max(max_active, active_count[k]);
+      for (int i = lo; i < lo + PIV; ++i) {
+        size_t q = (size_t)k * PIV + (i - lo);
+        if (i < hi) {
+          piv_slot[q] = slot_of[i];
+          piv_unknown[q] = order[i];
+          piv_diag[q] = order[i] < n ? M.P.delta_x : -M.P.eps_dual;
+        } else {
+          piv_slot[q] = dummies[i - hi];
+          piv_unknown[q] = -1;
+          piv_diag[q] = 1.0;
+        }
+      }
+      // release pivots and dummies
+      for (int i = lo; i < lo + PIV; ++i) free_slots.push_back(piv_slot[(size_t)k * PIV + (i - lo)]);
+      std::sort(free_slots.begin(), free_slots.end(), std::greater<int>());
+      active -= (hi - lo);
+    }
+    front = ((n_slots + PIV - 1) / PIV) * PIV;
+    for (int j = 0; j < n_unknowns; ++j) {
+      if (order[j] < n) var_slot[order[j]] = slot_of[j];
+      else row_slot[order[j] - n] = slot_of[j];
+    }
+    // blocks grouped by owning stage (stage of their earliest unknown).  The dynamic G offsets are
+    // handed out in stage order so that each stage reads ONE contiguous slice of G.
+    std::vector<std::vector<int>> owned(n_stages);
+    for (size_t bi = 0; bi < M.blocks.size(); ++bi) owned[block_minpos[bi] / PIV].push_back((int)bi);
+    g_doubles = 0;
+    for (int k = 0; k < n_stages; ++k) {
+      StageDesc &S = stages[k];
+      S.n_active = active_count[k];
+      S.g_begin = (int)g_doubles;
+      S.ent_begin = (int)eq_entries.size();
+      S.rhs_begin = (int)eq_rhs.size();
+      S.iq_begin = (int)iq_blocks.size();
+      for (int bi : owned[k]) {
+        Block &b = M.blocks[bi];
+        int loc = -1;
+        if (!b.gstatic) {
+          b.goff = (int)g_doubles;
+          loc = (int)(g_doubles - S.g_begin);
+          g_doubles += (long long)b.m * b.n;
+        }
+        if (b.kind == 0) {
+          for (int r = 0; r < b.m; ++r) {
+            const int sr = row_slot[b.row0 + r];
+            eq_rhs.push_back({b.row0 + r, sr});
+            for (int a = 0; a < b.n; ++a) {
+              EqEntry e;
+              e.src = b.gstatic ? -(b.goff + r * b.n + a + 1) : loc + r * b.n + a;
+              e.slot_r = (short)sr;
+              e.slot_c = (short)var_slot[M.block_cols[b.col_off + a]];
+              eq_entries.push_back(e);
+            }
+          }
+        } else {
+          IqBlock q;
+          q.m = b.m; q.n = b.n; q.row0 = b.row0; q.gloc = loc;
+          q.slot_off = (int)iq_slots.size();
+          q.pad0 = q.pad1 = q.pad2 = 0;
+          for (int a = 0; a < b.n; ++a) iq_slots.push_back((short)var_slot[M.block_cols[b.col_off + a]]);
+          iq_blocks.push_back(q);
+        }
+      }
+      S.g_len = (int)(g_doubles - S.g_begin);
+      S.ent_end = (int)eq_entries.size();
+      S.rhs_end = (int)eq_rhs.size();
+      S.iq_end = (int)iq_blocks.size();
+      max_stage_g = std::max(max_stage_g, S.g_len);
+    }
+    M.g_doubles = g_doubles;
+    M.finalize_goff();
+    // bytes = w * [ sum_k (p + c_k) * p  +  2 M ]   (matrix once, rhs in, solution out)
+    algorithmic_bytes = 0;
+    flops = 0;
+    for (int k = 0; k < n_stages; ++k) {
+      long long a = active_count[k];
+      algorithmic_bytes += 8LL * a * PIV;
+      flops += 2LL * PIV * a * a;
+    }
+    algorithmic_bytes += 8LL * 2 * n_unknowns;
+    return 0;
+  }
+};
+
+}  // namespace qtos
