@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: NLP solves/sec of the batched local planner on N MI355X GPUs.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch: B planning problems per GPU (seeded synthetic
+start/goal on the exp_1 flat heightfield, BASELINE.json configs[1]) solved to convergence on the
+device -- initial guess, constraint/Jacobian assembly, KKT factor+solve, line search -- with the
+inputs already resident in HBM, followed for N > 1 by the single all-gather that re-assembles the
+plan batch on every rank.  `value` = converged plans of all ranks / wall time (max over ranks).
+
+Extra objects on the JSON line:
+  roofline     dominant kernel (k_kkt): algorithmic bytes per launch (SURVEY.md 8d formula on the
+               planner's actual stage sizes) / average launch duration from HIP events.
+  cpu_baseline the CPU oracle (a port of the same algorithm, 1 thread) on a bounded sample of the
+               same workload, rank 0, N = 1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+REF_LOG_PLANS_PER_S = 1.0 / 0.745  # logs/towr_log.out:81-82, unknown CPU -- not this metric's baseline
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="plans per GPU per step")
+    ap.add_argument("--transcription", default="knots100", choices=["knots100", "reference_compat"])
+    ap.add_argument("--workload", default="exp1_flat", choices=["exp1_flat", "exp5_step"])
+    ap.add_argument("--cpu-sample", type=int, default=96, help="plans timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per k_kkt launch from a separate rocprofv3 --pmc pass")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    from qtos_amd.dist import gather_plans
+    cfg = PlannerConfig.knots100() if args.transcription == "knots100" else PlannerConfig.reference_compat()
+    B = args.batch
+    P = Planner(cfg, max_batch=B, device=local_rank)
+    d = P.dims
+    terrain = None
+    if args.workload == "exp5_step":
+        terrain = workloads.exp5_terrain()
+        P.set_heightfields(terrain[0], terrain[1])
+        start_np, goal_np = workloads.step_goals(B, seed=1 + rank, terrain=terrain)
+    else:
+        hxy, cell = workloads.exp1_terrain()   # 40 x 20 cells of zeros: the terrain path is live
+        P.set_heightfields(hxy, cell)
+        start_np, goal_np = workloads.flat_goals(B, seed=rank)   # weak scaling: B plans per GPU
+
+    # inputs and outputs resident in HBM before the timed region
+    start = torch.as_tensor(start_np, dtype=torch.float64, device=dev).contiguous()
+    goal = torch.as_tensor(goal_np, dtype=torch.float64, device=dev).contiguous()
+    nodes = torch.empty((B, d.n_vars), dtype=torch.float64, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    iters = torch.empty((B,), dtype=torch.int32, device=dev)
+    viol = torch.empty((B,), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        rc = P.lib.qtos_plan_batch_device(P.h, B, start.data_ptr(), goal.data_ptr(), None, None,
+                                          nodes.data_ptr(), status.data_ptr(), iters.data_ptr(),
+                                          viol.data_ptr(), C.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError("qtos_plan_batch_device failed: %d %s" % (rc, P.lib.qtos_last_error(P.h)))
+        if world > 1:
+            return gather_plans(nodes, status, B * world)
+        return nodes, status
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    kkt_s, kkt_n, tot_s, it_sum = 0.0, 0, 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        all_nodes, all_status = step()
+        tm = P.timing()   # HIP events recorded on the launch stream around every k_kkt launch
+        kkt_s += tm["kkt_seconds"]
+        kkt_n += tm["kkt_launches"]
+        tot_s += tm["total_seconds"]
+        it_sum += tm["iterations"]
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    solved = (all_status == 0).sum().to(torch.float64).reshape(1)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    n_solved = int(solved.item())          # after the gather every rank sees the whole batch
+    total_plans = B * world
+    value = n_solved * args.steps / elapsed
+    st = status.cpu().numpy()
+    itn = iters.cpu().numpy()
+
+    out = {
+        "metric": "NLP solves/sec (100-knot SOLO12 gait, 5 s horizon, converged to 1e-4)",
+        "value": round(value, 2), "unit": "plans/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "batch=%d/GPU %s goals, %s transcription (%d base polynomials, %d vars, %d "
+                        "constraint rows), walk gait of the reference's golden plans" %
+                        (B, "exp_1 flat-ground" if args.workload == "exp1_flat" else "exp_5 step-climb",
+                         args.transcription, d.n_base_nodes - 1, d.n_vars, d.n_cons),
+            "global_batch": total_plans, "converged": n_solved, "iterations_max": int(itn.max()),
+            "iterations_mean": round(float(itn.mean()), 2), "parallelism": "batch-shard x%d + 1 all-gather" % world,
+            "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front,
+        },
+    }
+    if kkt_n:
+        avg = kkt_s / kkt_n
+        alg_bytes = float(B) * d.kkt_algorithmic_bytes
+        achieved = alg_bytes / avg / 1e9
+        out["roofline"] = {
+            "kernel": "k_kkt", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": args.traffic_bytes,
+            "bytes_per_launch": alg_bytes, "avg_launch_ms": round(1e3 * avg, 4), "launches": kkt_n,
+            "fp64_tflops": round(B * d.kkt_flops / avg / 1e12, 3), "fp64_peak_tflops": 78.6,
+            "kkt_share_of_device_time": round(kkt_s / max(tot_s, 1e-12), 3),
+        }
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle.oracle import Oracle
+        O = Oracle(cfg.oracle_dict(), height=None if terrain is None else terrain[0],
+                   hcell=0.1 if terrain is None else terrain[1])
+        n_s = min(args.cpu_sample, B)
+        nodes_h = nodes.cpu().numpy()
+        tc = time.perf_counter()
+        ok, worst = 0, 0.0
+        for b in range(n_s):
+            s, g = start_np[b], goal_np[b]
+            xo, info = O.solve(O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g))
+            ok += int(info.status == 0)
+            worst = max(worst, float(np.abs(xo - nodes_h[b]).max()))
+        tc = time.perf_counter() - tc
+        out["cpu_baseline"] = {
+            "value": round(ok / tc, 3), "unit": "plans/s", "cores": 1, "kind": "port",
+            "sample": "first %d problems of the same batch, oracle/qtos_oracle.c (same algorithm, skyline "
+                      "LDL^T), 1 thread; max |gpu - cpu| nodes = %.1e" % (n_s, worst),
+            "reference_log_plans_per_s": round(REF_LOG_PLANS_PER_S, 2),
+            "reference_log_note": "Docker TOWR/Ipopt, logs/towr_log.out:81-82, unknown CPU, 1 thread; not runnable here",
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    P.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
 void qtos_planner_destroy(QtosPlanner *p);
 int qtos_planner_dims(const QtosPlanner *p, QtosDims *dims);
 const char *qtos_last_error(const QtosPlanner *p);
+/* Host-only structure analysis (no GPU needed): the dimensions a planner built from `params`
+ * would have; stage_active (may be NULL) receives the populated front size of each stage. */
+int qtos_analyze(const QtosParams *params, QtosDims *dims, int *stage_active, int max_stages);
 
 /* Terrain side channel.  Replaces `docker cp towr_heightfield.txt <id>:...`
  * (QTOS/utils.py:21-22; scripts/main.py:77-78; QTOS/generateHeightField.py:276-279).

@@ -50,7 +50,7 @@ EXPORTS = [
     "qtos_planner_create", "qtos_planner_destroy", "qtos_planner_dims", "qtos_last_error",
     "qtos_set_heightfields", "qtos_plan_batch", "qtos_plan_batch_device", "qtos_sample_csv",
     "qtos_sample_csv_device", "qtos_last_timing", "qtos_debug_eval", "qtos_debug_newton",
-    "qtos_debug_structure", "qtos_debug_trace",
+    "qtos_debug_structure", "qtos_debug_trace", "qtos_analyze",
 ]
 
 _lib = None
@@ -82,6 +82,7 @@ def load():
     lib.qtos_debug_newton.argtypes = [vp, C.c_int, dp, dp, ip, dp, dp, dp, dp]
     lib.qtos_debug_structure.argtypes = [vp, ip, ip, ip]
     lib.qtos_debug_trace.argtypes = [vp, C.c_int, dp]
+    lib.qtos_analyze.argtypes = [C.POINTER(QtosParams), C.POINTER(QtosDims), ip, C.c_int]
     _lib = lib
     return lib
 
@@ -117,6 +118,18 @@ def params_from_config(cfg):
     p.max_iter, p.tol = cfg.max_iter, cfg.tol
     p.mu_init, p.mu_min, p.delta_x, p.eps_dual = cfg.mu_init, cfg.mu_min, cfg.delta_x, cfg.eps_dual
     return p
+
+
+def analyze(cfg):
+    """Host-only structure analysis: (QtosDims, per-stage populated front sizes).  No GPU needed."""
+    lib = load()
+    p = params_from_config(cfg)
+    d = QtosDims()
+    act = np.zeros(4096, np.int32)
+    rc = lib.qtos_analyze(C.byref(p), C.byref(d), _ip(act), act.size)
+    if rc != 0:
+        raise ValueError("qtos_analyze failed (%d)" % rc)
+    return d, act[:d.n_stages].copy()
 
 
 class Planner:

@@ -569,11 +569,11 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     if (tid < PIV) A[tri(ps[tid], ps[tid])] += P.piv_diag[k * PIV + tid];
     for (int i = S.ent_begin + tid; i < S.ent_end; i += KT) {
       const EqEntry e = P.eq_entries[i];
-      A[trs(e.slot_r, e.slot_c)] = e.src >= 0 ? Gs[e.src] : P.g_static[-e.src - 1];
+      A[trs(e.slot_r, e.slot_c)] += e.src >= 0 ? G[e.src] : P.g_static[-e.src - 1];
     }
     for (int i = S.rhs_begin + tid; i < S.rhs_end; i += KT) {
       const EqRhs e = P.eq_rhs[i];
-      A[tri(F, e.slot)] = -g[e.row];
+      A[tri(F, e.slot)] -= g[e.row];
     }
     for (int q = S.iq_begin; q < S.iq_end; ++q) {
       const IqBlock Q = P.iq_blocks[q];

@@ -179,10 +179,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   return 0;
 }
 
-int qtos_planner_dims(const QtosPlanner *p, QtosDims *d) {
-  if (!p || !d) return -1;
-  const HostModel &M = p->M;
-  const Symbolic &S = p->S;
+static void fill_dims(const HostModel &M, const Symbolic &S, QtosDims *d) {
   std::memset(d, 0, sizeof(*d));
   d->n_vars = M.n_vars; d->n_cons = M.n_cons; d->n_free = S.n_free;
   for (int r = 0; r < M.n_cons; ++r) {
@@ -200,10 +197,27 @@ int qtos_planner_dims(const QtosPlanner *p, QtosDims *d) {
   d->pivots = PIV; d->front = S.front;
   d->n_base_nodes = M.n_base_nodes; d->n_dyn_times = (int)M.t_dyn.size(); d->n_rom_times = (int)M.t_rom.size();
   d->n_rows_csv = (int)std::llround(M.T * 1000.0) + 1;
-  d->panel_doubles = p->dp.panel_stride; d->g_doubles = S.g_doubles;
+  d->panel_doubles = (long long)S.n_stages * (S.front + PIV + 1) * PIV; d->g_doubles = S.g_doubles;
   d->kkt_algorithmic_bytes = S.algorithmic_bytes; d->kkt_flops = S.flops;
   d->envelope = S.envelope; d->max_active = S.max_active;
   d->duration = M.T;
+}
+
+int qtos_planner_dims(const QtosPlanner *p, QtosDims *d) {
+  if (!p || !d) return -1;
+  fill_dims(p->M, p->S, d);
+  return 0;
+}
+
+int qtos_analyze(const QtosParams *params, QtosDims *d, int *stage_active, int max_stages) {
+  if (!params || !d) return -1;
+  HostModel M;
+  Symbolic S;
+  if (M.build(*params)) return -1;
+  if (S.build(M)) return -1;
+  fill_dims(M, S, d);
+  if (stage_active)
+    for (int k = 0; k < S.n_stages && k < max_stages; ++k) stage_active[k] = S.stages[k].n_active;
   return 0;
 }
 

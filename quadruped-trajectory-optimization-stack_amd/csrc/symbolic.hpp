@@ -30,7 +30,7 @@ struct StageDesc {
 };
 // K[slot_r][slot_c] = G value (equality Jacobian entry = coupling multiplier <-> variable)
 struct EqEntry {
-  int src;   // >= 0: index into the stage's G slice (LDS copy); < 0: -(index+1) into g_static
+  int src;   // >= 0: offset into the problem's G buffer; < 0: -(index+1) into g_static
   short slot_r, slot_c;
 };
 struct EqRhs {
@@ -92,23 +92,29 @@ struct Symbolic {
     // envelope: first[j] = smallest position coupled with j
     std::vector<int> first(n_unknowns);
     std::iota(first.begin(), first.end(), 0);
-    std::vector<int> block_minpos(M.blocks.size());
+    // Pattern of K: an inequality block couples all of its columns with each other (Ji' S Ji);
+    // an equality block couples each multiplier with the columns of its row and nothing else.
+    std::vector<int> block_minpos(M.blocks.size(), 0);
     for (size_t bi = 0; bi < M.blocks.size(); ++bi) {
       const Block &b = M.blocks[bi];
-      int mn = n_unknowns;
-      for (int a = 0; a < b.n; ++a) mn = std::min(mn, var_pos[M.block_cols[b.col_off + a]]);
-      if (b.kind == 0)
-        for (int r = 0; r < b.m; ++r) mn = std::min(mn, row_pos[b.row0 + r]);
-      block_minpos[bi] = mn;
-      for (int a = 0; a < b.n; ++a) {
-        int p = var_pos[M.block_cols[b.col_off + a]];
-        first[p] = std::min(first[p], mn);
-      }
-      if (b.kind == 0)
-        for (int r = 0; r < b.m; ++r) {
-          int p = row_pos[b.row0 + r];
+      if (b.kind == 1) {
+        int mn = n_unknowns;
+        for (int a = 0; a < b.n; ++a) mn = std::min(mn, var_pos[M.block_cols[b.col_off + a]]);
+        block_minpos[bi] = mn;
+        for (int a = 0; a < b.n; ++a) {
+          int p = var_pos[M.block_cols[b.col_off + a]];
           first[p] = std::min(first[p], mn);
         }
+      } else {
+        for (int r = 0; r < b.m; ++r) {
+          const int pr = row_pos[b.row0 + r];
+          for (int a = 0; a < b.n; ++a) {
+            const int pa = var_pos[M.block_cols[b.col_off + a]];
+            const int lo = std::min(pr, pa), hi = std::max(pr, pa);
+            first[hi] = std::min(first[hi], lo);
+          }
+        }
+      }
     }
     n_stages = (n_unknowns + PIV - 1) / PIV;
     // slot allocation
@@ -170,52 +176,59 @@ struct Symbolic {
       if (order[j] < n) var_slot[order[j]] = slot_of[j];
       else row_slot[order[j] - n] = slot_of[j];
     }
-    // blocks grouped by owning stage (stage of their earliest unknown).  The dynamic G offsets are
-    // handed out in stage order so that each stage reads ONE contiguous slice of G.
+    // Inequality blocks are assembled at the stage of their earliest column; their G blocks are laid
+    // out in that order so that each stage reads ONE contiguous slice of G.  An equality entry
+    // K[multiplier][variable] is assembled at the stage that eliminates the earlier of the two
+    // (both have a slot by then); equality G blocks follow the inequality slices in the buffer.
     std::vector<std::vector<int>> owned(n_stages);
-    for (size_t bi = 0; bi < M.blocks.size(); ++bi) owned[block_minpos[bi] / PIV].push_back((int)bi);
+    for (size_t bi = 0; bi < M.blocks.size(); ++bi)
+      if (M.blocks[bi].kind == 1) owned[block_minpos[bi] / PIV].push_back((int)bi);
     g_doubles = 0;
     for (int k = 0; k < n_stages; ++k) {
       StageDesc &S = stages[k];
       S.n_active = active_count[k];
       S.g_begin = (int)g_doubles;
-      S.ent_begin = (int)eq_entries.size();
-      S.rhs_begin = (int)eq_rhs.size();
       S.iq_begin = (int)iq_blocks.size();
       for (int bi : owned[k]) {
         Block &b = M.blocks[bi];
-        int loc = -1;
-        if (!b.gstatic) {
-          b.goff = (int)g_doubles;
-          loc = (int)(g_doubles - S.g_begin);
-          g_doubles += (long long)b.m * b.n;
-        }
-        if (b.kind == 0) {
-          for (int r = 0; r < b.m; ++r) {
-            const int sr = row_slot[b.row0 + r];
-            eq_rhs.push_back({b.row0 + r, sr});
-            for (int a = 0; a < b.n; ++a) {
-              EqEntry e;
-              e.src = b.gstatic ? -(b.goff + r * b.n + a + 1) : loc + r * b.n + a;
-              e.slot_r = (short)sr;
-              e.slot_c = (short)var_slot[M.block_cols[b.col_off + a]];
-              eq_entries.push_back(e);
-            }
-          }
-        } else {
-          IqBlock q;
-          q.m = b.m; q.n = b.n; q.row0 = b.row0; q.gloc = loc;
-          q.slot_off = (int)iq_slots.size();
-          q.pad0 = q.pad1 = q.pad2 = 0;
-          for (int a = 0; a < b.n; ++a) iq_slots.push_back((short)var_slot[M.block_cols[b.col_off + a]]);
-          iq_blocks.push_back(q);
-        }
+        b.goff = (int)g_doubles;
+        IqBlock q;
+        q.m = b.m; q.n = b.n; q.row0 = b.row0; q.gloc = (int)(g_doubles - S.g_begin);
+        q.slot_off = (int)iq_slots.size();
+        q.pad0 = q.pad1 = q.pad2 = 0;
+        for (int a = 0; a < b.n; ++a) iq_slots.push_back((short)var_slot[M.block_cols[b.col_off + a]]);
+        iq_blocks.push_back(q);
+        g_doubles += (long long)b.m * b.n;
       }
       S.g_len = (int)(g_doubles - S.g_begin);
-      S.ent_end = (int)eq_entries.size();
-      S.rhs_end = (int)eq_rhs.size();
       S.iq_end = (int)iq_blocks.size();
       max_stage_g = std::max(max_stage_g, S.g_len);
+    }
+    std::vector<std::vector<EqEntry>> ent(n_stages);
+    std::vector<std::vector<EqRhs>> rhs(n_stages);
+    for (Block &b : M.blocks) {
+      if (b.kind != 0) continue;
+      if (!b.gstatic) { b.goff = (int)g_doubles; g_doubles += (long long)b.m * b.n; }
+      for (int r = 0; r < b.m; ++r) {
+        const int pr = row_pos[b.row0 + r], sr = row_slot[b.row0 + r];
+        rhs[pr / PIV].push_back({b.row0 + r, sr});
+        for (int a = 0; a < b.n; ++a) {
+          const int var = M.block_cols[b.col_off + a];
+          EqEntry e;
+          e.src = b.gstatic ? -(b.goff + r * b.n + a + 1) : b.goff + r * b.n + a;
+          e.slot_r = (short)sr;
+          e.slot_c = (short)var_slot[var];
+          ent[std::min(pr, var_pos[var]) / PIV].push_back(e);
+        }
+      }
+    }
+    for (int k = 0; k < n_stages; ++k) {
+      stages[k].ent_begin = (int)eq_entries.size();
+      eq_entries.insert(eq_entries.end(), ent[k].begin(), ent[k].end());
+      stages[k].ent_end = (int)eq_entries.size();
+      stages[k].rhs_begin = (int)eq_rhs.size();
+      eq_rhs.insert(eq_rhs.end(), rhs[k].begin(), rhs[k].end());
+      stages[k].rhs_end = (int)eq_rhs.size();
     }
     M.g_doubles = g_doubles;
     M.finalize_goff();

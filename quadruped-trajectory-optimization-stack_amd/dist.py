@@ -1,0 +1,55 @@
+"""Multi-GPU sharding of a plan batch: one process per GPU, contiguous shards, one all-gather.
+
+Planning problems are independent (the reference already runs 32 at once as separate processes,
+QTOS/generateHeightField.py:344-352), so the only exchange is re-assembling the plan batch:
+``all_gather`` of the solution nodes (n_vars doubles per plan) and the status words.  With
+``torch.distributed`` backend "nccl" this is one RCCL all-gather over xGMI; "gloo" is used by the
+CPU tests.  The 1 kHz CSV rows (1.48 MB per plan) are sampled after the gather, never shipped.
+"""
+import numpy as np
+
+
+def shard_bounds(n_items, world_size, rank):
+    """Contiguous [begin, end) of rank's shard; the first (n_items % world_size) ranks get one more."""
+    base, rem = divmod(n_items, world_size)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def gather_plans(nodes_local, status_local, n_total, group=None):
+    """All-gather the per-rank shards (torch tensors, same device) into full (n_total, n_vars) /
+    (n_total,) tensors on every rank.  Shards are padded to equal length so ONE collective moves
+    the nodes and one the status words."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    per = -(-n_total // world)
+    n_vars = nodes_local.shape[1]
+    pad_nodes = torch.zeros((per, n_vars), dtype=nodes_local.dtype, device=nodes_local.device)
+    pad_status = torch.full((per,), -1, dtype=status_local.dtype, device=status_local.device)
+    pad_nodes[:nodes_local.shape[0]] = nodes_local
+    pad_status[:status_local.shape[0]] = status_local
+    all_nodes = torch.empty((world * per, n_vars), dtype=nodes_local.dtype, device=nodes_local.device)
+    all_status = torch.empty((world * per,), dtype=status_local.dtype, device=status_local.device)
+    dist.all_gather_into_tensor(all_nodes, pad_nodes, group=group)
+    dist.all_gather_into_tensor(all_status, pad_status, group=group)
+    keep = []
+    for r in range(world):
+        b, e = shard_bounds(n_total, world, r)
+        keep.append(torch.arange(r * per, r * per + (e - b), device=nodes_local.device))
+    keep = torch.cat(keep)
+    return all_nodes[keep], all_status[keep]
+
+
+def plan_sharded(solve_fn, start, goal, group=None, device="cpu"):
+    """solve_fn(start_shard, goal_shard) -> (nodes, status) numpy; returns the full batch on every
+    rank.  start/goal: full-batch numpy arrays, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    b, e = shard_bounds(len(start), world, rank)
+    nodes, status = solve_fn(start[b:e], goal[b:e])
+    tn = torch.as_tensor(np.ascontiguousarray(nodes), dtype=torch.float64, device=device)
+    ts = torch.as_tensor(np.ascontiguousarray(status).astype(np.int32), device=device)
+    all_nodes, all_status = gather_plans(tn, ts, len(start), group)
+    return all_nodes.cpu().numpy(), all_status.cpu().numpy()

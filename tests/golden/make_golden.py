@@ -168,6 +168,53 @@ def parse_log(path):
     return dims
 
 
+def boundary_fixtures():
+    """Outputs of the reference's own boundary code (imported here, never shipped): cmd_args strings,
+    heightfield file text, and the tile -> map -> solver-map pipeline."""
+    import hashlib
+    import tempfile
+    import types
+    sys.modules.setdefault("pybullet", types.ModuleType("pybullet"))
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from QTOS import utils as rutils
+        from QTOS import generateHeightField as ghf
+        out = {"cmd_args": [], "heightfield": {}}
+        arg_sets = [
+            {"-g": [0.520000318742596, 3.541584398612406e-07, 0.24], "-s": [0, 0, 0.24],
+             "-e1": [0.21, 0.19, 0.0], "-e2": [0.21, -0.19, 0.0], "-e3": [-0.21, 0.19, 0.0],
+             "-e4": [-0.21, -0.19, 0.0], "-s_ang": [0, 0, 0], "-resolution": 0.01, "sim": object},
+            {"-s": [0.335266, -0.0123145, 0.221551], "-g": [0.9100042764299588, 0.0, 0.24],
+             "-s_ang": [-0.0422299, -0.0416417, 0.00880732], "-e1": [0.548758, 0.14327, 0],
+             "-t": 3.756, "s_vel": [0.135043, -0.422901, -0.014325],
+             "s_ang_vel": [-0.98238, -0.256968, 0.932169], "-resolution": 0.01, "-r": 5.0,
+             "f_steps": 2500, "-duration": None},
+        ]
+        for a in arg_sets:
+            printable = {k: v for k, v in a.items() if not isinstance(v, type)}
+            out["cmd_args"].append({"args": printable, "string": rutils.cmd_args(a)})
+        for name, maps, scale in (("exp_1", ["plane", "plane"], 1), ("exp_5", ["climb_2", "climb_1"], 11),
+                                  ("exp_3", ["feasibility", "feasibility_1", "plane"], 1)):
+            obj = object.__new__(ghf.Height_Map_Generator)
+            ghf.Maps.__init__(obj, maps, 20, scale)
+            towr = obj.towr_map_adjustment(np.transpose(obj.map.copy()), shift_z=0.0, shift_down_num=0)
+            with tempfile.NamedTemporaryFile("r", suffix=".txt") as tf:
+                obj.create_height_file(tf.name, towr)
+                text = open(tf.name).read()
+            out["heightfield"][name] = {
+                "tiles": maps, "mesh_scale": scale, "map_shape": list(obj.map.shape),
+                "towr_shape": list(towr.shape), "sha256": hashlib.sha256(text.encode()).hexdigest(),
+                "n_chars": len(text), "head": text[:160], "text": text if len(text) < 20000 else None,
+                "map_checksum": float(np.sum(obj.map * np.arange(obj.map.size).reshape(obj.map.shape))),
+                "resolution": 1 / (obj.map.shape[0] / 2),
+            }
+        return out
+    finally:
+        os.chdir(cwd)
+
+
 def main():
     gait = np.loadtxt(os.path.join(REF, "test/data/traj/gait.csv"), delimiter=",")
     towr = np.loadtxt(os.path.join(REF, "data/traj/towr.csv"), delimiter=",")
@@ -192,6 +239,7 @@ def main():
                             rows=rows[keep], inputs=json.dumps(inputs[name]),
                             phase_durations=np.array(phase_durations()))
     np.savez_compressed(os.path.join(OUT, "gv3_partial.npz"), rows=gv3[::10], row_idx=np.arange(0, 1254, 10))
+    json.dump(boundary_fixtures(), open(os.path.join(OUT, "boundary.json"), "w"), indent=1)
     dims = parse_log(os.path.join(REF, "logs/towr_log.out"))
     json.dump(dims, open(os.path.join(OUT, "nlp_dims.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in dims.items() if not k.endswith("_sets")}))

@@ -1,0 +1,112 @@
+"""P4 boundary parity: flag strings, heightfield file bytes, CSV format, the C ABI's
+exported symbols and the planner's structural dimensions (host-only analysis, no GPU)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+
+from conftest import GOLDEN, ROOT
+
+FIX = json.load(open(os.path.join(GOLDEN, "boundary.json")))
+
+
+def test_cmd_args_strings_equal_reference():
+    from qtos_amd import flags
+    for case in FIX["cmd_args"]:
+        assert flags.cmd_args(case["args"]) == case["string"]
+
+
+def test_parse_flags_inverts_cmd_args():
+    from qtos_amd import flags
+    for case in FIX["cmd_args"]:
+        back = flags.parse_flags(case["string"])
+        for k, v in case["args"].items():
+            if k in flags.FLAGS and v:
+                assert np.allclose(np.ravel(back[k]), np.ravel(v), rtol=0, atol=0)
+    start, goal, t0 = flags.problem_arrays(flags.parse_flags(FIX["cmd_args"][1]["string"]))
+    assert len(start) == 24 and t0 == 3.756 and goal[0] == 0.9100042764299588
+    assert start[18:21] == [0.135043, -0.422901, -0.014325]
+
+
+def test_heightfield_files_equal_reference(tmp_path):
+    from qtos_amd import heightfield
+    for name, ref in FIX["heightfield"].items():
+        tiles = []
+        for t in ref["tiles"]:
+            fname = {"feasibility": "feasibility_test", "feasibility_1": "feasibility_test_1"}.get(t, t)
+            tiles.append(heightfield.read_tile(os.path.join(GOLDEN, "heightfields", fname + ".txt")))
+        m = heightfield.build_map(tiles, ref["mesh_scale"])
+        assert list(m.shape) == ref["map_shape"]
+        assert abs(float(np.sum(m * np.arange(m.size).reshape(m.shape))) - ref["map_checksum"]) < 1e-9
+        assert heightfield.cell_size(m) == ref["resolution"]
+        tw = heightfield.towr_map(m)
+        assert list(tw.shape) == ref["towr_shape"]
+        path = tmp_path / (name + ".txt")
+        heightfield.write_height_file(str(path), tw)
+        text = open(path).read()
+        assert len(text) == ref["n_chars"] and text[:160] == ref["head"]
+        assert hashlib.sha256(text.encode()).hexdigest() == ref["sha256"]
+        if ref["text"] is not None:
+            assert text == ref["text"]
+        assert np.array_equal(heightfield.read_height_file(str(path)), tw)
+
+
+def test_csv_format(tmp_path):
+    from qtos_amd import csvio
+    rows = np.zeros((3, 37))
+    rows[:, 0] = [0, 0.001, 0.002]
+    rows[1, 1] = 6.9309e-07
+    rows[2, 3] = 0.240002
+    p = tmp_path / "t.csv"
+    csvio.write_csv(str(p), rows)
+    lines = open(p).read().split("\n")
+    assert lines[1].startswith("0.001,6.9309e-07,0,0,") and lines[2].split(",")[3] == "0.240002"
+    assert np.array_equal(csvio.read_csv(str(p)), rows)
+    assert csvio.COLUMN_MAP["HR_force"] == slice(34, 37)
+
+
+def test_c_abi_exports_every_declared_symbol(hip_lib):
+    hdr = open(os.path.join(ROOT, "include", "qtos_planner.h")).read()
+    names = sorted(set(re.findall(r"\b(qtos_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 14
+    from qtos_amd import capi
+    assert sorted(capi.EXPORTS) == names
+    for n in names:
+        assert hasattr(hip_lib, n), n
+
+
+def test_planner_dimensions_match_reference_log(hip_lib, cfg):
+    """Same NLP as logs/towr_log.out:40-52: 1040 variables (1005 free), 706 + 1024 constraints,
+    bound split 112 / 816 / 96 -- computed by the product's own host code."""
+    from qtos_amd import capi
+    dims = json.load(open(os.path.join(GOLDEN, "nlp_dims.json")))
+    d, act = capi.analyze(cfg)
+    assert (d.n_vars, d.n_cons, d.n_free) == (1040, 1730, dims["n_vars_free"])
+    assert (d.n_eq, d.n_ineq) == (dims["n_eq"], dims["n_ineq"])
+    assert (d.n_ineq_lower, d.n_ineq_both, d.n_ineq_upper) == (112, 816, 96)
+    assert (d.n_base_nodes, d.n_dyn_times, d.n_rom_times, d.n_rows_csv) == (51, 52, 64, 5001)
+    assert d.n_unknowns == d.n_free + d.n_eq_work and d.n_stages == -(-d.n_unknowns // 16)
+    assert act.max() <= d.front <= 128 and d.front % 16 == 0
+    # SURVEY.md 8d byte formula evaluated on the actual stage sizes
+    assert d.kkt_algorithmic_bytes == 8 * (16 * int(act.sum()) + 2 * d.n_unknowns)
+
+
+def test_knots100_structure(hip_lib):
+    from qtos_amd import capi
+    from qtos_amd.config import PlannerConfig
+    d, act = capi.analyze(PlannerConfig.knots100())
+    assert d.n_base_nodes == 101 and d.n_dyn_times == 102 and d.n_vars == 1640
+    assert act.max() <= d.front <= 128
+
+
+def test_bad_parameters_are_rejected(hip_lib, cfg):
+    from qtos_amd import capi
+    p = capi.params_from_config(cfg)
+    p.n_phases[0] = 4  # even: does not end in stance
+    d = capi.QtosDims()
+    assert hip_lib.qtos_analyze(C.byref(p), C.byref(d), None, 0) == -1
+    h = C.c_void_p()
+    assert hip_lib.qtos_planner_create(C.byref(p), 1, 0, C.byref(h)) < 0 and not h

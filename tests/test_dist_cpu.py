@@ -1,0 +1,52 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the shard + all-gather logic (dist.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from qtos_amd import dist as qd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, n = 7, 5  # ragged: 4 + 3
+    start = np.arange(B * 24, dtype=float).reshape(B, 24)
+    goal = np.arange(B * 3, dtype=float).reshape(B, 3)
+
+    def fake_solve(s, g):  # stands in for the GPU solve: nodes encode which problem they belong to
+        return s[:, :n] * 2.0 + g[:, :1], (s[:, 0] % 2).astype(np.int32)
+
+    nodes, status = qd.plan_sharded(fake_solve, start, goal)
+    np.save(os.path.join(tmp, "nodes%d.npy" % rank), nodes)
+    np.save(os.path.join(tmp, "status%d.npy" % rank), status)
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_batch():
+    from qtos_amd.dist import shard_bounds
+    for B in (1, 7, 256, 2048, 2049):
+        for W in (1, 2, 3, 8):
+            spans = [shard_bounds(B, W, r) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(W - 1))
+            assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+def test_world_size_2_gloo_allgather(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    B, n = 7, 5
+    start = np.arange(B * 24, dtype=float).reshape(B, 24)
+    goal = np.arange(B * 3, dtype=float).reshape(B, 3)
+    want_nodes = start[:, :n] * 2.0 + goal[:, :1]
+    want_status = (start[:, 0] % 2).astype(np.int32)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / ("nodes%d.npy" % r)), want_nodes)
+        assert np.array_equal(np.load(tmp_path / ("status%d.npy" % r)), want_status)

@@ -1,0 +1,314 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Every check goes through the C ABI
+(csrc/libqtos_planner.so via capi.py) and compares with the CPU oracle on the same seeded inputs,
+with the committed golden plans, or through size-independent properties at the full batch size.
+
+Floating-point tolerances (all double precision):
+  constraint values / Jacobian entries  1e-10 abs   (same formulas, different summation order)
+  one KKT solve                          1e-6 rel    (indefinite system, cond ~1e9, vs dense LAPACK)
+  full NLP solve, nodes                  1e-6 abs    (north_star allows 1e-3 m; we hold 1e-6)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_gv, oracle_problem, start_vector
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def planner(cfg):
+    from qtos_amd.capi import Planner
+    p = Planner(cfg, max_batch=256)
+    yield p
+    p.close()
+
+
+def _random_problems(n, seed, hard=False):
+    from qtos_amd import workloads
+    start, goal = workloads.flat_goals(n, seed)
+    if hard:
+        rng = np.random.default_rng(seed + 100)
+        goal[:, 0] += rng.uniform(0.0, 0.3, n)
+        goal[:, 1] += rng.uniform(-0.15, 0.15, n)
+    return start, goal
+
+
+def _oracle_solve(O, start, goal):
+    xs, infos = [], []
+    for s, g in zip(start, goal):
+        q = O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g, (0, 0, 0), (0, 0, 0), 0.0)
+        x, info = O.solve(q)
+        xs.append(x)
+        infos.append((info.status, info.iters, info.inf_pr))
+    return np.array(xs), infos
+
+
+def test_dims_match_reference_log(planner):
+    d = planner.dims
+    assert (d.n_vars, d.n_free, d.n_eq, d.n_ineq) == (1040, 1005, 706, 1024)
+    assert (d.n_ineq_lower, d.n_ineq_both, d.n_ineq_upper) == (112, 816, 96)
+
+
+def test_constraints_and_jacobian_match_oracle(planner, oracle, gv1):
+    rng = np.random.default_rng(0)
+    inp = gv1["inputs"]
+    B = 6
+    x = gv1["x"][None] + 0.02 * rng.standard_normal((B, planner.n))
+    lo, hi = oracle.var_bounds(oracle_problem(oracle, inp))
+    fx = lo == hi
+    x[:, fx] = lo[fx]
+    start = np.repeat(start_vector(inp)[None], B, 0)
+    goal = np.repeat(np.array(inp["g"])[None], B, 0)
+    g, J = planner.debug_eval(start, goal, x)
+    rk, vf, _ = planner.structure()
+    assert np.array_equal(vf == 0, fx)
+    for b in range(B):
+        go, Jo = oracle.constraints(x[b]), oracle.jacobian(x[b])
+        Jo[:, fx] = 0
+        Jo[rk == 0] = 0
+        assert np.abs(g[b] - go).max() < 1e-10
+        assert np.abs(J[b] - Jo).max() < 1e-10
+        assert np.array_equal(J[b] != 0, Jo != 0)
+
+
+def test_terrain_constraints_and_jacobian_match_oracle(cfg, gv1):
+    from oracle.oracle import Oracle
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    hxy, cell = workloads.exp5_terrain()
+    O = Oracle(cfg.oracle_dict(), height=hxy, hcell=cell)
+    P = Planner(cfg, max_batch=4)
+    P.set_heightfields(hxy, cell)
+    rng = np.random.default_rng(5)
+    inp = gv1["inputs"]
+    x = gv1["x"][None] + 0.02 * rng.standard_normal((3, P.n))
+    x[:, 612:752] += 0.3  # footholds spread over the ledges
+    lo, hi = O.var_bounds(oracle_problem(O, inp))
+    fx = lo == hi
+    x[:, fx] = lo[fx]
+    start = np.repeat(start_vector(inp)[None], 3, 0)
+    goal = np.repeat(np.array(inp["g"])[None], 3, 0)
+    g, J = P.debug_eval(start, goal, x)
+    rk, _, _ = P.structure()
+    for b in range(3):
+        go, Jo = O.constraints(x[b]), O.jacobian(x[b])
+        Jo[:, fx] = 0
+        Jo[rk == 0] = 0
+        assert np.abs(g[b] - go).max() < 1e-10
+        assert np.abs(J[b] - Jo).max() < 1e-9
+    P.close()
+
+
+def test_kkt_solve_matches_dense_reference(planner, oracle, gv1, cfg):
+    """One condensed KKT solve with random barrier weights vs LAPACK and vs the oracle's LDL^T."""
+    import ctypes as C
+    from oracle.oracle import lib as olib
+    rng = np.random.default_rng(1)
+    inp = gv1["inputs"]
+    B = 4
+    x = gv1["x"][None] + 0.01 * rng.standard_normal((B, planner.n))
+    lo, hi = oracle.var_bounds(oracle_problem(oracle, inp))
+    fx = lo == hi
+    x[:, fx] = lo[fx]
+    start = np.repeat(start_vector(inp)[None], B, 0)
+    goal = np.repeat(np.array(inp["g"])[None], B, 0)
+    rk, _, _ = planner.structure()
+    I = rk == 2
+    sig = np.zeros((B, planner.m))
+    w = np.zeros((B, planner.m))
+    sig[:, I] = 10.0 ** rng.uniform(-3, 3, (B, I.sum()))
+    w[:, I] = rng.standard_normal((B, I.sum()))
+    dx = planner.debug_newton(start, goal, x, sig, w)
+    free, E, Ii = np.nonzero(~fx)[0], np.nonzero(rk == 1)[0], np.nonzero(I)[0]
+    nf, nE = len(free), len(E)
+    for b in range(B):
+        Jo, go = oracle.jacobian(x[b]), oracle.constraints(x[b])
+        JE, JI = Jo[np.ix_(E, free)], Jo[np.ix_(Ii, free)]
+        K = np.zeros((nf + nE, nf + nE))
+        K[:nf, :nf] = cfg.delta_x * np.eye(nf) + JI.T @ (sig[b, Ii][:, None] * JI)
+        K[nf:, :nf] = JE
+        K[:nf, nf:] = JE.T
+        K[nf:, nf:] = -cfg.eps_dual * np.eye(nE)
+        rhs = np.concatenate([-JI.T @ w[b, Ii], -go[E]])
+        ref = np.linalg.solve(K, rhs)[:nf]
+        scale = np.abs(ref).max()
+        assert np.abs(dx[b, free] - ref).max() <= 1e-6 * scale
+        sol = rhs.copy()
+        Kc = np.ascontiguousarray(K)
+        assert olib().qo_ldlt_solve_dense(nf + nE, Kc.ctypes.data_as(C.POINTER(C.c_double)),
+                                          sol.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        assert np.abs(dx[b, free] - sol[:nf]).max() <= 1e-6 * scale
+        assert np.all(dx[b, fx] == 0)
+
+
+def test_full_solve_matches_oracle_on_seeded_batch(planner, oracle):
+    start, goal = _random_problems(12, seed=11)
+    nodes, status, iters, viol = planner.plan(start, goal)
+    xo, infos = _oracle_solve(oracle, start, goal)
+    assert (status == 0).all() and all(i[0] == 0 for i in infos)
+    assert [int(i) for i in iters] == [i[1] for i in infos]
+    assert np.abs(nodes - xo).max() < 1e-6
+    for b in range(len(start)):
+        assert oracle.max_violation(nodes[b]) <= 1e-4 + 1e-9
+        tr = planner.trace(b)
+        assert tr.shape[0] == iters[b] + 1 and abs(tr[0, 0] - 19.4) < 0.5
+
+
+def test_harder_goals_match_oracle(planner, oracle):
+    start, goal = _random_problems(6, seed=21, hard=True)
+    nodes, status, iters, viol = planner.plan(start, goal)
+    xo, infos = _oracle_solve(oracle, start, goal)
+    for b in range(len(start)):
+        assert int(status[b]) == infos[b][0]
+        if status[b] == 0:
+            assert np.abs(nodes[b] - xo[b]).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", ["gv1", "gv2"])
+def test_golden_inputs_p2_p3(planner, oracle, name):
+    gv = load_gv(name)
+    inp = gv["inputs"]
+    start, goal = start_vector(inp)[None], np.array(inp["g"])[None]
+    # P3 cold start: converges from the logged inf_pr 19.4 in O(10) iterations
+    nodes, status, iters, viol = planner.plan(start, goal)
+    assert status[0] == 0 and iters[0] <= 15 and viol[0] <= 1e-4
+    assert float("%.2e" % planner.trace(0)[0, 0]) == 19.4
+    xo, info = oracle.solve(oracle_problem(oracle, inp))
+    assert np.abs(nodes[0] - xo).max() < 1e-6
+    # P2 warm start at the reference's own plan: must stay within 1e-3 m of it
+    nodes, status, iters, viol = planner.plan(start, goal, warm=gv["x"][None])
+    assert status[0] == 0 and iters[0] <= 2
+    d = np.abs(nodes[0] - gv["x"])
+    assert d[:612].reshape(-1, 6)[:, :3].max() < 1e-3 and d[612:752].max() < 1e-3
+    # sampled CSV rows of the warm-started plan equal the reference's CSV to 1e-3
+    rows = planner.sample(nodes, inp["t0"])[0]
+    err = np.abs(rows[gv["row_idx"]] - gv["rows"])
+    if name == "gv2":
+        err[0] = 0
+    assert err[:, 0].max() < 1e-9 and err[:, 1:19].max() < 1e-3
+
+
+def test_sampler_matches_oracle_and_reference_csv(planner, oracle, gv1):
+    rows = planner.sample(gv1["x"][None], gv1["inputs"]["t0"])[0]
+    ro = oracle.sample(gv1["x"], gv1["inputs"]["t0"])
+    assert rows.shape == (5001, 37)
+    assert np.abs(rows - ro).max() < 1e-12
+    err = np.abs(rows[gv1["row_idx"]] - gv1["rows"])
+    assert err[:, 1:19].max() < 2e-5 and err[:, 25:].max() < 2e-4
+
+
+def test_full_batch_properties_and_determinism(planner, cfg):
+    """BASELINE configs[1]-sized batch on the reference transcription: size-independent properties."""
+    from qtos_amd import workloads
+    start, goal = workloads.flat_goals(256, seed=0)
+    n1, s1, i1, v1 = planner.plan(start, goal)
+    n2, s2, i2, v2 = planner.plan(start, goal)
+    assert np.array_equal(n1, n2) and np.array_equal(s1, s2)      # bitwise reproducible
+    assert (s1 == 0).all() and v1.max() <= cfg.tol and i1.max() <= 15
+    rk, vf, _ = planner.structure()
+    fixed = np.nonzero(vf == 0)[0]
+    # fixed variables carry the inputs exactly: start state, goal xy, zero final velocities
+    assert np.array_equal(n1[:, 0:3], start[:, 0:3]) and np.array_equal(n1[:, 306:309], start[:, 3:6])
+    nb = planner.dims.n_base_nodes - 1
+    assert np.array_equal(n1[:, 6 * nb:6 * nb + 2], goal[:, :2])
+    assert len(fixed) == 35
+    # batch order independence: a permuted batch gives the permuted result
+    perm = np.random.default_rng(0).permutation(256)
+    n3, _, _, _ = planner.plan(start[perm], goal[perm])
+    assert np.array_equal(n3, n1[perm])
+    # translation equivariance on flat ground: shifting start and goal in x shifts the plan
+    sh = start.copy()
+    sh[:, [0, 6, 9, 12, 15]] += 0.5
+    gsh = goal.copy()
+    gsh[:, 0] += 0.5
+    n4, s4, _, _ = planner.plan(sh[:16], gsh[:16])
+    xcols = np.zeros(planner.n, bool)
+    xcols[np.arange(0, 306, 6)] = True
+    for e in range(4):
+        off = 612 + 35 * e
+        for s in range(5):
+            xcols[off + 8 * s] = True
+        for s in range(4):
+            xcols[off + 8 * s + 3] = True
+    diff = n4 - n1[:16]
+    assert np.abs(diff[:, xcols] - 0.5).max() < 1e-6 and np.abs(diff[:, ~xcols]).max() < 1e-6
+
+
+def test_knots100_batch_matches_oracle(oracle):
+    """BASELINE configs[1] transcription (100 base polynomials): GPU vs oracle on a seeded sample."""
+    from oracle.oracle import Oracle
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig.knots100()
+    P = Planner(cfg, max_batch=256)
+    O = Oracle(cfg.oracle_dict())
+    assert P.n == O.n == 1640 and P.m == O.m
+    start, goal = workloads.flat_goals(256, seed=0)
+    nodes, status, iters, viol = P.plan(start, goal)
+    assert (status == 0).all() and viol.max() <= cfg.tol
+    xo, infos = _oracle_solve(O, start[:4], goal[:4])
+    assert np.abs(nodes[:4] - xo).max() < 1e-6
+    assert [int(i) for i in iters[:4]] == [i[1] for i in infos]
+    P.close()
+
+
+def test_step_terrain_batch(cfg):
+    """BASELINE configs[2]: exp_5 heightfield, terrain constraint active: stance feet end up ON the
+    terrain, swing apexes above it; sample checked against the oracle on the same terrain."""
+    from oracle.oracle import Oracle
+    from qtos_amd import heightfield, workloads
+    from qtos_amd.capi import Planner
+    hxy, cell = workloads.exp5_terrain()
+    start, goal = workloads.step_goals(64, seed=1, terrain=(hxy, cell))
+    P = Planner(cfg, max_batch=64)
+    P.set_heightfields(hxy, cell)
+    nodes, status, iters, viol = P.plan(start, goal)
+    ok = status == 0
+    assert ok.mean() >= 0.9
+    O = Oracle(cfg.oracle_dict(), height=hxy, hcell=cell)
+    for b in np.nonzero(ok)[0][:8]:
+        assert O.max_violation(nodes[b]) <= 1e-4 + 1e-9
+        for e in range(4):
+            off = 612 + 35 * e
+            for s in range(1, 5):
+                p = nodes[b, off + 8 * s: off + 8 * s + 3]
+                assert abs(p[2] - float(heightfield.height_at(hxy, cell, p[0], p[1]))) <= 1e-4
+    for b in range(3):
+        s, g = start[b], goal[b]
+        q = O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g, (0, 0, 0), (0, 0, 0), 0.0)
+        xo, info = O.solve(q)
+        assert int(status[b]) == info.status
+        if info.status == 0:
+            assert np.abs(nodes[b] - xo).max() < 1e-5
+    P.close()
+
+
+def test_local_planner_writes_reference_csv(tmp_path, gv1):
+    from qtos_amd import csvio, flags
+    from qtos_amd.planner import LocalPlanner
+    inp = gv1["inputs"]
+    args = {"-g": inp["g"], "-s": inp["s"], "-s_ang": [0, 0, 0], "-e1": inp["ee"][0], "-e2": inp["ee"][1],
+            "-e3": inp["ee"][2], "-e4": inp["ee"][3], "-t": 3.756, "-resolution": 0.01, "scripts": {}}
+    lp = LocalPlanner(max_batch=4)
+    out = tmp_path / "towr.csv"
+    assert lp.solve(args, out_csv=str(out)) == 0
+    rows = csvio.read_csv(str(out))
+    assert rows.shape == (5001, 37)
+    assert rows[0, 0] == 3.756 and abs(rows[-1, 0] - 8.756) < 1e-9
+    assert np.allclose(rows[0, 1:4], inp["s"]) and np.allclose(rows[0, 7:19], np.ravel(inp["ee"]))
+    assert np.allclose(rows[-1, 1:3], inp["g"][:2], atol=1e-6)
+    # first line is printed like the reference prints it (%g)
+    first = open(out).readline().strip().split(",")
+    assert first[0] == "3.756" and first[3] == "0.24"
+    # batch form returns one exit status per problem
+    assert lp.solve_batch([args, args]) == [0, 0]
+    # the argv twin accepts the reference's flag string
+    from qtos_amd import main as cli
+    out2 = tmp_path / "traj.csv"
+    assert cli.main(flags.cmd_args(args).split() + ["--out", str(out2)]) == 0
+    assert np.array_equal(csvio.read_csv(str(out2)), rows)
+    lp.close()
