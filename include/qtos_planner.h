@@ -37,6 +37,7 @@ typedef struct QtosParams {
   double nominal_stance[QTOS_NEE][3], max_dev[3];
   double mu, f_max, t_swing_avg;
   int honor_start_velocity; /* 0 = reference behaviour (plans start at rest), 1 = use s_vel */
+  int terrain_mode;         /* 0 bilinear heightfield (exact slope), 1 nearest cell (flat ledges) */
   int max_iter;
   double tol, mu_init, mu_min, delta_x, eps_dual;
 } QtosParams;

@@ -27,6 +27,7 @@ class QoParams(C.Structure):
         ("height", C.POINTER(C.c_double)),
         ("hnx", C.c_int), ("hny", C.c_int),
         ("hcell", C.c_double), ("hx0", C.c_double), ("hy0", C.c_double),
+        ("terrain_mode", C.c_int),
     ]
 
 
@@ -126,6 +127,7 @@ class Oracle:
         for k in range(3):
             p.max_dev[k] = cfg["max_dev"][k]
         p.mu, p.f_max, p.t_swing_avg = cfg["mu"], cfg["f_max"], cfg["t_swing_avg"]
+        p.terrain_mode = int(cfg.get("terrain_mode", 0))
         self._height = None
         if height is not None:
             self._height = np.ascontiguousarray(height, dtype=np.float64)

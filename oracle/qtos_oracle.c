@@ -296,6 +296,15 @@ static terr terrain_at(const qo_params *p, double x, double y) {
   if (!p->height) return t;
   double fx = (x - p->hx0) / p->hcell, fy = (y - p->hy0) / p->hcell;
   double mx = p->hnx - 1, my = p->hny - 1;
+  if (p->terrain_mode == 1) { /* nearest cell: ledges stay flat, steps are jumps */
+    int jx = (int)floor(fx + 0.5), jy = (int)floor(fy + 0.5);
+    if (jx < 0) jx = 0;
+    if (jy < 0) jy = 0;
+    if (jx > p->hnx - 1) jx = p->hnx - 1;
+    if (jy > p->hny - 1) jy = p->hny - 1;
+    t.h = p->height[jx * p->hny + jy];
+    return t;
+  }
   int cx = 0, cy = 0; /* clamped => zero gradient in that direction */
   if (fx <= 0) { fx = 0; cx = 1; }
   if (fx >= mx) { fx = mx; cx = 1; }

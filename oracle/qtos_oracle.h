@@ -47,6 +47,7 @@ typedef struct {
   const double *height;
   int hnx, hny;
   double hcell, hx0, hy0;
+  int terrain_mode; /* 0 bilinear (C0, exact slope), 1 nearest cell (piecewise constant, zero slope) */
 } qo_params;
 
 /* One planning problem = the reference's solver flags (QTOS/utils.py:26 _flags). */

@@ -23,7 +23,7 @@ class QtosParams(C.Structure):
         ("mass", C.c_double), ("gravity", C.c_double), ("inertia_b", C.c_double * 9),
         ("nominal_stance", (C.c_double * 3) * NEE), ("max_dev", C.c_double * 3),
         ("mu", C.c_double), ("f_max", C.c_double), ("t_swing_avg", C.c_double),
-        ("honor_start_velocity", C.c_int),
+        ("honor_start_velocity", C.c_int), ("terrain_mode", C.c_int),
         ("max_iter", C.c_int),
         ("tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
         ("delta_x", C.c_double), ("eps_dual", C.c_double),
@@ -115,6 +115,7 @@ def params_from_config(cfg):
         p.max_dev[k] = cfg.max_deviation[k]
     p.mu, p.f_max, p.t_swing_avg = cfg.friction, cfg.force_limit, cfg.t_swing_avg
     p.honor_start_velocity = int(cfg.honor_start_velocity)
+    p.terrain_mode = int(cfg.terrain_mode)
     p.max_iter, p.tol = cfg.max_iter, cfg.tol
     p.mu_init, p.mu_min, p.delta_x, p.eps_dual = cfg.mu_init, cfg.mu_min, cfg.delta_x, cfg.eps_dual
     return p

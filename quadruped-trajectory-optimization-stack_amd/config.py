@@ -67,6 +67,12 @@ class PlannerConfig:
     # The reference solver ignores s_vel / s_ang_vel (towr.csv rows 1255.. restart from rest);
     # set True to start from the hand-over velocities instead.
     honor_start_velocity: bool = False
+    # Heightfield lookup between grid points: 0 = bilinear (continuous, exact slope in the Jacobian),
+    # 1 = nearest cell (ledges stay flat, steps are jumps).  The fork's choice is unknown; the
+    # reference upsamples its tiles by replication (QTOS/generateHeightField.py:39-56), i.e. its
+    # terrain IS piecewise constant, and on the exp_5 steps nearest-cell converges in 4-7
+    # iterations where the 9 mm bilinear ramps (slope 2.7) stall a third of the solves.
+    terrain_mode: int = 1
     hz: float = 1000.0                     # CSV sampling rate (scripts/run.py consumes 1 kHz rows)
     # solver
     max_iter: int = 40
@@ -100,4 +106,5 @@ class PlannerConfig:
                     dt_base=self.dt_base, dt_dyn=self.dt_dynamic, dt_rom=self.dt_range_of_motion,
                     force_polys_per_stance=self.force_polys_per_stance, mass=self.mass,
                     gravity=self.gravity, inertia_b=self.inertia_b, max_dev=self.max_deviation,
-                    mu=self.friction, f_max=self.force_limit, t_swing_avg=self.t_swing_avg)
+                    mu=self.friction, f_max=self.force_limit, t_swing_avg=self.t_swing_avg,
+                    terrain_mode=self.terrain_mode)

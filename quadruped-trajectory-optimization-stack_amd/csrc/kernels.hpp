@@ -46,7 +46,7 @@ struct DevPlan {
   double tol, mu_init, mu_min, delta_x, eps_dual;
   int max_iter;
   const double *height;
-  int n_maps, hnx, hny;
+  int n_maps, hnx, hny, terrain_mode;
   double hcell, hx0, hy0;
   long long g_doubles, panel_stride;  // per problem
 };
@@ -157,6 +157,13 @@ __device__ inline Terr terrain_at(const DevPlan &P, int map, double x, double y)
   const double *H = P.height + (size_t)map * P.hnx * P.hny;
   double fx = (x - P.hx0) / P.hcell, fy = (y - P.hy0) / P.hcell;
   const double mx = P.hnx - 1, my = P.hny - 1;
+  if (P.terrain_mode == 1) {  // nearest cell: ledges stay flat, steps are jumps
+    int jx = (int)floor(fx + 0.5), jy = (int)floor(fy + 0.5);
+    jx = min(max(jx, 0), P.hnx - 1);
+    jy = min(max(jy, 0), P.hny - 1);
+    t.h = H[jx * P.hny + jy];
+    return t;
+  }
   bool cx = false, cy = false;
   if (fx <= 0) { fx = 0; cx = true; }
   if (fx >= mx) { fx = mx; cx = true; }

@@ -65,11 +65,14 @@ def read_height_file(path):
     return np.array(rows)
 
 
-def height_at(height_xy, cell, x, y, x0=-1.0, y0=-1.0):
-    """Bilinear terrain height, clamped at the border: the interpolation the planner kernels use."""
+def height_at(height_xy, cell, x, y, x0=-1.0, y0=-1.0, mode=0):
+    """Terrain height as the planner kernels evaluate it: mode 0 bilinear (clamped at the border),
+    mode 1 nearest cell."""
     h = np.asarray(height_xy, float)
     fx = np.clip((np.asarray(x, float) - x0) / cell, 0, h.shape[0] - 1)
     fy = np.clip((np.asarray(y, float) - y0) / cell, 0, h.shape[1] - 1)
+    if mode == 1:
+        return h[np.floor(fx + 0.5).astype(int), np.floor(fy + 0.5).astype(int)]
     ix = np.clip(np.floor(fx).astype(int), 0, max(h.shape[0] - 2, 0))
     iy = np.clip(np.floor(fy).astype(int), 0, max(h.shape[1] - 2, 0))
     ix1 = np.minimum(ix + 1, h.shape[0] - 1)

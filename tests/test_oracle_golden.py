@@ -102,10 +102,15 @@ def test_jacobian_against_finite_differences(oracle, gv1):
         assert np.abs(fd - J[:, c]).max() <= 1e-6 * (1 + np.abs(J[:, c]).max())
 
 
-def test_terrain_bilinear_and_jacobian(cfg):
+def test_terrain_bilinear_and_jacobian():
     from oracle.oracle import Oracle
     from qtos_amd import heightfield, workloads
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig.reference_compat(terrain_mode=0)
     hxy, cell = workloads.exp5_terrain()
+    On = Oracle(PlannerConfig.reference_compat(terrain_mode=1).oracle_dict(), height=hxy, hcell=cell)
+    assert On.terrain_height(0.33, 0.0) == 0.025 and On.terrain_height(0.1, 0.0) == 0.0  # flat ledges
+    assert abs(On.terrain_height(0.33, 0.0) - float(heightfield.height_at(hxy, cell, 0.33, 0.0, mode=1))) == 0
     O = Oracle(cfg.oracle_dict(), height=hxy, hcell=cell)
     rng = np.random.default_rng(0)
     for _ in range(50):
