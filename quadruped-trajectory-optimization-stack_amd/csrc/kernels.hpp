@@ -38,6 +38,9 @@ struct DevPlan {
   const IqBlock *iq_blocks;
   const short *iq_slots;
   int max_stage_g;
+  const int *srec, *srec_off, *pack_src, *drec_off;  // packed per-stage records (symbolic.hpp)
+  int max_srec, max_drec, stream_len;
+  int dbg;  // timing ablation mask (QTOS_DBG), 0 in production
   const double *con_lo, *con_hi;
   const int *row_kind;
   const InitDesc *init;
@@ -54,7 +57,7 @@ struct DevPlan {
 struct DevWork {
   const double *start, *goal, *warm;
   const int *map_id;
-  double *x, *xt, *g, *gt, *s, *zl, *zu, *ds, *dzl, *dzu, *sig, *w, *G, *panel, *dx;
+  double *x, *xt, *g, *gt, *s, *zl, *zu, *ds, *dzl, *dzu, *sig, *w, *G, *panel, *dx, *stream;
   double *mu, *viol, *trace;
   int *status, *iters, *done, *n_active;
 };
@@ -435,6 +438,25 @@ __device__ inline void record_trace(const DevPlan &P, const DevWork &W, int b, i
   }
 }
 
+// Gathers this problem's linearisation into the stage-ordered stream k_kkt reads (one contiguous
+// slice per stage).  Runs right after the values were produced, while they are hot in L2.
+__device__ inline void pack_stream(const DevPlan &P, const double *G, const double *g, const double *sig,
+                                   const double *w, double *stream) {
+  for (int i = threadIdx.x; i < P.stream_len; i += blockDim.x) {
+    const int s = P.pack_src[i], kind = s >> 28, idx = s & 0x0fffffff;
+    double v;
+    switch (kind) {
+      case 0: v = G[idx]; break;
+      case 1: v = P.g_static[idx]; break;
+      case 2: v = -g[idx]; break;
+      case 3: v = sig[idx]; break;
+      case 4: v = w[idx]; break;
+      default: v = P.piv_diag[idx]; break;
+    }
+    stream[i] = v;
+  }
+}
+
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
@@ -506,6 +528,9 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
   __syncthreads();
   eval_all<true>(P, map, x, g, W.G + (size_t)b * P.g_doubles);
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m);
+  __syncthreads();
+  pack_stream(P, W.G + (size_t)b * P.g_doubles, g, W.sig + (size_t)b * m, W.w + (size_t)b * m,
+              W.stream + (size_t)b * P.stream_len);
 }
 
 // =================================================================================================
@@ -543,6 +568,16 @@ __device__ inline void invert16(double *Bm /* 16 x PLD in LDS, symmetric */, int
   for (int j = 0; j < 4; ++j) Bm[i * PLD + 4 * c + j] = a[j];
 }
 
+// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
+// stall every phase on the in-flight prefetch loads and factor-panel stores (cdna_hip_programming.md
+// section 5 "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int PFD = 6, PFS = 6;  // per-thread prefetch registers: doubles / ints of the next stage's records
+
 __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
   if (b >= B || W.done[b]) return;
@@ -554,155 +589,216 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   double *Wn = Pn + (F + 1) * PLD;    // (F+1) * PLD
   double *Bm = Wn + (F + 1) * PLD;    // PIV * PLD
   double *xs = Bm + PIV * PLD;        // F
-  double *Gs = xs + F;                // max_stage_g: this stage's slice of G
-  __shared__ int ps[PIV];
-  const int m = P.n_cons, n = P.n_vars;
-  const double *G = W.G + (size_t)b * P.g_doubles;
-  const double *g = W.g + (size_t)b * m, *sig = W.sig + (size_t)b * m, *wv = W.w + (size_t)b * m;
+  double *dbuf = xs + F;              // max_drec: this stage's dynamic record
+  int *sbuf = (int *)(dbuf + P.max_drec);   // max_srec: this stage's static record
+  int *soff = sbuf + P.max_srec;      // n_stages + 1
+  int *doff = soff + P.n_stages + 1;  // n_stages + 1
+  const int n = P.n_vars;
+  const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
   double *dx = W.dx + (size_t)b * n;
-  const int pstride = (F + PIV + 1) * PIV;  // doubles per stage: C (F x 16), Binv (16 x 16), b1 (16)
+  const int pstride = (F + PIV + 1) * PIV;  // doubles per stage: Binv (16 x 16), b1 (16), C (hi x 16)
 
   for (int i = tid; i < ntri; i += KT) A[i] = 0.0;
   for (int v = tid; v < n; v += KT) dx[v] = 0.0;
+  for (int i = tid; i <= P.n_stages; i += KT) { soff[i] = P.srec_off[i]; doff[i] = P.drec_off[i]; }
+  __syncthreads();
+  // records of stage 0
+  for (int i = tid; i < soff[1] - soff[0]; i += KT) sbuf[i] = P.srec[soff[0] + i];
+  for (int i = tid; i < doff[1] - doff[0]; i += KT) dbuf[i] = stream[doff[0] + i];
+  __syncthreads();
 
-  for (int k = 0; k < P.n_stages; ++k) {
-    const StageDesc S = P.stages[k];
-    // ---- stage's slice of G: one contiguous, coalesced read into LDS --------------------------
-    for (int i = tid; i < S.g_len; i += KT) Gs[i] = G[S.g_begin + i];
-    if (tid < PIV) ps[tid] = P.piv_slot[k * PIV + tid];
-    __syncthreads();
-    // ---- assembly --------------------------------------------------------------------------------
-    if (tid < PIV) A[tri(ps[tid], ps[tid])] += P.piv_diag[k * PIV + tid];
-    for (int i = S.ent_begin + tid; i < S.ent_end; i += KT) {
-      const EqEntry e = P.eq_entries[i];
-      A[trs(e.slot_r, e.slot_c)] += e.src >= 0 ? G[e.src] : P.g_static[-e.src - 1];
+  for (int k = 0; k < ((P.dbg & 32) ? 0 : P.n_stages); ++k) {
+    // ---- prefetch the next stage's records into registers (lands while this stage computes) ----
+    double pfd[PFD];
+    int pfs[PFS];
+    int nd = 0, ns = 0;
+    if (k + 1 < P.n_stages) {
+      nd = doff[k + 2] - doff[k + 1];
+      ns = soff[k + 2] - soff[k + 1];
+      const double *dsrc = stream + doff[k + 1];
+      const int *ssrc = P.srec + soff[k + 1];
+#pragma unroll
+      for (int j = 0; j < PFD; ++j) { const int i = tid + j * KT; pfd[j] = i < nd ? dsrc[i] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < PFS; ++j) { const int i = tid + j * KT; pfs[j] = i < ns ? ssrc[i] : 0; }
     }
-    for (int i = S.rhs_begin + tid; i < S.rhs_end; i += KT) {
-      const EqRhs e = P.eq_rhs[i];
-      A[tri(F, e.slot)] -= g[e.row];
+    const int n_ent = sbuf[0], n_rhs = sbuf[1], n_iq = sbuf[2], hi = sbuf[3];
+    const int *ps = sbuf + 4;
+    // ---- assembly from the LDS records ---------------------------------------------------------
+    if (tid < PIV) A[tri(ps[tid], ps[tid])] += dbuf[tid];
+    {
+      const int *eidx = sbuf + 4 + PIV;
+      const double *eval = dbuf + PIV;
+      for (int i = tid; i < n_ent; i += KT) A[eidx[i]] += eval[i];
+      const int *rsl = eidx + n_ent;
+      const double *rval = eval + n_ent;
+      for (int i = tid; i < n_rhs; i += KT) A[tri(F, rsl[i])] += rval[i];
     }
-    for (int q = S.iq_begin; q < S.iq_end; ++q) {
-      const IqBlock Q = P.iq_blocks[q];
-      const short *sl = P.iq_slots + Q.slot_off;
-      const double *Gb = Gs + Q.gloc;
-      __syncthreads();
-      const int npair = (Q.n * (Q.n + 1)) >> 1;
-      for (int i = tid; i < npair + Q.n; i += KT) {
+    const int *iqh = sbuf + 4 + PIV + n_ent + n_rhs;
+    for (int q = 0; q < ((P.dbg & 2) ? 0 : n_iq); ++q) {
+      const int qm = iqh[4 * q], qn = iqh[4 * q + 1];
+      const double *Gb = dbuf + iqh[4 * q + 2];
+      const int *sl = sbuf + iqh[4 * q + 3];
+      const double *sg = Gb + qm * qn, *wq = sg + qm;
+      lds_barrier();
+      const int npair = (qn * (qn + 1)) >> 1;
+      for (int i = tid; i < npair + qn; i += KT) {
         if (i < npair) {
-          // (a, c) with c <= a from the linear index
-          int a = (int)((sqrt(8.0 * i + 1.0) - 1.0) * 0.5);
+          int a = (int)((sqrtf(8.0f * i + 1.0f) - 1.0f) * 0.5f);
           while (((a + 1) * (a + 2)) >> 1 <= i) ++a;
           while ((a * (a + 1)) >> 1 > i) --a;
           const int c = i - ((a * (a + 1)) >> 1);
           double acc = 0;
-          for (int r = 0; r < Q.m; ++r) acc += sig[Q.row0 + r] * Gb[r * Q.n + a] * Gb[r * Q.n + c];
+          for (int r = 0; r < qm; ++r) acc += sg[r] * Gb[r * qn + a] * Gb[r * qn + c];
           A[trs(sl[a], sl[c])] += acc;
         } else {
           const int a = i - npair;
           double acc = 0;
-          for (int r = 0; r < Q.m; ++r) acc += Gb[r * Q.n + a] * wv[Q.row0 + r];
+          for (int r = 0; r < qm; ++r) acc += Gb[r * qn + a] * wq[r];
           A[tri(F, sl[a])] -= acc;
         }
       }
     }
-    __syncthreads();
-    // ---- pivot columns -> panel; pivot block -> Bm ------------------------------------------
-    for (int i = tid; i < (F + 1) * PIV; i += KT) {
-      const int r = i / PIV, j = i - r * PIV;
+    lds_barrier();
+    // ---- pivot columns -> panel (rows 0..hi-1 and the rhs row F); pivot block -> Bm -----------
+    const int hi16 = (hi + 15) & ~15;   // rows hi..hi16-1 are inactive slots: their entries are zero
+    for (int i = tid; i < (hi16 + 1) * PIV; i += KT) {
+      const int rr = i >> 4, j = i & 15;
+      const int r = rr < hi16 ? rr : F;
       Pn[r * PLD + j] = A[trs(r, ps[j])];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < PIV * PIV) {
       const int i = tid / PIV, j = tid - i * PIV;
       Bm[i * PLD + j] = Pn[ps[i] * PLD + j];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid >= 256 && tid < 256 + PIV * PIV) {  // pivot rows leave the panel (not part of the border)
       const int t = tid - 256, i = t / PIV, j = t - i * PIV;
       Pn[ps[i] * PLD + j] = 0.0;
     }
-    if (tid < 64) invert16(Bm, tid);
-    __syncthreads();
+    if (tid < 64 && !(P.dbg & 1)) invert16(Bm, tid);
+    lds_barrier();
     // ---- Wn = Pn * Binv -------------------------------------------------------------------------
-    for (int i = tid; i < (F + 1) * PIV; i += KT) {
-      const int r = i / PIV, j = i - r * PIV;
+    for (int i = tid; i < ((P.dbg & 16) ? 0 : (hi16 + 1) * PIV); i += KT) {
+      const int rr = i >> 4, j = i & 15;
+      const int r = rr < hi16 ? rr : F;
       double acc = 0;
 #pragma unroll
       for (int q = 0; q < PIV; ++q) acc += Pn[r * PLD + q] * Bm[q * PLD + j];
       Wn[r * PLD + j] = acc;
     }
-    __syncthreads();
-    // ---- Schur complement on the lower triangle: A[r][c] -= Wn[r][:] . Pn[c][:], c <= r <= F ---
-    {
-      const int nt4 = (F + 4) / 4;  // 4-row tiles covering rows 0..F
-      const int ntile = (nt4 * (nt4 + 1)) >> 1;
-      for (int t = tid; t < ntile; t += KT) {
-        int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-        while (((tr + 1) * (tr + 2)) >> 1 <= t) ++tr;
-        while ((tr * (tr + 1)) >> 1 > t) --tr;
-        const int tc = t - ((tr * (tr + 1)) >> 1);
-        const int r0 = tr * 4, c0 = tc * 4;
-        double acc[4][4] = {{0}};
+    lds_barrier();
+    // ---- Schur complement A[r][c] -= Wn[r][:] . Pn[c][:] on the lower triangle of the active slots,
+    //      16 x 16 tiles on the f64 matrix cores (v_mfma_f64_16x16x4_f64: lane l feeds
+    //      A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; result reg g holds
+    //      D[(l >> 4) + 4 g][l & 15]); the rhs row F is a short VALU pass ------------------------
+    if (!(P.dbg & 4)) {
+      const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+      const int nt16 = hi16 >> 4, ntile = (nt16 * (nt16 + 1)) >> 1;
+      for (int t = wv; t < ntile; t += KT / 64) {
+        int R = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+        while (((R + 1) * (R + 2)) >> 1 <= t) ++R;
+        while ((R * (R + 1)) >> 1 > t) --R;
+        const int C = t - ((R * (R + 1)) >> 1);
+        const int col = 16 * C + li;
+        d4_t acc;
 #pragma unroll
-        for (int q = 0; q < PIV; ++q) {
-          double wr[4], pc[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) wr[i] = (r0 + i <= F) ? Wn[(r0 + i) * PLD + q] : 0.0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) pc[j] = (c0 + j <= F) ? Pn[(c0 + j) * PLD + q] : 0.0;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] += wr[i] * pc[j];
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * R + lk + 4 * g;
+          acc[g] = col <= row ? A[tri(row, col)] : 0.0;
         }
+        const double *wrow = Wn + (16 * R + li) * PLD + lk;
+        const double *prow = Pn + (16 * C + li) * PLD + lk;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-wrow[4 * s4], prow[4 * s4], acc, 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = r0 + i, c = c0 + j;
-            if (r <= F && c <= r && c < F) A[tri(r, c)] -= acc[i][j];
-          }
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * R + lk + 4 * g;
+          if (col <= row) A[tri(row, col)] = acc[g];
+        }
+      }
+      for (int c = tid; c < hi16; c += KT) {
+        double acc = 0;
+#pragma unroll
+        for (int q = 0; q < PIV; ++q) acc += Wn[F * PLD + q] * Pn[c * PLD + q];
+        A[tri(F, c)] -= acc;
       }
     }
-    // ---- factor panel to HBM: C (F x 16), Binv (16 x 16), b1 (16) -----------------------------
+    // ---- factor panel to HBM: Binv (16 x 16), b1 (16), C (hi x 16) ----------------------------
     {
       double *pk = panel + (size_t)k * pstride;
-      for (int i = tid; i < F * PIV; i += KT) pk[i] = Pn[(i / PIV) * PLD + (i % PIV)];
-      if (tid < PIV * PIV) pk[F * PIV + tid] = Bm[(tid / PIV) * PLD + (tid % PIV)];
-      if (tid < PIV) pk[(F + PIV) * PIV + tid] = Pn[F * PLD + tid];
+      if (tid < PIV * PIV) pk[tid] = Bm[(tid / PIV) * PLD + (tid % PIV)];
+      if (tid < PIV) pk[PIV * PIV + tid] = Pn[F * PLD + tid];
+      for (int i = tid; i < hi * PIV; i += KT) pk[PIV * PIV + PIV + i] = Pn[(i >> 4) * PLD + (i & 15)];
     }
-    __syncthreads();
-    // ---- retire the pivots: their rows / columns are recycled by later unknowns ---------------
-    for (int i = tid; i < PIV * (F + 1); i += KT) {
-      const int j = i / (F + 1), r = i - j * (F + 1);
-      A[trs(r, ps[j])] = 0.0;
+    lds_barrier();
+    // ---- retire the pivots; install the next stage's records ----------------------------------
+    for (int i = tid; i < PIV * (hi + 1); i += KT) {
+      const int j = i / (hi + 1), rr = i - j * (hi + 1);
+      A[trs(rr < hi ? rr : F, ps[j])] = 0.0;
     }
-    __syncthreads();
+    lds_barrier();
+    if (k + 1 < P.n_stages) {
+#pragma unroll
+      for (int j = 0; j < PFD; ++j) { const int i = tid + j * KT; if (i < nd) dbuf[i] = pfd[j]; }
+#pragma unroll
+      for (int j = 0; j < PFS; ++j) { const int i = tid + j * KT; if (i < ns) sbuf[i] = pfs[j]; }
+    }
+    lds_barrier();
   }
-  // ---- backward substitution: x1 = Binv (b1 - C^T x2) -------------------------------------------
+  // ---- backward substitution: x1 = Binv (b1 - C^T x2), panels prefetched one stage ahead -------
+  __syncthreads();  // drains the factor-panel stores: they are read back below
   for (int i = tid; i < F; i += KT) xs[i] = 0.0;
+  constexpr int PFB = 5;  // (F + 17) * 16 / 512 <= 5 for F <= 128
+  double pfb[PFB];
+  {
+    const double *pk = panel + (size_t)(P.n_stages - 1) * pstride;
+    const int hi = P.srec[soff[P.n_stages - 1] + 3], cnt = (hi + PIV + 1) * PIV;
+#pragma unroll
+    for (int j = 0; j < PFB; ++j) { const int i = tid + j * KT; pfb[j] = i < cnt ? pk[i] : 0.0; }
+  }
   __syncthreads();
-  for (int k = P.n_stages - 1; k >= 0; --k) {
-    const double *pk = panel + (size_t)k * pstride;
+  for (int k = (P.dbg & 8) ? -1 : P.n_stages - 1; k >= 0; --k) {
+    const int hi = P.srec[soff[k] + 3], cnt = (hi + PIV + 1) * PIV;
+    // install panel k: Binv -> Bm, b1 -> Wn[0..15] scratch row 40, C -> Pn
+#pragma unroll
+    for (int j = 0; j < PFB; ++j) {
+      const int i = tid + j * KT;
+      if (i < cnt) {
+        if (i < PIV * PIV) Bm[(i / PIV) * PLD + (i % PIV)] = pfb[j];
+        else if (i < PIV * PIV + PIV) Wn[40 * PLD + (i - PIV * PIV)] = pfb[j];
+        else { const int e = i - PIV * PIV - PIV; Pn[(e / PIV) * PLD + (e % PIV)] = pfb[j]; }
+      }
+    }
+    if (tid < PIV) sbuf[tid] = P.srec[soff[k] + 4 + tid];
+    __syncthreads();
+    if (k > 0) {  // prefetch panel k-1
+      const double *pk = panel + (size_t)(k - 1) * pstride;
+      const int hi2 = P.srec[soff[k - 1] + 3], cnt2 = (hi2 + PIV + 1) * PIV;
+#pragma unroll
+      for (int j = 0; j < PFB; ++j) { const int i = tid + j * KT; pfb[j] = i < cnt2 ? pk[i] : 0.0; }
+    }
     // partial sums: thread (j, q) accumulates rows r = q, q+32, ... of column j
-    const int j = tid & (PIV - 1), q = tid >> 4;  // q in 0..31
-    double acc = 0;
-    for (int r = q; r < F; r += KT / PIV) acc += pk[r * PIV + j] * xs[r];
-    Wn[q * PLD + j] = acc;
-    if (tid < PIV * PIV) Bm[(tid / PIV) * PLD + (tid % PIV)] = pk[F * PIV + tid];
-    if (tid < PIV) ps[tid] = P.piv_slot[k * PIV + tid];
+    {
+      const int j = tid & (PIV - 1), q = tid >> 4;  // q in 0..31
+      double acc = 0;
+      for (int r = q; r < hi; r += KT / PIV) acc += Pn[r * PLD + j] * xs[r];
+      Wn[q * PLD + j] = acc;
+    }
     __syncthreads();
     if (tid < PIV) {
-      double t = pk[(F + PIV) * PIV + tid];
+      double t = Wn[40 * PLD + tid];
       for (int qq = 0; qq < KT / PIV; ++qq) t -= Wn[qq * PLD + tid];
-      Pn[tid] = t;
+      Wn[41 * PLD + tid] = t;
     }
     __syncthreads();
     if (tid < PIV) {
       double v = 0;
-      for (int i = 0; i < PIV; ++i) v += Bm[tid * PLD + i] * Pn[i];
-      xs[ps[tid]] = v;
+      for (int i = 0; i < PIV; ++i) v += Bm[tid * PLD + i] * Wn[41 * PLD + i];
+      xs[sbuf[tid]] = v;
       const int u = P.piv_unknown[k * PIV + tid];
       if (u >= 0 && u < n) dx[u] = v;
     }
@@ -803,6 +899,9 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   __syncthreads();
   eval_all<true>(P, map, x, g, W.G + (size_t)b * P.g_doubles);
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m);
+  __syncthreads();
+  pack_stream(P, W.G + (size_t)b * P.g_doubles, g, W.sig + (size_t)b * m, W.w + (size_t)b * m,
+              W.stream + (size_t)b * P.stream_len);
 }
 
 // =================================================================================================

@@ -126,6 +126,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(M.con_lo, &D.con_lo)); TRY(p->upload(M.con_hi, &D.con_hi));
   TRY(p->upload(M.row_kind, &D.row_kind)); TRY(p->upload(M.init, &D.init));
   D.max_stage_g = S.max_stage_g;
+  TRY(p->upload(S.srec, &D.srec)); TRY(p->upload(S.srec_off, &D.srec_off));
+  TRY(p->upload(S.pack_src, &D.pack_src)); TRY(p->upload(S.drec_off, &D.drec_off));
+  D.max_srec = S.max_srec; D.max_drec = S.max_drec; D.stream_len = (int)S.pack_src.size();
   D.mass = M.P.mass; D.gravity = M.P.gravity; D.mu_fric = M.P.mu; D.f_max = M.P.f_max; D.T = M.T;
   for (int i = 0; i < 9; ++i) D.Ib[i] = M.P.inertia_b[i];
   for (int e = 0; e < NEE; ++e)
@@ -133,12 +136,19 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.tol = M.P.tol; D.mu_init = M.P.mu_init; D.mu_min = M.P.mu_min; D.delta_x = M.P.delta_x;
   D.eps_dual = M.P.eps_dual; D.max_iter = M.P.max_iter;
   D.terrain_mode = M.P.terrain_mode;
+  D.dbg = getenv("QTOS_DBG") ? atoi(getenv("QTOS_DBG")) : 0;
   D.g_doubles = S.g_doubles;
   D.panel_stride = (long long)S.n_stages * (S.front + PIV + 1) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  size_t lds_d = (size_t)((F + 1) * (F + 2) / 2) + 2 * (size_t)(F + 1) * PLD + PIV * PLD + F + S.max_stage_g + 8;
-  p->kkt_lds = lds_d * sizeof(double);
+  size_t lds_d = (size_t)((F + 1) * (F + 2) / 2) + 2 * (size_t)(F + 1) * PLD + PIV * PLD + F + S.max_drec + 8;
+  p->kkt_lds = lds_d * sizeof(double) + ((size_t)S.max_srec + 2 * (size_t)(S.n_stages + 1) + 8) * sizeof(int);
+  if (S.max_drec > PFD * KT || S.max_srec > PFS * KT || (F + PIV + 1) * PIV > 5 * KT) {
+    p->err = "stage record exceeds the prefetch registers";
+    fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints)\n", S.max_drec, S.max_srec);
+    qtos_planner_destroy(p);
+    return -4;
+  }
   if (p->kkt_lds > 160 * 1024 - 256) {
     p->err = "front too large for LDS";
     fprintf(stderr, "qtos: front %d needs %zu B of LDS\n", F, p->kkt_lds);
@@ -165,6 +175,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.dzl, Bm * m)); TRY(p->alloc(&W.dzu, Bm * m)); TRY(p->alloc(&W.sig, Bm * m));
   TRY(p->alloc(&W.w, Bm * m)); TRY(p->alloc(&W.G, Bm * (size_t)S.g_doubles));
   TRY(p->alloc(&W.panel, Bm * (size_t)D.panel_stride));
+  TRY(p->alloc(&W.stream, Bm * (size_t)S.pack_src.size()));
   TRY(p->alloc(&W.mu, Bm)); TRY(p->alloc(&W.viol, Bm));
   TRY(p->alloc(&W.trace, Bm * (size_t)(M.P.max_iter + 1) * 4));
   TRY(p->alloc(&W.status, Bm)); TRY(p->alloc(&W.iters, Bm)); TRY(p->alloc(&W.done, Bm));
@@ -362,6 +373,14 @@ __global__ __launch_bounds__(256) void k_debug_eval(DevPlan P, DevWork W, int B)
   if (threadIdx.x == 0) W.done[b] = 0;
 }
 
+__global__ __launch_bounds__(256) void k_debug_pack(DevPlan P, DevWork W, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const size_t m = P.n_cons;
+  pack_stream(P, W.G + (size_t)b * P.g_doubles, W.g + b * m, W.sig + b * m, W.w + b * m,
+              W.stream + (size_t)b * P.stream_len);
+}
+
 static int debug_upload(QtosPlanner *p, int B, const double *start, const double *goal, const int *map_id, const double *nodes, DevWork *W) {
   if (!p || B < 1 || B > p->max_batch || !start || !goal || !nodes) return -1;
   HIPCHK(p, hipSetDevice(p->device));
@@ -408,6 +427,7 @@ int qtos_debug_newton(QtosPlanner *p, int B, const double *start, const double *
   const size_t n = p->M.n_vars, m = p->M.n_cons;
   HIPCHK(p, hipMemcpy(W.sig, sig, (size_t)B * m * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(p, hipMemcpy(W.w, w, (size_t)B * m * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_debug_pack, dim3(B), dim3(256), 0, 0, p->dp, W, B);
   hipLaunchKernelGGL(k_kkt, dim3(B), dim3(KT), p->kkt_lds, 0, p->dp, W, B);
   HIPCHK(p, hipDeviceSynchronize());
   HIPCHK(p, hipMemcpy(dx_out, W.dx, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost));

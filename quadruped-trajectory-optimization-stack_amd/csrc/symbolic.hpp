@@ -56,7 +56,16 @@ struct Symbolic {
   std::vector<EqRhs> eq_rhs;
   std::vector<IqBlock> iq_blocks;
   std::vector<short> iq_slots;    // front slot of every column of every inequality block
-  int max_stage_g = 0;            // longest G slice of a stage (LDS staging size)
+  int max_stage_g = 0;            // longest G slice of a stage
+  // Packed per-stage records consumed by k_kkt (each is ONE contiguous, coalesced read):
+  //   static  srec[srec_off[k] ..]: n_ent, n_rhs, n_iq, hi, piv_slot[16], tri index per equality
+  //           entry, slot per rhs entry, {m, n, gloc, sloc} per inequality block, slot lists
+  //   dynamic stream (per problem), drec_off[k] ..: piv_diag[16], equality values, -g of the rhs
+  //           rows, then per inequality block G (m x n), sig (m), w (m)
+  // pack_src[i] says where stream element i comes from: (kind << 28) | index, kind 0 G, 1 g_static,
+  // 2 -g[row], 3 sig[row], 4 w[row], 5 piv_diag
+  std::vector<int> srec, srec_off, pack_src, drec_off, stage_hi;
+  int max_srec = 0, max_drec = 0;
   long long g_doubles = 0;
   long long algorithmic_bytes = 0, flops = 0, envelope = 0;
   int max_active = 0;
@@ -129,6 +138,8 @@ struct Symbolic {
     std::vector<std::vector<int>> enter(n_stages);
     for (int j = 0; j < n_unknowns; ++j) enter[first[j] / PIV].push_back(j);
     std::vector<int> free_slots;  // kept sorted descending so pop_back gives the smallest
+    std::vector<char> in_use;
+    stage_hi.assign(n_stages, 0);
     int n_slots = 0;
     max_active = 0;
     envelope = 0;
@@ -141,6 +152,8 @@ struct Symbolic {
         if (!free_slots.empty()) { s = free_slots.back(); free_slots.pop_back(); }
         else s = n_slots++;
         slot_of[j] = s;
+        if ((int)in_use.size() <= s) in_use.resize(s + 1, 0);
+        in_use[s] = 1;
         active++;
       }
       // dummy pivots of the (short) last stage need distinct unused slots
@@ -151,6 +164,14 @@ struct Symbolic {
         if (!free_slots.empty()) { s = free_slots.back(); free_slots.pop_back(); }
         else s = n_slots++;
         dummies.push_back(s);
+        if ((int)in_use.size() <= s) in_use.resize(s + 1, 0);
+        in_use[s] = 1;
+      }
+      {
+        int hi = 0;
+        for (int t = 0; t < (int)in_use.size(); ++t)
+          if (in_use[t]) hi = t + 1;
+        stage_hi[k] = ((hi + 3) / 4) * 4;
       }
       active_count[k] = active + (int)dummies.size();
       max_active = std::max(max_active, active_count[k]);
@@ -167,7 +188,10 @@ struct Symbolic {
         }
       }
       // release pivots and dummies
-      for (int i = lo; i < lo + PIV; ++i) free_slots.push_back(piv_slot[(size_t)k * PIV + (i - lo)]);
+      for (int i = lo; i < lo + PIV; ++i) {
+        free_slots.push_back(piv_slot[(size_t)k * PIV + (i - lo)]);
+        in_use[piv_slot[(size_t)k * PIV + (i - lo)]] = 0;
+      }
       std::sort(free_slots.begin(), free_slots.end(), std::greater<int>());
       active -= (hi - lo);
     }
@@ -232,6 +256,48 @@ struct Symbolic {
     }
     M.g_doubles = g_doubles;
     M.finalize_goff();
+    // ---- packed records ----
+    auto trs = [](int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
+    srec_off.assign(n_stages + 1, 0);
+    drec_off.assign(n_stages + 1, 0);
+    for (int k = 0; k < n_stages; ++k) {
+      const StageDesc &S = stages[k];
+      srec_off[k] = (int)srec.size();
+      drec_off[k] = (int)pack_src.size();
+      const int n_ent = S.ent_end - S.ent_begin, n_rhs = S.rhs_end - S.rhs_begin, n_iq = S.iq_end - S.iq_begin;
+      srec.push_back(n_ent); srec.push_back(n_rhs); srec.push_back(n_iq); srec.push_back(stage_hi[k]);
+      for (int i = 0; i < PIV; ++i) {
+        srec.push_back(piv_slot[(size_t)k * PIV + i]);
+        pack_src.push_back((5 << 28) | (k * PIV + i));
+      }
+      for (int i = S.ent_begin; i < S.ent_end; ++i) {
+        const EqEntry &e = eq_entries[i];
+        srec.push_back(trs(e.slot_r, e.slot_c));
+        pack_src.push_back(e.src >= 0 ? e.src : ((1 << 28) | (-e.src - 1)));
+      }
+      for (int i = S.rhs_begin; i < S.rhs_end; ++i) {
+        srec.push_back(eq_rhs[i].slot);
+        pack_src.push_back((2 << 28) | eq_rhs[i].row);
+      }
+      // inequality block headers, then their slot lists
+      const int hdr = (int)srec.size();
+      srec.resize(srec.size() + 4 * (size_t)n_iq);
+      for (int q = 0; q < n_iq; ++q) {
+        const IqBlock &Q = iq_blocks[S.iq_begin + q];
+        srec[hdr + 4 * q + 0] = Q.m;
+        srec[hdr + 4 * q + 1] = Q.n;
+        srec[hdr + 4 * q + 2] = (int)pack_src.size() - drec_off[k];
+        srec[hdr + 4 * q + 3] = (int)srec.size() - srec_off[k];
+        for (int a = 0; a < Q.n; ++a) srec.push_back(iq_slots[Q.slot_off + a]);
+        for (int i = 0; i < Q.m * Q.n; ++i) pack_src.push_back(S.g_begin + Q.gloc + i);
+        for (int r = 0; r < Q.m; ++r) pack_src.push_back((3 << 28) | (Q.row0 + r));
+        for (int r = 0; r < Q.m; ++r) pack_src.push_back((4 << 28) | (Q.row0 + r));
+      }
+      max_srec = std::max(max_srec, (int)srec.size() - srec_off[k]);
+      max_drec = std::max(max_drec, (int)pack_src.size() - drec_off[k]);
+    }
+    srec_off[n_stages] = (int)srec.size();
+    drec_off[n_stages] = (int)pack_src.size();
     // bytes = w * [ sum_k (p + c_k) * p  +  2 M ]   (matrix once, rhs in, solution out)
     algorithmic_bytes = 0;
     flops = 0;

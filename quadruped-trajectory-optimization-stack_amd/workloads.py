@@ -44,7 +44,7 @@ def exp1_terrain():
     return heightfield.towr_map(m), heightfield.cell_size(m)
 
 
-def step_goals(batch, seed=1, terrain=None):
+def step_goals(batch, seed=1, terrain=None, mode=1):
     """configs[2]: starts on the flat part x in [0, 0.2], goals stepping onto the 0.025/0.05 m
     ledges at x ~ 0.3-0.5 (tile rows 13-19 of climb_2); feet start on the terrain surface."""
     rng = np.random.default_rng(seed)
@@ -55,7 +55,7 @@ def step_goals(batch, seed=1, terrain=None):
     start = []
     for x in x0:
         feet = NOMINAL_FEET + np.array([x, 0.0, 0.0])
-        fz = heightfield.height_at(height_xy, cell, feet[:, 0], feet[:, 1])
-        start.append(rest_start(x, 0.0, 0.24 + float(heightfield.height_at(height_xy, cell, x, 0.0)), fz))
+        fz = heightfield.height_at(height_xy, cell, feet[:, 0], feet[:, 1], mode=mode)
+        start.append(rest_start(x, 0.0, 0.24 + float(heightfield.height_at(height_xy, cell, x, 0.0, mode=mode)), fz))
     goal = np.stack([x0 + dx, dy, np.full(batch, 0.24)], axis=1)
     return np.stack(start), goal
