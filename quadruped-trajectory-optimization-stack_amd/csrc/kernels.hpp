@@ -542,32 +542,6 @@ constexpr int PLD = PIV + 1;
 __device__ __forceinline__ int tri(int r, int c) { return ((r * (r + 1)) >> 1) + c; }  // c <= r
 __device__ __forceinline__ int trs(int a, int b) { return a >= b ? tri(a, b) : tri(b, a); }
 
-__device__ inline void invert16(double *Bm /* 16 x PLD in LDS, symmetric */, int lane) {
-  // in-place Gauss-Jordan without pivoting (quasi-definite block, fixed order); one wave.
-  // lane (i, c) = (lane >> 2, lane & 3) owns B[i][4c .. 4c+3]
-  const int i = lane >> 2, c = lane & 3;
-  double a[4];
-  for (int j = 0; j < 4; ++j) a[j] = Bm[i * PLD + 4 * c + j];
-#pragma unroll
-  for (int k = 0; k < PIV; ++k) {
-    const int kc = k >> 2, ke = k & 3;
-    // pivot row segment for my columns, pivot value, my row's k-th entry
-    double rk[4];
-    for (int j = 0; j < 4; ++j) rk[j] = __shfl(a[j], 4 * k + c);
-    const double p = __shfl(a[ke], 4 * k + kc);
-    double f = __shfl(a[ke], 4 * i + kc);
-    const double ip = 1.0 / p;
-    if (c == kc) rk[ke] = 1.0;  // the pivot column of the pivot row becomes 1 before scaling
-    if (i == k) {
-      for (int j = 0; j < 4; ++j) a[j] = rk[j] * ip;
-    } else {
-      if (c == kc) a[ke] = 0.0;
-      for (int j = 0; j < 4; ++j) a[j] -= f * rk[j] * ip;
-    }
-  }
-  for (int j = 0; j < 4; ++j) Bm[i * PLD + 4 * c + j] = a[j];
-}
-
 // Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
 // stall every phase on the in-flight prefetch loads and factor-panel stores (cdna_hip_programming.md
 // section 5 "Pipelining across barriers").
@@ -576,128 +550,233 @@ __device__ __forceinline__ void lds_barrier() {
 }
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-constexpr int PFD = 6, PFS = 6;  // per-thread prefetch registers: doubles / ints of the next stage's records
+// In-register LDL^T of a symmetric 16 x 16 block by one wave, no pivoting (the KKT matrix is
+// quasi-definite and the elimination order is fixed).  Lane (i, c) = (lane >> 2, lane & 3) owns
+// B[i][4c .. 4c+3]; both triangles are kept up to date so row k can be read as column k.
+// Result: strict lower triangle -> Lm (unit lower L), 1/d -> dinv.
+__device__ inline void ldlt16(const double *Bsrc /* 16 x PLD */, double *Lm, double *dinv, int lane) {
+  const int i = lane >> 2, c = lane & 3;
+  double a[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = Bsrc[i * PLD + 4 * c + j];
+#pragma unroll
+  for (int k = 0; k < PIV - 1; ++k) {
+    const int kc = k >> 2, ke = k & 3;
+    const double dk = __shfl(a[ke], 4 * k + kc);
+    const double lik = __shfl(a[ke], 4 * i + kc);
+    double rk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rk[j] = __shfl(a[j], 4 * k + c);
+    const double f = lik * (1.0 / dk);
+    if (i > k) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * c + j > k) a[j] -= f * rk[j];
+      if (c == kc) a[ke] = f;  // L[i][k]
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = 4 * c + j;
+    if (col < i) Lm[i * PLD + col] = a[j];
+    if (col == i) dinv[i] = 1.0 / a[j];
+  }
+}
 
+constexpr int PFD = 6, PFS = 6;  // per-thread prefetch registers: doubles / ints of a stage's records
+
+// assembly of one stage's records (already in LDS) into the front
+__device__ inline void assemble_stage(double *A, int F, const int *sbuf, const double *dbuf, int tid) {
+  const int n_ent = sbuf[0], n_rhs = sbuf[1], n_iq = sbuf[2];
+  const int *ps = sbuf + 4;
+  if (tid < PIV) A[tri(ps[tid], ps[tid])] += dbuf[tid];
+  const int *eidx = sbuf + 4 + PIV;
+  const double *eval = dbuf + PIV;
+  for (int i = tid; i < n_ent; i += KT) A[eidx[i]] += eval[i];
+  const int *rsl = eidx + n_ent;
+  const double *rval = eval + n_ent;
+  for (int i = tid; i < n_rhs; i += KT) A[tri(F, rsl[i])] += rval[i];
+  const int *iqh = rsl + n_rhs;
+  for (int q = 0; q < n_iq; ++q) {
+    const int qm = iqh[4 * q], qn = iqh[4 * q + 1];
+    const double *Gb = dbuf + iqh[4 * q + 2];
+    const int *sl = sbuf + iqh[4 * q + 3];
+    const double *sg = Gb + qm * qn, *wq = sg + qm;
+    lds_barrier();  // blocks of one stage may touch the same entries
+    const int npair = (qn * (qn + 1)) >> 1;
+    for (int i = tid; i < npair + qn; i += KT) {
+      if (i < npair) {
+        int a = (int)((sqrtf(8.0f * i + 1.0f) - 1.0f) * 0.5f);
+        while (((a + 1) * (a + 2)) >> 1 <= i) ++a;
+        while ((a * (a + 1)) >> 1 > i) --a;
+        const int c = i - ((a * (a + 1)) >> 1);
+        double acc = 0;
+        for (int r = 0; r < qm; ++r) acc += sg[r] * Gb[r * qn + a] * Gb[r * qn + c];
+        A[trs(sl[a], sl[c])] += acc;
+      } else {
+        const int a = i - npair;
+        double acc = 0;
+        for (int r = 0; r < qm; ++r) acc += Gb[r * qn + a] * wq[r];
+        A[tri(F, sl[a])] -= acc;
+      }
+    }
+  }
+}
+
+// k_kkt: one workgroup (KT threads, 8 waves) per problem; software-pipelined over the stage chain:
+//   S1  Y_k = P_k L_k^-T (row per thread), retire the pivots of stage k
+//   S2  assemble stage k+1 into the front (records prefetched one stage earlier)
+//   S3  early gather: P_{k+1} = A[:, piv_{k+1}] - Y_k D_k^-1 Y_k[piv_{k+1}]^T  (the columns the NEXT
+//       factorisation needs, with stage k's update applied on the fly)
+//   S4  wave 0: LDL^T of the next pivot block   ||   waves 1-7: full Schur update of the front on
+//       the f64 matrix cores + factor panel of stage k to HBM
 __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
   if (b >= B || W.done[b]) return;
   extern __shared__ double lds[];
   const int F = P.front, tid = threadIdx.x;
   const int ntri = ((F + 1) * (F + 2)) >> 1;
-  double *A = lds;                    // lower triangle incl. rhs row F
-  double *Pn = A + ntri;              // (F+1) * PLD
-  double *Wn = Pn + (F + 1) * PLD;    // (F+1) * PLD
-  double *Bm = Wn + (F + 1) * PLD;    // PIV * PLD
-  double *xs = Bm + PIV * PLD;        // F
-  double *dbuf = xs + F;              // max_drec: this stage's dynamic record
-  int *sbuf = (int *)(dbuf + P.max_drec);   // max_srec: this stage's static record
-  int *soff = sbuf + P.max_srec;      // n_stages + 1
-  int *doff = soff + P.n_stages + 1;  // n_stages + 1
-  const int n = P.n_vars;
+  const int PSZ = (F + 1) * PLD;
+  double *A = lds;                      // lower triangle incl. rhs row F
+  double *Pbuf = A + ntri;              // 2 panels of (F+1) x PLD
+  double *Lbuf = Pbuf + 2 * PSZ;        // 2 x (PIV x PLD)
+  double *dvb = Lbuf + 2 * PIV * PLD;   // 2 x PIV   (1/d)
+  double *xs = dvb + 2 * PIV;           // F
+  double *red = xs + F;                 // 34 x PLD  backward-pass scratch
+  double *dbuf = red + 34 * PLD;        // max_drec
+  int *sbuf = (int *)(dbuf + P.max_drec);   // max_srec
+  int *soff = sbuf + P.max_srec;        // n_stages + 1
+  int *doff = soff + P.n_stages + 1;    // n_stages + 1
+  int *psb = doff + P.n_stages + 1;     // 2 x PIV pivot slots (current / next stage)
+  int *hib = psb + 2 * PIV;             // 2: hi of current / next stage
+  const int n = P.n_vars, NS = P.n_stages;
   const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
   double *dx = W.dx + (size_t)b * n;
-  const int pstride = (F + PIV + 1) * PIV;  // doubles per stage: Binv (16 x 16), b1 (16), C (hi x 16)
+  const int pstride = (F + PIV + 2) * PIV;  // per stage: L (16 x 16), 1/d (16), y_F (16), Y (hi x 16)
 
   for (int i = tid; i < ntri; i += KT) A[i] = 0.0;
   for (int v = tid; v < n; v += KT) dx[v] = 0.0;
-  for (int i = tid; i <= P.n_stages; i += KT) { soff[i] = P.srec_off[i]; doff[i] = P.drec_off[i]; }
+  for (int i = tid; i <= NS; i += KT) { soff[i] = P.srec_off[i]; doff[i] = P.drec_off[i]; }
   __syncthreads();
-  // records of stage 0
+  // ---- prologue: assemble stage 0, gather and factor its pivot block, stage records of stage 1 ----
   for (int i = tid; i < soff[1] - soff[0]; i += KT) sbuf[i] = P.srec[soff[0] + i];
   for (int i = tid; i < doff[1] - doff[0]; i += KT) dbuf[i] = stream[doff[0] + i];
   __syncthreads();
+  if (tid < PIV) psb[tid] = sbuf[4 + tid];
+  if (tid == 0) hib[0] = sbuf[3];
+  assemble_stage(A, F, sbuf, dbuf, tid);
+  __syncthreads();
+  for (int i = tid; i < (F + 1) * PIV; i += KT) {
+    const int r = i >> 4, j = i & 15;
+    Pbuf[r * PLD + j] = A[trs(r, psb[j])];
+  }
+  if (NS > 1) {
+    for (int i = tid; i < soff[2] - soff[1]; i += KT) sbuf[i] = P.srec[soff[1] + i];
+    for (int i = tid; i < doff[2] - doff[1]; i += KT) dbuf[i] = stream[doff[1] + i];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    double *Bs = red;  // 16 x PLD scratch
+    for (int e = tid; e < PIV * PIV; e += 64) Bs[(e >> 4) * PLD + (e & 15)] = Pbuf[psb[e >> 4] * PLD + (e & 15)];
+    ldlt16(Bs, Lbuf, dvb, tid);
+    for (int e = tid; e < PIV * PIV; e += 64) Pbuf[psb[e >> 4] * PLD + (e & 15)] = 0.0;  // pivot rows leave the panel
+  }
+  __syncthreads();
 
-  for (int k = 0; k < ((P.dbg & 32) ? 0 : P.n_stages); ++k) {
-    // ---- prefetch the next stage's records into registers (lands while this stage computes) ----
+  int cur = 0;
+  for (int k = 0; k < NS; ++k) {
+    const int nxt = cur ^ 1;
+    double *Y = Pbuf + cur * PSZ, *Pn = Pbuf + nxt * PSZ;
+    const double *Lm = Lbuf + cur * PIV * PLD, *dinv = dvb + cur * PIV;
+    const int *ps = psb + cur * PIV;
+    const int hi = hib[cur], hi16 = (hi + 15) & ~15;
+    const bool has_next = k + 1 < NS;
+    // prefetch the records of stage k+2 (installed at the end of this stage)
     double pfd[PFD];
     int pfs[PFS];
     int nd = 0, ns = 0;
-    if (k + 1 < P.n_stages) {
-      nd = doff[k + 2] - doff[k + 1];
-      ns = soff[k + 2] - soff[k + 1];
-      const double *dsrc = stream + doff[k + 1];
-      const int *ssrc = P.srec + soff[k + 1];
+    if (k + 2 < NS) {
+      nd = doff[k + 3] - doff[k + 2];
+      ns = soff[k + 3] - soff[k + 2];
+      const double *dsrc = stream + doff[k + 2];
+      const int *ssrc = P.srec + soff[k + 2];
 #pragma unroll
       for (int j = 0; j < PFD; ++j) { const int i = tid + j * KT; pfd[j] = i < nd ? dsrc[i] : 0.0; }
 #pragma unroll
       for (int j = 0; j < PFS; ++j) { const int i = tid + j * KT; pfs[j] = i < ns ? ssrc[i] : 0; }
     }
-    const int n_ent = sbuf[0], n_rhs = sbuf[1], n_iq = sbuf[2], hi = sbuf[3];
-    const int *ps = sbuf + 4;
-    // ---- assembly from the LDS records ---------------------------------------------------------
-    if (tid < PIV) A[tri(ps[tid], ps[tid])] += dbuf[tid];
-    {
-      const int *eidx = sbuf + 4 + PIV;
-      const double *eval = dbuf + PIV;
-      for (int i = tid; i < n_ent; i += KT) A[eidx[i]] += eval[i];
-      const int *rsl = eidx + n_ent;
-      const double *rval = eval + n_ent;
-      for (int i = tid; i < n_rhs; i += KT) A[tri(F, rsl[i])] += rval[i];
-    }
-    const int *iqh = sbuf + 4 + PIV + n_ent + n_rhs;
-    for (int q = 0; q < ((P.dbg & 2) ? 0 : n_iq); ++q) {
-      const int qm = iqh[4 * q], qn = iqh[4 * q + 1];
-      const double *Gb = dbuf + iqh[4 * q + 2];
-      const int *sl = sbuf + iqh[4 * q + 3];
-      const double *sg = Gb + qm * qn, *wq = sg + qm;
-      lds_barrier();
-      const int npair = (qn * (qn + 1)) >> 1;
-      for (int i = tid; i < npair + qn; i += KT) {
-        if (i < npair) {
-          int a = (int)((sqrtf(8.0f * i + 1.0f) - 1.0f) * 0.5f);
-          while (((a + 1) * (a + 2)) >> 1 <= i) ++a;
-          while ((a * (a + 1)) >> 1 > i) --a;
-          const int c = i - ((a * (a + 1)) >> 1);
-          double acc = 0;
-          for (int r = 0; r < qm; ++r) acc += sg[r] * Gb[r * qn + a] * Gb[r * qn + c];
-          A[trs(sl[a], sl[c])] += acc;
-        } else {
-          const int a = i - npair;
-          double acc = 0;
-          for (int r = 0; r < qm; ++r) acc += Gb[r * qn + a] * wq[r];
-          A[tri(F, sl[a])] -= acc;
-        }
+    // ---- S1: Y = P L^-T, one row per thread (rows 0..F; row F is the right-hand side) ----------
+    if (tid <= F && !(P.dbg & 1)) {
+      double y[PIV];
+      double *row = Y + tid * PLD;
+#pragma unroll
+      for (int j = 0; j < PIV; ++j) y[j] = row[j];
+#pragma unroll
+      for (int q = 0; q < PIV - 1; ++q)
+#pragma unroll
+        for (int j = q + 1; j < PIV; ++j) y[j] -= y[q] * Lm[j * PLD + q];
+#pragma unroll
+      for (int j = 0; j < PIV; ++j) row[j] = y[j];
+    } else {
+      // the other waves retire the pivots of stage k: their rows / columns are recycled
+      for (int i = tid - (F + 1); i < PIV * (hi + 1); i += KT - (F + 1)) {
+        const int j = i / (hi + 1), rr = i - j * (hi + 1);
+        A[trs(rr < hi ? rr : F, ps[j])] = 0.0;
       }
     }
     lds_barrier();
-    // ---- pivot columns -> panel (rows 0..hi-1 and the rhs row F); pivot block -> Bm -----------
-    const int hi16 = (hi + 15) & ~15;   // rows hi..hi16-1 are inactive slots: their entries are zero
-    for (int i = tid; i < (hi16 + 1) * PIV; i += KT) {
-      const int rr = i >> 4, j = i & 15;
-      const int r = rr < hi16 ? rr : F;
-      Pn[r * PLD + j] = A[trs(r, ps[j])];
+    // ---- S2: assemble stage k+1 ------------------------------------------------------------------
+    if (has_next) {
+      if (tid < PIV) psb[nxt * PIV + tid] = sbuf[4 + tid];
+      if (tid == 0) hib[nxt] = sbuf[3];
+      if (!(P.dbg & 2)) assemble_stage(A, F, sbuf, dbuf, tid);
     }
     lds_barrier();
-    if (tid < PIV * PIV) {
-      const int i = tid / PIV, j = tid - i * PIV;
-      Bm[i * PLD + j] = Pn[ps[i] * PLD + j];
-    }
-    lds_barrier();
-    if (tid >= 256 && tid < 256 + PIV * PIV) {  // pivot rows leave the panel (not part of the border)
-      const int t = tid - 256, i = t / PIV, j = t - i * PIV;
-      Pn[ps[i] * PLD + j] = 0.0;
-    }
-    if (tid < 64 && !(P.dbg & 1)) invert16(Bm, tid);
-    lds_barrier();
-    // ---- Wn = Pn * Binv -------------------------------------------------------------------------
-    for (int i = tid; i < ((P.dbg & 16) ? 0 : (hi16 + 1) * PIV); i += KT) {
-      const int rr = i >> 4, j = i & 15;
-      const int r = rr < hi16 ? rr : F;
-      double acc = 0;
-#pragma unroll
-      for (int q = 0; q < PIV; ++q) acc += Pn[r * PLD + q] * Bm[q * PLD + j];
-      Wn[r * PLD + j] = acc;
-    }
-    lds_barrier();
-    // ---- Schur complement A[r][c] -= Wn[r][:] . Pn[c][:] on the lower triangle of the active slots,
-    //      16 x 16 tiles on the f64 matrix cores (v_mfma_f64_16x16x4_f64: lane l feeds
-    //      A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; result reg g holds
-    //      D[(l >> 4) + 4 g][l & 15]); the rhs row F is a short VALU pass ------------------------
-    if (!(P.dbg & 4)) {
+    // ---- S3: early gather of the next pivot columns with this stage's update applied:
+    //      P_next[r][j] = A[r][piv_j] - sum_q Y[r][q] (Y[piv_j][q] / d_q), 16-row tiles on the matrix
+    //      cores (one tile per wave), the rhs row by 16 lanes -----------------------------------
+    if (has_next) {
+      const int *psn = psb + nxt * PIV;
       const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+      const int pcol = psn[li];
+      const double *zrow = Y + pcol * PLD + lk;   // B operand: Z[k][j] = Y[piv_j][k] / d_k
+      double zb[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) zb[s4] = (P.dbg & 4) ? 0.0 : zrow[4 * s4] * dinv[lk + 4 * s4];
+      for (int R = wv; R < (F >> 4); R += KT / 64) {
+        d4_t acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = A[trs(16 * R + lk + 4 * g, pcol)];
+        const double *yrow = Y + (16 * R + li) * PLD + lk;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-yrow[4 * s4], zb[s4], acc, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Pn[(16 * R + lk + 4 * g) * PLD + li] = acc[g];
+      }
+      if (tid >= KT - PIV) {  // rhs row F
+        const int j = tid - (KT - PIV), pc = psn[j];
+        double acc = A[tri(F, pc)];
+#pragma unroll
+        for (int q = 0; q < PIV; ++q) acc -= Y[F * PLD + q] * dinv[q] * Y[pc * PLD + q];
+        Pn[F * PLD + j] = acc;
+      }
+    }
+    lds_barrier();
+    // ---- S4: wave 0 factors the next pivot block; waves 1..7 apply stage k's update ------------
+    if (tid < 64) {
+      if (has_next) {
+        const int *psn = psb + nxt * PIV;
+        double *Bs = red;
+        for (int e = tid; e < PIV * PIV; e += 64) Bs[(e >> 4) * PLD + (e & 15)] = Pn[psn[e >> 4] * PLD + (e & 15)];
+        if (!(P.dbg & 8)) ldlt16(Bs, Lbuf + nxt * PIV * PLD, dvb + nxt * PIV, tid);
+        for (int e = tid; e < PIV * PIV; e += 64) Pn[psn[e >> 4] * PLD + (e & 15)] = 0.0;
+      }
+    } else {
+      const int wv = (tid >> 6) - 1, lane = tid & 63, li = lane & 15, lk = lane >> 4;
       const int nt16 = hi16 >> 4, ntile = (nt16 * (nt16 + 1)) >> 1;
-      for (int t = wv; t < ntile; t += KT / 64) {
+      for (int t = wv; t < ((P.dbg & 16) ? 0 : ntile); t += KT / 64 - 1) {
         int R = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
         while (((R + 1) * (R + 2)) >> 1 <= t) ++R;
         while ((R * (R + 1)) >> 1 > t) --R;
@@ -709,100 +788,103 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
           const int row = 16 * R + lk + 4 * g;
           acc[g] = col <= row ? A[tri(row, col)] : 0.0;
         }
-        const double *wrow = Wn + (16 * R + li) * PLD + lk;
-        const double *prow = Pn + (16 * C + li) * PLD + lk;
+        const double *wrow = Y + (16 * R + li) * PLD + lk;
+        const double *prow = Y + (16 * C + li) * PLD + lk;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-wrow[4 * s4], prow[4 * s4], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-wrow[4 * s4] * dinv[lk + 4 * s4], prow[4 * s4], acc, 0, 0, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = 16 * R + lk + 4 * g;
           if (col <= row) A[tri(row, col)] = acc[g];
         }
       }
-      for (int c = tid; c < hi16; c += KT) {
+      const int t2 = tid - 64;
+      for (int c = t2; c < hi16; c += KT - 64) {  // right-hand-side row
         double acc = 0;
 #pragma unroll
-        for (int q = 0; q < PIV; ++q) acc += Wn[F * PLD + q] * Pn[c * PLD + q];
+        for (int q = 0; q < PIV; ++q) acc += Y[F * PLD + q] * dinv[q] * Y[c * PLD + q];
         A[tri(F, c)] -= acc;
       }
-    }
-    // ---- factor panel to HBM: Binv (16 x 16), b1 (16), C (hi x 16) ----------------------------
-    {
+      // factor panel of stage k to HBM
       double *pk = panel + (size_t)k * pstride;
-      if (tid < PIV * PIV) pk[tid] = Bm[(tid / PIV) * PLD + (tid % PIV)];
-      if (tid < PIV) pk[PIV * PIV + tid] = Pn[F * PLD + tid];
-      for (int i = tid; i < hi * PIV; i += KT) pk[PIV * PIV + PIV + i] = Pn[(i >> 4) * PLD + (i & 15)];
+      for (int i = t2; i < PIV * PIV; i += KT - 64) pk[i] = Lm[(i >> 4) * PLD + (i & 15)];
+      if (t2 < PIV) pk[PIV * PIV + t2] = dinv[t2];
+      else if (t2 < 2 * PIV) pk[PIV * PIV + t2] = Y[F * PLD + (t2 - PIV)];
+      for (int i = t2; i < ((P.dbg & 32) ? 0 : hi * PIV); i += KT - 64) pk[PIV * PIV + 2 * PIV + i] = Y[(i >> 4) * PLD + (i & 15)];
     }
     lds_barrier();
-    // ---- retire the pivots; install the next stage's records ----------------------------------
-    for (int i = tid; i < PIV * (hi + 1); i += KT) {
-      const int j = i / (hi + 1), rr = i - j * (hi + 1);
-      A[trs(rr < hi ? rr : F, ps[j])] = 0.0;
-    }
-    lds_barrier();
-    if (k + 1 < P.n_stages) {
+    // ---- install the records of stage k+2 ------------------------------------------------------
+    if (k + 2 < NS) {
 #pragma unroll
       for (int j = 0; j < PFD; ++j) { const int i = tid + j * KT; if (i < nd) dbuf[i] = pfd[j]; }
 #pragma unroll
       for (int j = 0; j < PFS; ++j) { const int i = tid + j * KT; if (i < ns) sbuf[i] = pfs[j]; }
     }
-    lds_barrier();
+    cur = nxt;
   }
-  // ---- backward substitution: x1 = Binv (b1 - C^T x2), panels prefetched one stage ahead -------
+  // ---- backward substitution: L^T x1 = D^-1 (y_F - Y^T x2), panels prefetched one stage ahead ----
   __syncthreads();  // drains the factor-panel stores: they are read back below
   for (int i = tid; i < F; i += KT) xs[i] = 0.0;
-  constexpr int PFB = 5;  // (F + 17) * 16 / 512 <= 5 for F <= 128
+  constexpr int PFB = 5;  // (F + 18) * 16 / 512 <= 5 for F <= 128
   double pfb[PFB];
+  double *Yb = Pbuf, *Lb = Lbuf, *dvs = dvb, *yF = dvb + PIV;
   {
-    const double *pk = panel + (size_t)(P.n_stages - 1) * pstride;
-    const int hi = P.srec[soff[P.n_stages - 1] + 3], cnt = (hi + PIV + 1) * PIV;
+    const double *pk = panel + (size_t)(NS - 1) * pstride;
+    const int hi = P.srec[soff[NS - 1] + 3], cnt = (hi + PIV + 2) * PIV;
 #pragma unroll
     for (int j = 0; j < PFB; ++j) { const int i = tid + j * KT; pfb[j] = i < cnt ? pk[i] : 0.0; }
   }
   __syncthreads();
-  for (int k = (P.dbg & 8) ? -1 : P.n_stages - 1; k >= 0; --k) {
-    const int hi = P.srec[soff[k] + 3], cnt = (hi + PIV + 1) * PIV;
-    // install panel k: Binv -> Bm, b1 -> Wn[0..15] scratch row 40, C -> Pn
+  for (int k = (P.dbg & 64) ? -1 : NS - 1; k >= 0; --k) {
+    const int hi = P.srec[soff[k] + 3], cnt = (hi + PIV + 2) * PIV;
 #pragma unroll
     for (int j = 0; j < PFB; ++j) {
       const int i = tid + j * KT;
       if (i < cnt) {
-        if (i < PIV * PIV) Bm[(i / PIV) * PLD + (i % PIV)] = pfb[j];
-        else if (i < PIV * PIV + PIV) Wn[40 * PLD + (i - PIV * PIV)] = pfb[j];
-        else { const int e = i - PIV * PIV - PIV; Pn[(e / PIV) * PLD + (e % PIV)] = pfb[j]; }
+        if (i < PIV * PIV) Lb[(i >> 4) * PLD + (i & 15)] = pfb[j];
+        else if (i < PIV * PIV + PIV) dvs[i - PIV * PIV] = pfb[j];
+        else if (i < PIV * PIV + 2 * PIV) yF[i - PIV * PIV - PIV] = pfb[j];
+        else { const int e = i - PIV * PIV - 2 * PIV; Yb[(e >> 4) * PLD + (e & 15)] = pfb[j]; }
       }
     }
-    if (tid < PIV) sbuf[tid] = P.srec[soff[k] + 4 + tid];
-    __syncthreads();
+    if (tid < PIV) psb[tid] = P.srec[soff[k] + 4 + tid];
+    lds_barrier();
     if (k > 0) {  // prefetch panel k-1
       const double *pk = panel + (size_t)(k - 1) * pstride;
-      const int hi2 = P.srec[soff[k - 1] + 3], cnt2 = (hi2 + PIV + 1) * PIV;
+      const int hi2 = P.srec[soff[k - 1] + 3], cnt2 = (hi2 + PIV + 2) * PIV;
 #pragma unroll
       for (int j = 0; j < PFB; ++j) { const int i = tid + j * KT; pfb[j] = i < cnt2 ? pk[i] : 0.0; }
     }
-    // partial sums: thread (j, q) accumulates rows r = q, q+32, ... of column j
-    {
-      const int j = tid & (PIV - 1), q = tid >> 4;  // q in 0..31
+    {  // partial sums: thread (j, q) accumulates rows r = q, q+32, ... of column j; lanes of one
+       // wave hold 4 row groups per column -> fold them with two shuffles, one value per wave left
+      const int j = tid & (PIV - 1), q = tid >> 4;
       double acc = 0;
-      for (int r = q; r < hi; r += KT / PIV) acc += Pn[r * PLD + j] * xs[r];
-      Wn[q * PLD + j] = acc;
+      for (int r = q; r < hi; r += KT / PIV) acc += Yb[r * PLD + j] * xs[r];
+      acc += __shfl_xor(acc, 16);
+      acc += __shfl_xor(acc, 32);
+      if ((tid & 63) < PIV) red[(tid >> 6) * PLD + j] = acc;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < PIV) {
-      double t = Wn[40 * PLD + tid];
-      for (int qq = 0; qq < KT / PIV; ++qq) t -= Wn[qq * PLD + tid];
-      Wn[41 * PLD + tid] = t;
+      // u = D^-1 (y_F - Y^T x2); then L^T x1 = u by back substitution across the 16 lanes
+      double u = yF[tid];
+#pragma unroll
+      for (int qq = 0; qq < KT / 64; ++qq) u -= red[qq * PLD + tid];
+      u *= dvs[tid];
+      double lc[PIV];
+#pragma unroll
+      for (int i = 1; i < PIV; ++i) lc[i] = i > tid ? Lb[i * PLD + tid] : 0.0;
+#pragma unroll
+      for (int i = PIV - 1; i > 0; --i) {
+        const double xi = __shfl(u, i, PIV);
+        u -= lc[i] * xi;
+      }
+      xs[psb[tid]] = u;
+      const int un = P.piv_unknown[k * PIV + tid];
+      if (un >= 0 && un < n) dx[un] = u;
     }
-    __syncthreads();
-    if (tid < PIV) {
-      double v = 0;
-      for (int i = 0; i < PIV; ++i) v += Bm[tid * PLD + i] * Wn[41 * PLD + i];
-      xs[sbuf[tid]] = v;
-      const int u = P.piv_unknown[k * PIV + tid];
-      if (u >= 0 && u < n) dx[u] = v;
-    }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
