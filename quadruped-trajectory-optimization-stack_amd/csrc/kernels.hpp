@@ -27,6 +27,8 @@ struct DevPlan {
   const TerrInst *terr;
   const ForceInst *force;
   const LinRow *lin;
+  const ColDesc *dyn_cols, *rom_cols;
+  int n_dyn_cols, n_rom_cols;
   const Block *blocks;
   const int *block_cols;
   const double *g_static;
@@ -39,6 +41,7 @@ struct DevPlan {
   const short *iq_slots;
   int max_stage_g;
   const int *srec, *srec_off, *pack_src, *drec_off;  // packed per-stage records (symbolic.hpp)
+  const int *eq_pos, *rhs_pos, *sig_pos, *w_pos;     // direct-write maps into the stream
   int max_srec, max_drec, stream_len;
   int dbg;  // timing ablation mask (QTOS_DBG), 0 in production
   const double *con_lo, *con_hi;
@@ -200,44 +203,43 @@ __device__ inline void terrain_basis(const Terr &t, int which, double b[3], doub
 }
 
 // ---- per-instance evaluation ------------------------------------------------------------------
-// JAC = false: constraint values only;  JAC = true: values + dense block G (row-major m x ncol)
+// Dynamics / range-of-motion blocks are linearised in two phases so that every Jacobian entry is
+// written exactly once and all threads of the workgroup share the work:
+//   phase A (thread per instance): constraint values + the small local Jacobians -> LDS
+//   phase B (thread per block column): the 6 (3) entries of that column from the local Jacobians
+//                                      and the column's combined Hermite weights (ColDesc)
+constexpr int DYN_LOC = 54;  // A_th, A_thd, A_thdd (9 each), sum f (3), f_e (12), r - p_e (12)
+constexpr int ROM_LOC = 18;  // R (9), d/dtheta_j [R^T (p - r)] as columns (9)
+
 template <bool JAC>
-__device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double *x, double *g, double *Gp) {
+__device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double *x, double *g, double *loc) {
   double r[3], a[3], th[3], thd[3], thdd[3];
   vec_eval(I.r, x, r); vec_eval(I.a, x, a);
   vec_eval(I.th, x, th); vec_eval(I.thd, x, thd); vec_eval(I.thdd, x, thdd);
   double ga[3], gl[3];
   dyn_angular<double>(P.Ib, th, thd, thdd, ga);
   gl[0] = P.mass * a[0]; gl[1] = P.mass * a[1]; gl[2] = P.mass * a[2] + P.mass * P.gravity;
-  double *G = nullptr;
-  const int nc = I.ncol;
   const bool jac = JAC && I.in_kkt;
   if (jac) {
-    G = Gp + I.goff;
-    for (int i = 0; i < 6 * nc; ++i) G[i] = 0.0;
     // angular rows wrt Euler angles / rates / accelerations: 9 forward-mode passes
+#pragma unroll
     for (int what = 0; what < 3; ++what)
+#pragma unroll
       for (int j = 0; j < 3; ++j) {
         D1 t0[3], t1[3], t2[3], o[3];
-        for (int i = 0; i < 3; ++i) { t0[i] = {th[i], 0.0}; t1[i] = {thd[i], 0.0}; t2[i] = {thdd[i], 0.0}; }
-        if (what == 0) t0[j].d = 1.0;
-        if (what == 1) t1[j].d = 1.0;
-        if (what == 2) t2[j].d = 1.0;
-        dyn_angular<D1>(P.Ib, t0, t1, t2, o);
-        const VecIn &in = what == 0 ? I.th : (what == 1 ? I.thd : I.thdd);
-        for (int s = 0; s < 4; ++s) {
-          int c = I.c_ang[3 * s + j];
-          if (c < 0) continue;
-          for (int i = 0; i < 3; ++i) G[i * nc + c] += o[i].d * in.w[s];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          t0[i] = {th[i], (what == 0 && i == j) ? 1.0 : 0.0};
+          t1[i] = {thd[i], (what == 1 && i == j) ? 1.0 : 0.0};
+          t2[i] = {thdd[i], (what == 2 && i == j) ? 1.0 : 0.0};
         }
-      }
-    for (int s = 0; s < 4; ++s)
-      for (int d = 0; d < 3; ++d) {
-        int c = I.c_lin[3 * s + d];
-        if (c >= 0) G[(3 + d) * nc + c] += P.mass * I.a.w[s];
+        dyn_angular<D1>(P.Ib, t0, t1, t2, o);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) loc[9 * what + 3 * i + j] = o[i].d;
       }
   }
   double sf[3] = {0, 0, 0};
+#pragma unroll
   for (int e = 0; e < NEE; ++e) {
     double pe[3], f[3];
     vec_eval(I.p[e], x, pe);
@@ -249,67 +251,82 @@ __device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double
     ga[2] -= f[0] * d[1] - f[1] * d[0];
     gl[0] -= f[0]; gl[1] -= f[1]; gl[2] -= f[2];
     if (jac) {
-      sf[0] += f[0]; sf[1] += f[1]; sf[2] += f[2];
-      // d g_ang / d p = [f]x ; d g_ang / d f = [d]x ; d g_lin / d f = -I
-      const double Fx[9] = {0, -f[2], f[1], f[2], 0, -f[0], -f[1], f[0], 0};
-      const double Dx[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
-      for (int s = 0; s < 4; ++s)
-        for (int dd = 0; dd < 3; ++dd) {
-          int cp = I.c_p[e][3 * s + dd], cf = I.c_f[e][3 * s + dd];
-          if (cp >= 0)
-            for (int i = 0; i < 3; ++i) G[i * nc + cp] += Fx[3 * i + dd] * I.p[e].w[s];
-          if (cf >= 0) {
-            for (int i = 0; i < 3; ++i) G[i * nc + cf] += Dx[3 * i + dd] * I.f[e].w[s];
-            G[(3 + dd) * nc + cf] -= I.f[e].w[s];
-          }
-        }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { sf[i] += f[i]; loc[30 + 3 * e + i] = f[i]; loc[42 + 3 * e + i] = d[i]; }
     }
   }
-  if (jac) {
-    const double Sx[9] = {0, sf[2], -sf[1], -sf[2], 0, sf[0], sf[1], -sf[0], 0};  // -[sum f]x
-    for (int s = 0; s < 4; ++s)
-      for (int dd = 0; dd < 3; ++dd) {
-        int c = I.c_lin[3 * s + dd];
-        if (c >= 0)
-          for (int i = 0; i < 3; ++i) G[i * nc + c] += Sx[3 * i + dd] * I.r.w[s];
-      }
-  }
+  if (jac) { loc[27] = sf[0]; loc[28] = sf[1]; loc[29] = sf[2]; }
+#pragma unroll
   for (int i = 0; i < 3; ++i) { g[I.row0 + i] = ga[i]; g[I.row0 + 3 + i] = gl[i]; }
 }
 
+// element (i, d) of the cross-product matrix [v]x
+__device__ __forceinline__ double skew_el(const double *v, int i, int d) {
+  if (i == d) return 0.0;
+  const int k = 3 - i - d;                       // the remaining axis
+  const double sgn = ((d - i + 3) % 3 == 1) ? -1.0 : 1.0;   // [v]x[0][1] = -v2, [0][2] = +v1, ...
+  return sgn * v[k];
+}
+
+__device__ inline void dyn_column(const DevPlan &P, const ColDesc &C, const double *loc_all, double *G) {
+  const double *loc = loc_all + (size_t)C.inst * DYN_LOC;
+  const int *pos = P.eq_pos + C.gbase;   // the block's rows land at their own stream positions
+  const int d = C.dim, nc = C.ncol;
+  double v[6];
+  if (C.kind == 0) {        // base position / acceleration: d g_ang / d r = -[sum f]x ; d g_lin / d a = m I
+    for (int i = 0; i < 3; ++i) v[i] = -skew_el(loc + 27, i, d) * C.w0;
+    for (int i = 0; i < 3; ++i) v[3 + i] = i == d ? P.mass * C.w1 : 0.0;
+  } else if (C.kind == 1) { // Euler angles / rates / accelerations
+    for (int i = 0; i < 3; ++i)
+      v[i] = loc[3 * i + d] * C.w0 + loc[9 + 3 * i + d] * C.w1 + loc[18 + 3 * i + d] * C.w2;
+    for (int i = 0; i < 3; ++i) v[3 + i] = 0.0;
+  } else if (C.kind < 6) {  // foot position: d g_ang / d p = [f]x
+    const double *f = loc + 30 + 3 * (C.kind - 2);
+    for (int i = 0; i < 3; ++i) v[i] = skew_el(f, i, d) * C.w0;
+    for (int i = 0; i < 3; ++i) v[3 + i] = 0.0;
+  } else {                  // foot force: d g_ang / d f = [r - p]x ; d g_lin / d f = -I
+    const double *dd = loc + 42 + 3 * (C.kind - 6);
+    for (int i = 0; i < 3; ++i) v[i] = skew_el(dd, i, d) * C.w0;
+    for (int i = 0; i < 3; ++i) v[3 + i] = i == d ? -C.w0 : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) G[pos[i * nc]] = v[i];
+}
+
 template <bool JAC>
-__device__ inline void eval_rom(const DevPlan &P, const RomInst &I, const double *x, double *g, double *Gp) {
+__device__ inline void eval_rom(const DevPlan &P, const RomInst &I, const double *x, double *g, double *loc) {
   double r[3], th[3], pe[3];
   vec_eval(I.r, x, r); vec_eval(I.th, x, th); vec_eval(I.p, x, pe);
   const double d[3] = {pe[0] - r[0], pe[1] - r[1], pe[2] - r[2]};
   double R[9];
   rotation<double>(th, R);
+#pragma unroll
   for (int i = 0; i < 3; ++i) g[I.row0 + i] = R[i] * d[0] + R[3 + i] * d[1] + R[6 + i] * d[2];
   if (JAC) {
-    const int nc = I.ncol;
-    double *G = Gp + I.goff;
-    for (int i = 0; i < 3 * nc; ++i) G[i] = 0.0;
-    for (int s = 0; s < 4; ++s)
-      for (int dd = 0; dd < 3; ++dd) {
-        int cp = I.c_p[3 * s + dd], cl = I.c_lin[3 * s + dd];
-        for (int i = 0; i < 3; ++i) {
-          const double rt = R[3 * dd + i];  // (R^T)[i][dd]
-          if (cp >= 0) G[i * nc + cp] += rt * I.p.w[s];
-          if (cl >= 0) G[i * nc + cl] -= rt * I.r.w[s];
-        }
-      }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) loc[i] = R[i];
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
-      D1 t0[3] = {{th[0], 0.0}, {th[1], 0.0}, {th[2], 0.0}};
-      t0[j].d = 1.0;
+      D1 t0[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t0[i] = {th[i], i == j ? 1.0 : 0.0};
       D1 Rd[9];
       rotation<D1>(t0, Rd);
-      for (int s = 0; s < 4; ++s) {
-        int c = I.c_ang[3 * s + j];
-        if (c < 0) continue;
-        for (int i = 0; i < 3; ++i)
-          G[i * nc + c] += (Rd[i].d * d[0] + Rd[3 + i].d * d[1] + Rd[6 + i].d * d[2]) * I.th.w[s];
-      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) loc[9 + 3 * i + j] = Rd[i].d * d[0] + Rd[3 + i].d * d[1] + Rd[6 + i].d * d[2];
     }
+  }
+}
+
+__device__ inline void rom_column(const ColDesc &C, const double *loc_all, double *G) {
+  const double *loc = loc_all + (size_t)C.inst * ROM_LOC;
+  double *col = G + C.gbase;
+  const int d = C.dim, nc = C.ncol;
+  if (C.kind == 1) {
+    for (int i = 0; i < 3; ++i) col[i * nc] = loc[9 + 3 * i + d] * C.w0;
+  } else {
+    const double sgn = C.kind == 2 ? 1.0 : -1.0;   // d/dp = R^T, d/dr = -R^T ; (R^T)[i][d] = R[3d + i]
+    for (int i = 0; i < 3; ++i) col[i * nc] = sgn * loc[3 * d + i] * C.w0;
   }
 }
 
@@ -318,10 +335,17 @@ __device__ inline void eval_terr(const DevPlan &P, const TerrInst &I, int map, c
   const Terr t = terrain_at(P, map, x[I.vx], x[I.vy]);
   g[I.row] = x[I.vz] - t.h;
   if (JAC && I.in_kkt) {
-    double *G = Gp + I.goff;
-    if (I.cx >= 0) G[I.cx] = -t.hx;
-    if (I.cy >= 0) G[I.cy] = -t.hy;
-    if (I.cz >= 0) G[I.cz] = 1.0;
+    if (P.row_kind[I.row] == 1) {   // stance row: equality block, entries at their stream positions
+      const int *pos = P.eq_pos + I.goff;
+      if (I.cx >= 0) Gp[pos[I.cx]] = -t.hx;
+      if (I.cy >= 0) Gp[pos[I.cy]] = -t.hy;
+      if (I.cz >= 0) Gp[pos[I.cz]] = 1.0;
+    } else {
+      double *G = Gp + I.goff;
+      if (I.cx >= 0) G[I.cx] = -t.hx;
+      if (I.cy >= 0) G[I.cy] = -t.hy;
+      if (I.cz >= 0) G[I.cz] = 1.0;
+    }
   }
 }
 
@@ -352,13 +376,22 @@ __device__ inline void eval_force(const DevPlan &P, const ForceInst &I, int map,
   }
 }
 
-// all constraint rows of one problem, by the whole workgroup
+// all constraint rows of one problem, by the whole workgroup; `loc` = LDS scratch of
+// max(DYN_LOC * n_dyn, ROM_LOC * n_rom) doubles (only used when JAC)
 template <bool JAC>
-__device__ inline void eval_all(const DevPlan &P, int map, const double *x, double *g, double *G) {
+__device__ inline void eval_all(const DevPlan &P, int map, const double *x, double *g, double *G, double *loc) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  // heavy instances first so that the tail is short
-  for (int i = tid; i < P.n_dyn; i += nt) eval_dyn<JAC>(P, P.dyn[i], x, g, G);
-  for (int i = tid; i < P.n_rom; i += nt) eval_rom<JAC>(P, P.rom[i], x, g, G);
+  for (int i = tid; i < P.n_dyn; i += nt) eval_dyn<JAC>(P, P.dyn[i], x, g, JAC ? loc + (size_t)i * DYN_LOC : nullptr);
+  if (JAC) {
+    __syncthreads();
+    for (int c = tid; c < P.n_dyn_cols; c += nt) dyn_column(P, P.dyn_cols[c], loc, G);
+    __syncthreads();
+  }
+  for (int i = tid; i < P.n_rom; i += nt) eval_rom<JAC>(P, P.rom[i], x, g, JAC ? loc + (size_t)i * ROM_LOC : nullptr);
+  if (JAC) {
+    __syncthreads();
+    for (int c = tid; c < P.n_rom_cols; c += nt) rom_column(P.rom_cols[c], loc, G);
+  }
   for (int i = tid; i < P.n_force; i += nt) eval_force<JAC>(P, P.force[i], map, x, g, G);
   for (int i = tid; i < P.n_terr; i += nt) eval_terr<JAC>(P, P.terr[i], map, x, g, G);
   for (int i = tid; i < P.n_lin; i += nt) {
@@ -390,16 +423,20 @@ __device__ inline double wg_reduce(double v, double *scratch) {
 
 // barrier weights of every inequality row: sig = zl/(s-l) + zu/(u-s), w = sig (g - s) - mu/(s-l) + mu/(u-s)
 __device__ inline void barrier_terms(const DevPlan &P, const double *g, const double *s, const double *zl,
-                                     const double *zu, double mu, double *sig, double *w) {
+                                     const double *zu, double mu, double *sig, double *w, double *stream) {
   for (int r = threadIdx.x; r < P.n_cons; r += blockDim.x) {
+    if (P.row_kind[r] == 1) { stream[P.rhs_pos[r]] = -g[r]; continue; }
     if (P.row_kind[r] != 2) continue;
     const double l = P.con_lo[r], u = P.con_hi[r];
     const bool hl = l > -1e19, hu = u < 1e19;
     const double dl = hl ? s[r] - l : 1.0, du = hu ? u - s[r] : 1.0;
     const double sg = (hl ? zl[r] / dl : 0.0) + (hu ? zu[r] / du : 0.0);
     const double gmu = -(hl ? mu / dl : 0.0) + (hu ? mu / du : 0.0);
+    const double wr = sg * (g[r] - s[r]) + gmu;
     sig[r] = sg;
-    w[r] = sg * (g[r] - s[r]) + gmu;
+    w[r] = wr;
+    stream[P.sig_pos[r]] = sg;
+    stream[P.w_pos[r]] = wr;
   }
 }
 
@@ -462,6 +499,7 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
   if (b >= B) return;
   __shared__ double scratch[256];
+  extern __shared__ double evl[];
   const int n = P.n_vars, m = P.n_cons, tid = threadIdx.x;
   double *x = W.x + (size_t)b * n, *g = W.g + (size_t)b * m;
   double *s = W.s + (size_t)b * m, *zl = W.zl + (size_t)b * m, *zu = W.zu + (size_t)b * m;
@@ -491,7 +529,7 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
     x[v] = val;
   }
   __syncthreads();
-  eval_all<false>(P, map, x, g, nullptr);
+  if (!(P.dbg & 1024)) eval_all<false>(P, map, x, g, nullptr, nullptr);
   __syncthreads();
   // slack initialisation: push strictly inside the bounds (Ipopt bound_push / bound_frac = 0.01)
   for (int r = tid; r < m; r += blockDim.x) {
@@ -526,11 +564,8 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
   }
   if (conv) return;
   __syncthreads();
-  eval_all<true>(P, map, x, g, W.G + (size_t)b * P.g_doubles);
-  barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m);
-  __syncthreads();
-  pack_stream(P, W.G + (size_t)b * P.g_doubles, g, W.sig + (size_t)b * m, W.w + (size_t)b * m,
-              W.stream + (size_t)b * P.stream_len);
+  if (!(P.dbg & 512)) eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl);
+  barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
 }
 
 // =================================================================================================
@@ -893,12 +928,13 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   const int b = blockIdx.x;
   if (b >= B || W.done[b]) return;
   __shared__ double scratch[256];
+  extern __shared__ double evl[];
   const int n = P.n_vars, m = P.n_cons, tid = threadIdx.x;
   double *x = W.x + (size_t)b * n, *xt = W.xt + (size_t)b * n, *dx = W.dx + (size_t)b * n;
   double *g = W.g + (size_t)b * m, *gt = W.gt + (size_t)b * m;
   double *s = W.s + (size_t)b * m, *zl = W.zl + (size_t)b * m, *zu = W.zu + (size_t)b * m;
   double *ds = W.ds + (size_t)b * m, *dzl = W.dzl + (size_t)b * m, *dzu = W.dzu + (size_t)b * m;
-  const double *G = W.G + (size_t)b * P.g_doubles;
+  const double *G = W.stream + (size_t)b * P.stream_len;
   const int map = W.map_id ? W.map_id[b] : 0;
   double mu = W.mu[b];
   // ds = Ji dx + (g - s) through the inequality blocks
@@ -939,7 +975,7 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   for (int ls = 0; ls < 6; ++ls) {
     for (int v = tid; v < n; v += blockDim.x) xt[v] = x[v] + al * dx[v];
     __syncthreads();
-    eval_all<false>(P, map, xt, gt, nullptr);
+    eval_all<false>(P, map, xt, gt, nullptr, nullptr);
     __syncthreads();
     th = l1_infeasibility(P, gt, s, ds, al, scratch);
     if (th <= (1.0 - 1e-4 * al) * th0 || th < 1e-9) break;
@@ -979,11 +1015,8 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   }
   if (conv || bad) return;
   __syncthreads();
-  eval_all<true>(P, map, x, g, W.G + (size_t)b * P.g_doubles);
-  barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m);
-  __syncthreads();
-  pack_stream(P, W.G + (size_t)b * P.g_doubles, g, W.sig + (size_t)b * m, W.w + (size_t)b * m,
-              W.stream + (size_t)b * P.stream_len);
+  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl);
+  barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
 }
 
 // =================================================================================================

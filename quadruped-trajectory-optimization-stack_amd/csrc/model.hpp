@@ -53,6 +53,13 @@ struct LinRow {  // 1 row with constant coefficients (acceleration continuity, s
   int var[8];
   double coef[8];
 };
+// One column of a dynamics / range-of-motion Jacobian block: which local Jacobian feeds it and the
+// combined Hermite weights of the node slots that map onto this variable (written exactly once).
+struct ColDesc {
+  int inst, gbase, ncol;       // instance index, offset of G[0][col], row stride
+  short kind, dim;             // dyn: 0 lin, 1 ang, 2+e foot e position, 6+e foot e force; rom: 0 lin, 1 ang, 2 foot
+  double w0, w1, w2;
+};
 // K2 assembly block: m consecutive constraint rows sharing one dense column list
 struct Block {
   int kind;  // 0 equality, 1 inequality
@@ -204,6 +211,7 @@ struct HostModel {
     blocks.push_back(b);
     return (int)blocks.size() - 1;
   }
+  std::vector<ColDesc> dyn_cols, rom_cols;
   // instances hold a block id in .goff until the offsets are final
   void finalize_goff() {
     auto fix = [&](int &goff) { if (goff >= 0) goff = blocks[goff].goff; };
@@ -211,6 +219,48 @@ struct HostModel {
     for (auto &i : rom) fix(i.goff);
     for (auto &i : terr) fix(i.goff);
     for (auto &i : force) fix(i.goff);
+    // column descriptors: every G entry of a dynamics / range-of-motion block is written once
+    auto add = [](std::vector<ColDesc> &cols, size_t first, int inst, int gbase0, int ncol, int kind,
+                  const short cmap[12], const VecIn *in0, const VecIn *in1, const VecIn *in2) {
+      for (int s = 0; s < 4; ++s)
+        for (int d = 0; d < 3; ++d) {
+          const int c = cmap[3 * s + d];
+          if (c < 0) continue;
+          ColDesc *cd = nullptr;
+          for (size_t i = first; i < cols.size(); ++i)
+            if (cols[i].gbase == gbase0 + c) { cd = &cols[i]; break; }
+          if (!cd) {
+            ColDesc nw;
+            std::memset(&nw, 0, sizeof(nw));
+            nw.inst = inst; nw.gbase = gbase0 + c; nw.ncol = ncol; nw.kind = (short)kind; nw.dim = (short)d;
+            cols.push_back(nw);
+            cd = &cols.back();
+          }
+          cd->w0 += in0->w[s];
+          if (in1) cd->w1 += in1->w[s];
+          if (in2) cd->w2 += in2->w[s];
+        }
+    };
+    dyn_cols.clear();
+    rom_cols.clear();
+    for (size_t k = 0; k < dyn.size(); ++k) {
+      const DynInst &I = dyn[k];
+      if (!I.in_kkt) continue;
+      const size_t first = dyn_cols.size();
+      add(dyn_cols, first, (int)k, I.goff, I.ncol, 0, I.c_lin, &I.r, &I.a, nullptr);
+      add(dyn_cols, first, (int)k, I.goff, I.ncol, 1, I.c_ang, &I.th, &I.thd, &I.thdd);
+      for (int e = 0; e < NEE; ++e) {
+        add(dyn_cols, first, (int)k, I.goff, I.ncol, 2 + e, I.c_p[e], &I.p[e], nullptr, nullptr);
+        add(dyn_cols, first, (int)k, I.goff, I.ncol, 6 + e, I.c_f[e], &I.f[e], nullptr, nullptr);
+      }
+    }
+    for (size_t k = 0; k < rom.size(); ++k) {
+      const RomInst &I = rom[k];
+      const size_t first = rom_cols.size();
+      add(rom_cols, first, (int)k, I.goff, I.ncol, 0, I.c_lin, &I.r, nullptr, nullptr);
+      add(rom_cols, first, (int)k, I.goff, I.ncol, 1, I.c_ang, &I.th, nullptr, nullptr);
+      add(rom_cols, first, (int)k, I.goff, I.ncol, 2, I.c_p, &I.p, nullptr, nullptr);
+    }
   }
 
   int build(const QtosParams &params) {

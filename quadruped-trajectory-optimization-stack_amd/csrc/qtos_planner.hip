@@ -36,7 +36,7 @@ struct QtosPlanner {
   int *h_active = nullptr;  // pinned
   std::vector<hipEvent_t> ev;  // 2 per iteration (kkt begin/end) + 2 (total)
   int last_launches = 0, last_iters = 0;
-  size_t kkt_lds = 0;
+  size_t kkt_lds = 0, eval_lds = 0;
   std::string err;
 
   template <class T>
@@ -76,6 +76,7 @@ static int upload_spline(QtosPlanner *p, const Spline &S, SampleSpline *out) {
 }
 
 extern "C" {
+__global__ void k_debug_eval(DevPlan P, DevWork W, int B);
 
 const char *qtos_last_error(const QtosPlanner *p) { return p ? p->err.c_str() : "null planner"; }
 
@@ -117,6 +118,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.n_force = (int)M.force.size(); D.n_lin = (int)M.linrow.size(); D.n_blocks = (int)M.blocks.size();
   TRY(p->upload(M.dyn, &D.dyn)); TRY(p->upload(M.rom, &D.rom)); TRY(p->upload(M.terr, &D.terr));
   TRY(p->upload(M.force, &D.force)); TRY(p->upload(M.linrow, &D.lin));
+  TRY(p->upload(M.dyn_cols, &D.dyn_cols)); TRY(p->upload(M.rom_cols, &D.rom_cols));
+  D.n_dyn_cols = (int)M.dyn_cols.size(); D.n_rom_cols = (int)M.rom_cols.size();
   TRY(p->upload(M.blocks, &D.blocks)); TRY(p->upload(M.block_cols, &D.block_cols));
   TRY(p->upload(M.g_static, &D.g_static));
   TRY(p->upload(S.piv_slot, &D.piv_slot)); TRY(p->upload(S.piv_unknown, &D.piv_unknown));
@@ -128,6 +131,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.max_stage_g = S.max_stage_g;
   TRY(p->upload(S.srec, &D.srec)); TRY(p->upload(S.srec_off, &D.srec_off));
   TRY(p->upload(S.pack_src, &D.pack_src)); TRY(p->upload(S.drec_off, &D.drec_off));
+  TRY(p->upload(S.eq_pos, &D.eq_pos)); TRY(p->upload(S.rhs_pos, &D.rhs_pos));
+  TRY(p->upload(S.sig_pos, &D.sig_pos)); TRY(p->upload(S.w_pos, &D.w_pos));
   D.max_srec = S.max_srec; D.max_drec = S.max_drec; D.stream_len = (int)S.pack_src.size();
   D.mass = M.P.mass; D.gravity = M.P.gravity; D.mu_fric = M.P.mu; D.f_max = M.P.f_max; D.T = M.T;
   for (int i = 0; i < 9; ++i) D.Ib[i] = M.P.inertia_b[i];
@@ -160,6 +165,10 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     hipError_t e = hipFuncSetAttribute((const void *)k_kkt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
   }
+  p->eval_lds = sizeof(double) * std::max((size_t)DYN_LOC * M.dyn.size(), (size_t)ROM_LOC * M.rom.size());
+  if (p->eval_lds > 150 * 1024) { p->err = "too many dynamics knots for the LDS scratch"; qtos_planner_destroy(p); return -4; }
+  for (const void *fn : {(const void *)k_start, (const void *)k_step, (const void *)k_debug_eval})
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->eval_lds) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   // sampling tables
   SamplePlan &SP = p->sp;
   std::memset(&SP, 0, sizeof(SP));
@@ -174,9 +183,15 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.g, Bm * m)); TRY(p->alloc(&W.gt, Bm * m)); TRY(p->alloc(&W.s, Bm * m));
   TRY(p->alloc(&W.zl, Bm * m)); TRY(p->alloc(&W.zu, Bm * m)); TRY(p->alloc(&W.ds, Bm * m));
   TRY(p->alloc(&W.dzl, Bm * m)); TRY(p->alloc(&W.dzu, Bm * m)); TRY(p->alloc(&W.sig, Bm * m));
-  TRY(p->alloc(&W.w, Bm * m)); TRY(p->alloc(&W.G, Bm * (size_t)S.g_doubles));
+  TRY(p->alloc(&W.w, Bm * m));
   TRY(p->alloc(&W.panel, Bm * (size_t)D.panel_stride));
   TRY(p->alloc(&W.stream, Bm * (size_t)S.pack_src.size()));
+  {  // constants of the stream (static Jacobian values, pivot diagonals): written once per problem
+    std::vector<double> one(S.pack_src.size(), 0.0);
+    for (size_t i = 0; i < S.const_pos.size(); ++i) one[S.const_pos[i]] = S.const_val[i];
+    for (size_t b = 0; b < Bm; ++b)
+      HIPCHK(p, hipMemcpy(W.stream + b * one.size(), one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   TRY(p->alloc(&W.mu, Bm)); TRY(p->alloc(&W.viol, Bm));
   TRY(p->alloc(&W.trace, Bm * (size_t)(M.P.max_iter + 1) * 4));
   TRY(p->alloc(&W.status, Bm)); TRY(p->alloc(&W.iters, Bm)); TRY(p->alloc(&W.done, Bm));
@@ -266,7 +281,7 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
   const DevPlan &D = p->dp;
   HIPCHK(p, hipMemsetAsync(W.n_active, 0, sizeof(int), st));
   HIPCHK(p, hipEventRecord(p->ev[0], st));
-  hipLaunchKernelGGL(k_start, dim3(B), dim3(256), 0, st, D, W, B);
+  hipLaunchKernelGGL(k_start, dim3(B), dim3(256), p->eval_lds, st, D, W, B);
   int launches = 0, it = 0;
   for (it = 0; it < D.max_iter; ++it) {
     HIPCHK(p, hipMemcpyAsync(p->h_active, W.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -282,7 +297,7 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
     hipLaunchKernelGGL(k_kkt, dim3(B), dim3(KT), p->kkt_lds, st, D, W, B);
     HIPCHK(p, hipEventRecord(p->ev[3 + 2 * launches], st));
     launches++;
-    hipLaunchKernelGGL(k_step, dim3(B), dim3(256), 0, st, D, W, B, it);
+    hipLaunchKernelGGL(k_step, dim3(B), dim3(256), p->eval_lds, st, D, W, B, it);
   }
   HIPCHK(p, hipMemcpyAsync(d_nodes_out, W.x, (size_t)B * D.n_vars * sizeof(double), hipMemcpyDeviceToDevice, st));
   if (d_status_out) HIPCHK(p, hipMemcpyAsync(d_status_out, W.status, B * sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -376,7 +391,8 @@ __global__ __launch_bounds__(256) void k_debug_eval(DevPlan P, DevWork W, int B)
                           : W.warm[(size_t)b * n + v];
   }
   __syncthreads();
-  eval_all<true>(P, W.map_id ? W.map_id[b] : 0, x, g, W.G + (size_t)b * P.g_doubles);
+  extern __shared__ double evl[];
+  eval_all<true>(P, W.map_id ? W.map_id[b] : 0, x, g, W.stream + (size_t)b * P.stream_len, evl);
   if (threadIdx.x == 0) W.done[b] = 0;
 }
 
@@ -384,8 +400,12 @@ __global__ __launch_bounds__(256) void k_debug_pack(DevPlan P, DevWork W, int B)
   const int b = blockIdx.x;
   if (b >= B) return;
   const size_t m = P.n_cons;
-  pack_stream(P, W.G + (size_t)b * P.g_doubles, W.g + b * m, W.sig + b * m, W.w + b * m,
-              W.stream + (size_t)b * P.stream_len);
+  const double *g = W.g + b * m, *sig = W.sig + b * m, *w = W.w + b * m;
+  double *stream = W.stream + (size_t)b * P.stream_len;
+  for (int r = threadIdx.x; r < P.n_cons; r += blockDim.x) {
+    if (P.row_kind[r] == 1) stream[P.rhs_pos[r]] = -g[r];
+    if (P.row_kind[r] == 2) { stream[P.sig_pos[r]] = sig[r]; stream[P.w_pos[r]] = w[r]; }
+  }
 }
 
 static int debug_upload(QtosPlanner *p, int B, const double *start, const double *goal, const int *map_id, const double *nodes, DevWork *W) {
@@ -398,7 +418,7 @@ static int debug_upload(QtosPlanner *p, int B, const double *start, const double
   HIPCHK(p, hipMemcpy(p->d_warm, nodes, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice));
   *W = p->wk;
   W->start = p->d_start; W->goal = p->d_goal; W->map_id = map_id ? p->d_map : nullptr; W->warm = p->d_warm;
-  hipLaunchKernelGGL(k_debug_eval, dim3(B), dim3(256), 0, 0, p->dp, *W, B);
+  hipLaunchKernelGGL(k_debug_eval, dim3(B), dim3(256), p->eval_lds, 0, p->dp, *W, B);
   HIPCHK(p, hipDeviceSynchronize());
   return 0;
 }
@@ -412,16 +432,20 @@ int qtos_debug_eval(QtosPlanner *p, int B, const double *start, const double *go
   const size_t n = M.n_vars, m = M.n_cons;
   if (g_out) HIPCHK(p, hipMemcpy(g_out, W.g, (size_t)B * m * sizeof(double), hipMemcpyDeviceToHost));
   if (J_out) {
-    std::vector<double> G((size_t)B * p->S.g_doubles);
-    HIPCHK(p, hipMemcpy(G.data(), W.G, G.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const size_t SL = p->S.pack_src.size();
+    std::vector<double> G((size_t)B * SL);
+    HIPCHK(p, hipMemcpy(G.data(), W.stream, G.size() * sizeof(double), hipMemcpyDeviceToHost));
     std::memset(J_out, 0, (size_t)B * m * n * sizeof(double));
     for (int b = 0; b < B; ++b)
-      for (const Block &blk : M.blocks) {
-        const double *Gb = blk.gstatic ? M.g_static.data() + blk.goff : G.data() + (size_t)b * p->S.g_doubles + blk.goff;
+      for (const Block &blk : M.blocks)
         for (int r = 0; r < blk.m; ++r)
-          for (int a = 0; a < blk.n; ++a)
-            J_out[((size_t)b * m + blk.row0 + r) * n + M.block_cols[blk.col_off + a]] = Gb[r * blk.n + a];
-      }
+          for (int a = 0; a < blk.n; ++a) {
+            double v;
+            if (blk.gstatic) v = M.g_static[blk.goff + r * blk.n + a];
+            else if (blk.kind == 1) v = G[(size_t)b * SL + blk.goff + r * blk.n + a];
+            else v = G[(size_t)b * SL + p->S.eq_pos[blk.goff + r * blk.n + a]];
+            J_out[((size_t)b * m + blk.row0 + r) * n + M.block_cols[blk.col_off + a]] = v;
+          }
   }
   return 0;
 }

@@ -65,6 +65,12 @@ struct Symbolic {
   // pack_src[i] says where stream element i comes from: (kind << 28) | index, kind 0 G, 1 g_static,
   // 2 -g[row], 3 sig[row], 4 w[row], 5 piv_diag
   std::vector<int> srec, srec_off, pack_src, drec_off, stage_hi;
+  // The linearisation kernels write straight into the stream: eq_pos maps the (virtual) G offset of
+  // an equality-block entry to its stream position; inequality blocks are contiguous in the stream
+  // (Block::goff = stream offset); rhs/sig/w positions per constraint row; constants (static
+  // Jacobian values, pivot diagonals) are written once per problem at planner creation.
+  std::vector<int> eq_pos, rhs_pos, sig_pos, w_pos, const_pos;
+  std::vector<double> const_val;
   int max_srec = 0, max_drec = 0;
   long long g_doubles = 0;
   long long algorithmic_bytes = 0, flops = 0, envelope = 0;
@@ -255,7 +261,6 @@ struct Symbolic {
       stages[k].rhs_end = (int)eq_rhs.size();
     }
     M.g_doubles = g_doubles;
-    M.finalize_goff();
     // ---- packed records ----
     auto trs = [](int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
     srec_off.assign(n_stages + 1, 0);
@@ -298,6 +303,25 @@ struct Symbolic {
     }
     srec_off[n_stages] = (int)srec.size();
     drec_off[n_stages] = (int)pack_src.size();
+    // ---- direct-write maps derived from the stream layout ----
+    eq_pos.assign((size_t)std::max<long long>(g_doubles, 1), -1);
+    rhs_pos.assign(m, -1);
+    sig_pos.assign(m, -1);
+    w_pos.assign(m, -1);
+    std::vector<int> iq_first((size_t)std::max<long long>(g_doubles, 1), -1);  // virtual G offset -> stream pos
+    for (int i = 0; i < (int)pack_src.size(); ++i) {
+      const int kind = pack_src[i] >> 28, idx = pack_src[i] & 0x0fffffff;
+      if (kind == 0) { eq_pos[idx] = i; iq_first[idx] = i; }
+      else if (kind == 1) { const_pos.push_back(i); const_val.push_back(M.g_static[idx]); }
+      else if (kind == 2) rhs_pos[idx] = i;
+      else if (kind == 3) sig_pos[idx] = i;
+      else if (kind == 4) w_pos[idx] = i;
+      else { const_pos.push_back(i); const_val.push_back(piv_diag[idx]); }
+    }
+    // inequality blocks: contiguous in the stream -> their goff becomes the stream offset itself
+    for (Block &b : M.blocks)
+      if (b.kind == 1) b.goff = iq_first[b.goff];
+    M.finalize_goff();
     // bytes = w * [ sum_k (p + c_k) * p  +  2 M ]   (matrix once, rhs in, solution out)
     algorithmic_bytes = 0;
     flops = 0;
