@@ -215,6 +215,77 @@ def boundary_fixtures():
         os.chdir(cwd)
 
 
+def planner_fixtures():
+    """Outputs of the reference's global planner / stitcher (imported here, never shipped)."""
+    import tempfile
+    import types
+    sys.modules.setdefault("pybullet", types.ModuleType("pybullet"))
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)   # the reference writes ./data/plots/... relative to the cwd
+    os.makedirs("data/plots", exist_ok=True)
+    try:
+        import io
+        import contextlib
+        from QTOS import planner as rpl
+        from QTOS import combiner as rcb
+        import QTOS.config.global_cfg as gcfg
+        out = {"path_solver": [], "global_planner": [], "stitch": []}
+        wall = np.zeros((20, 40))
+        wall[4:16, 18:21] = 0.5          # a wall across the straight line, passable on both sides
+        for name, m, start, goal in (("flat", np.zeros((20, 40)), [0, 0, .24], [2.5, 0, .24]),
+                                     ("wall", wall, [0, 0, .24], [2.5, 0, .24])):
+            with contextlib.redirect_stdout(io.StringIO()):
+                ps = rpl.PATH_Solver(m, start, goal, {"step_size": 1.0}, grid_res=0.1, visual=False)
+            ts = [0.0, 1.3, 5.0, 12.5, 20.0, float(ps.predicted_t)]
+            out["path_solver"].append({
+                "name": name, "map": m.tolist(), "start": start, "goal": goal, "step_size": 1.0,
+                "path": [list(map(int, c)) for c in ps.path], "predicted_t": float(ps.predicted_t),
+                "t": ts, "x": [float(ps.spine_x_track(t)) for t in ts], "y": [float(ps.spine_y_track(t)) for t in ts]})
+        # Global_Planner.update -> pop on the exp_1 map (SURVEY.md 8c cross-check values)
+        gcfg.ROBOT_CFG.robot_goal = [2.5, 0, 0.24]
+        sim = types.SimpleNamespace(height_map=np.zeros((20, 40)), bool_map=None)
+        args = {"args": {"resolution": 0.1}, "sim": sim, "-s": [0, 0, 0.24], "step_size": 1.0}
+        with contextlib.redirect_stdout(io.StringIO()):
+            gp = rpl.Global_Planner(args, lookahead=3750)
+        seq = []
+        for t in (0.0, 2.5, 5.0):
+            gp.update(t, [0.0, 0.0], [0.0, 0.0], np.zeros(3))
+        while not gp.empty():
+            s_, g_ = gp.pop()
+            seq.append({"start": [float(v) for v in s_], "goal": [float(v) for v in g_]})
+        out["global_planner"] = {"lookahead": 3750, "update_times": [0.0, 2.5, 5.0], "popped": seq}
+        # Combiner._state / combine on the canned plan
+        gait_path = os.path.join(REF, "test/data/traj/gait.csv")
+        for last_t, look, cutoff in ((0.006, 3750, 2500), (1.25, 2750, 1200), (0.0, 100, 0)):
+            cb = object.__new__(rcb.Combiner)
+            cb.current_traj = gait_path
+            cb.new_traj = os.path.join(tmp, "new.csv")
+            cb.last_timestep, cb.lookahead, cb.lookahead_original = last_t, look, look
+            cb.cutoff_idx, cb.next_traj_step = cutoff, 0
+            cb.height_set = {0.0}
+            with contextlib.redirect_stdout(io.StringIO()):
+                st = cb._state()
+            # a "new plan" = the canned plan shifted in time; combine old + new like the reference
+            new = np.loadtxt(gait_path, delimiter=",")
+            new[:, 0] += 100.0
+            np.savetxt(cb.new_traj, new[:50], delimiter=",", fmt="%g")
+            cb.combine()
+            comb = np.loadtxt(cb.new_traj, delimiter=",")
+            out["stitch"].append({
+                "last_timestep": last_t, "lookahead": look, "cutoff_idx": cutoff,
+                "state": {k: [float(x) for x in v] for k, v in st.items()},
+                "lookahead_after": int(cb.lookahead), "next_traj_step": int(cb.next_traj_step),
+                "combined_shape": list(comb.shape), "combined_t_first": float(comb[0, 0]),
+                "combined_t_last_old": float(comb[comb[:, 0] < 50][-1, 0]),
+                "combined_t_first_new": float(comb[comb[:, 0] > 50][0, 0]),
+                "combined_sum": float(comb.sum())})
+        return out
+    finally:
+        os.chdir(cwd)
+
+
 def main():
     gait = np.loadtxt(os.path.join(REF, "test/data/traj/gait.csv"), delimiter=",")
     towr = np.loadtxt(os.path.join(REF, "data/traj/towr.csv"), delimiter=",")
@@ -240,6 +311,7 @@ def main():
                             phase_durations=np.array(phase_durations()))
     np.savez_compressed(os.path.join(OUT, "gv3_partial.npz"), rows=gv3[::10], row_idx=np.arange(0, 1254, 10))
     json.dump(boundary_fixtures(), open(os.path.join(OUT, "boundary.json"), "w"), indent=1)
+    json.dump(planner_fixtures(), open(os.path.join(OUT, "planner.json"), "w"))
     dims = parse_log(os.path.join(REF, "logs/towr_log.out"))
     json.dump(dims, open(os.path.join(OUT, "nlp_dims.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in dims.items() if not k.endswith("_sets")}))
