@@ -281,6 +281,31 @@ def planner_fixtures():
                 "combined_t_last_old": float(comb[comb[:, 0] < 50][-1, 0]),
                 "combined_t_first_new": float(comb[comb[:, 0] > 50][0, 0]),
                 "combined_sum": float(comb.sum())})
+        # PATH_MAP: patch enumeration and failure-stamp neighbourhoods on the exp_3 map
+        os.chdir(REF)
+        from QTOS import generateHeightField as ghf
+        obj = object.__new__(ghf.Height_Map_Generator)
+        ghf.Maps.__init__(obj, ["feasibility", "feasibility_1", "plane"], 20, 1)
+        pm = object.__new__(ghf.PATH_MAP)
+        pm.origin_shift_x = pm.origin_shift_y = 1.0
+
+        class _Q:
+            def __init__(self):
+                self.items = []
+
+            def put(self, d):
+                self.items.append(d)
+        pm.data_queue = _Q()
+        pm.probe_map(obj.map, 3, 0.1)
+        nb = ((-3, 0), (3, 0), (0, -3), (0, 3))
+        out["path_map"] = {
+            "tiles": ["feasibility_test", "feasibility_test_1", "plane"], "multi_map_shift": 3,
+            "patches": [[list(map(float, d.map_coords_start)), list(map(float, d.map_coords_goal)),
+                         list(map(int, d.map_idx_start)), list(map(int, d.map_idx_goal))]
+                        for d in pm.data_queue.items],
+            "hull": pm.find_convex_hull(nb).tolist(),
+        }
+        os.chdir(tmp)
         return out
     finally:
         os.chdir(cwd)

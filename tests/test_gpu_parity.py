@@ -326,3 +326,55 @@ def test_local_planner_writes_reference_csv(tmp_path, gv1):
     assert cli.main(flags.cmd_args(args).split() + ["--out", str(out2)]) == 0
     assert np.array_equal(csvio.read_csv(str(out2)), rows)
     lp.close()
+
+
+def test_feasibility_map_batched():
+    """SURVEY.md 8f row 2 on the GPU: exp_3's 48 probe patches as ONE batch (the reference runs 48
+    docker processes, 32 at a time) -> exit codes -> boolean map that A* can consume."""
+    from qtos_amd import feasibility, heightfield
+    from qtos_amd.global_planner import PathSolver
+    from qtos_amd.planner import LocalPlanner
+    tiles = [heightfield.read_tile(os.path.join(GOLDEN, "heightfields", t + ".txt"))
+             for t in ("feasibility_test", "feasibility_test_1", "plane")]
+    m = heightfield.build_map(tiles, 1)
+    lp = LocalPlanner(max_batch=64)
+    lp.set_heightfield(heightfield.towr_map(m), heightfield.cell_size(m))
+    bm, patches, statuses = feasibility.feasibility_map(lp, m, multi_map_shift=3)
+    assert len(patches) == 48 and len(statuses) == 48 and bm.shape == m.shape
+    assert set(statuses) <= {0, 1, 2}
+    # every failed patch blocks its start and goal cells, every cell blocked belongs to some failure
+    for (_, _, s, g), rc in zip(patches, statuses):
+        if rc != 0:
+            assert bm[s] == 1 and bm[g] == 1
+    if all(rc == 0 for rc in statuses):
+        assert bm.sum() == 0
+    ps = PathSolver(m, [0, 0, 0.24], [4.5, 0, 0.24], 1.0, 0.1, bool_map=bm)
+    assert ps.path is None or ps.path[0] == ps.start_idx
+    lp.close()
+
+
+def test_replan_loop_stitches_two_plans(gv1):
+    """SURVEY.md 8f row 1 end to end: plan, pick the hand-over row like Combiner._state, re-plan from
+    it, splice like Combiner.combine."""
+    from qtos_amd.planner import LocalPlanner
+    from qtos_amd.stitcher import Stitcher
+    inp = gv1["inputs"]
+    args = {"-g": [0.52, 0.0, 0.24], "-s": inp["s"], "-s_ang": [0, 0, 0], "-e1": inp["ee"][0],
+            "-e2": inp["ee"][1], "-e3": inp["ee"][2], "-e4": inp["ee"][3], "-resolution": 0.01}
+    lp = LocalPlanner(max_batch=4)
+    assert lp.solve(args, out_csv=None) == 0
+    old = lp.last["rows"][0]
+    st = Stitcher(lookahead=3750, height_set=(0.0,))
+    st.cutoff_idx = 2500
+    state = st.state(np.round(old, 6), last_timestep=0.006)
+    assert st.legs_in_contact(state)
+    args2 = st.plan_args(args, state, runtime=0.006, goal=[0.91, 0.0, 0.24])
+    assert lp.solve(args2, out_csv=None) == 0
+    new = lp.last["rows"][0]
+    assert abs(new[0, 0] - args2["-t"]) < 1e-12
+    comb = st.combine(old, new)
+    t = comb[:, 0]
+    assert np.all(np.diff(t) > 0) and abs(np.diff(t).max() - 0.001) < 1e-9      # seamless time base
+    j = np.nonzero(t >= args2["-t"])[0][0]
+    assert np.abs(comb[j + 1, 1:19] - comb[j, 1:19]).max() < 2e-3               # positions continuous
+    lp.close()

@@ -90,3 +90,22 @@ def test_plan_args_fill_the_solver_flags():
     start, goal, t0 = flags.problem_arrays(args)
     assert np.allclose(start[0:3], gv["inputs"]["s"], atol=1e-6)
     assert np.allclose(start[18:21], gv["inputs"]["s_vel_flag"], atol=1e-6)
+
+
+def test_feasibility_probe_and_stamp_match_reference():
+    """patch enumeration + failure neighbourhood of PATH_MAP."""
+    from qtos_amd import feasibility, heightfield
+    ref = FIX["path_map"]
+    tiles = [heightfield.read_tile(os.path.join(GOLDEN, "heightfields", t + ".txt")) for t in ref["tiles"]]
+    m = heightfield.build_map(tiles, 1)
+    patches = feasibility.probe_patches(m, ref["multi_map_shift"], 0.1)
+    assert len(patches) == len(ref["patches"])
+    for p, r in zip(patches, ref["patches"]):
+        assert list(p[0]) == r[0] and list(p[1]) == r[1] and list(p[2]) == r[2] and list(p[3]) == r[3]
+    assert sorted(map(list, feasibility.diamond(1))) == sorted(ref["hull"])
+    a = feasibility.patch_args(patches[0][0], patches[0][1])
+    assert a["-s"][2] == patches[0][0][2] + 0.24 and a["-r"] == 5.0 and a["-e4"][0] == patches[0][0][0] - 0.21
+    bm = feasibility.stamp(m.shape, patches, [0 if i % 3 else 1 for i in range(len(patches))])
+    assert bm.shape == m.shape and set(np.unique(bm)) <= {0, 1} and bm.sum() > 0
+    s_idx = patches[0][2]
+    assert bm[s_idx[0], s_idx[1]] == 1 or bm[tuple(patches[0][3])] == 1
