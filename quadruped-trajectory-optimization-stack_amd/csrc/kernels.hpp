@@ -586,37 +586,54 @@ __device__ __forceinline__ void lds_barrier() {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // In-register LDL^T of a symmetric 16 x 16 block by one wave, no pivoting (the KKT matrix is
-// quasi-definite and the elimination order is fixed).  Lane (i, c) = (lane >> 2, lane & 3) owns
-// B[i][4c .. 4c+3]; both triangles are kept up to date so row k can be read as column k.
-// Result: strict lower triangle -> Lm (unit lower L), 1/d -> dinv.
-__device__ inline void ldlt16(const double *Bsrc /* 16 x PLD */, double *Lm, double *dinv, int lane) {
-  const int i = lane >> 2, c = lane & 3;
-  double a[4];
+// quasi-definite and the elimination order is fixed).  Lane i (mod 16) holds ROW i in 16
+// registers.  Step k: every lane scales its own B[i][k] by 1/d_k (no cross-lane traffic), and row
+// k -- wave-uniform -- is read from lane k with v_readlane; no LDS round trips on the 15-step
+// dependency chain.  Reciprocals: v_rcp_f64 + two Newton steps instead of the IEEE division
+// sequence (which costs hundreds of cycles per step on the critical path).
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), lane);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), lane);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ void ldlt16(const double *Bsrc /* 16 x PLD */, double *Lm, double *dinv, int lane) {
+  const int i = lane & 15;
+  double a[PIV];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) a[j] = Bsrc[i * PLD + 4 * c + j];
+  for (int j = 0; j < PIV; ++j) a[j] = Bsrc[i * PLD + j];
+  double myinv = 0.0;
 #pragma unroll
-  for (int k = 0; k < PIV - 1; ++k) {
-    const int kc = k >> 2, ke = k & 3;
-    const double dk = __shfl(a[ke], 4 * k + kc);
-    const double lik = __shfl(a[ke], 4 * i + kc);
-    double rk[4];
+  for (int k = 0; k < PIV; ++k) {
+    const double inv = fast_rcp(readlane_d(a[k], k));   // 1 / d_k
+    if (i == k) myinv = inv;
+    if (k == PIV - 1) break;
+    const double li = i > k ? a[k] * inv : 0.0;          // L[i][k] for rows i > k, 0 for finished rows
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rk[j] = __shfl(a[j], 4 * k + c);
-    const double f = lik * (1.0 / dk);
-    if (i > k) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * c + j > k) a[j] -= f * rk[j];
-      if (c == kc) a[ke] = f;  // L[i][k]
-    }
+    for (int j = k + 1; j < PIV; ++j) a[j] -= li * readlane_d(a[j], k);   // B[k][j] is wave-uniform
+    if (i > k) a[k] = li;
   }
+  if (lane < PIV) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = 4 * c + j;
-    if (col < i) Lm[i * PLD + col] = a[j];
-    if (col == i) dinv[i] = 1.0 / a[j];
+    for (int j = 0; j < PIV; ++j)
+      if (j < i) Lm[i * PLD + j] = a[j];
+    dinv[i] = myinv;
   }
 }
+
+#ifdef QTOS_STAMPS
+#define STAMP2(i) do { if (tid == 64) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps2[i] += t_ - tlast2; tlast2 = t_; } } while (0)
+#define STAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#define STAMP2(i) do {} while (0)
+#endif
 
 constexpr int PFD = 6, PFS = 6;  // per-thread prefetch registers: doubles / ints of a stage's records
 
@@ -658,6 +675,32 @@ __device__ inline void assemble_stage(double *A, int F, const int *sbuf, const d
   }
 }
 
+// Forward substitution y <- y L^-T with FOUR lanes per row: lane c of a quad owns columns c, c+4,
+// c+8, c+12.  Step Q broadcasts y[Q] inside the quad with a DPP quad_perm move (no LDS) and every
+// lane updates its columns j > Q.  The first quad carries the right-hand-side row as a second row.
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, SRC * 0x55, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, SRC * 0x55, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int Q>
+__device__ __forceinline__ void ysolve_steps(double (&y)[4], double (&yF)[4], const double *Lm, int cq) {
+  if constexpr (Q < PIV - 1) {
+    const double yq = quad_bcast<Q & 3>(y[Q >> 2]);
+    const double yFq = quad_bcast<Q & 3>(yF[Q >> 2]);
+#pragma unroll
+    for (int jj = Q >> 2; jj < 4; ++jj) {
+      const double l = Lm[(4 * jj + cq) * PLD + Q];
+      const double m = (jj > (Q >> 2) || cq > (Q & 3)) ? l : 0.0;   // only columns j = 4 jj + cq > Q
+      y[jj] -= yq * m;
+      yF[jj] -= yFq * m;
+    }
+    ysolve_steps<Q + 1>(y, yF, Lm, cq);
+  }
+}
+
 // k_kkt: one workgroup (KT threads, 8 waves) per problem; software-pipelined over the stage chain:
 //   S1  Y_k = P_k L_k^-T (row per thread), retire the pivots of stage k
 //   S2  assemble stage k+1 into the front (records prefetched one stage earlier)
@@ -684,6 +727,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   int *doff = soff + P.n_stages + 1;    // n_stages + 1
   int *psb = doff + P.n_stages + 1;     // 2 x PIV pivot slots (current / next stage)
   int *hib = psb + 2 * PIV;             // 2: hi of current / next stage
+  int *tileRC = hib + 2;                // (R << 8) | C of lower-triangular tile t, t < 45
   const int n = P.n_vars, NS = P.n_stages;
   const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
@@ -693,6 +737,11 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   for (int i = tid; i < ntri; i += KT) A[i] = 0.0;
   for (int v = tid; v < n; v += KT) dx[v] = 0.0;
   for (int i = tid; i <= NS; i += KT) { soff[i] = P.srec_off[i]; doff[i] = P.drec_off[i]; }
+  if (tid < 45) {
+    int R = 0;
+    while (((R + 1) * (R + 2)) >> 1 <= tid) ++R;
+    tileRC[tid] = (R << 8) | (tid - ((R * (R + 1)) >> 1));
+  }
   __syncthreads();
   // ---- prologue: assemble stage 0, gather and factor its pivot block, stage records of stage 1 ----
   for (int i = tid; i < soff[1] - soff[0]; i += KT) sbuf[i] = P.srec[soff[0] + i];
@@ -719,6 +768,11 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   }
   __syncthreads();
 
+#ifdef QTOS_STAMPS
+  unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  unsigned long long stamps2[4] = {0, 0, 0, 0}, tlast2 = 0;
+  if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
+#endif
   int cur = 0;
   for (int k = 0; k < NS; ++k) {
     const int nxt = cur ^ 1;
@@ -741,26 +795,26 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #pragma unroll
       for (int j = 0; j < PFS; ++j) { const int i = tid + j * KT; pfs[j] = i < ns ? ssrc[i] : 0; }
     }
-    // ---- S1: Y = P L^-T, one row per thread (rows 0..F; row F is the right-hand side) ----------
-    if (tid <= F && !(P.dbg & 1)) {
-      double y[PIV];
-      double *row = Y + tid * PLD;
+    // ---- S1: retire the pivots of stage k (their rows / columns are recycled), then Y = P L^-T with
+    //      four lanes per row (rows 0..F-1 on quads 0..F-1, the rhs row F rides on quad 0) -------
+    for (int i = tid; i < PIV * (hi + 1); i += KT) {
+      const int j = i & 15, rr = i >> 4;
+      A[trs(rr < hi ? rr : F, ps[j])] = 0.0;
+    }
+    {
+      const int r0 = tid >> 2, cq = tid & 3;
+      if (r0 < F) {
+        double y[4], yF[4];
+        double *row = Y + r0 * PLD, *rowF = Y + F * PLD;
 #pragma unroll
-      for (int j = 0; j < PIV; ++j) y[j] = row[j];
+        for (int jj = 0; jj < 4; ++jj) { y[jj] = row[4 * jj + cq]; yF[jj] = r0 == 0 ? rowF[4 * jj + cq] : 0.0; }
+        ysolve_steps<0>(y, yF, Lm, cq);
 #pragma unroll
-      for (int q = 0; q < PIV - 1; ++q)
-#pragma unroll
-        for (int j = q + 1; j < PIV; ++j) y[j] -= y[q] * Lm[j * PLD + q];
-#pragma unroll
-      for (int j = 0; j < PIV; ++j) row[j] = y[j];
-    } else {
-      // the other waves retire the pivots of stage k: their rows / columns are recycled
-      for (int i = tid - (F + 1); i < PIV * (hi + 1); i += KT - (F + 1)) {
-        const int j = i / (hi + 1), rr = i - j * (hi + 1);
-        A[trs(rr < hi ? rr : F, ps[j])] = 0.0;
+        for (int jj = 0; jj < 4; ++jj) { row[4 * jj + cq] = y[jj]; if (r0 == 0) rowF[4 * jj + cq] = yF[jj]; }
       }
     }
     lds_barrier();
+    STAMP(0);
     // ---- S2: assemble stage k+1 ------------------------------------------------------------------
     if (has_next) {
       if (tid < PIV) psb[nxt * PIV + tid] = sbuf[4 + tid];
@@ -768,6 +822,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       if (!(P.dbg & 2)) assemble_stage(A, F, sbuf, dbuf, tid);
     }
     lds_barrier();
+    STAMP(1);
     // ---- S3: early gather of the next pivot columns with this stage's update applied:
     //      P_next[r][j] = A[r][piv_j] - sum_q Y[r][q] (Y[piv_j][q] / d_q), 16-row tiles on the matrix
     //      cores (one tile per wave), the rhs row by 16 lanes -----------------------------------
@@ -790,15 +845,15 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) Pn[(16 * R + lk + 4 * g) * PLD + li] = acc[g];
       }
-      if (tid >= KT - PIV) {  // rhs row F
-        const int j = tid - (KT - PIV), pc = psn[j];
-        double acc = A[tri(F, pc)];
-#pragma unroll
-        for (int q = 0; q < PIV; ++q) acc -= Y[F * PLD + q] * dinv[q] * Y[pc * PLD + q];
-        Pn[F * PLD + j] = acc;
+      if (tid >= KT - PIV * PIV) {  // rhs row F: lane (j, q) forms one product, 16-lane shuffle tree sums over q
+        const int t = tid - (KT - PIV * PIV), j = t >> 4, q = t & 15, pc = psn[j];
+        double v = Y[F * PLD + q] * dinv[q] * Y[pc * PLD + q];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        if (q == 0) Pn[F * PLD + j] = A[tri(F, pc)] - v;
       }
     }
     lds_barrier();
+    STAMP(2);
     // ---- S4: wave 0 factors the next pivot block; waves 1..7 apply stage k's update ------------
     if (tid < 64) {
       if (has_next) {
@@ -808,47 +863,68 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         if (!(P.dbg & 8)) ldlt16(Bs, Lbuf + nxt * PIV * PLD, dvb + nxt * PIV, tid);
         for (int e = tid; e < PIV * PIV; e += 64) Pn[psn[e >> 4] * PLD + (e & 15)] = 0.0;
       }
+      STAMP(3);
     } else {
+#ifdef QTOS_STAMPS
+      if (tid == 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast2) :: "memory");
+#endif
       const int wv = (tid >> 6) - 1, lane = tid & 63, li = lane & 15, lk = lane >> 4;
       const int nt16 = hi16 >> 4, ntile = (nt16 * (nt16 + 1)) >> 1;
-      for (int t = wv; t < ((P.dbg & 16) ? 0 : ntile); t += KT / 64 - 1) {
-        int R = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
-        while (((R + 1) * (R + 2)) >> 1 <= t) ++R;
-        while ((R * (R + 1)) >> 1 > t) --R;
-        const int C = t - ((R * (R + 1)) >> 1);
-        const int col = 16 * C + li;
-        d4_t acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = 16 * R + lk + 4 * g;
-          acc[g] = col <= row ? A[tri(row, col)] : 0.0;
-        }
+      for (int t = wv; t < ntile; t += KT / 64 - 1) {
+        const int rc = tileRC[t], R = rc >> 8, C = rc & 255;
+        const int col = 16 * C + li, row0 = 16 * R + lk;
         const double *wrow = Y + (16 * R + li) * PLD + lk;
         const double *prow = Y + (16 * C + li) * PLD + lk;
+        double wa[4], pb[4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-wrow[4 * s4] * dinv[lk + 4 * s4], prow[4 * s4], acc, 0, 0, 0);
+        for (int s4 = 0; s4 < 4; ++s4) { wa[s4] = -wrow[4 * s4] * dinv[lk + 4 * s4]; pb[s4] = prow[4 * s4]; }
+        d4_t acc;
+        if (R != C) {   // off-diagonal tile: every element is below the diagonal, no masks
+          int idx[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = 16 * R + lk + 4 * g;
-          if (col <= row) A[tri(row, col)] = acc[g];
+          for (int g = 0; g < 4; ++g) { idx[g] = tri(row0 + 4 * g, col); acc[g] = A[idx[g]]; }
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s4], pb[s4], acc, 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) A[idx[g]] = acc[g];
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = row0 + 4 * g;
+            acc[g] = col <= row ? A[tri(row, col)] : 0.0;
+          }
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s4], pb[s4], acc, 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = row0 + 4 * g;
+            if (col <= row) A[tri(row, col)] = acc[g];
+          }
         }
       }
+      STAMP2(0);
       const int t2 = tid - 64;
-      for (int c = t2; c < hi16; c += KT - 64) {  // right-hand-side row
-        double acc = 0;
+      {  // right-hand-side row: 4 lanes per column, each sums 4 of the 16 products
+        const int q4 = (t2 & 3) * 4;
+        for (int c = t2 >> 2; c < hi16; c += (KT - 64) >> 2) {   // uniform within each 4-lane group
+          double acc = 0;
 #pragma unroll
-        for (int q = 0; q < PIV; ++q) acc += Y[F * PLD + q] * dinv[q] * Y[c * PLD + q];
-        A[tri(F, c)] -= acc;
+          for (int q = 0; q < 4; ++q) acc += Y[F * PLD + q4 + q] * dinv[q4 + q] * Y[c * PLD + q4 + q];
+          acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+          if ((t2 & 3) == 0) A[tri(F, c)] -= acc;
+        }
       }
+      STAMP2(1);
       // factor panel of stage k to HBM
       double *pk = panel + (size_t)k * pstride;
       for (int i = t2; i < PIV * PIV; i += KT - 64) pk[i] = Lm[(i >> 4) * PLD + (i & 15)];
       if (t2 < PIV) pk[PIV * PIV + t2] = dinv[t2];
       else if (t2 < 2 * PIV) pk[PIV * PIV + t2] = Y[F * PLD + (t2 - PIV)];
       for (int i = t2; i < ((P.dbg & 32) ? 0 : hi * PIV); i += KT - 64) pk[PIV * PIV + 2 * PIV + i] = Y[(i >> 4) * PLD + (i & 15)];
+      STAMP2(2);
     }
     lds_barrier();
+    STAMP(4);
     // ---- install the records of stage k+2 ------------------------------------------------------
     if (k + 2 < NS) {
 #pragma unroll
@@ -857,9 +933,11 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       for (int j = 0; j < PFS; ++j) { const int i = tid + j * KT; if (i < ns) sbuf[i] = pfs[j]; }
     }
     cur = nxt;
+    STAMP(5);
   }
   // ---- backward substitution: L^T x1 = D^-1 (y_F - Y^T x2), panels prefetched one stage ahead ----
   __syncthreads();  // drains the factor-panel stores: they are read back below
+  STAMP(6);
   for (int i = tid; i < F; i += KT) xs[i] = 0.0;
   constexpr int PFB = 5;  // (F + 18) * 16 / 512 <= 5 for F <= 128
   double pfb[PFB];
@@ -921,6 +999,11 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     }
     lds_barrier();
   }
+#ifdef QTOS_STAMPS
+  STAMP(7);
+  if (tid == 0 && W.trace) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 30) * 4 + i] = (double)stamps[i];
+  if (tid == 64 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 32) * 4 + i] = (double)stamps2[i];
+#endif
 }
 
 // =================================================================================================

@@ -148,7 +148,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   const int F = S.front;
   size_t lds_d = (size_t)((F + 1) * (F + 2) / 2) + 2 * (size_t)(F + 1) * PLD + 2 * PIV * PLD + 2 * PIV + F +
                  34 * PLD + S.max_drec + 8;
-  p->kkt_lds = lds_d * sizeof(double) + ((size_t)S.max_srec + 2 * (size_t)(S.n_stages + 1) + 2 * PIV + 2 + 8) * sizeof(int);
+  p->kkt_lds = lds_d * sizeof(double) + ((size_t)S.max_srec + 2 * (size_t)(S.n_stages + 1) + 2 * PIV + 2 + 48 + 8) * sizeof(int);
   if (S.max_drec > PFD * KT || S.max_srec > PFS * KT || (F + PIV + 2) * PIV > 5 * KT) {
     p->err = "stage record exceeds the prefetch registers";
     fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints)\n", S.max_drec, S.max_srec);
@@ -480,7 +480,8 @@ int qtos_debug_trace(QtosPlanner *p, int b, double *trace_out) {
   int iters = 0;
   HIPCHK(p, hipMemcpy(&iters, p->wk.iters + b, sizeof(int), hipMemcpyDeviceToHost));
   const int rows = iters + 1, stride = p->M.P.max_iter + 1;
-  HIPCHK(p, hipMemcpy(trace_out, p->wk.trace + (size_t)b * stride * 4, (size_t)rows * 4 * sizeof(double), hipMemcpyDeviceToHost));
+  // the caller's buffer holds max_iter + 1 rows (diagnostic builds park phase stamps past `rows`)
+  HIPCHK(p, hipMemcpy(trace_out, p->wk.trace + (size_t)b * stride * 4, (size_t)stride * 4 * sizeof(double), hipMemcpyDeviceToHost));
   return rows;
 }
 
