@@ -59,3 +59,45 @@ def step_goals(batch, seed=1, terrain=None, mode=1):
         start.append(rest_start(x, 0.0, 0.24 + float(heightfield.height_at(height_xy, cell, x, 0.0, mode=mode)), fz))
     goal = np.stack([x0 + dx, dy, np.full(batch, 0.24)], axis=1)
     return np.stack(start), goal
+
+
+def mixed_terrains(mesh_scale=11):
+    """configs[3]: exp_1 / exp_3 / exp_5 heightfields on ONE common grid (the planner takes a stack of
+    equally shaped maps + a map index per problem).  All three are built at mesh_scale 11 -- the
+    reference upsamples by replication, so the coarser experiments are represented exactly -- and
+    padded with flat ground to exp_3's length.  Returns (maps[3][nx][ny], cell)."""
+    e1 = heightfield.build_map([tile("plane"), tile("plane")], mesh_scale)
+    e3 = heightfield.build_map([tile("feasibility_test"), tile("feasibility_test_1"), tile("plane")], mesh_scale)
+    e5 = heightfield.build_map([tile("climb_2"), tile("climb_1")], mesh_scale)
+    nx = max(m.shape[1] for m in (e1, e3, e5))
+    out = []
+    for m in (e1, e3, e5):
+        t = heightfield.towr_map(m)
+        pad = np.zeros((nx, t.shape[1]))
+        pad[:t.shape[0]] = t
+        out.append(pad)
+    return np.stack(out), heightfield.cell_size(e1)
+
+
+def mixed_goals(batch, seed=2, terrains=None):
+    """A third each of exp_1 flat goals, exp_3 corridor goals (y = 0 lane between the blocks, x in
+    [0, 3.5]) and exp_5 step goals; returns (start, goal, map_id)."""
+    maps, cell = terrains if terrains is not None else mixed_terrains()
+    rng = np.random.default_rng(seed)
+    n1 = batch // 3
+    n3 = batch // 3
+    n5 = batch - n1 - n3
+    s1, g1 = flat_goals(n1, seed)
+    x0 = rng.uniform(0.0, 3.5, n3)
+    s3 = []
+    for x in x0:
+        feet = NOMINAL_FEET + np.array([x, 0.0, 0.0])
+        fz = heightfield.height_at(maps[1], cell, feet[:, 0], feet[:, 1], mode=1)
+        s3.append(rest_start(x, 0.0, 0.24 + float(heightfield.height_at(maps[1], cell, x, 0.0, mode=1)), fz))
+    g3 = np.stack([x0 + rng.uniform(0.3, 0.5, n3), rng.uniform(-0.03, 0.03, n3), np.full(n3, 0.24)], axis=1)
+    s5, g5 = step_goals(n5, seed + 1, terrain=(maps[2], cell))
+    start = np.concatenate([s1, np.stack(s3), s5])
+    goal = np.concatenate([g1, g3, g5])
+    map_id = np.concatenate([np.zeros(n1, np.int32), np.ones(n3, np.int32), np.full(n5, 2, np.int32)])
+    perm = rng.permutation(batch)
+    return start[perm], goal[perm], map_id[perm]

@@ -378,3 +378,52 @@ def test_replan_loop_stitches_two_plans(gv1):
     j = np.nonzero(t >= args2["-t"])[0][0]
     assert np.abs(comb[j + 1, 1:19] - comb[j, 1:19]).max() < 2e-3               # positions continuous
     lp.close()
+
+
+def test_mixed_terrain_batch_with_map_ids(cfg):
+    """BASELINE configs[3] (single-GPU shard of it): exp_1 / exp_3 / exp_5 patches in one batch, a
+    heightfield index per problem; every converged plan is feasible on ITS OWN terrain."""
+    from oracle.oracle import Oracle
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    maps, cell = workloads.mixed_terrains()
+    start, goal, map_id = workloads.mixed_goals(96, seed=2, terrains=(maps, cell))
+    P = Planner(cfg, max_batch=96)
+    P.set_heightfields(maps, cell)
+    nodes, status, iters, viol = P.plan(start, goal, map_id=map_id)
+    assert (status == 0).mean() >= 0.85
+    for k in range(3):
+        assert (status[map_id == k] == 0).mean() >= 0.7
+    oracles = [Oracle(cfg.oracle_dict(), height=maps[k], hcell=cell) for k in range(3)]
+    checked = 0
+    for b in np.nonzero(status == 0)[0][:24]:
+        assert oracles[map_id[b]].max_violation(nodes[b]) <= 1e-4 + 1e-9
+        checked += 1
+    assert checked >= 12
+    # same problems solved one map at a time give the same plans (map index only selects terrain)
+    sel = np.nonzero(map_id == 2)[0][:8]
+    P.set_heightfields(maps[2], cell)
+    n2, s2, _, _ = P.plan(start[sel], goal[sel])
+    assert np.array_equal(s2, status[sel]) and np.array_equal(n2, nodes[sel])
+    P.close()
+
+
+def test_trot_gait_solves(oracle):
+    """A diagonal-pair trot schedule (BASELINE.json names a trot; the reference's committed gait is
+    the walk): same code path, different phase table; GPU vs oracle on a few goals."""
+    from oracle.oracle import Oracle
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig(gait="trot")
+    P = Planner(cfg, max_batch=8)
+    O = Oracle(cfg.oracle_dict())
+    start, goal = workloads.flat_goals(8, seed=5)
+    nodes, status, iters, viol = P.plan(start, goal)
+    xo, infos = _oracle_solve(O, start[:3], goal[:3])
+    for b in range(3):
+        assert int(status[b]) == infos[b][0]
+        if status[b] == 0 and int(iters[b]) == infos[b][1]:
+            assert np.abs(nodes[b] - xo[b]).max() < 1e-5
+    assert (status == 0).mean() >= 0.5
+    P.close()
