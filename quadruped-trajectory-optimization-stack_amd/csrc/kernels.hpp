@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
     x[v] = val;
   }
   __syncthreads();
-  if (!(P.dbg & 1024)) eval_all<false>(P, map, x, g, nullptr, nullptr);
+  eval_all<false>(P, map, x, g, nullptr, nullptr);
   __syncthreads();
   // slack initialisation: push strictly inside the bounds (Ipopt bound_push / bound_frac = 0.01)
   for (int r = tid; r < m; r += blockDim.x) {
@@ -564,7 +564,8 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
   }
   if (conv) return;
   __syncthreads();
-  if (!(P.dbg & 512)) eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl);
+  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl);
+  __syncthreads();
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
 }
 
@@ -1099,6 +1100,7 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   if (conv || bad) return;
   __syncthreads();
   eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl);
+  __syncthreads();
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
 }
 
