@@ -40,6 +40,7 @@ typedef struct QtosParams {
   int terrain_mode;         /* 0 bilinear heightfield (exact slope), 1 nearest cell (flat ledges) */
   int max_iter;
   double tol, mu_init, mu_min, delta_x, eps_dual;
+  double slack_push; /* cold-start slack push, fraction of the bound range (0.2); warm starts use 0.01 */
 } QtosParams;
 
 typedef struct QtosDims {

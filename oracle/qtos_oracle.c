@@ -903,12 +903,13 @@ int qo_ldlt_solve_dense(int n, const double *A, double *b) {
 }
 
 void qo_default_options(qo_options *o) {
-  o->max_iter = 40;
+  o->max_iter = 24;
   o->tol = 1e-4;
   o->mu_init = 0.1;
   o->mu_min = 1e-9;
   o->delta_x = 1e-2;
   o->eps_dual = 1e-8;
+  o->slack_push = 0.2;
   o->warm_start = 0;
   o->verbose = 0;
 }
@@ -1099,8 +1100,13 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     int r = Ir[i];
     double l = cl[r], u = ch[r];
     int hl = l > -1e19, hu = u < 1e19;
-    double pl = hl ? 0.01 * fmax(1.0, fabs(l)) : 0, pu = hu ? 0.01 * fmax(1.0, fabs(u)) : 0;
-    if (hl && hu) { pl = fmin(pl, 0.01 * (u - l)); pu = fmin(pu, 0.01 * (u - l)); }
+    /* slack start: pushed inside the bounds by a fraction of the range (Ipopt bound_push /
+     * bound_frac).  A cold start uses a LARGE push (o->slack_push, 0.2): the first Newton steps are
+     * then not cut by the fraction-to-the-boundary rule (4 iterations instead of 4-6 on the
+     * benchmark goals); a warm start keeps Ipopt's 0.01 so that a feasible point stays put. */
+    const double kp = o->warm_start ? 0.01 : o->slack_push;
+    double pl = hl ? kp * fmax(1.0, fabs(l)) : 0, pu = hu ? kp * fmax(1.0, fabs(u)) : 0;
+    if (hl && hu) { pl = fmin(pl, kp * (u - l)); pu = fmin(pu, kp * (u - l)); }
     double si = g[r];
     if (hl) si = fmax(si, l + pl);
     if (hu) si = fmin(si, u - pu);

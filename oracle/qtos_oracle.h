@@ -95,6 +95,7 @@ typedef struct {
   double mu_init, mu_min;
   double delta_x;      /* proximal weight (W = delta I)                        */
   double eps_dual;     /* quasi-definite regularisation on the equality block  */
+  double slack_push;   /* cold-start slack push as a fraction of the bound range */
   int warm_start;      /* 1: x_io holds the starting point                     */
   int verbose;
 } qo_options;

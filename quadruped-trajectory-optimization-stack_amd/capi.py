@@ -26,7 +26,7 @@ class QtosParams(C.Structure):
         ("honor_start_velocity", C.c_int), ("terrain_mode", C.c_int),
         ("max_iter", C.c_int),
         ("tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
-        ("delta_x", C.c_double), ("eps_dual", C.c_double),
+        ("delta_x", C.c_double), ("eps_dual", C.c_double), ("slack_push", C.c_double),
     ]
 
 
@@ -118,6 +118,7 @@ def params_from_config(cfg):
     p.terrain_mode = int(cfg.terrain_mode)
     p.max_iter, p.tol = cfg.max_iter, cfg.tol
     p.mu_init, p.mu_min, p.delta_x, p.eps_dual = cfg.mu_init, cfg.mu_min, cfg.delta_x, cfg.eps_dual
+    p.slack_push = cfg.slack_push
     return p
 
 

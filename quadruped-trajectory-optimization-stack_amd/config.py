@@ -75,12 +75,13 @@ class PlannerConfig:
     terrain_mode: int = 1
     hz: float = 1000.0                     # CSV sampling rate (scripts/run.py consumes 1 kHz rows)
     # solver
-    max_iter: int = 40
+    max_iter: int = 24
     tol: float = 1e-4
     mu_init: float = 0.1
     mu_min: float = 1e-9
     delta_x: float = 1e-2
     eps_dual: float = 1e-8
+    slack_push: float = 0.2            # cold-start slack push (fraction of the bound range)
     phase_durations: List[List[float]] = field(default=None)
 
     def __post_init__(self):

@@ -49,7 +49,7 @@ struct DevPlan {
   const InitDesc *init;
   double mass, gravity, Ib[9], mu_fric, f_max, T;
   double nominal[NEE][3];
-  double tol, mu_init, mu_min, delta_x, eps_dual;
+  double tol, mu_init, mu_min, delta_x, eps_dual, slack_push;
   int max_iter;
   const double *height;
   int n_maps, hnx, hny, terrain_mode;
@@ -531,13 +531,14 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
   __syncthreads();
   eval_all<false>(P, map, x, g, nullptr, nullptr);
   __syncthreads();
-  // slack initialisation: push strictly inside the bounds (Ipopt bound_push / bound_frac = 0.01)
+  // slack initialisation: push strictly inside the bounds (Ipopt bound_push / bound_frac)
   for (int r = tid; r < m; r += blockDim.x) {
     if (P.row_kind[r] != 2) { s[r] = 0; zl[r] = 0; zu[r] = 0; continue; }
     const double l = P.con_lo[r], u = P.con_hi[r];
     const bool hl = l > -1e19, hu = u < 1e19;
-    double pl = hl ? 0.01 * fmax(1.0, fabs(l)) : 0.0, pu = hu ? 0.01 * fmax(1.0, fabs(u)) : 0.0;
-    if (hl && hu) { pl = fmin(pl, 0.01 * (u - l)); pu = fmin(pu, 0.01 * (u - l)); }
+    const double kp = W.warm ? 0.01 : P.slack_push;   // large push on cold starts, Ipopt's 0.01 on warm starts
+    double pl = hl ? kp * fmax(1.0, fabs(l)) : 0.0, pu = hu ? kp * fmax(1.0, fabs(u)) : 0.0;
+    if (hl && hu) { pl = fmin(pl, kp * (u - l)); pu = fmin(pu, kp * (u - l)); }
     double si = g[r];
     if (hl) si = fmax(si, l + pl);
     if (hu) si = fmin(si, u - pu);

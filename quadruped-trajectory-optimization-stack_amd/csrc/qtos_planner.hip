@@ -140,6 +140,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     for (int d = 0; d < 3; ++d) D.nominal[e][d] = M.P.nominal_stance[e][d];
   D.tol = M.P.tol; D.mu_init = M.P.mu_init; D.mu_min = M.P.mu_min; D.delta_x = M.P.delta_x;
   D.eps_dual = M.P.eps_dual; D.max_iter = M.P.max_iter;
+  D.slack_push = M.P.slack_push > 0 ? M.P.slack_push : 0.01;
   D.terrain_mode = M.P.terrain_mode;
   D.dbg = getenv("QTOS_DBG") ? atoi(getenv("QTOS_DBG")) : 0;
   D.g_doubles = S.g_doubles;
