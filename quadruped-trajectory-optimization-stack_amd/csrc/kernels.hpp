@@ -734,7 +734,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
   double *dx = W.dx + (size_t)b * n;
-  const int pstride = (F + PIV + 2) * PIV;  // per stage: L (16 x 16), 1/d (16), y_F (16), Y (hi x 16)
+  const int pstride = (F + PIV + 4) * PIV;  // per stage: L (16 x 16), 1/d (16), y_F (16), pivot slots (16), hi (+15 pad), Y (hi x 16)
 
   for (int i = tid; i < ntri; i += KT) A[i] = 0.0;
   for (int v = tid; v < n; v += KT) dx[v] = 0.0;
@@ -917,12 +917,15 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         }
       }
       STAMP2(1);
-      // factor panel of stage k to HBM
+      // factor panel of stage k to HBM (everything the backward pass needs, so that it never has to
+      // touch the static tables again)
       double *pk = panel + (size_t)k * pstride;
       for (int i = t2; i < PIV * PIV; i += KT - 64) pk[i] = Lm[(i >> 4) * PLD + (i & 15)];
       if (t2 < PIV) pk[PIV * PIV + t2] = dinv[t2];
       else if (t2 < 2 * PIV) pk[PIV * PIV + t2] = Y[F * PLD + (t2 - PIV)];
-      for (int i = t2; i < ((P.dbg & 32) ? 0 : hi * PIV); i += KT - 64) pk[PIV * PIV + 2 * PIV + i] = Y[(i >> 4) * PLD + (i & 15)];
+      else if (t2 < 3 * PIV) pk[PIV * PIV + t2] = (double)ps[t2 - 2 * PIV];
+      else if (t2 == 3 * PIV) pk[PIV * PIV + t2] = (double)hi;
+      for (int i = t2; i < hi * PIV; i += KT - 64) pk[PIV * PIV + 4 * PIV + i] = Y[(i >> 4) * PLD + (i & 15)];
       STAMP2(2);
     }
     lds_barrier();
@@ -941,36 +944,35 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   __syncthreads();  // drains the factor-panel stores: they are read back below
   STAMP(6);
   for (int i = tid; i < F; i += KT) xs[i] = 0.0;
-  constexpr int PFB = 5;  // (F + 18) * 16 / 512 <= 5 for F <= 128
+  constexpr int PFB = 5;  // (F + 20) * 16 / 512 <= 5 for F <= 128
+  const int pcnt = (F + PIV + 4) * PIV;   // whole panel slot: no dependence on the stage's hi
   double pfb[PFB];
-  double *Yb = Pbuf, *Lb = Lbuf, *dvs = dvb, *yF = dvb + PIV;
+  double *Yb = Pbuf, *Lb = Lbuf, *dvs = dvb, *yF = dvb + PIV, *meta = red + 33 * PLD;  // meta: ps[16], hi
   {
     const double *pk = panel + (size_t)(NS - 1) * pstride;
-    const int hi = P.srec[soff[NS - 1] + 3], cnt = (hi + PIV + 2) * PIV;
 #pragma unroll
-    for (int j = 0; j < PFB; ++j) { const int i = tid + j * KT; pfb[j] = i < cnt ? pk[i] : 0.0; }
+    for (int j = 0; j < PFB; ++j) { const int i = tid + j * KT; pfb[j] = i < pcnt ? pk[i] : 0.0; }
   }
   __syncthreads();
-  for (int k = (P.dbg & 64) ? -1 : NS - 1; k >= 0; --k) {
-    const int hi = P.srec[soff[k] + 3], cnt = (hi + PIV + 2) * PIV;
+  for (int k = NS - 1; k >= 0; --k) {
 #pragma unroll
     for (int j = 0; j < PFB; ++j) {
       const int i = tid + j * KT;
-      if (i < cnt) {
+      if (i < pcnt) {
         if (i < PIV * PIV) Lb[(i >> 4) * PLD + (i & 15)] = pfb[j];
         else if (i < PIV * PIV + PIV) dvs[i - PIV * PIV] = pfb[j];
         else if (i < PIV * PIV + 2 * PIV) yF[i - PIV * PIV - PIV] = pfb[j];
-        else { const int e = i - PIV * PIV - 2 * PIV; Yb[(e >> 4) * PLD + (e & 15)] = pfb[j]; }
+        else if (i < PIV * PIV + 4 * PIV) { const int e = i - PIV * PIV - 2 * PIV; if (e <= PIV) meta[e] = pfb[j]; }
+        else { const int e = i - PIV * PIV - 4 * PIV; Yb[(e >> 4) * PLD + (e & 15)] = pfb[j]; }
       }
     }
-    if (tid < PIV) psb[tid] = P.srec[soff[k] + 4 + tid];
     lds_barrier();
-    if (k > 0) {  // prefetch panel k-1
+    if (k > 0) {  // prefetch panel k-1 (lands while this stage computes)
       const double *pk = panel + (size_t)(k - 1) * pstride;
-      const int hi2 = P.srec[soff[k - 1] + 3], cnt2 = (hi2 + PIV + 2) * PIV;
 #pragma unroll
-      for (int j = 0; j < PFB; ++j) { const int i = tid + j * KT; pfb[j] = i < cnt2 ? pk[i] : 0.0; }
+      for (int j = 0; j < PFB; ++j) { const int i = tid + j * KT; pfb[j] = i < pcnt ? pk[i] : 0.0; }
     }
+    const int hi = (int)meta[PIV];
     {  // partial sums: thread (j, q) accumulates rows r = q, q+32, ... of column j; lanes of one
        // wave hold 4 row groups per column -> fold them with two shuffles, one value per wave left
       const int j = tid & (PIV - 1), q = tid >> 4;
@@ -981,23 +983,24 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       if ((tid & 63) < PIV) red[(tid >> 6) * PLD + j] = acc;
     }
     lds_barrier();
-    if (tid < PIV) {
-      // u = D^-1 (y_F - Y^T x2); then L^T x1 = u by back substitution across the 16 lanes
-      double u = yF[tid];
+    if (tid < 64) {
+      // u = D^-1 (y_F - Y^T x2); then L^T x1 = u by back substitution: lane i holds u_i and column i
+      // of L; x_i is wave-uniform once final and is read with v_readlane
+      const int i0 = tid & 15;
+      double u = yF[i0];
 #pragma unroll
-      for (int qq = 0; qq < KT / 64; ++qq) u -= red[qq * PLD + tid];
-      u *= dvs[tid];
+      for (int qq = 0; qq < KT / 64; ++qq) u -= red[qq * PLD + i0];
+      u *= dvs[i0];
       double lc[PIV];
 #pragma unroll
-      for (int i = 1; i < PIV; ++i) lc[i] = i > tid ? Lb[i * PLD + tid] : 0.0;
+      for (int i = 1; i < PIV; ++i) lc[i] = i > i0 ? Lb[i * PLD + i0] : 0.0;
 #pragma unroll
-      for (int i = PIV - 1; i > 0; --i) {
-        const double xi = __shfl(u, i, PIV);
-        u -= lc[i] * xi;
+      for (int i = PIV - 1; i > 0; --i) u -= lc[i] * readlane_d(u, i);
+      if (tid < PIV) {
+        xs[(int)meta[tid]] = u;
+        const int un = P.piv_unknown[k * PIV + tid];
+        if (un >= 0 && un < n) dx[un] = u;
       }
-      xs[psb[tid]] = u;
-      const int un = P.piv_unknown[k * PIV + tid];
-      if (un >= 0 && un < n) dx[un] = u;
     }
     lds_barrier();
   }

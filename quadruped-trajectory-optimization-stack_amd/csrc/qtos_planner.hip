@@ -144,13 +144,13 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.terrain_mode = M.P.terrain_mode;
   D.dbg = getenv("QTOS_DBG") ? atoi(getenv("QTOS_DBG")) : 0;
   D.g_doubles = S.g_doubles;
-  D.panel_stride = (long long)S.n_stages * (S.front + PIV + 2) * PIV;
+  D.panel_stride = (long long)S.n_stages * (S.front + PIV + 4) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
   size_t lds_d = (size_t)((F + 1) * (F + 2) / 2) + 2 * (size_t)(F + 1) * PLD + 2 * PIV * PLD + 2 * PIV + F +
                  34 * PLD + S.max_drec + 8;
   p->kkt_lds = lds_d * sizeof(double) + ((size_t)S.max_srec + 2 * (size_t)(S.n_stages + 1) + 2 * PIV + 2 + 48 + 8) * sizeof(int);
-  if (S.max_drec > PFD * KT || S.max_srec > PFS * KT || (F + PIV + 2) * PIV > 5 * KT) {
+  if (S.max_drec > PFD * KT || S.max_srec > PFS * KT || (F + PIV + 4) * PIV > 5 * KT) {
     p->err = "stage record exceeds the prefetch registers";
     fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints)\n", S.max_drec, S.max_srec);
     qtos_planner_destroy(p);
@@ -226,7 +226,7 @@ static void fill_dims(const HostModel &M, const Symbolic &S, QtosDims *d) {
   d->pivots = PIV; d->front = S.front;
   d->n_base_nodes = M.n_base_nodes; d->n_dyn_times = (int)M.t_dyn.size(); d->n_rom_times = (int)M.t_rom.size();
   d->n_rows_csv = (int)std::llround(M.T * 1000.0) + 1;
-  d->panel_doubles = (long long)S.n_stages * (S.front + PIV + 2) * PIV; d->g_doubles = S.g_doubles;
+  d->panel_doubles = (long long)S.n_stages * (S.front + PIV + 4) * PIV; d->g_doubles = S.g_doubles;
   d->kkt_algorithmic_bytes = S.algorithmic_bytes; d->kkt_flops = S.flops;
   d->envelope = S.envelope; d->max_active = S.max_active;
   d->duration = M.T;

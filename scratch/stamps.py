@@ -3,7 +3,7 @@ import numpy as np
 from qtos_amd import capi, workloads
 capi.LIB_PATH = capi.LIB_PATH.replace("libqtos_planner.so", "libqtos_planner_stamps.so")
 from qtos_amd.config import PlannerConfig
-cfg = PlannerConfig.knots100()
+cfg = PlannerConfig.knots100(max_iter=40)
 P = capi.Planner(cfg, max_batch=256)
 start, goal = workloads.flat_goals(256, 0)
 P.plan(start, goal)
