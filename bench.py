@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--workload", default="exp1_flat", choices=["exp1_flat", "exp5_step"])
     ap.add_argument("--cpu-sample", type=int, default=96, help="plans timed on the CPU oracle (0 = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per k_kkt launch from a separate rocprofv3 --pmc pass")
+                    help="HBM bytes per k_kkt launch from a separate rocprofv3 --pmc pass "
+                         "(default: the newest profiles/*_pmc_hbm.json, collected with this same command)")
     args = ap.parse_args()
 
     import torch
@@ -142,6 +143,17 @@ def main():
             "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front,
         },
     }
+    traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
+    if traffic is None and args.transcription == "knots100" and args.workload == "exp1_flat" and B == 256:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")),
+                       key=lambda f: (os.path.basename(f)[:3], "final" in f, f))   # newest round, its final pass
+        if files:
+            try:
+                traffic = json.load(open(files[-1]))["k_kkt_traffic_bytes_per_launch"]["fetch_x2"]
+                traffic_src = os.path.relpath(files[-1], ROOT)
+            except Exception:
+                traffic = None
     if kkt_n:
         avg = kkt_s / kkt_n
         alg_bytes = float(B) * d.kkt_algorithmic_bytes
@@ -149,7 +161,7 @@ def main():
         out["roofline"] = {
             "kernel": "k_kkt", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": args.traffic_bytes,
+            "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
             "bytes_per_launch": alg_bytes, "avg_launch_ms": round(1e3 * avg, 4), "launches": kkt_n,
             "fp64_tflops": round(B * d.kkt_flops / avg / 1e12, 3), "fp64_peak_tflops": 78.6,
             "kkt_share_of_device_time": round(kkt_s / max(tot_s, 1e-12), 3),
