@@ -43,7 +43,6 @@ struct DevPlan {
   const int *srec, *srec_off, *pack_src, *drec_off;  // packed per-stage records (symbolic.hpp)
   const int *eq_pos, *rhs_pos, *sig_pos, *w_pos;     // direct-write maps into the stream
   int max_srec, max_drec, stream_len;
-  int dbg;  // timing ablation mask (QTOS_DBG), 0 in production
   const double *con_lo, *con_hi;
   const int *row_kind;
   const InitDesc *init;
@@ -640,7 +639,7 @@ __device__ __forceinline__ void ldlt16(const double *Bsrc /* 16 x PLD */, double
 constexpr int PFD = 6, PFS = 6;  // per-thread prefetch registers: doubles / ints of a stage's records
 
 // assembly of one stage's records (already in LDS) into the front
-__device__ inline void assemble_stage(double *A, int F, const int *sbuf, const double *dbuf, int tid) {
+__device__ inline void assemble_stage(double *A, int F, const int *sbuf, const double *dbuf, const int *pairAC, int tid) {
   const int n_ent = sbuf[0], n_rhs = sbuf[1], n_iq = sbuf[2];
   const int *ps = sbuf + 4;
   if (tid < PIV) A[tri(ps[tid], ps[tid])] += dbuf[tid];
@@ -730,6 +729,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   int *psb = doff + P.n_stages + 1;     // 2 x PIV pivot slots (current / next stage)
   int *hib = psb + 2 * PIV;             // 2: hi of current / next stage
   int *tileRC = hib + 2;                // (R << 8) | C of lower-triangular tile t, t < 45
+  int *pairAC = tileRC + 48;            // (a << 8) | c of lower-triangular pair i, i < 528 (n <= 32)
   const int n = P.n_vars, NS = P.n_stages;
   const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
@@ -744,6 +744,12 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     while (((R + 1) * (R + 2)) >> 1 <= tid) ++R;
     tileRC[tid] = (R << 8) | (tid - ((R * (R + 1)) >> 1));
   }
+  for (int i = tid; i < 528; i += KT) {
+    int a = (int)((sqrtf(8.0f * i + 1.0f) - 1.0f) * 0.5f);
+    while (((a + 1) * (a + 2)) >> 1 <= i) ++a;
+    while ((a * (a + 1)) >> 1 > i) --a;
+    pairAC[i] = (a << 8) | (i - ((a * (a + 1)) >> 1));
+  }
   __syncthreads();
   // ---- prologue: assemble stage 0, gather and factor its pivot block, stage records of stage 1 ----
   for (int i = tid; i < soff[1] - soff[0]; i += KT) sbuf[i] = P.srec[soff[0] + i];
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   __syncthreads();
   if (tid < PIV) psb[tid] = sbuf[4 + tid];
   if (tid == 0) hib[0] = sbuf[3];
-  assemble_stage(A, F, sbuf, dbuf, tid);
+  assemble_stage(A, F, sbuf, dbuf, pairAC, tid);
   __syncthreads();
   for (int i = tid; i < (F + 1) * PIV; i += KT) {
     const int r = i >> 4, j = i & 15;
@@ -821,7 +827,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     if (has_next) {
       if (tid < PIV) psb[nxt * PIV + tid] = sbuf[4 + tid];
       if (tid == 0) hib[nxt] = sbuf[3];
-      if (!(P.dbg & 2)) assemble_stage(A, F, sbuf, dbuf, tid);
+      assemble_stage(A, F, sbuf, dbuf, pairAC, tid);
     }
     lds_barrier();
     STAMP(1);
@@ -835,7 +841,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       const double *zrow = Y + pcol * PLD + lk;   // B operand: Z[k][j] = Y[piv_j][k] / d_k
       double zb[4];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) zb[s4] = (P.dbg & 4) ? 0.0 : zrow[4 * s4] * dinv[lk + 4 * s4];
+      for (int s4 = 0; s4 < 4; ++s4) zb[s4] = zrow[4 * s4] * dinv[lk + 4 * s4];
       for (int R = wv; R < (F >> 4); R += KT / 64) {
         d4_t acc;
 #pragma unroll
@@ -862,7 +868,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         const int *psn = psb + nxt * PIV;
         double *Bs = red;
         for (int e = tid; e < PIV * PIV; e += 64) Bs[(e >> 4) * PLD + (e & 15)] = Pn[psn[e >> 4] * PLD + (e & 15)];
-        if (!(P.dbg & 8)) ldlt16(Bs, Lbuf + nxt * PIV * PLD, dvb + nxt * PIV, tid);
+        ldlt16(Bs, Lbuf + nxt * PIV * PLD, dvb + nxt * PIV, tid);
         for (int e = tid; e < PIV * PIV; e += 64) Pn[psn[e >> 4] * PLD + (e & 15)] = 0.0;
       }
       STAMP(3);
@@ -872,36 +878,43 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #endif
       const int wv = (tid >> 6) - 1, lane = tid & 63, li = lane & 15, lk = lane >> 4;
       const int nt16 = hi16 >> 4, ntile = (nt16 * (nt16 + 1)) >> 1;
-      for (int t = wv; t < ntile; t += KT / 64 - 1) {
-        const int rc = tileRC[t], R = rc >> 8, C = rc & 255;
-        const int col = 16 * C + li, row0 = 16 * R + lk;
-        const double *wrow = Y + (16 * R + li) * PLD + lk;
-        const double *prow = Y + (16 * C + li) * PLD + lk;
-        double wa[4], pb[4];
+      double dv4[4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { wa[s4] = -wrow[4 * s4] * dinv[lk + 4 * s4]; pb[s4] = prow[4 * s4]; }
-        d4_t acc;
-        if (R != C) {   // off-diagonal tile: every element is below the diagonal, no masks
-          int idx[4];
+      for (int s4 = 0; s4 < 4; ++s4) dv4[s4] = -dinv[lk + 4 * s4];
+      // two tiles in flight per wave: the second tile's LDS reads overlap the first tile's MFMA chain
+      for (int t = wv; t < ntile; t += 2 * (KT / 64 - 1)) {
+        const int t1 = t + (KT / 64 - 1);
+        const bool two = t1 < ntile;
+        const int rc0 = tileRC[t], rc1 = tileRC[two ? t1 : t];
+        const int R0 = rc0 >> 8, C0 = rc0 & 255, R1 = rc1 >> 8, C1 = rc1 & 255;
+        const int col0 = 16 * C0 + li, col1 = 16 * C1 + li;
+        const double *w0 = Y + (16 * R0 + li) * PLD + lk, *p0 = Y + (16 * C0 + li) * PLD + lk;
+        const double *w1 = Y + (16 * R1 + li) * PLD + lk, *p1 = Y + (16 * C1 + li) * PLD + lk;
+        double wa0[4], pb0[4], wa1[4], pb1[4];
+        int i0[4], i1[4];
+        d4_t a0, a1;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) { idx[g] = tri(row0 + 4 * g, col); acc[g] = A[idx[g]]; }
+        for (int g = 0; g < 4; ++g) {
+          const int r0 = 16 * R0 + lk + 4 * g, r1 = 16 * R1 + lk + 4 * g;
+          i0[g] = tri(r0, min(col0, r0));   // masked elements (col > row, diagonal tiles) read a valid
+          i1[g] = tri(r1, min(col1, r1));   // dummy and are never written back
+          a0[g] = A[i0[g]];
+          a1[g] = A[i1[g]];
+        }
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s4], pb[s4], acc, 0, 0, 0);
+        for (int s4 = 0; s4 < 4; ++s4) {
+          wa0[s4] = w0[4 * s4] * dv4[s4]; pb0[s4] = p0[4 * s4];
+          wa1[s4] = w1[4 * s4] * dv4[s4]; pb1[s4] = p1[4 * s4];
+        }
 #pragma unroll
-          for (int g = 0; g < 4; ++g) A[idx[g]] = acc[g];
-        } else {
+        for (int s4 = 0; s4 < 4; ++s4) {
+          a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa0[s4], pb0[s4], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa1[s4], pb1[s4], a1, 0, 0, 0);
+        }
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int row = row0 + 4 * g;
-            acc[g] = col <= row ? A[tri(row, col)] : 0.0;
-          }
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s4], pb[s4], acc, 0, 0, 0);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int row = row0 + 4 * g;
-            if (col <= row) A[tri(row, col)] = acc[g];
-          }
+        for (int g = 0; g < 4; ++g) {
+          if (col0 <= 16 * R0 + lk + 4 * g) A[i0[g]] = a0[g];
+          if (two && col1 <= 16 * R1 + lk + 4 * g) A[i1[g]] = a1[g];
         }
       }
       STAMP2(0);

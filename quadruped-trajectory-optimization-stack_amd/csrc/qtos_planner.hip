@@ -142,14 +142,13 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.eps_dual = M.P.eps_dual; D.max_iter = M.P.max_iter;
   D.slack_push = M.P.slack_push > 0 ? M.P.slack_push : 0.01;
   D.terrain_mode = M.P.terrain_mode;
-  D.dbg = getenv("QTOS_DBG") ? atoi(getenv("QTOS_DBG")) : 0;
   D.g_doubles = S.g_doubles;
   D.panel_stride = (long long)S.n_stages * (S.front + PIV + 4) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
   size_t lds_d = (size_t)((F + 1) * (F + 2) / 2) + 2 * (size_t)(F + 1) * PLD + 2 * PIV * PLD + 2 * PIV + F +
                  34 * PLD + S.max_drec + 8;
-  p->kkt_lds = lds_d * sizeof(double) + ((size_t)S.max_srec + 2 * (size_t)(S.n_stages + 1) + 2 * PIV + 2 + 48 + 8) * sizeof(int);
+  p->kkt_lds = lds_d * sizeof(double) + ((size_t)S.max_srec + 2 * (size_t)(S.n_stages + 1) + 2 * PIV + 2 + 48 + 528 + 8) * sizeof(int);
   if (S.max_drec > PFD * KT || S.max_srec > PFS * KT || (F + PIV + 4) * PIV > 5 * KT) {
     p->err = "stage record exceeds the prefetch registers";
     fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints)\n", S.max_drec, S.max_srec);
