@@ -636,46 +636,43 @@ __device__ __forceinline__ void ldlt16(const double *Bsrc /* 16 x PLD */, double
 #define STAMP2(i) do {} while (0)
 #endif
 
-constexpr int PFD = 6, PFS = 6;  // per-thread prefetch registers: doubles / ints of a stage's records
+constexpr int PFD = 6, PFS = 8;  // per-thread prefetch registers: doubles / ints of a stage's records
 
-// assembly of one stage's records (already in LDS) into the front
-__device__ inline void assemble_stage(double *A, int F, const int *sbuf, const double *dbuf, const int *pairAC, int tid) {
+// assembly of one stage's records (already in LDS) into the front.  Pass 1: pivot diagonals,
+// equality entries, multiplier right-hand sides (all distinct targets).  Pass 2: the inequality
+// blocks through the gather table: one thread per target entry sums its contributions
+// (sum_r sig_r G[r][a] G[r][c], or -sum_r G[r][a] w_r for the rhs) in a fixed order.
+constexpr int SHDR = 8;   // static record header ints
+__device__ inline void assemble_stage(double *A, int F, const int *sbuf, const double *dbuf, int tid) {
   const int n_ent = sbuf[0], n_rhs = sbuf[1], n_iq = sbuf[2];
-  const int *ps = sbuf + 4;
+  const int *ps = sbuf + SHDR;
   if (tid < PIV) A[tri(ps[tid], ps[tid])] += dbuf[tid];
-  const int *eidx = sbuf + 4 + PIV;
+  const int *eidx = sbuf + SHDR + PIV;
   const double *eval = dbuf + PIV;
   for (int i = tid; i < n_ent; i += KT) A[eidx[i]] += eval[i];
   const int *rsl = eidx + n_ent;
   const double *rval = eval + n_ent;
   for (int i = tid; i < n_rhs; i += KT) A[tri(F, rsl[i])] += rval[i];
+  if (n_iq == 0) return;
   const int *iqh = rsl + n_rhs;
-  for (int q = 0; q < n_iq; ++q) {
-    const int qm = iqh[4 * q], qn = iqh[4 * q + 1];
-    const double *Gb = dbuf + iqh[4 * q + 2];
-    const int *sl = sbuf + iqh[4 * q + 3];
-    const double *sg = Gb + qm * qn, *wq = sg + qm;
-    lds_barrier();  // blocks of one stage may touch the same entries
-    const int npair = (qn * (qn + 1)) >> 1;
-    for (int i = tid; i < npair + qn; i += KT) {
-      if (i < npair) {
-        int a = (int)((sqrtf(8.0f * i + 1.0f) - 1.0f) * 0.5f);
-        while (((a + 1) * (a + 2)) >> 1 <= i) ++a;
-        while ((a * (a + 1)) >> 1 > i) --a;
-        const int c = i - ((a * (a + 1)) >> 1);
-        double acc = 0;
-        for (int r = 0; r < qm; ++r) acc += sg[r] * Gb[r * qn + a] * Gb[r * qn + c];
-        A[trs(sl[a], sl[c])] += acc;
-      } else {
-        const int a = i - npair;
-        double acc = 0;
-        for (int r = 0; r < qm; ++r) acc += Gb[r * qn + a] * wq[r];
-        A[tri(F, sl[a])] -= acc;
-      }
+  const int n_tgt = sbuf[5];
+  const int *tg = sbuf + sbuf[4];                     // n_tgt + 1 ints: (tri << 12) | first contribution
+  const unsigned short *cl = (const unsigned short *)(tg + n_tgt + 1);
+  lds_barrier();   // a pivot diagonal / rhs entry above can also be a gather target
+  for (int t = tid; t < n_tgt; t += KT) {
+    const int tv = tg[t], c0 = tv & 4095, c1 = tg[t + 1] & 4095;
+    double acc = 0;
+    for (int j = c0; j < c1; ++j) {
+      const int code = cl[j], q = code >> 12, a = (code >> 6) & 63, c = code & 63;
+      const int qm = iqh[4 * q], qn = iqh[4 * q + 1];
+      const double *Gb = dbuf + iqh[4 * q + 2];
+      const double *sg = Gb + qm * qn, *wq = sg + qm;
+      if (c == 63) { for (int r = 0; r < qm; ++r) acc -= Gb[r * qn + a] * wq[r]; }
+      else { for (int r = 0; r < qm; ++r) acc += sg[r] * Gb[r * qn + a] * Gb[r * qn + c]; }
     }
+    A[tv >> 12] += acc;
   }
 }
-
 // Forward substitution y <- y L^-T with FOUR lanes per row: lane c of a quad owns columns c, c+4,
 // c+8, c+12.  Step Q broadcasts y[Q] inside the quad with a DPP quad_perm move (no LDS) and every
 // lane updates its columns j > Q.  The first quad carries the right-hand-side row as a second row.
@@ -729,7 +726,6 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   int *psb = doff + P.n_stages + 1;     // 2 x PIV pivot slots (current / next stage)
   int *hib = psb + 2 * PIV;             // 2: hi of current / next stage
   int *tileRC = hib + 2;                // (R << 8) | C of lower-triangular tile t, t < 45
-  int *pairAC = tileRC + 48;            // (a << 8) | c of lower-triangular pair i, i < 528 (n <= 32)
   const int n = P.n_vars, NS = P.n_stages;
   const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
@@ -744,20 +740,14 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     while (((R + 1) * (R + 2)) >> 1 <= tid) ++R;
     tileRC[tid] = (R << 8) | (tid - ((R * (R + 1)) >> 1));
   }
-  for (int i = tid; i < 528; i += KT) {
-    int a = (int)((sqrtf(8.0f * i + 1.0f) - 1.0f) * 0.5f);
-    while (((a + 1) * (a + 2)) >> 1 <= i) ++a;
-    while ((a * (a + 1)) >> 1 > i) --a;
-    pairAC[i] = (a << 8) | (i - ((a * (a + 1)) >> 1));
-  }
   __syncthreads();
   // ---- prologue: assemble stage 0, gather and factor its pivot block, stage records of stage 1 ----
   for (int i = tid; i < soff[1] - soff[0]; i += KT) sbuf[i] = P.srec[soff[0] + i];
   for (int i = tid; i < doff[1] - doff[0]; i += KT) dbuf[i] = stream[doff[0] + i];
   __syncthreads();
-  if (tid < PIV) psb[tid] = sbuf[4 + tid];
+  if (tid < PIV) psb[tid] = sbuf[SHDR + tid];
   if (tid == 0) hib[0] = sbuf[3];
-  assemble_stage(A, F, sbuf, dbuf, pairAC, tid);
+  assemble_stage(A, F, sbuf, dbuf, tid);
   __syncthreads();
   for (int i = tid; i < (F + 1) * PIV; i += KT) {
     const int r = i >> 4, j = i & 15;
@@ -825,9 +815,9 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     STAMP(0);
     // ---- S2: assemble stage k+1 ------------------------------------------------------------------
     if (has_next) {
-      if (tid < PIV) psb[nxt * PIV + tid] = sbuf[4 + tid];
+      if (tid < PIV) psb[nxt * PIV + tid] = sbuf[SHDR + tid];
       if (tid == 0) hib[nxt] = sbuf[3];
-      assemble_stage(A, F, sbuf, dbuf, pairAC, tid);
+      assemble_stage(A, F, sbuf, dbuf, tid);
     }
     lds_barrier();
     STAMP(1);

@@ -12,6 +12,7 @@
 // ever copied between stages (slots of eliminated pivots are recycled).
 #pragma once
 #include <algorithm>
+#include <map>
 #include <numeric>
 #include <vector>
 
@@ -58,8 +59,9 @@ struct Symbolic {
   std::vector<short> iq_slots;    // front slot of every column of every inequality block
   int max_stage_g = 0;            // longest G slice of a stage
   // Packed per-stage records consumed by k_kkt (each is ONE contiguous, coalesced read):
-  //   static  srec[srec_off[k] ..]: n_ent, n_rhs, n_iq, hi, piv_slot[16], tri index per equality
-  //           entry, slot per rhs entry, {m, n, gloc, sloc} per inequality block, slot lists
+  //   static  srec[srec_off[k] ..]: n_ent, n_rhs, n_iq, hi, gather offset, n_tgt, 0, 0, piv_slot[16],
+  //           tri index per equality entry, slot per rhs entry, {m, n, gloc, sloc} per inequality
+  //           block, slot lists, gather table (target, first contribution), contributions
   //   dynamic stream (per problem), drec_off[k] ..: piv_diag[16], equality values, -g of the rhs
   //           rows, then per inequality block G (m x n), sig (m), w (m)
   // pack_src[i] says where stream element i comes from: (kind << 28) | index, kind 0 G, 1 g_static,
@@ -271,6 +273,7 @@ struct Symbolic {
       drec_off[k] = (int)pack_src.size();
       const int n_ent = S.ent_end - S.ent_begin, n_rhs = S.rhs_end - S.rhs_begin, n_iq = S.iq_end - S.iq_begin;
       srec.push_back(n_ent); srec.push_back(n_rhs); srec.push_back(n_iq); srec.push_back(stage_hi[k]);
+      srec.push_back(0); srec.push_back(0); srec.push_back(0); srec.push_back(0);   // [4] gather table offset, [5] n_tgt
       for (int i = 0; i < PIV; ++i) {
         srec.push_back(piv_slot[(size_t)k * PIV + i]);
         pack_src.push_back((5 << 28) | (k * PIV + i));
@@ -297,6 +300,38 @@ struct Symbolic {
         for (int i = 0; i < Q.m * Q.n; ++i) pack_src.push_back(S.g_begin + Q.gloc + i);
         for (int r = 0; r < Q.m; ++r) pack_src.push_back((3 << 28) | (Q.row0 + r));
         for (int r = 0; r < Q.m; ++r) pack_src.push_back((4 << 28) | (Q.row0 + r));
+      }
+      // gather table of the inequality blocks: target entry -> contributions (q << 16 | a << 8 | c;
+      // c = 255: right-hand-side contribution of column a).  One thread owns one target, so the
+      // blocks of a stage are assembled in ONE pass without conflicts and in a fixed order.
+      {
+        std::map<int, std::vector<int>> tmap;
+        for (int q = 0; q < n_iq; ++q) {
+          const IqBlock &Q = iq_blocks[S.iq_begin + q];
+          for (int a = 0; a < Q.n; ++a) {
+            const int sa = iq_slots[Q.slot_off + a];
+            for (int c = 0; c <= a; ++c) tmap[trs(sa, iq_slots[Q.slot_off + c])].push_back((q << 16) | (a << 8) | c);
+            tmap[front * (front + 1) / 2 + sa].push_back((q << 16) | (a << 8) | 255);
+          }
+        }
+        srec[srec_off[k] + 4] = (int)srec.size() - srec_off[k];
+        srec[srec_off[k] + 5] = (int)tmap.size();
+        // packed: one int per target (tri << 12 | first contribution), contributions as 16-bit codes
+        // (q << 12 | a << 6 | c, c = 63: rhs), two per int
+        int cpos = 0;
+        std::vector<int> codes;
+        for (auto &kv : tmap) {
+          srec.push_back((kv.first << 12) | cpos);
+          cpos += (int)kv.second.size();
+          for (int code : kv.second) {
+            const int q = code >> 16, a = (code >> 8) & 255, c = code & 255;
+            codes.push_back((q << 12) | (a << 6) | (c == 255 ? 63 : c));
+          }
+        }
+        if (cpos >= 4096 || n_iq > 15) { err = "gather table overflow"; return -1; }
+        srec.push_back(cpos);   // sentinel: end of the last target's contributions
+        for (size_t i = 0; i < codes.size(); i += 2)
+          srec.push_back(codes[i] | ((i + 1 < codes.size() ? codes[i + 1] : 0) << 16));
       }
       max_srec = std::max(max_srec, (int)srec.size() - srec_off[k]);
       max_drec = std::max(max_drec, (int)pack_src.size() - drec_off[k]);
