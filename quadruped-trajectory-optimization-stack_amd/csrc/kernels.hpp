@@ -445,10 +445,13 @@ __device__ inline void infeasibility(const DevPlan &P, const double *g, const do
   double v = 0, t = 0;
   for (int r = threadIdx.x; r < P.n_cons; r += blockDim.x) {
     const int k = P.row_kind[r];
-    if (k == 1) { v = fmax(v, fabs(g[r])); t = fmax(t, fabs(g[r])); }
-    else if (k == 2) {
-      v = fmax(v, fmax(P.con_lo[r] - g[r], g[r] - P.con_hi[r]));
-      t = fmax(t, fabs(g[r] - s[r]));
+    if (k == 0) continue;
+    const double gr = g[r];
+    if (!(gr == gr) || !(s[r] == s[r])) { v = t = INFINITY; continue; }   // fmax would swallow a NaN
+    if (k == 1) { v = fmax(v, fabs(gr)); t = fmax(t, fabs(gr)); }
+    else {
+      v = fmax(v, fmax(P.con_lo[r] - gr, gr - P.con_hi[r]));
+      t = fmax(t, fabs(gr - s[r]));
     }
   }
   viol = wg_reduce<1>(v, scratch);
@@ -553,16 +556,17 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
     zu[r] = u < 1e19 ? mu / (u - s[r]) : 0.0;
   }
   const bool conv = viol <= P.tol && theta <= P.tol;
+  const bool bad = !(viol < INFINITY) || !(theta < INFINITY);   // NaN / inf in the inputs
   if (tid == 0) {
     W.mu[b] = mu;
     W.viol[b] = viol;
     W.iters[b] = 0;
-    W.status[b] = conv ? 0 : 1;
-    W.done[b] = conv ? 1 : 0;
-    if (!conv) atomicAdd(W.n_active, 1);
+    W.status[b] = conv ? 0 : (bad ? 2 : 1);
+    W.done[b] = (conv || bad) ? 1 : 0;
+    if (!conv && !bad) atomicAdd(W.n_active, 1);
     record_trace(P, W, b, 0, viol, theta, 0.0, mu);
   }
-  if (conv) return;
+  if (conv || bad) return;
   __syncthreads();
   eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl);
   __syncthreads();
@@ -1092,7 +1096,7 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   double viol, theta;
   infeasibility(P, g, s, scratch, viol, theta);
   const bool conv = viol <= P.tol && theta <= P.tol;
-  const bool bad = !(viol == viol) || !(th == th);
+  const bool bad = !(viol < INFINITY) || !(th < INFINITY);
   if (tid == 0) {
     W.mu[b] = mu;
     W.viol[b] = viol;
