@@ -88,13 +88,20 @@ def mixed_goals(batch, seed=2, terrains=None):
     n3 = batch // 3
     n5 = batch - n1 - n3
     s1, g1 = flat_goals(n1, seed)
-    x0 = rng.uniform(0.0, 3.5, n3)
-    s3 = []
-    for x in x0:
+    # exp_3: the robot walks in the free lane between the 0.5 m blocks: start and goal stances are
+    # drawn (rejection sampling) where all four feet stand on the floor
+    s3, g3 = [], []
+    while len(s3) < n3:
+        x = rng.uniform(0.0, 3.5)
+        dx, dy = rng.uniform(0.3, 0.5), rng.uniform(-0.03, 0.03)
         feet = NOMINAL_FEET + np.array([x, 0.0, 0.0])
-        fz = heightfield.height_at(maps[1], cell, feet[:, 0], feet[:, 1], mode=1)
-        s3.append(rest_start(x, 0.0, 0.24 + float(heightfield.height_at(maps[1], cell, x, 0.0, mode=1)), fz))
-    g3 = np.stack([x0 + rng.uniform(0.3, 0.5, n3), rng.uniform(-0.03, 0.03, n3), np.full(n3, 0.24)], axis=1)
+        feet_goal = NOMINAL_FEET + np.array([x + dx, dy, 0.0])
+        pts = np.concatenate([feet, feet_goal, 0.5 * (feet + feet_goal)])
+        if np.any(heightfield.height_at(maps[1], cell, pts[:, 0], pts[:, 1], mode=1) != 0.0):
+            continue
+        s3.append(rest_start(x, 0.0, 0.24, np.zeros(4)))
+        g3.append([x + dx, dy, 0.24])
+    g3 = np.array(g3)
     s5, g5 = step_goals(n5, seed + 1, terrain=(maps[2], cell))
     start = np.concatenate([s1, np.stack(s3), s5])
     goal = np.concatenate([g1, g3, g5])

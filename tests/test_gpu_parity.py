@@ -391,11 +391,9 @@ def test_mixed_terrain_batch_with_map_ids(cfg):
     P = Planner(cfg, max_batch=96)
     P.set_heightfields(maps, cell)
     nodes, status, iters, viol = P.plan(start, goal, map_id=map_id)
-    # exp_3 starts are drawn along the y = 0 lane and a few land inside a block: those problems are
-    # infeasible for the oracle as well (it stops at the iteration limit with the same violation)
-    assert (status == 0).mean() >= 0.8
+    assert (status == 0).mean() >= 0.85
     for k in range(3):
-        assert (status[map_id == k] == 0).mean() >= 0.6
+        assert (status[map_id == k] == 0).mean() >= 0.75
     oracles = [Oracle(cfg.oracle_dict(), height=maps[k], hcell=cell) for k in range(3)]
     checked = 0
     for b in np.nonzero(status == 0)[0][:24]:
