@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="plans per GPU per step")
     ap.add_argument("--transcription", default="knots100", choices=["knots100", "reference_compat"])
-    ap.add_argument("--workload", default="exp1_flat", choices=["exp1_flat", "exp5_step"])
+    ap.add_argument("--workload", default="exp1_flat", choices=["exp1_flat", "exp5_step", "mixed"])
     ap.add_argument("--cpu-sample", type=int, default=96, help="plans timed on the CPU oracle (0 = skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per k_kkt launch from a separate rocprofv3 --pmc pass "
@@ -69,7 +69,12 @@ def main():
     P = Planner(cfg, max_batch=B, device=local_rank)
     d = P.dims
     terrain = None
-    if args.workload == "exp5_step":
+    map_id_np = None
+    if args.workload == "mixed":     # BASELINE configs[3] shard: exp_1 / exp_3 / exp_5 patches, one map index per problem
+        maps, cell = workloads.mixed_terrains()
+        P.set_heightfields(maps, cell)
+        start_np, goal_np, map_id_np = workloads.mixed_goals(B, seed=2 + rank, terrains=(maps, cell))
+    elif args.workload == "exp5_step":
         terrain = workloads.exp5_terrain()
         P.set_heightfields(terrain[0], terrain[1])
         start_np, goal_np = workloads.step_goals(B, seed=1 + rank, terrain=terrain)
@@ -85,10 +90,12 @@ def main():
     status = torch.empty((B,), dtype=torch.int32, device=dev)
     iters = torch.empty((B,), dtype=torch.int32, device=dev)
     viol = torch.empty((B,), dtype=torch.float64, device=dev)
+    map_id = None if map_id_np is None else torch.as_tensor(map_id_np, dtype=torch.int32, device=dev).contiguous()
     stream = torch.cuda.current_stream(dev)
 
     def step():
-        rc = P.lib.qtos_plan_batch_device(P.h, B, start.data_ptr(), goal.data_ptr(), None, None,
+        rc = P.lib.qtos_plan_batch_device(P.h, B, start.data_ptr(), goal.data_ptr(),
+                                          None if map_id is None else map_id.data_ptr(), None,
                                           nodes.data_ptr(), status.data_ptr(), iters.data_ptr(),
                                           viol.data_ptr(), C.c_void_p(stream.cuda_stream))
         if rc != 0:
@@ -136,7 +143,8 @@ def main():
         "config": {
             "workload": "batch=%d/GPU %s goals, %s transcription (%d base polynomials, %d vars, %d "
                         "constraint rows), walk gait of the reference's golden plans" %
-                        (B, "exp_1 flat-ground" if args.workload == "exp1_flat" else "exp_5 step-climb",
+                        (B, {"exp1_flat": "exp_1 flat-ground", "exp5_step": "exp_5 step-climb",
+                             "mixed": "mixed exp_1/exp_3/exp_5"}[args.workload],
                          args.transcription, d.n_base_nodes - 1, d.n_vars, d.n_cons),
             "global_batch": total_plans, "converged": n_solved, "iterations_max": int(itn.max()),
             "iterations_mean": round(float(itn.mean()), 2), "parallelism": "batch-shard x%d + 1 all-gather" % world,
@@ -166,7 +174,7 @@ def main():
             "fp64_tflops": round(B * d.kkt_flops / avg / 1e12, 3), "fp64_peak_tflops": 78.6,
             "kkt_share_of_device_time": round(kkt_s / max(tot_s, 1e-12), 3),
         }
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and args.workload != "mixed":
         from oracle.oracle import Oracle
         O = Oracle(cfg.oracle_dict(), height=None if terrain is None else terrain[0],
                    hcell=0.1 if terrain is None else terrain[1])
