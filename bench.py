@@ -41,6 +41,10 @@ def main():
     ap.add_argument("--transcription", default="knots100", choices=["knots100", "reference_compat"])
     ap.add_argument("--workload", default="exp1_flat", choices=["exp1_flat", "exp5_step", "mixed"])
     ap.add_argument("--cpu-sample", type=int, default=96, help="plans timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="batches in flight per GPU (each on its own planner handle + HIP stream, driven by its own "
+                         "host thread): 2 lets the next batch use the CUs idled by early-converged problems. "
+                         "Default 1 = the configuration BASELINE.json names")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per k_kkt launch from a separate rocprofv3 --pmc pass "
                          "(default: the newest profiles/*_pmc_hbm.json, collected with this same command)")
@@ -109,12 +113,55 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # optional: several batches in flight (same inputs, separate planner handles / streams / outputs)
+    lanes = []
+    if args.inflight > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        for _ in range(args.inflight):
+            Pl = Planner(cfg, max_batch=B, device=local_rank)
+            if args.workload == "mixed":
+                Pl.set_heightfields(maps, cell)
+            elif terrain is not None:
+                Pl.set_heightfields(terrain[0], terrain[1])
+            else:
+                Pl.set_heightfields(hxy, cell)
+            lanes.append(dict(P=Pl, stream=torch.cuda.Stream(dev), nodes=torch.empty_like(nodes),
+                              status=torch.empty_like(status), iters=torch.empty_like(iters), viol=torch.empty_like(viol)))
+        pool = ThreadPoolExecutor(args.inflight)
+
+        def lane_step(L):
+            rc = L["P"].lib.qtos_plan_batch_device(L["P"].h, B, start.data_ptr(), goal.data_ptr(),
+                                                   None if map_id is None else map_id.data_ptr(), None,
+                                                   L["nodes"].data_ptr(), L["status"].data_ptr(), L["iters"].data_ptr(),
+                                                   L["viol"].data_ptr(), C.c_void_p(L["stream"].cuda_stream))
+            if rc != 0:
+                raise RuntimeError("qtos_plan_batch_device failed: %d" % rc)
+            L["stream"].synchronize()
+            return int((L["status"] == 0).sum().item())
+
     for _ in range(args.warmup):
         step()
     sync()
     kkt_s, kkt_n, tot_s, it_sum = 0.0, 0, 0.0, 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    solved_inflight = None
+    if lanes:
+        for L in lanes:
+            lane_step(L)
+        sync()
+        t0 = time.perf_counter()
+        futs = [pool.submit(lane_step, lanes[i % len(lanes)]) for i in range(len(lanes))]
+        done_steps, solved_inflight, nxt = 0, 0, len(lanes)
+        while done_steps < args.steps:          # keep `inflight` batches running until K are done
+            f = futs.pop(0)
+            solved_inflight += f.result()
+            done_steps += 1
+            if nxt < args.steps:
+                futs.append(pool.submit(lane_step, lanes[nxt % len(lanes)]))
+                nxt += 1
+        all_nodes, all_status = lanes[0]["nodes"], lanes[0]["status"]
+    else:
+        t0 = time.perf_counter()
+    for _ in range(0 if lanes else args.steps):
         all_nodes, all_status = step()
         tm = P.timing()   # HIP events recorded on the launch stream around every k_kkt launch
         kkt_s += tm["kkt_seconds"]
@@ -131,6 +178,8 @@ def main():
     n_solved = int(solved.item())          # after the gather every rank sees the whole batch
     total_plans = B * world
     value = n_solved * args.steps / elapsed
+    if solved_inflight is not None:
+        value = solved_inflight / elapsed
     st = status.cpu().numpy()
     itn = iters.cpu().numpy()
 
@@ -149,6 +198,7 @@ def main():
             "global_batch": total_plans, "converged": n_solved, "iterations_max": int(itn.max()),
             "iterations_mean": round(float(itn.mean()), 2), "parallelism": "batch-shard x%d + 1 all-gather" % world,
             "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front,
+            "batches_in_flight": args.inflight,
         },
     }
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
