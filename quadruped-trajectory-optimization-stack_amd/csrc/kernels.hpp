@@ -608,27 +608,73 @@ __device__ __forceinline__ double fast_rcp(double d) {
   r = fma(fma(-d, r, 1.0), r, r);
   return r;
 }
-__device__ __forceinline__ void ldlt16(const double *Bsrc /* 16 x PLD */, double *Lm, double *dinv, int lane) {
-  const int i = lane & 15;
-  double a[PIV];
-#pragma unroll
-  for (int j = 0; j < PIV; ++j) a[j] = Bsrc[i * PLD + j];
-  double myinv = 0.0;
-#pragma unroll
-  for (int k = 0; k < PIV; ++k) {
-    const double inv = fast_rcp(readlane_d(a[k], k));   // 1 / d_k
-    if (i == k) myinv = inv;
-    if (k == PIV - 1) break;
-    const double li = i > k ? a[k] * inv : 0.0;          // L[i][k] for rows i > k, 0 for finished rows
-#pragma unroll
-    for (int j = k + 1; j < PIV; ++j) a[j] -= li * readlane_d(a[j], k);   // B[k][j] is wave-uniform
-    if (i > k) a[k] = li;
+// row_newbcast:K -- every lane of a 16-lane DPP row reads lane K of its own row (gfx90a+)
+template <int K>
+__device__ __forceinline__ double bc16(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// c += bcast_K(a) * b as ONE DP-ALU DPP instruction (the f64 FMA reads its first operand from lane K
+// of the 16-lane row; v_fmac_f64 is the VOP2 form that can carry DPP); callers keep two instructions between a VALU write of `a` and this read.
+template <int K>
+__device__ __forceinline__ void fma_bc(double &c, double a, double b) {
+  asm volatile("v_fmac_f64 %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(c) : "v"(a), "v"(b), "n"(K));
+}
+// a += bcast_K(a) * b (the broadcast source is the accumulator itself)
+template <int K>
+__device__ __forceinline__ void fma_bc_self(double &a, double b) {
+  asm volatile("v_fmac_f64 %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b), "n"(K));
+}
+template <int K, int J, int END>
+__device__ __forceinline__ void bc_update(double (&r)[PIV], double m) {
+  if constexpr (J < END) {
+    fma_bc_self<K>(r[J], m);
+    bc_update<K, J + 1, END>(r, m);
   }
-  if (lane < PIV) {
+}
+template <int K>
+__device__ __forceinline__ void ldlt16_steps(double (&a)[PIV], double (&v)[PIV], double &myinv, int i) {
+  if constexpr (K < PIV) {
+    const double inv = fast_rcp(bc16<K>(a[K]));   // 1 / d_K
+    if (i == K) myinv = inv;
+    if constexpr (K < PIV - 1) {
+      const double li = i > K ? a[K] * inv : 0.0;  // L[i][K] for rows i > K, 0 for finished rows
+      const double nli = -li;
+      bc_update<K, K + 1, PIV>(a, nli);   // trailing block: a[j] -= L[i][K] B[K][j], j > K
+      bc_update<K, 0, K>(v, nli);         // inverse: row i -= L[i][K] * (row K of L^-1), columns < K
+      v[K] = nli;                         // (L^-1)[K][K] = 1
+      asm volatile("s_nop 1" : "+v"(v[K]));   // DPP hazard: two wait states between this VALU write and the row read
+      if (i > K) a[K] = li;
+    }
+    ldlt16_steps<K + 1>(a, v, myinv, i);
+  }
+}
+// In-register LDL^T of a symmetric 16 x 16 block by one wave, no pivoting, plus the inverse of the
+// unit lower-triangular factor (stage updates then become plain matrix products on the matrix
+// cores).  Lane i of every 16-lane row holds ROW i of the block; the wave-uniform row K is read
+// with DPP row broadcasts folded into the f64 FMAs: no LDS traffic and no scalar round trips on
+// the 16-step dependency chain.  Lanes 0..15 write L (strictly lower part valid), lanes 16..31
+// write L^-1 (full rows, zeros above the unit diagonal).
+__device__ __forceinline__ void ldlt16(const double *Bsrc /* 16 x PLD */, double *Lm, double *Li, double *dinv, int lane) {
+  const int i = lane & 15;
+  double a[PIV], v[PIV];
 #pragma unroll
-    for (int j = 0; j < PIV; ++j)
-      if (j < i) Lm[i * PLD + j] = a[j];
-    dinv[i] = myinv;
+  for (int j = 0; j < PIV; ++j) { a[j] = Bsrc[i * PLD + j]; v[j] = 0.0; }
+  double myinv = 0.0;
+  // pin the 32 row registers before the DPP chain starts (EXEC / VALU-write hazards of the hand-written
+  // DPP instructions are not tracked by the compiler)
+#define QTOS_PIN16(r) asm volatile("s_nop 4" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]))
+  QTOS_PIN16(a);
+  QTOS_PIN16(v);
+#undef QTOS_PIN16
+  ldlt16_steps<0>(a, v, myinv, i);
+  if (lane < 2 * PIV) {
+    double *dst = (lane < PIV ? Lm : Li) + i * PLD;
+#pragma unroll
+    for (int j = 0; j < PIV; ++j) dst[j] = lane < PIV ? a[j] : (j == i ? 1.0 : v[j]);
+    if (lane < PIV) dinv[i] = myinv;
   }
 }
 
@@ -720,9 +766,10 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   double *A = lds;                      // lower triangle incl. rhs row F
   double *Pbuf = A + ntri;              // 2 panels of (F+1) x PLD
   double *Lbuf = Pbuf + 2 * PSZ;        // 2 x (PIV x PLD)
-  double *dvb = Lbuf + 2 * PIV * PLD;   // 2 x PIV   (1/d)
-  double *xs = dvb + 2 * PIV;           // F
-  double *red = xs + F;                 // 34 x PLD  backward-pass scratch
+  double *Libuf = Lbuf + 2 * PIV * PLD; // 2 x (PIV x PLD)  inverse of the unit lower factor
+  double *dvb = Libuf + 2 * PIV * PLD;  // 2 x PIV   (1/d)
+  double *xs = dvb + 2 * PIV;           // 128 (solution by front slot, backward pass)
+  double *red = xs + 128;               // 34 x PLD  scratch
   double *dbuf = red + 34 * PLD;        // max_drec
   int *sbuf = (int *)(dbuf + P.max_drec);   // max_srec
   int *soff = sbuf + P.max_srec;        // n_stages + 1
@@ -734,7 +781,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
   double *dx = W.dx + (size_t)b * n;
-  const int pstride = (F + PIV + 4) * PIV;  // per stage: L (16 x 16), 1/d (16), y_F (16), pivot slots (16), hi (+15 pad), Y (hi x 16)
+  const int pstride = (F + PIV + 4) * PIV;  // per stage: L^-1 (16 x 16), 1/d (16), y_F (16), pivot slots (16), hi (+15 pad), Y (hi x 16)
 
   for (int i = tid; i < ntri; i += KT) A[i] = 0.0;
   for (int v = tid; v < n; v += KT) dx[v] = 0.0;
@@ -765,7 +812,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   if (tid < 64) {
     double *Bs = red;  // 16 x PLD scratch
     for (int e = tid; e < PIV * PIV; e += 64) Bs[(e >> 4) * PLD + (e & 15)] = Pbuf[psb[e >> 4] * PLD + (e & 15)];
-    ldlt16(Bs, Lbuf, dvb, tid);
+    ldlt16(Bs, Lbuf, Libuf, dvb, tid);
     for (int e = tid; e < PIV * PIV; e += 64) Pbuf[psb[e >> 4] * PLD + (e & 15)] = 0.0;  // pivot rows leave the panel
   }
   __syncthreads();
@@ -862,7 +909,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         const int *psn = psb + nxt * PIV;
         double *Bs = red;
         for (int e = tid; e < PIV * PIV; e += 64) Bs[(e >> 4) * PLD + (e & 15)] = Pn[psn[e >> 4] * PLD + (e & 15)];
-        ldlt16(Bs, Lbuf + nxt * PIV * PLD, dvb + nxt * PIV, tid);
+        ldlt16(Bs, Lbuf + nxt * PIV * PLD, Libuf + nxt * PIV * PLD, dvb + nxt * PIV, tid);
         for (int e = tid; e < PIV * PIV; e += 64) Pn[psn[e >> 4] * PLD + (e & 15)] = 0.0;
       }
       STAMP(3);
@@ -927,7 +974,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       // factor panel of stage k to HBM (everything the backward pass needs, so that it never has to
       // touch the static tables again)
       double *pk = panel + (size_t)k * pstride;
-      for (int i = t2; i < PIV * PIV; i += KT - 64) pk[i] = Lm[(i >> 4) * PLD + (i & 15)];
+      for (int i = t2; i < PIV * PIV; i += KT - 64) pk[i] = Libuf[cur * PIV * PLD + (i >> 4) * PLD + (i & 15)];
       if (t2 < PIV) pk[PIV * PIV + t2] = dinv[t2];
       else if (t2 < 2 * PIV) pk[PIV * PIV + t2] = Y[F * PLD + (t2 - PIV)];
       else if (t2 < 3 * PIV) pk[PIV * PIV + t2] = (double)ps[t2 - 2 * PIV];
@@ -947,69 +994,61 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     cur = nxt;
     STAMP(5);
   }
-  // ---- backward substitution: L^T x1 = D^-1 (y_F - Y^T x2), panels prefetched one stage ahead ----
+  // ---- backward substitution: x1 = L^-T D^-1 (y_F - Y^T x2).  Stage k belongs to wave (NS-1-k) mod 8,
+  //      which holds that stage's whole factor panel in registers (loaded eight stages ahead, so the
+  //      HBM latency is off the chain); per stage one wave does a 128 x 16 dot-product sweep against
+  //      the solution kept in LDS, a 4-way lane fold and a 16 x 16 product with L^-T via DPP row
+  //      broadcasts.  One LDS-only barrier per stage hands the solution to the next wave.
   __syncthreads();  // drains the factor-panel stores: they are read back below
   STAMP(6);
-  for (int i = tid; i < F; i += KT) xs[i] = 0.0;
-  constexpr int PFB = 5;  // (F + 20) * 16 / 512 <= 5 for F <= 128
-  const int pcnt = (F + PIV + 4) * PIV;   // whole panel slot: no dependence on the stage's hi
-  double pfb[PFB];
-  double *Yb = Pbuf, *Lb = Lbuf, *dvs = dvb, *yF = dvb + PIV, *meta = red + 33 * PLD;  // meta: ps[16], hi
+  for (int i = tid; i < 128; i += KT) xs[i] = 0.0;
   {
-    const double *pk = panel + (size_t)(NS - 1) * pstride;
+    constexpr int RB = 32;   // rows per lane: F / 4 <= 32
+    const int wv = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+    double yv[RB], lc[PIV], dv = 0, yf = 0, psl = 0;   // psl: pivot slot, converted at use (no early wait on the load)
+    int unk = -1;
+    auto load_panel = [&](int k) {
+      const double *pk = panel + (size_t)k * pstride;
 #pragma unroll
-    for (int j = 0; j < PFB; ++j) { const int i = tid + j * KT; pfb[j] = i < pcnt ? pk[i] : 0.0; }
-  }
-  __syncthreads();
-  for (int k = NS - 1; k >= 0; --k) {
+      for (int jj = 0; jj < PIV; ++jj) lc[jj] = pk[jj * PIV + j];          // column j of L^-1
+      dv = pk[PIV * PIV + j];
+      yf = pk[PIV * PIV + PIV + j];
+      psl = pk[PIV * PIV + 2 * PIV + j];
+      unk = P.piv_unknown[k * PIV + j];
+      const double *yk = pk + PIV * PIV + 4 * PIV;
 #pragma unroll
-    for (int j = 0; j < PFB; ++j) {
-      const int i = tid + j * KT;
-      if (i < pcnt) {
-        if (i < PIV * PIV) Lb[(i >> 4) * PLD + (i & 15)] = pfb[j];
-        else if (i < PIV * PIV + PIV) dvs[i - PIV * PIV] = pfb[j];
-        else if (i < PIV * PIV + 2 * PIV) yF[i - PIV * PIV - PIV] = pfb[j];
-        else if (i < PIV * PIV + 4 * PIV) { const int e = i - PIV * PIV - 2 * PIV; if (e <= PIV) meta[e] = pfb[j]; }
-        else { const int e = i - PIV * PIV - 4 * PIV; Yb[(e >> 4) * PLD + (e & 15)] = pfb[j]; }
+      for (int i = 0; i < RB; ++i) yv[i] = 4 * i < F ? yk[(q + 4 * i) * PIV + j] : 0.0;   // wave-uniform predicate
+    };
+    if (NS - 1 - wv >= 0) load_panel(NS - 1 - wv);
+    __syncthreads();
+    for (int bs = 0; bs < NS; ++bs) {
+      const int k = NS - 1 - bs;
+      if ((bs & 7) == wv) {
+        double acc0 = 0, acc1 = 0;
+#pragma unroll
+        for (int i = 0; i < RB; i += 2) {   // xs has 128 entries; rows >= F carry yv = 0, xs = 0
+          acc0 = fma(yv[i], xs[q + 4 * i], acc0);
+          acc1 = fma(yv[i + 1], xs[q + 4 * i + 4], acc1);
+        }
+        double acc = acc0 + acc1;
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        double u = (yf - acc) * dv;        // u_j on every lane with (lane & 15) == j
+        asm volatile("s_nop 4" : "+v"(u));
+        double x0 = 0, x1 = 0;             // x_i = sum_jj (L^-1)[jj][i] u_jj
+        fma_bc<0>(x0, u, lc[0]);   fma_bc<1>(x1, u, lc[1]);   fma_bc<2>(x0, u, lc[2]);   fma_bc<3>(x1, u, lc[3]);
+        fma_bc<4>(x0, u, lc[4]);   fma_bc<5>(x1, u, lc[5]);   fma_bc<6>(x0, u, lc[6]);   fma_bc<7>(x1, u, lc[7]);
+        fma_bc<8>(x0, u, lc[8]);   fma_bc<9>(x1, u, lc[9]);   fma_bc<10>(x0, u, lc[10]); fma_bc<11>(x1, u, lc[11]);
+        fma_bc<12>(x0, u, lc[12]); fma_bc<13>(x1, u, lc[13]); fma_bc<14>(x0, u, lc[14]); fma_bc<15>(x1, u, lc[15]);
+        const double xi = x0 + x1;
+        if (lane < PIV) {
+          xs[(int)psl] = xi;
+          if (unk >= 0 && unk < n) dx[unk] = xi;
+        }
+        if (k - 8 >= 0) load_panel(k - 8);
       }
+      lds_barrier();
     }
-    lds_barrier();
-    if (k > 0) {  // prefetch panel k-1 (lands while this stage computes)
-      const double *pk = panel + (size_t)(k - 1) * pstride;
-#pragma unroll
-      for (int j = 0; j < PFB; ++j) { const int i = tid + j * KT; pfb[j] = i < pcnt ? pk[i] : 0.0; }
-    }
-    const int hi = (int)meta[PIV];
-    {  // partial sums: thread (j, q) accumulates rows r = q, q+32, ... of column j; lanes of one
-       // wave hold 4 row groups per column -> fold them with two shuffles, one value per wave left
-      const int j = tid & (PIV - 1), q = tid >> 4;
-      double acc = 0;
-      for (int r = q; r < hi; r += KT / PIV) acc += Yb[r * PLD + j] * xs[r];
-      acc += __shfl_xor(acc, 16);
-      acc += __shfl_xor(acc, 32);
-      if ((tid & 63) < PIV) red[(tid >> 6) * PLD + j] = acc;
-    }
-    lds_barrier();
-    if (tid < 64) {
-      // u = D^-1 (y_F - Y^T x2); then L^T x1 = u by back substitution: lane i holds u_i and column i
-      // of L; x_i is wave-uniform once final and is read with v_readlane
-      const int i0 = tid & 15;
-      double u = yF[i0];
-#pragma unroll
-      for (int qq = 0; qq < KT / 64; ++qq) u -= red[qq * PLD + i0];
-      u *= dvs[i0];
-      double lc[PIV];
-#pragma unroll
-      for (int i = 1; i < PIV; ++i) lc[i] = i > i0 ? Lb[i * PLD + i0] : 0.0;
-#pragma unroll
-      for (int i = PIV - 1; i > 0; --i) u -= lc[i] * readlane_d(u, i);
-      if (tid < PIV) {
-        xs[(int)meta[tid]] = u;
-        const int un = P.piv_unknown[k * PIV + tid];
-        if (un >= 0 && un < n) dx[un] = u;
-      }
-    }
-    lds_barrier();
   }
 #ifdef QTOS_STAMPS
   STAMP(7);

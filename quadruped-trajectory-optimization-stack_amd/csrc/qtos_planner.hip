@@ -146,7 +146,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.panel_stride = (long long)S.n_stages * (S.front + PIV + 4) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  size_t lds_d = (size_t)((F + 1) * (F + 2) / 2) + 2 * (size_t)(F + 1) * PLD + 2 * PIV * PLD + 2 * PIV + F +
+  size_t lds_d = (size_t)((F + 1) * (F + 2) / 2) + 2 * (size_t)(F + 1) * PLD + 4 * PIV * PLD + 2 * PIV + 128 +
                  34 * PLD + S.max_drec + 8;
   p->kkt_lds = lds_d * sizeof(double) + ((size_t)S.max_srec + 2 * (size_t)(S.n_stages + 1) + 2 * PIV + 2 + 48 + 528 + 8) * sizeof(int);
   if (S.max_drec > PFD * KT || S.max_srec > PFS * KT || (F + PIV + 4) * PIV > 5 * KT) {

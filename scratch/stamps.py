@@ -4,12 +4,13 @@ from qtos_amd import capi, workloads
 capi.LIB_PATH = capi.LIB_PATH.replace("libqtos_planner.so", "libqtos_planner_stamps.so")
 from qtos_amd.config import PlannerConfig
 cfg = PlannerConfig.knots100(max_iter=40)
-P = capi.Planner(cfg, max_batch=256)
-start, goal = workloads.flat_goals(256, 0)
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+P = capi.Planner(cfg, max_batch=NB)
+start, goal = workloads.flat_goals(NB, 0)
 P.plan(start, goal)
 names = ["S1 Ysolve+retire", "S2 assemble", "S3 gather", "S4 wave0 ldlt", "S4 rest (to barrier)", "install", "drain", "backward"]
 tot = np.zeros(8)
-for b in (0, 5, 100):
+for b in (0, 5, NB - 1):
     t = np.zeros((cfg.max_iter + 1, 4))
     P.lib.qtos_debug_trace(P.h, b, t.ctypes.data_as(C.POINTER(C.c_double)))
     st = t[30:32].ravel()
