@@ -50,7 +50,7 @@ EXPORTS = [
     "qtos_planner_create", "qtos_planner_destroy", "qtos_planner_dims", "qtos_last_error",
     "qtos_set_heightfields", "qtos_plan_batch", "qtos_plan_batch_device", "qtos_sample_csv",
     "qtos_sample_csv_device", "qtos_last_timing", "qtos_debug_eval", "qtos_debug_newton",
-    "qtos_debug_structure", "qtos_debug_trace", "qtos_analyze",
+    "qtos_debug_structure", "qtos_debug_trace", "qtos_debug_factor", "qtos_analyze",
 ]
 
 _lib = None
@@ -82,6 +82,7 @@ def load():
     lib.qtos_debug_newton.argtypes = [vp, C.c_int, dp, dp, ip, dp, dp, dp, dp]
     lib.qtos_debug_structure.argtypes = [vp, ip, ip, ip]
     lib.qtos_debug_trace.argtypes = [vp, C.c_int, dp]
+    lib.qtos_debug_factor.argtypes = [vp, C.c_int, dp, ip]
     lib.qtos_analyze.argtypes = [C.POINTER(QtosParams), C.POINTER(QtosDims), ip, C.c_int]
     _lib = lib
     return lib
@@ -237,6 +238,14 @@ class Planner:
         order = np.empty(self.dims.n_unknowns, np.int32)
         self.lib.qtos_debug_structure(self.h, _ip(rk), _ip(vf), _ip(order))
         return rk, vf, order
+
+    def factor(self, b):
+        """(panels [n_stages, front + 1, 16], pivot slots [n_stages, 16]) of problem b's last KKT solve."""
+        d = self.dims
+        pan = np.zeros((d.n_stages, d.front + 1, 16))
+        ps = np.zeros((d.n_stages, 16), dtype=np.int32)
+        self._chk(self.lib.qtos_debug_factor(self.h, b, _dp(pan), _ip(ps)), "qtos_debug_factor")
+        return pan, ps
 
     def trace(self, b):
         t = np.zeros((self.cfg.max_iter + 1, 4))

@@ -477,25 +477,6 @@ __device__ inline void record_trace(const DevPlan &P, const DevWork &W, int b, i
   }
 }
 
-// Gathers this problem's linearisation into the stage-ordered stream k_kkt reads (one contiguous
-// slice per stage).  Runs right after the values were produced, while they are hot in L2.
-__device__ inline void pack_stream(const DevPlan &P, const double *G, const double *g, const double *sig,
-                                   const double *w, double *stream) {
-  for (int i = threadIdx.x; i < P.stream_len; i += blockDim.x) {
-    const int s = P.pack_src[i], kind = s >> 28, idx = s & 0x0fffffff;
-    double v;
-    switch (kind) {
-      case 0: v = G[idx]; break;
-      case 1: v = P.g_static[idx]; break;
-      case 2: v = -g[idx]; break;
-      case 3: v = sig[idx]; break;
-      case 4: v = w[idx]; break;
-      default: v = P.piv_diag[idx]; break;
-    }
-    stream[i] = v;
-  }
-}
-
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
@@ -574,11 +555,36 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
 }
 
 // =================================================================================================
-// k_kkt: one workgroup (KT threads) per problem.
-//   LDS: A   lower triangle of the symmetric front, rows 0..F; row F is the right-hand side
-//        Pn[(F+1) x 17] pivot columns (border panel C; pivot rows zeroed), Wn = Pn * Binv
+// k_kkt: one workgroup (KT threads = 8 waves) per problem: fused assembly + block LDL^T of the
+// condensed KKT chain (16 pivots per stage) + forward/backward substitution.
+//
+// Where the data lives
+//   LDS   A      lower triangle of the ASSEMBLED entries of the front (original matrix entries only;
+//                rows 0..F-1 by front slot, row F = assembled right-hand side)
+//         PB[3]  three (F+1) x 17 panels: the pivot columns P_k of the current stage, Y_k = P_k L^-T,
+//                and the columns of the next stage under construction
+//         UF     accumulated right-hand-side updates by front slot
+//   VGPR  U      the accumulated Schur updates  -sum_k Y_k D_k^-1 Y_k^T  as 16 x 16 tiles in the
+//                f64 MFMA accumulator layout, six tiles on each of waves 1..6 (36 = lower triangle
+//                of a 128-slot front); they never touch LDS except for the 16 columns a stage
+//                extracts
+//   HBM   per stage V_k = Y_k D^-1 L^-1 (hi x 16) and w_k = L^-T D^-1 y_F: all the backward pass needs
+//
+// Two phases per stage, two LDS-only barriers:
+//   AB(k)  every wave owns one 16-row tile R of the panel: Y = P L^-T, the rows of the next pivots
+//          Y[piv_{k+1}] (recomputed by every wave: an MFMA accumulator IS a valid A/B operand, so no
+//          LDS round trip and no barrier between the products), the next pivot columns
+//          P_{k+1} = A[:, piv] + U[:, piv] - Y D^-1 Y[piv]^T, and V -> HBM.  16 MFMAs per wave.
+//   C(k)   wave 0: in-register LDL^T + L^-1 of the next 16 x 16 pivot block (DPP row broadcasts);
+//          waves 1..6: U -= Y D^-1 Y^T on the matrix cores, retire the next pivots' rows/columns,
+//          extract the columns of stage k+2, then assemble stage k+2's records into A;
+//          wave 7: right-hand-side row (y_F, w, updates).
+// The backward pass is one barrier per stage: every wave reduces its 16 rows of V^T x against the
+// solution, partial sums meet in LDS, every wave forms the 16 new solution entries redundantly.
 constexpr int KT = 512;
 constexpr int PLD = PIV + 1;
+constexpr int MAXT = 6;   // U tiles per update wave
+constexpr int TB = 2;     // tiles processed together in the update phase
 __device__ __forceinline__ int tri(int r, int c) { return ((r * (r + 1)) >> 1) + c; }  // c <= r
 __device__ __forceinline__ int trs(int a, int b) { return a >= b ? tri(a, b) : tri(b, a); }
 
@@ -589,19 +595,9 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
 
-// In-register LDL^T of a symmetric 16 x 16 block by one wave, no pivoting (the KKT matrix is
-// quasi-definite and the elimination order is fixed).  Lane i (mod 16) holds ROW i in 16
-// registers.  Step k: every lane scales its own B[i][k] by 1/d_k (no cross-lane traffic), and row
-// k -- wave-uniform -- is read from lane k with v_readlane; no LDS round trips on the 15-step
-// dependency chain.  Reciprocals: v_rcp_f64 + two Newton steps instead of the IEEE division
-// sequence (which costs hundreds of cycles per step on the critical path).
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-  const unsigned long long u = __double_as_longlong(v);
-  const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), lane);
-  const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), lane);
-  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
   r = fma(fma(-d, r, 1.0), r, r);
@@ -616,13 +612,9 @@ __device__ __forceinline__ double bc16(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-// c += bcast_K(a) * b as ONE DP-ALU DPP instruction (the f64 FMA reads its first operand from lane K
-// of the 16-lane row; v_fmac_f64 is the VOP2 form that can carry DPP); callers keep two instructions between a VALU write of `a` and this read.
-template <int K>
-__device__ __forceinline__ void fma_bc(double &c, double a, double b) {
-  asm volatile("v_fmac_f64 %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(c) : "v"(a), "v"(b), "n"(K));
-}
-// a += bcast_K(a) * b (the broadcast source is the accumulator itself)
+// a += bcast_K(a) * b as ONE DP-ALU DPP instruction (v_fmac_f64 is the VOP2 form that can carry DPP;
+// the broadcast source is the accumulator itself).  Callers keep two instructions between a VALU
+// write of `a` and this cross-lane read.
 template <int K>
 __device__ __forceinline__ void fma_bc_self(double &a, double b) {
   asm volatile("v_fmac_f64 %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b), "n"(K));
@@ -646,23 +638,20 @@ __device__ __forceinline__ void ldlt16_steps(double (&a)[PIV], double (&v)[PIV],
       bc_update<K, 0, K>(v, nli);         // inverse: row i -= L[i][K] * (row K of L^-1), columns < K
       v[K] = nli;                         // (L^-1)[K][K] = 1
       asm volatile("s_nop 1" : "+v"(v[K]));   // DPP hazard: two wait states between this VALU write and the row read
-      if (i > K) a[K] = li;
     }
     ldlt16_steps<K + 1>(a, v, myinv, i);
   }
 }
-// In-register LDL^T of a symmetric 16 x 16 block by one wave, no pivoting, plus the inverse of the
-// unit lower-triangular factor (stage updates then become plain matrix products on the matrix
-// cores).  Lane i of every 16-lane row holds ROW i of the block; the wave-uniform row K is read
-// with DPP row broadcasts folded into the f64 FMAs: no LDS traffic and no scalar round trips on
-// the 16-step dependency chain.  Lanes 0..15 write L (strictly lower part valid), lanes 16..31
-// write L^-1 (full rows, zeros above the unit diagonal).
-__device__ __forceinline__ void ldlt16(const double *Bsrc /* 16 x PLD */, double *Lm, double *Li, double *dinv, int lane) {
-  const int i = lane & 15;
-  double a[PIV], v[PIV];
+// In-register LDL^T of a symmetric 16 x 16 block by one wave, no pivoting (the KKT matrix is
+// quasi-definite and the elimination order is fixed), plus the inverse of the unit lower-triangular
+// factor, so that every other product of the stage is a plain matrix product on the matrix cores.
+// Lane i of every 16-lane DPP row holds ROW i of the block in a[0..15]; the wave-uniform row K is
+// read with DPP row broadcasts folded into the f64 FMAs: no LDS traffic and no scalar round trips
+// on the 16-step dependency chain.  On return v[j] = (L^-1)[i][j] for j < i, myinv = 1 / d_i.
+__device__ __forceinline__ void ldlt16(double (&a)[PIV], double (&v)[PIV], double &myinv, int i) {
 #pragma unroll
-  for (int j = 0; j < PIV; ++j) { a[j] = Bsrc[i * PLD + j]; v[j] = 0.0; }
-  double myinv = 0.0;
+  for (int j = 0; j < PIV; ++j) v[j] = 0.0;
+  myinv = 0.0;
   // pin the 32 row registers before the DPP chain starts (EXEC / VALU-write hazards of the hand-written
   // DPP instructions are not tracked by the compiler)
 #define QTOS_PIN16(r) asm volatile("s_nop 4" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]))
@@ -670,46 +659,34 @@ __device__ __forceinline__ void ldlt16(const double *Bsrc /* 16 x PLD */, double
   QTOS_PIN16(v);
 #undef QTOS_PIN16
   ldlt16_steps<0>(a, v, myinv, i);
-  if (lane < 2 * PIV) {
-    double *dst = (lane < PIV ? Lm : Li) + i * PLD;
-#pragma unroll
-    for (int j = 0; j < PIV; ++j) dst[j] = lane < PIV ? a[j] : (j == i ? 1.0 : v[j]);
-    if (lane < PIV) dinv[i] = myinv;
-  }
 }
 
 #ifdef QTOS_STAMPS
-#define STAMP2(i) do { if (tid == 64) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps2[i] += t_ - tlast2; tlast2 = t_; } } while (0)
-#define STAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[i] += t_ - tlast; tlast = t_; } } while (0)
+#define STAMPW(w, arr, i) do { if (tid == 64 * (w)) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); arr[i] += t_ - tl_##arr; tl_##arr = t_; } } while (0)
 #else
-#define STAMP(i) do {} while (0)
-#define STAMP2(i) do {} while (0)
+#define STAMPW(w, arr, i) do {} while (0)
 #endif
 
-constexpr int PFD = 6, PFS = 8;  // per-thread prefetch registers: doubles / ints of a stage's records
-
-// assembly of one stage's records (already in LDS) into the front.  Pass 1: pivot diagonals,
-// equality entries, multiplier right-hand sides (all distinct targets).  Pass 2: the inequality
-// blocks through the gather table: one thread per target entry sums its contributions
-// (sum_r sig_r G[r][a] G[r][c], or -sum_r G[r][a] w_r for the rhs) in a fixed order.
+// Assembly of one stage's records (already in LDS) into A by `nth` threads, ONE pass without
+// barriers: equality entries and multiplier right-hand sides are distinct targets, the inequality
+// blocks go through the gather table (one thread per target entry sums its contributions
+// sum_r sig_r G[r][a] G[r][c], or -sum_r G[r][a] w_r for the rhs, in a fixed order); no target of
+// one kind is a target of another (pivot diagonals are added when the pivot columns are gathered).
 constexpr int SHDR = 8;   // static record header ints
-__device__ inline void assemble_stage(double *A, int F, const int *sbuf, const double *dbuf, int tid) {
+__device__ __forceinline__ void assemble_stage(double *A, int F, const int *sbuf, const double *dbuf, int t0, int nth) {
   const int n_ent = sbuf[0], n_rhs = sbuf[1], n_iq = sbuf[2];
-  const int *ps = sbuf + SHDR;
-  if (tid < PIV) A[tri(ps[tid], ps[tid])] += dbuf[tid];
   const int *eidx = sbuf + SHDR + PIV;
   const double *eval = dbuf + PIV;
-  for (int i = tid; i < n_ent; i += KT) A[eidx[i]] += eval[i];
+  for (int i = t0; i < n_ent; i += nth) A[eidx[i]] += eval[i];
   const int *rsl = eidx + n_ent;
   const double *rval = eval + n_ent;
-  for (int i = tid; i < n_rhs; i += KT) A[tri(F, rsl[i])] += rval[i];
+  for (int i = t0; i < n_rhs; i += nth) A[tri(F, rsl[i])] += rval[i];
   if (n_iq == 0) return;
   const int *iqh = rsl + n_rhs;
   const int n_tgt = sbuf[5];
   const int *tg = sbuf + sbuf[4];                     // n_tgt + 1 ints: (tri << 12) | first contribution
   const unsigned short *cl = (const unsigned short *)(tg + n_tgt + 1);
-  lds_barrier();   // a pivot diagonal / rhs entry above can also be a gather target
-  for (int t = tid; t < n_tgt; t += KT) {
+  for (int t = t0; t < n_tgt; t += nth) {
     const int tv = tg[t], c0 = tv & 4095, c1 = tg[t + 1] & 4095;
     double acc = 0;
     for (int j = c0; j < c1; ++j) {
@@ -723,339 +700,493 @@ __device__ inline void assemble_stage(double *A, int F, const int *sbuf, const d
     A[tv >> 12] += acc;
   }
 }
-// Forward substitution y <- y L^-T with FOUR lanes per row: lane c of a quad owns columns c, c+4,
-// c+8, c+12.  Step Q broadcasts y[Q] inside the quad with a DPP quad_perm move (no LDS) and every
-// lane updates its columns j > Q.  The first quad carries the right-hand-side row as a second row.
-template <int SRC>
-__device__ __forceinline__ double quad_bcast(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, SRC * 0x55, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, SRC * 0x55, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
+
+// 128-bit pivot-slot mask: lane l of the wave holds word l & 3; the 16 bits of slot group `grp` are
+// fetched with a scalar-indexed v_readlane (a select chain over scalars would be turned into a
+// stack table by the compiler)
+struct Mask128 {
+  int v;
+};
+__device__ __forceinline__ Mask128 load_mask(const unsigned *pm4, int lane) {
+  Mask128 m;
+  m.v = (int)pm4[lane & 3];
+  return m;
 }
-template <int Q>
-__device__ __forceinline__ void ysolve_steps(double (&y)[4], double (&yF)[4], const double *Lm, int cq) {
-  if constexpr (Q < PIV - 1) {
-    const double yq = quad_bcast<Q & 3>(y[Q >> 2]);
-    const double yFq = quad_bcast<Q & 3>(yF[Q >> 2]);
-#pragma unroll
-    for (int jj = Q >> 2; jj < 4; ++jj) {
-      const double l = Lm[(4 * jj + cq) * PLD + Q];
-      const double m = (jj > (Q >> 2) || cq > (Q & 3)) ? l : 0.0;   // only columns j = 4 jj + cq > Q
-      y[jj] -= yq * m;
-      yF[jj] -= yFq * m;
-    }
-    ysolve_steps<Q + 1>(y, yF, Lm, cq);
-  }
+__device__ __forceinline__ unsigned grp16(const Mask128 &m, int grp) {
+  return ((unsigned)__builtin_amdgcn_readlane(m.v, grp >> 1) >> ((grp & 1) * 16)) & 0xffffu;
+}
+struct KktLds {
+  double *A, *PB, *Lib, *dvb, *dgb, *UF, *xs, *red, *dbuf;
+  int *sbuf, *soff, *doff, *psb, *hib, *hiall, *jm;
+  unsigned *pm;
+};
+// LDS footprint in bytes (host and device agree through this one function)
+__host__ __device__ inline size_t kkt_lds_layout(int F, int NS, int max_srec, int max_drec, size_t *off /* 17 */) {
+  size_t o = 0;
+  auto take = [&](size_t n_doubles) { size_t r = o; o += (n_doubles + 1) & ~(size_t)1; return r; };
+  off[0] = take((size_t)((F + 1) * (F + 2) / 2));   // A
+  off[1] = take(3 * (size_t)(F + 1) * PLD);         // PB
+  off[2] = take(2 * PIV * PLD);                      // Lib
+  off[3] = take(2 * PIV);                            // dvb
+  off[4] = take(3 * PIV);                            // dgb
+  off[5] = take(128);                                // UF
+  off[6] = take(128);                                // xs
+  off[7] = take(2 * 8 * PIV);                        // red
+  off[8] = take((size_t)max_drec);                   // dbuf
+  size_t oi = o * 2;                                 // ints from here
+  auto takei = [&](size_t n) { size_t r = oi; oi += (n + 3) & ~(size_t)3; return r; };
+  off[9] = takei((size_t)max_srec);                  // sbuf
+  off[10] = takei((size_t)NS + 1);                   // soff
+  off[11] = takei((size_t)NS + 1);                   // doff
+  off[12] = takei(3 * PIV);                          // psb
+  off[13] = takei(4);                                // hib
+  off[14] = takei((size_t)NS + 1);                   // hiall
+  off[15] = takei(2 * 128);                          // jm
+  off[16] = takei(8);                                // pm
+  return oi * sizeof(int);
 }
 
-// k_kkt: one workgroup (KT threads, 8 waves) per problem; software-pipelined over the stage chain:
-//   S1  Y_k = P_k L_k^-T (row per thread), retire the pivots of stage k
-//   S2  assemble stage k+1 into the front (records prefetched one stage earlier)
-//   S3  early gather: P_{k+1} = A[:, piv_{k+1}] - Y_k D_k^-1 Y_k[piv_{k+1}]^T  (the columns the NEXT
-//       factorisation needs, with stage k's update applied on the fly)
-//   S4  wave 0: LDL^T of the next pivot block   ||   waves 1-7: full Schur update of the front on
-//       the f64 matrix cores + factor panel of stage k to HBM
 __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
   if (b >= B || W.done[b]) return;
   extern __shared__ double lds[];
-  const int F = P.front, tid = threadIdx.x;
+  const int F = P.front, NT = F >> 4, tid = threadIdx.x, NS = P.n_stages, n = P.n_vars;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int ntri = ((F + 1) * (F + 2)) >> 1;
   const int PSZ = (F + 1) * PLD;
-  double *A = lds;                      // lower triangle incl. rhs row F
-  double *Pbuf = A + ntri;              // 2 panels of (F+1) x PLD
-  double *Lbuf = Pbuf + 2 * PSZ;        // 2 x (PIV x PLD)
-  double *Libuf = Lbuf + 2 * PIV * PLD; // 2 x (PIV x PLD)  inverse of the unit lower factor
-  double *dvb = Libuf + 2 * PIV * PLD;  // 2 x PIV   (1/d)
-  double *xs = dvb + 2 * PIV;           // 128 (solution by front slot, backward pass)
-  double *red = xs + 128;               // 34 x PLD  scratch
-  double *dbuf = red + 34 * PLD;        // max_drec
-  int *sbuf = (int *)(dbuf + P.max_drec);   // max_srec
-  int *soff = sbuf + P.max_srec;        // n_stages + 1
-  int *doff = soff + P.n_stages + 1;    // n_stages + 1
-  int *psb = doff + P.n_stages + 1;     // 2 x PIV pivot slots (current / next stage)
-  int *hib = psb + 2 * PIV;             // 2: hi of current / next stage
-  int *tileRC = hib + 2;                // (R << 8) | C of lower-triangular tile t, t < 45
-  const int n = P.n_vars, NS = P.n_stages;
+  size_t off[17];
+  kkt_lds_layout(F, NS, P.max_srec, P.max_drec, off);
+  double *A = lds + off[0], *PB = lds + off[1], *Lib = lds + off[2], *dvb = lds + off[3], *dgb = lds + off[4];
+  double *UF = lds + off[5], *xs = lds + off[6], *red = lds + off[7], *dbuf = lds + off[8];
+  int *ilds = (int *)lds;
+  int *sbuf = ilds + off[9], *soff = ilds + off[10], *doff = ilds + off[11], *psb = ilds + off[12], *hib = ilds + off[13];
+  int *hiall = ilds + off[14], *jm = ilds + off[15];
+  unsigned *pm = (unsigned *)(ilds + off[16]);
   const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
   double *dx = W.dx + (size_t)b * n;
-  const int pstride = (F + PIV + 4) * PIV;  // per stage: L^-1 (16 x 16), 1/d (16), y_F (16), pivot slots (16), hi (+15 pad), Y (hi x 16)
+  const int pstride = (F + 1) * PIV;   // per stage: w (16), V (F x 16)
+
+  // ---- U tiles of this wave (waves 1..6): tile t = (wv-1) + 6 i of the lower triangle ------------
+  d4_t U[MAXT];
+  int tRC[MAXT];   // (R << 8) | C, or -1
+  const int ntile_all = (NT * (NT + 1)) >> 1;
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    U[i] = d4_t{0.0, 0.0, 0.0, 0.0};
+    const int t = (wv - 1) + 6 * i;
+    int R = 0;
+    while (((R + 1) * (R + 2)) >> 1 <= t) ++R;
+    const bool valid = wv >= 1 && wv <= 6 && t < ntile_all;
+    tRC[i] = valid ? (R << 8) | (t - ((R * (R + 1)) >> 1)) : -1;
+  }
+  // bit g of ge4 / gt4: row lk + 4g of a diagonal tile lies on or below / strictly below column li
+  unsigned ge4 = 0u, gt4 = 0u;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { ge4 |= (lk + 4 * g >= li ? 1u : 0u) << g; gt4 |= (lk + 4 * g > li ? 1u : 0u) << g; }
 
   for (int i = tid; i < ntri; i += KT) A[i] = 0.0;
+  for (int i = tid; i < 3 * PSZ; i += KT) PB[i] = 0.0;
+  for (int i = tid; i < 128; i += KT) { UF[i] = 0.0; xs[i] = 0.0; }
   for (int v = tid; v < n; v += KT) dx[v] = 0.0;
   for (int i = tid; i <= NS; i += KT) { soff[i] = P.srec_off[i]; doff[i] = P.drec_off[i]; }
-  if (tid < 45) {
-    int R = 0;
-    while (((R + 1) * (R + 2)) >> 1 <= tid) ++R;
-    tileRC[tid] = (R << 8) | (tid - ((R * (R + 1)) >> 1));
-  }
-  __syncthreads();
-  // ---- prologue: assemble stage 0, gather and factor its pivot block, stage records of stage 1 ----
-  for (int i = tid; i < soff[1] - soff[0]; i += KT) sbuf[i] = P.srec[soff[0] + i];
-  for (int i = tid; i < doff[1] - doff[0]; i += KT) dbuf[i] = stream[doff[0] + i];
-  __syncthreads();
-  if (tid < PIV) psb[tid] = sbuf[SHDR + tid];
-  if (tid == 0) hib[0] = sbuf[3];
-  assemble_stage(A, F, sbuf, dbuf, tid);
-  __syncthreads();
-  for (int i = tid; i < (F + 1) * PIV; i += KT) {
-    const int r = i >> 4, j = i & 15;
-    Pbuf[r * PLD + j] = A[trs(r, psb[j])];
-  }
-  if (NS > 1) {
-    for (int i = tid; i < soff[2] - soff[1]; i += KT) sbuf[i] = P.srec[soff[1] + i];
-    for (int i = tid; i < doff[2] - doff[1]; i += KT) dbuf[i] = stream[doff[1] + i];
-  }
-  __syncthreads();
-  if (tid < 64) {
-    double *Bs = red;  // 16 x PLD scratch
-    for (int e = tid; e < PIV * PIV; e += 64) Bs[(e >> 4) * PLD + (e & 15)] = Pbuf[psb[e >> 4] * PLD + (e & 15)];
-    ldlt16(Bs, Lbuf, Libuf, dvb, tid);
-    for (int e = tid; e < PIV * PIV; e += 64) Pbuf[psb[e >> 4] * PLD + (e & 15)] = 0.0;  // pivot rows leave the panel
-  }
   __syncthreads();
 
+  // header of the stage whose records sit in sbuf / dbuf: pivot slots, diagonals, hi, slot -> pivot
+  // index map and pivot bit mask (ring buffers by stage)
+  auto header_from_lds = [&](int s) __attribute__((always_inline)) {
+    if (tid < 4) pm[(s & 1) * 4 + tid] = 0u;
+    if (tid < PIV) {
+      const int slot = sbuf[SHDR + tid];
+      psb[(s % 3) * PIV + tid] = slot;
+      jm[(s & 1) * 128 + slot] = tid;
+      dgb[(s % 3) * PIV + tid] = dbuf[tid];
+      atomicOr(&pm[(s & 1) * 4 + (slot >> 5)], 1u << (slot & 31));
+    }
+    if (tid == 0) { hib[s % 3] = sbuf[3]; hiall[s] = (sbuf[3] + 15) & ~15; }
+  };
+  auto load_records = [&](int s) __attribute__((always_inline)) {
+    for (int i = tid; i < soff[s + 1] - soff[s]; i += KT) sbuf[i] = P.srec[soff[s] + i];
+    for (int i = tid; i < doff[s + 1] - doff[s]; i += KT) dbuf[i] = stream[doff[s] + i];
+  };
+  // wave 0: LDL^T + L^-1 of the pivot block of the panel Pn (rows = pivot slots psn), then the pivot
+  // rows leave the panel
+  auto factor_block = [&](double *Pn, const int myps, double *Lin, double *dvn) __attribute__((always_inline)) {
+    double a[PIV], v[PIV], myinv;
+#pragma unroll
+    for (int j = 0; j < PIV; ++j) {
+      const int pj = __builtin_amdgcn_readlane(myps, j);
+      a[j] = Pn[li >= j ? myps * PLD + j : pj * PLD + li];   // lower triangle (by pivot index), mirrored
+    }
+    ldlt16(a, v, myinv, li);
+    if (lane >= PIV && lane < 2 * PIV) {
+#pragma unroll
+      for (int j = 0; j < PIV; ++j) Lin[li * PLD + j] = j == li ? 1.0 : v[j];
+    }
+    if (lane < PIV) {
+      dvn[li] = myinv;
+#pragma unroll
+      for (int j = 0; j < PIV; ++j) Pn[myps * PLD + j] = 0.0;
+    }
+  };
+
+  // ---- prologue: assemble stages 0 and 1, gather and factor the pivot block of stage 0, leave the
+  //      records of stage 2 in LDS ----------------------------------------------------------------
+  //      (stage 1 may reuse the slots of stage 0's pivots: it is assembled after they were gathered)
+  load_records(0);
+  __syncthreads();
+  header_from_lds(0);
+  assemble_stage(A, F, sbuf, dbuf, tid, KT);
+  __syncthreads();
+  {
+    double *P0 = PB;   // stage 0 lives in panel 0
+    const int *ps0 = psb;
+    for (int i = tid; i < (F + 1) * PIV; i += KT) {
+      const int r = i >> 4, j = i & 15, c = ps0[j];
+      P0[r * PLD + j] = (r < F ? A[trs(r, c)] : A[tri(F, c)]) + (r == c ? dgb[j] : 0.0);
+    }
+    __syncthreads();
+    for (int i = tid; i < (F + 1) * PIV; i += KT) {
+      const int r = i >> 4, j = i & 15, c = ps0[j];
+      A[r < F ? trs(r, c) : tri(F, c)] = 0.0;
+    }
+    __syncthreads();
+    if (wv == 0) factor_block(P0, ps0[li], Lib, dvb);
+  }
+  for (int s = 1; s < 3 && s < NS; ++s) {
+    load_records(s);
+    __syncthreads();
+    header_from_lds(s);
+    if (s == 1) assemble_stage(A, F, sbuf, dbuf, tid, KT);
+    __syncthreads();
+  }
+
 #ifdef QTOS_STAMPS
-  unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-  unsigned long long stamps2[4] = {0, 0, 0, 0}, tlast2 = 0;
-  if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
+  unsigned long long st0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_st0 = 0;
+  unsigned long long st1[4] = {0, 0, 0, 0}, tl_st1 = 0;
+  unsigned long long st7[4] = {0, 0, 0, 0}, tl_st7 = 0;
+  if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st0) :: "memory");
 #endif
-  int cur = 0;
+  constexpr int PFD2 = 2, PFS4 = 2;   // per-thread prefetch registers: 128-bit loads of a stage's records
+  d2_t pfd[PFD2];
+  i4_t pfs[PFS4];
+  int pf_nd2 = 0, pf_ns4 = 0;
+  int prow_next = NS > 1 ? psb[PIV + li] : 0;   // pivot slot li of stage k+1
+  const int tid_outer = tid, lane_outer = lane;
   for (int k = 0; k < NS; ++k) {
-    const int nxt = cur ^ 1;
-    double *Y = Pbuf + cur * PSZ, *Pn = Pbuf + nxt * PSZ;
-    const double *Lm = Lbuf + cur * PIV * PLD, *dinv = dvb + cur * PIV;
-    const int *ps = psb + cur * PIV;
-    const int hi = hib[cur], hi16 = (hi + 15) & ~15;
+    // per-iteration opaque copies of the thread / lane index: everything derived from them is
+    // recomputed each stage instead of being hoisted out of the loop into (spilled) registers
+    int tid = tid_outer, lane = lane_outer;
+    asm volatile("" : "+v"(tid), "+v"(lane));
+    const int li = lane & 15, lk = lane >> 4;
+    const int pb = (k & 1) ? 2 : 0;
+    double *Pk = PB + pb * PSZ, *Yk = PB + PSZ, *Xn = PB + (2 - pb) * PSZ;
+    const double *Lik = Lib + (k & 1) * PIV * PLD, *dik = dvb + (k & 1) * PIV;
+    const int *psn = psb + ((k + 1) % 3) * PIV;
     const bool has_next = k + 1 < NS;
-    // prefetch the records of stage k+2 (installed at the end of this stage)
-    double pfd[PFD];
-    int pfs[PFS];
-    int nd = 0, ns = 0;
-    if (k + 2 < NS) {
-      nd = doff[k + 3] - doff[k + 2];
-      ns = soff[k + 3] - soff[k + 2];
-      const double *dsrc = stream + doff[k + 2];
-      const int *ssrc = P.srec + soff[k + 2];
+    // ---- install the records of stage k+2 (prefetched during stage k-1), prefetch stage k+3 --------
+    if (k >= 1 && k + 2 < NS) {
+      const int s = k + 2;
 #pragma unroll
-      for (int j = 0; j < PFD; ++j) { const int i = tid + j * KT; pfd[j] = i < nd ? dsrc[i] : 0.0; }
+      for (int jj = 0; jj < PFD2; ++jj) { const int i = tid + jj * KT; if (i < pf_nd2) ((d2_t *)dbuf)[i] = pfd[jj]; }
 #pragma unroll
-      for (int j = 0; j < PFS; ++j) { const int i = tid + j * KT; pfs[j] = i < ns ? ssrc[i] : 0; }
-    }
-    // ---- S1: retire the pivots of stage k (their rows / columns are recycled), then Y = P L^-T with
-    //      four lanes per row (rows 0..F-1 on quads 0..F-1, the rhs row F rides on quad 0) -------
-    for (int i = tid; i < PIV * (hi + 1); i += KT) {
-      const int j = i & 15, rr = i >> 4;
-      A[trs(rr < hi ? rr : F, ps[j])] = 0.0;
-    }
-    {
-      const int r0 = tid >> 2, cq = tid & 3;
-      if (r0 < F) {
-        double y[4], yF[4];
-        double *row = Y + r0 * PLD, *rowF = Y + F * PLD;
+      for (int jj = 0; jj < PFS4; ++jj) { const int i = tid + jj * KT; if (i < pf_ns4) ((i4_t *)sbuf)[i] = pfs[jj]; }
+      // header straight from the registers: ints 0..7 on thread 0..1, pivot slots on threads 2..5,
+      // pivot diagonals (doubles 0..15) on threads 0..7
+      if (tid < 4) pm[(s & 1) * 4 + tid] = 0u;
+      if (tid == 0) { hib[s % 3] = pfs[0][3]; hiall[s] = (pfs[0][3] + 15) & ~15; }
+      if (tid < 8) { dgb[(s % 3) * PIV + 2 * tid] = pfd[0][0]; dgb[(s % 3) * PIV + 2 * tid + 1] = pfd[0][1]; }
+      if (tid >= 2 && tid < 6) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { y[jj] = row[4 * jj + cq]; yF[jj] = r0 == 0 ? rowF[4 * jj + cq] : 0.0; }
-        ysolve_steps<0>(y, yF, Lm, cq);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { row[4 * jj + cq] = y[jj]; if (r0 == 0) rowF[4 * jj + cq] = yF[jj]; }
+        for (int e = 0; e < 4; ++e) {
+          const int slot = pfs[0][e], jidx = 4 * (tid - 2) + e;
+          psb[(s % 3) * PIV + jidx] = slot;
+          jm[(s & 1) * 128 + slot] = jidx;
+          atomicOr(&pm[(s & 1) * 4 + (slot >> 5)], 1u << (slot & 31));
+        }
       }
+    }
+    if (k + 3 < NS) {
+      const int s = k + 3;
+      pf_nd2 = (doff[s + 1] - doff[s]) >> 1;
+      pf_ns4 = (soff[s + 1] - soff[s]) >> 2;
+      const d2_t *dsrc = (const d2_t *)(stream + doff[s]);
+      const i4_t *ssrc = (const i4_t *)(P.srec + soff[s]);
+#pragma unroll
+      for (int jj = 0; jj < PFD2; ++jj) { const int i = tid + jj * KT; if (i < pf_nd2) pfd[jj] = dsrc[i]; }
+#pragma unroll
+      for (int jj = 0; jj < PFS4; ++jj) { const int i = tid + jj * KT; if (i < pf_ns4) pfs[jj] = ssrc[i]; }
+    }
+    STAMPW(0, st0, 5);
+    // ---- AB(k): one 16-row panel tile per wave.  All LDS reads are issued up front (no lane-dependent
+    //      branches around loads), then the 16 MFMAs, then the stores. --------------------------------
+    const int hi16 = (hib[k % 3] + 15) & ~15;
+    const Mask128 m1 = load_mask(pm + ((k + 1) & 1) * 4, lane);   // pivot slots of stage k+1
+    if (wv < NT) {
+      const int R = wv;
+      const int prow = has_next ? prow_next : 0;
+      const int *jmn = jm + ((k + 1) & 1) * 128;
+      double la[4], pr[4], pp[4], dn[4], lb[4], xv[4], av[4];
+      int jr[4], aidx[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int r = 16 * R + lk + 4 * s4;
+        la[s4] = Lik[li * PLD + lk + 4 * s4];
+        pr[s4] = Pk[(16 * R + li) * PLD + lk + 4 * s4];
+        pp[s4] = Pk[prow * PLD + lk + 4 * s4];
+        dn[s4] = dik[lk + 4 * s4];
+        lb[s4] = Lik[(lk + 4 * s4) * PLD + li];
+        xv[s4] = Xn[r * PLD + li];
+        jr[s4] = jmn[r];
+        aidx[s4] = trs(r, prow);
+        av[s4] = A[aidx[s4]];
+      }
+      const double dgn = dgb[((k + 1) % 3) * PIV + li];
+      d4_t yt = {0.0, 0.0, 0.0, 0.0}, zt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        yt = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], pr[s4], yt, 0, 0, 0);   // yt[g] = Y[16R+li][lk+4g]
+        zt = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], pp[s4], zt, 0, 0, 0);   // zt[g] = Y[piv_li][lk+4g]
+      }
+      STAMPW(0, st0, 6);
+      // next pivot columns: assembled entries (read here, retired below), extracted Schur updates,
+      // pivot diagonal; an entry between two pivots of stage k+1 is taken once, by the lane whose row
+      // has the larger pivot index
+      d4_t acc;
+      bool take[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = 16 * R + lk + 4 * g;
+        const bool rp = (grp16(m1, R) >> (lk + 4 * g)) & 1u;
+        take[g] = has_next && !(rp && jr[g] < li);
+        acc[g] = xv[g] + (take[g] ? av[g] : 0.0) + (r == prow ? dgn : 0.0);
+      }
+      double ya[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ya[g] = yt[g] * dn[g];
+      d4_t vt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        vt = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[s4], lb[s4], vt, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-ya[s4], zt[s4], acc, 0, 0, 0);
+      }
+      STAMPW(0, st0, 7);
+      // Y rows of the next pivots are stored as zeros: their rows/columns of U were extracted (and
+      // zeroed) one stage ago and must not be touched by this stage's update any more
+      const bool myrowpiv = has_next && ((grp16(m1, R) >> li) & 1u);
+      if (wv == 0 && has_next) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[(lk + 4 * g) * PIV + li] = zt[g];   // ZT[q][j] = Y[piv_j][q] for wave 7
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        Yk[(16 * R + li) * PLD + lk + 4 * g] = myrowpiv ? 0.0 : yt[g];
+        if (take[g]) A[aidx[g]] = 0.0;
+        if (has_next) Xn[(16 * R + lk + 4 * g) * PLD + li] = acc[g];
+      }
+      if (16 * R < hi16) {
+        double *pv = panel + (size_t)k * pstride + PIV;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pv[(16 * R + lk + 4 * g) * PIV + li] = vt[g];
+      }
+    }
+    if (wv == 7 && lane < PIV && has_next) {   // assembled right-hand side of the next pivots (read and retired)
+      const int idx = tri(F, prow_next);
+      Xn[F * PLD + lane] = A[idx];
+      A[idx] = 0.0;
     }
     lds_barrier();
-    STAMP(0);
-    // ---- S2: assemble stage k+1 ------------------------------------------------------------------
-    if (has_next) {
-      if (tid < PIV) psb[nxt * PIV + tid] = sbuf[SHDR + tid];
-      if (tid == 0) hib[nxt] = sbuf[3];
-      assemble_stage(A, F, sbuf, dbuf, tid);
-    }
-    lds_barrier();
-    STAMP(1);
-    // ---- S3: early gather of the next pivot columns with this stage's update applied:
-    //      P_next[r][j] = A[r][piv_j] - sum_q Y[r][q] (Y[piv_j][q] / d_q), 16-row tiles on the matrix
-    //      cores (one tile per wave), the rhs row by 16 lanes -----------------------------------
-    if (has_next) {
-      const int *psn = psb + nxt * PIV;
-      const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-      const int pcol = psn[li];
-      const double *zrow = Y + pcol * PLD + lk;   // B operand: Z[k][j] = Y[piv_j][k] / d_k
-      double zb[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) zb[s4] = zrow[4 * s4] * dinv[lk + 4 * s4];
-      for (int R = wv; R < (F >> 4); R += KT / 64) {
-        d4_t acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = A[trs(16 * R + lk + 4 * g, pcol)];
-        const double *yrow = Y + (16 * R + li) * PLD + lk;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-yrow[4 * s4], zb[s4], acc, 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) Pn[(16 * R + lk + 4 * g) * PLD + li] = acc[g];
-      }
-      if (tid >= KT - PIV * PIV) {  // rhs row F: lane (j, q) forms one product, 16-lane shuffle tree sums over q
-        const int t = tid - (KT - PIV * PIV), j = t >> 4, q = t & 15, pc = psn[j];
-        double v = Y[F * PLD + q] * dinv[q] * Y[pc * PLD + q];
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-        if (q == 0) Pn[F * PLD + j] = A[tri(F, pc)] - v;
-      }
-    }
-    lds_barrier();
-    STAMP(2);
-    // ---- S4: wave 0 factors the next pivot block; waves 1..7 apply stage k's update ------------
-    if (tid < 64) {
-      if (has_next) {
-        const int *psn = psb + nxt * PIV;
-        double *Bs = red;
-        for (int e = tid; e < PIV * PIV; e += 64) Bs[(e >> 4) * PLD + (e & 15)] = Pn[psn[e >> 4] * PLD + (e & 15)];
-        ldlt16(Bs, Lbuf + nxt * PIV * PLD, Libuf + nxt * PIV * PLD, dvb + nxt * PIV, tid);
-        for (int e = tid; e < PIV * PIV; e += 64) Pn[psn[e >> 4] * PLD + (e & 15)] = 0.0;
-      }
-      STAMP(3);
-    } else {
-#ifdef QTOS_STAMPS
-      if (tid == 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast2) :: "memory");
+    STAMPW(0, st0, 0);
+    // ---- C(k) ---------------------------------------------------------------------------------------
+    if (wv == 0) {
+#ifdef QTOS_EXP_TWICE
+      { int reps = 2; asm volatile("" : "+s"(reps));
+        for (int rep = 0; rep < reps; ++rep) if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV); }
+#else
+      if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV);
 #endif
-      const int wv = (tid >> 6) - 1, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-      const int nt16 = hi16 >> 4, ntile = (nt16 * (nt16 + 1)) >> 1;
+      STAMPW(0, st0, 1);
+#ifdef QTOS_EXP_ONLYW0
+    } else if (wv > 100) {
+#else
+    } else if (wv <= 6) {
+#endif
+#ifdef QTOS_STAMPS
+      if (tid == 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st1) :: "memory");
+#endif
+      const Mask128 m2 = load_mask(pm + (k & 1) * 4, lane);   // pivot slots of stage k+2
+      const bool extract = k + 2 < NS;
+      const int *jm2 = jm + (k & 1) * 128;
+      double *Xnn = Pk;   // the panel of stage k is dead: it receives the columns of stage k+2
       double dv4[4];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) dv4[s4] = -dinv[lk + 4 * s4];
-      // two tiles in flight per wave: the second tile's LDS reads overlap the first tile's MFMA chain
-      for (int t = wv; t < ntile; t += 2 * (KT / 64 - 1)) {
-        const int t1 = t + (KT / 64 - 1);
-        const bool two = t1 < ntile;
-        const int rc0 = tileRC[t], rc1 = tileRC[two ? t1 : t];
-        const int R0 = rc0 >> 8, C0 = rc0 & 255, R1 = rc1 >> 8, C1 = rc1 & 255;
-        const int col0 = 16 * C0 + li, col1 = 16 * C1 + li;
-        const double *w0 = Y + (16 * R0 + li) * PLD + lk, *p0 = Y + (16 * C0 + li) * PLD + lk;
-        const double *w1 = Y + (16 * R1 + li) * PLD + lk, *p1 = Y + (16 * C1 + li) * PLD + lk;
-        double wa0[4], pb0[4], wa1[4], pb1[4];
-        int i0[4], i1[4];
-        d4_t a0, a1;
+      for (int s4 = 0; s4 < 4; ++s4) dv4[s4] = -dik[lk + 4 * s4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int r0 = 16 * R0 + lk + 4 * g, r1 = 16 * R1 + lk + 4 * g;
-          i0[g] = tri(r0, min(col0, r0));   // masked elements (col > row, diagonal tiles) read a valid
-          i1[g] = tri(r1, min(col1, r1));   // dummy and are never written back
-          a0[g] = A[i0[g]];
-          a1[g] = A[i1[g]];
+      for (int t = 0; t < MAXT; ++t) {
+        int rc = tRC[t];
+        asm volatile("" : "+s"(rc));   // keep the per-tile scalars out of the (spilled) loop-invariant set
+        if (rc < 0) continue;
+        const int R = rc >> 8, C = rc & 255;
+        // U(R,C) -= Y_R D^-1 Y_C^T  (rows beyond the stage's range are zero in Y: no test needed)
+        const double *wrow = Yk + (16 * R + li) * PLD + lk, *prow2 = Yk + (16 * C + li) * PLD + lk;
+        double wa[4], pbv[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { wa[s4] = wrow[4 * s4] * dv4[s4]; pbv[s4] = prow2[4 * s4]; }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s4], pbv[s4], U[t], 0, 0, 0);
+        if (!extract) continue;
+        // columns / rows of the pivots of stage k+2 leave U (and are zeroed: later updates skip them)
+        const unsigned cw2 = grp16(m2, C), rw2 = grp16(m2, R);   // wave-uniform
+        if ((cw2 | rw2) == 0u) continue;
+        const unsigned cm = ((cw2 >> li) & 1u) ? (R > C ? 0xfu : ge4) : 0u;     // rows g this lane's column sends out
+        const unsigned rm = (rw2 >> lk) & 0x1111u;                                 // bit 4g: row lk + 4g is a pivot
+        const unsigned rmk = ((rm & 1u) | ((rm >> 3) & 2u) | ((rm >> 6) & 4u) | ((rm >> 9) & 8u)) & (R > C ? 0xfu : gt4);
+        if (rw2) {
+          double *xc = Xnn + (16 * C + li) * PLD;
+          const int *jr = jm2 + 16 * R + lk;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if ((rmk >> g) & 1u) xc[jr[4 * g]] = U[t][g];
         }
+        if (cw2) {
+          double *xr = Xnn + (16 * R + lk) * PLD + jm2[16 * C + li];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          wa0[s4] = w0[4 * s4] * dv4[s4]; pb0[s4] = p0[4 * s4];
-          wa1[s4] = w1[4 * s4] * dv4[s4]; pb1[s4] = p1[4 * s4];
+          for (int g = 0; g < 4; ++g)
+            if ((cm >> g) & 1u) xr[g * 4 * PLD] = U[t][g];
         }
+        const unsigned zm = cm | rmk;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa0[s4], pb0[s4], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa1[s4], pb1[s4], a1, 0, 0, 0);
+        for (int g = 0; g < 4; ++g)
+          if ((zm >> g) & 1u) U[t][g] = 0.0;
+      }
+      STAMPW(1, st1, 0);
+      if (extract) assemble_stage(A, F, sbuf, dbuf, tid - 64, 6 * 64);
+      STAMPW(1, st1, 1);
+#ifdef QTOS_EXP_ONLYW0
+    } else if (wv > 100) {
+#else
+    } else {
+#endif
+      // wave 7: right-hand-side row.  y_F = p_F L^-T, w = L^-T D^-1 y_F (to HBM), the update of the
+      // accumulated right-hand side, and the right-hand side of the next pivots
+#ifdef QTOS_STAMPS
+      if (tid == 448) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st7) :: "memory");
+#endif
+      double part = 0.0, lq[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        part += Lik[li * PLD + lk + 4 * s4] * Pk[F * PLD + lk + 4 * s4];
+        lq[s4] = Lik[(lk + 4 * s4) * PLD + li];
+      }
+      const double uf0 = UF[lane], uf1 = UF[lane + 64];
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      const double yd = part * dik[li];            // (y_F D^-1)[li] on every lane with that li
+      double ydq[PIV];
+#pragma unroll
+      for (int q = 0; q < PIV; ++q) ydq[q] = __shfl(yd, q);
+      double wsum = 0.0;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) wsum += __shfl(yd, lk + 4 * s4) * lq[s4];
+      wsum += __shfl_xor(wsum, 16);
+      wsum += __shfl_xor(wsum, 32);
+      if (lane < PIV) panel[(size_t)k * pstride + lane] = wsum;
+      if (has_next) {
+        // right-hand-side update for the columns c = lane and lane + 64
+        double a0 = 0.0, a1 = 0.0;
+        {
+          double yr[PIV];
+#pragma unroll
+          for (int q = 0; q < PIV; ++q) yr[q] = Yk[lane * PLD + q];
+#pragma unroll
+          for (int q = 0; q < PIV; ++q) a0 = fma(ydq[q], yr[q], a0);
+#pragma unroll
+          for (int q = 0; q < PIV; ++q) yr[q] = Yk[min(lane + 64, F - 1) * PLD + q];
+#pragma unroll
+          for (int q = 0; q < PIV; ++q) a1 = fma(ydq[q], yr[q], a1);
         }
+        UF[lane] = uf0 - a0;          // rows beyond the stage's range have Y = 0
+        UF[lane + 64] = lane + 64 < F ? uf1 - a1 : 0.0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double corr = 0.0;   // this stage's update of the next pivots' right-hand side (their Y rows are zero in LDS)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (col0 <= 16 * R0 + lk + 4 * g) A[i0[g]] = a0[g];
-          if (two && col1 <= 16 * R1 + lk + 4 * g) A[i1[g]] = a1[g];
+        for (int q = 0; q < PIV; ++q) corr = fma(ydq[q], red[q * PIV + li], corr);
+        if (lane < PIV) {
+          const int c = prow_next;
+          Xn[F * PLD + lane] += UF[c] - corr;
+          UF[c] = 0.0;
         }
       }
-      STAMP2(0);
-      const int t2 = tid - 64;
-      {  // right-hand-side row: 4 lanes per column, each sums 4 of the 16 products
-        const int q4 = (t2 & 3) * 4;
-        for (int c = t2 >> 2; c < hi16; c += (KT - 64) >> 2) {   // uniform within each 4-lane group
-          double acc = 0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc += Y[F * PLD + q4 + q] * dinv[q4 + q] * Y[c * PLD + q4 + q];
-          acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
-          if ((t2 & 3) == 0) A[tri(F, c)] -= acc;
-        }
-      }
-      STAMP2(1);
-      // factor panel of stage k to HBM (everything the backward pass needs, so that it never has to
-      // touch the static tables again)
-      double *pk = panel + (size_t)k * pstride;
-      for (int i = t2; i < PIV * PIV; i += KT - 64) pk[i] = Libuf[cur * PIV * PLD + (i >> 4) * PLD + (i & 15)];
-      if (t2 < PIV) pk[PIV * PIV + t2] = dinv[t2];
-      else if (t2 < 2 * PIV) pk[PIV * PIV + t2] = Y[F * PLD + (t2 - PIV)];
-      else if (t2 < 3 * PIV) pk[PIV * PIV + t2] = (double)ps[t2 - 2 * PIV];
-      else if (t2 == 3 * PIV) pk[PIV * PIV + t2] = (double)hi;
-      for (int i = t2; i < hi * PIV; i += KT - 64) pk[PIV * PIV + 4 * PIV + i] = Y[(i >> 4) * PLD + (i & 15)];
-      STAMP2(2);
+      STAMPW(7, st7, 0);
     }
     lds_barrier();
-    STAMP(4);
-    // ---- install the records of stage k+2 ------------------------------------------------------
-    if (k + 2 < NS) {
-#pragma unroll
-      for (int j = 0; j < PFD; ++j) { const int i = tid + j * KT; if (i < nd) dbuf[i] = pfd[j]; }
-#pragma unroll
-      for (int j = 0; j < PFS; ++j) { const int i = tid + j * KT; if (i < ns) sbuf[i] = pfs[j]; }
-    }
-    cur = nxt;
-    STAMP(5);
+    if (k + 2 < NS) prow_next = psb[((k + 2) % 3) * PIV + li];   // pivot slot li of the stage after next
+    STAMPW(0, st0, 2);
   }
-  // ---- backward substitution: x1 = L^-T D^-1 (y_F - Y^T x2).  Stage k belongs to wave (NS-1-k) mod 8,
-  //      which holds that stage's whole factor panel in registers (loaded eight stages ahead, so the
-  //      HBM latency is off the chain); per stage one wave does a 128 x 16 dot-product sweep against
-  //      the solution kept in LDS, a 4-way lane fold and a 16 x 16 product with L^-T via DPP row
-  //      broadcasts.  One LDS-only barrier per stage hands the solution to the next wave.
+  // ---- backward substitution: x_piv = w - V^T x, one barrier per stage.  Wave w owns rows 16w..16w+15
+  //      of every panel (prefetched four stages ahead into registers), partial sums meet in LDS and
+  //      every wave forms the 16 new entries redundantly (bitwise identical), so a wave only ever
+  //      reads solution entries it has written itself. --------------------------------------------
   __syncthreads();  // drains the factor-panel stores: they are read back below
-  STAMP(6);
-  for (int i = tid; i < 128; i += KT) xs[i] = 0.0;
+  STAMPW(0, st0, 3);
   {
-    constexpr int RB = 32;   // rows per lane: F / 4 <= 32
-    const int wv = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
-    double yv[RB], lc[PIV], dv = 0, yf = 0, psl = 0;   // psl: pivot slot, converted at use (no early wait on the load)
-    int unk = -1;
-    auto load_panel = [&](int k) {
-      const double *pk = panel + (size_t)k * pstride;
+    const int j = li, q = lk;
+    constexpr int DEPTH = 4;
+    double bv[DEPTH][4], bw[DEPTH];
+    int bps[DEPTH], bun[DEPTH];
+    // loads are unconditional (clamped indices) so that the compiler can wait with partial vmcnt
+    // counts instead of draining the whole prefetch ring at every stage
+    auto bload = [&](int k, double (&v)[4], double &wj, int &psj, int &unkj) __attribute__((always_inline)) {
+      const int kk = max(k, 0);
+      const double *pk = panel + (size_t)kk * pstride;
 #pragma unroll
-      for (int jj = 0; jj < PIV; ++jj) lc[jj] = pk[jj * PIV + j];          // column j of L^-1
-      dv = pk[PIV * PIV + j];
-      yf = pk[PIV * PIV + PIV + j];
-      psl = pk[PIV * PIV + 2 * PIV + j];
-      unk = P.piv_unknown[k * PIV + j];
-      const double *yk = pk + PIV * PIV + 4 * PIV;
-#pragma unroll
-      for (int i = 0; i < RB; ++i) yv[i] = 4 * i < F ? yk[(q + 4 * i) * PIV + j] : 0.0;   // wave-uniform predicate
+      for (int i = 0; i < 4; ++i) v[i] = pk[PIV + min(16 * wv + q + 4 * i, F - 1) * PIV + j];
+      wj = pk[j];
+      psj = P.piv_slot[kk * PIV + j];
+      unkj = P.piv_unknown[kk * PIV + j];
     };
-    if (NS - 1 - wv >= 0) load_panel(NS - 1 - wv);
-    __syncthreads();
-    for (int bs = 0; bs < NS; ++bs) {
-      const int k = NS - 1 - bs;
-      if ((bs & 7) == wv) {
-        double acc0 = 0, acc1 = 0;
+    auto bstep = [&](int k, const double (&v)[4], double wj, int psj, int unkj) __attribute__((always_inline)) {
+      const int nw = hiall[k] >> 4;
+      double p = 0.0;
 #pragma unroll
-        for (int i = 0; i < RB; i += 2) {   // xs has 128 entries; rows >= F carry yv = 0, xs = 0
-          acc0 = fma(yv[i], xs[q + 4 * i], acc0);
-          acc1 = fma(yv[i + 1], xs[q + 4 * i + 4], acc1);
-        }
-        double acc = acc0 + acc1;
-        acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
-        double u = (yf - acc) * dv;        // u_j on every lane with (lane & 15) == j
-        asm volatile("s_nop 4" : "+v"(u));
-        double x0 = 0, x1 = 0;             // x_i = sum_jj (L^-1)[jj][i] u_jj
-        fma_bc<0>(x0, u, lc[0]);   fma_bc<1>(x1, u, lc[1]);   fma_bc<2>(x0, u, lc[2]);   fma_bc<3>(x1, u, lc[3]);
-        fma_bc<4>(x0, u, lc[4]);   fma_bc<5>(x1, u, lc[5]);   fma_bc<6>(x0, u, lc[6]);   fma_bc<7>(x1, u, lc[7]);
-        fma_bc<8>(x0, u, lc[8]);   fma_bc<9>(x1, u, lc[9]);   fma_bc<10>(x0, u, lc[10]); fma_bc<11>(x1, u, lc[11]);
-        fma_bc<12>(x0, u, lc[12]); fma_bc<13>(x1, u, lc[13]); fma_bc<14>(x0, u, lc[14]); fma_bc<15>(x1, u, lc[15]);
-        const double xi = x0 + x1;
-        if (lane < PIV) {
-          xs[(int)psl] = xi;
-          if (unk >= 0 && unk < n) dx[unk] = xi;
-        }
-        if (k - 8 >= 0) load_panel(k - 8);
-      }
+      for (int i = 0; i < 4; ++i) p = fma(v[i], xs[16 * wv + q + 4 * i], p);
+      p += __shfl_xor(p, 16);
+      p += __shfl_xor(p, 32);
+      if (lane < PIV) red[(k & 1) * 128 + wv * PIV + j] = wv < nw ? p : 0.0;   // rows beyond the stage's range: no contribution
       lds_barrier();
+      double r8[8];
+#pragma unroll
+      for (int w2 = 0; w2 < 8; ++w2) r8[w2] = red[(k & 1) * 128 + w2 * PIV + j];
+      double s = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < 8; ++w2) s += r8[w2];
+      const double x = wj - s;
+      if (lane < PIV) {
+        xs[psj] = x;
+        if (wv == 0 && unkj >= 0 && unkj < n) dx[unkj] = x;
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) bload(NS - 1 - d, bv[d], bw[d], bps[d], bun[d]);
+    for (int k0 = NS - 1; k0 >= 0; k0 -= DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int k = k0 - d;
+        if (k >= 0) {
+          bstep(k, bv[d], bw[d], bps[d], bun[d]);
+          bload(k - DEPTH, bv[d], bw[d], bps[d], bun[d]);
+        }
+      }
     }
   }
 #ifdef QTOS_STAMPS
-  STAMP(7);
-  if (tid == 0 && W.trace) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 30) * 4 + i] = (double)stamps[i];
-  if (tid == 64 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 32) * 4 + i] = (double)stamps2[i];
+  STAMPW(0, st0, 4);
+  if (tid == 0 && W.trace) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 30) * 4 + i] = (double)st0[i];
+  if (tid == 64 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 32) * 4 + i] = (double)st1[i];
+  if (tid == 448 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 33) * 4 + i] = (double)st7[i];
 #endif
 }
+
 
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int it) {

@@ -143,15 +143,16 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.slack_push = M.P.slack_push > 0 ? M.P.slack_push : 0.01;
   D.terrain_mode = M.P.terrain_mode;
   D.g_doubles = S.g_doubles;
-  D.panel_stride = (long long)S.n_stages * (S.front + PIV + 4) * PIV;
+  D.panel_stride = (long long)S.n_stages * (S.front + 1) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  size_t lds_d = (size_t)((F + 1) * (F + 2) / 2) + 2 * (size_t)(F + 1) * PLD + 4 * PIV * PLD + 2 * PIV + 128 +
-                 34 * PLD + S.max_drec + 8;
-  p->kkt_lds = lds_d * sizeof(double) + ((size_t)S.max_srec + 2 * (size_t)(S.n_stages + 1) + 2 * PIV + 2 + 48 + 528 + 8) * sizeof(int);
-  if (S.max_drec > PFD * KT || S.max_srec > PFS * KT || (F + PIV + 4) * PIV > 5 * KT) {
+  {
+    size_t off[17];
+    p->kkt_lds = kkt_lds_layout(F, S.n_stages, S.max_srec, S.max_drec, off);
+  }
+  if (S.max_drec > 2 * 2 * KT || S.max_srec > 2 * 4 * KT || F > 128 || (S.pack_src.size() & 1)) {
     p->err = "stage record exceeds the prefetch registers";
-    fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints)\n", S.max_drec, S.max_srec);
+    fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints) or front %d > 128\n", S.max_drec, S.max_srec, F);
     qtos_planner_destroy(p);
     return -4;
   }
@@ -225,7 +226,7 @@ static void fill_dims(const HostModel &M, const Symbolic &S, QtosDims *d) {
   d->pivots = PIV; d->front = S.front;
   d->n_base_nodes = M.n_base_nodes; d->n_dyn_times = (int)M.t_dyn.size(); d->n_rom_times = (int)M.t_rom.size();
   d->n_rows_csv = (int)std::llround(M.T * 1000.0) + 1;
-  d->panel_doubles = (long long)S.n_stages * (S.front + PIV + 4) * PIV; d->g_doubles = S.g_doubles;
+  d->panel_doubles = (long long)S.n_stages * (S.front + 1) * PIV; d->g_doubles = S.g_doubles;
   d->kkt_algorithmic_bytes = S.algorithmic_bytes; d->kkt_flops = S.flops;
   d->envelope = S.envelope; d->max_active = S.max_active;
   d->duration = M.T;
@@ -471,6 +472,15 @@ int qtos_debug_structure(const QtosPlanner *p, int *row_kind, int *var_free, int
   if (var_free)
     for (int v = 0; v < p->M.n_vars; ++v) var_free[v] = p->M.is_free(v) ? 1 : 0;
   if (order) std::memcpy(order, p->S.order.data(), p->S.n_unknowns * sizeof(int));
+  return 0;
+}
+
+int qtos_debug_factor(QtosPlanner *p, int b, double *panel_out, int *piv_slot_out) {
+  if (!p || b < 0 || b >= p->max_batch) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  if (panel_out)
+    HIPCHK(p, hipMemcpy(panel_out, p->wk.panel + (size_t)b * p->dp.panel_stride, (size_t)p->dp.panel_stride * sizeof(double), hipMemcpyDeviceToHost));
+  if (piv_slot_out) std::memcpy(piv_slot_out, p->S.piv_slot.data(), p->S.piv_slot.size() * sizeof(int));
   return 0;
 }
 

@@ -65,7 +65,7 @@ struct Symbolic {
   //   dynamic stream (per problem), drec_off[k] ..: piv_diag[16], equality values, -g of the rhs
   //           rows, then per inequality block G (m x n), sig (m), w (m)
   // pack_src[i] says where stream element i comes from: (kind << 28) | index, kind 0 G, 1 g_static,
-  // 2 -g[row], 3 sig[row], 4 w[row], 5 piv_diag
+  // 2 -g[row], 3 sig[row], 4 w[row], 5 piv_diag, 6 alignment padding
   std::vector<int> srec, srec_off, pack_src, drec_off, stage_hi;
   // The linearisation kernels write straight into the stream: eq_pos maps the (virtual) G offset of
   // an equality-block entry to its stream position; inequality blocks are contiguous in the stream
@@ -269,6 +269,9 @@ struct Symbolic {
     drec_off.assign(n_stages + 1, 0);
     for (int k = 0; k < n_stages; ++k) {
       const StageDesc &S = stages[k];
+      // 16-byte aligned records: k_kkt moves them with 128-bit loads
+      while (srec.size() & 3) srec.push_back(0);
+      while (pack_src.size() & 1) pack_src.push_back(6 << 28);
       srec_off[k] = (int)srec.size();
       drec_off[k] = (int)pack_src.size();
       const int n_ent = S.ent_end - S.ent_begin, n_rhs = S.rhs_end - S.rhs_begin, n_iq = S.iq_end - S.iq_begin;
@@ -336,6 +339,10 @@ struct Symbolic {
       max_srec = std::max(max_srec, (int)srec.size() - srec_off[k]);
       max_drec = std::max(max_drec, (int)pack_src.size() - drec_off[k]);
     }
+    while (srec.size() & 3) srec.push_back(0);
+    while (pack_src.size() & 1) pack_src.push_back(6 << 28);
+    max_srec = (max_srec + 7) & ~3;   // a stage's record may end with alignment padding
+    max_drec = (max_drec + 3) & ~1;
     srec_off[n_stages] = (int)srec.size();
     drec_off[n_stages] = (int)pack_src.size();
     // ---- direct-write maps derived from the stream layout ----
@@ -351,7 +358,7 @@ struct Symbolic {
       else if (kind == 2) rhs_pos[idx] = i;
       else if (kind == 3) sig_pos[idx] = i;
       else if (kind == 4) w_pos[idx] = i;
-      else { const_pos.push_back(i); const_val.push_back(piv_diag[idx]); }
+      else if (kind == 5) { const_pos.push_back(i); const_val.push_back(piv_diag[idx]); }
     }
     // inequality blocks: contiguous in the stream -> their goff becomes the stream offset itself
     for (Block &b : M.blocks)

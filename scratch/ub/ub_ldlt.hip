@@ -15,7 +15,21 @@ __global__ void k(const double *Bin, double *out, unsigned long long *cyc, int r
   if (tid < 64 * nwaves) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int r = 0; r < reps; ++r) {
-      if (VAR == 0) ldlt16(Bs, Lm, Li, dv, tid & 63);
+      {
+        const int li = tid & 15, lane = tid & 63;
+        double a[PIV], v[PIV], myinv;
+#pragma unroll
+        for (int j = 0; j < PIV; ++j) a[j] = Bs[(li >= j ? li : j) * PLD + (li >= j ? j : li)];
+        ldlt16(a, v, myinv, li);
+        if (lane < PIV) {
+#pragma unroll
+          for (int j = 0; j < PIV; ++j) Lm[li * PLD + j] = a[j];
+          dv[li] = myinv;
+        } else if (lane < 2 * PIV) {
+#pragma unroll
+          for (int j = 0; j < PIV; ++j) Li[li * PLD + j] = j == li ? 1.0 : v[j];
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
@@ -39,13 +53,14 @@ int main() {
     hipDeviceSynchronize();
     unsigned long long c; hipMemcpy(&c, dC, 8, hipMemcpyDeviceToHost);
     std::vector<double> O(1024); hipMemcpy(O.data(), dO, 1024 * 8, hipMemcpyDeviceToHost);
-    // check: L D L^T == B and Li * L == I
+    // check: Linv B Linv^T == diag(1 / dinv)
     double e1 = 0, e2 = 0;
-    for (int i = 0; i < 16; ++i) for (int j = 0; j <= i; ++j) {
-      double s = 0; for (int q = 0; q <= j; ++q) { double li = q == i ? 1 : (q < i ? O[i * 16 + q] : 0), lj = q == j ? 1 : (q < j ? O[j * 16 + q] : 0); s += li * lj / O[512 + q]; }
-      e1 = fmax(e1, fabs(s - B[i * 16 + j]));
-      double t = 0; for (int q = j; q <= i; ++q) { double lq = q == j ? 1 : O[q * 16 + j]; t += O[256 + i * 16 + q] * (q >= j ? lq : 0); }
-      e2 = fmax(e2, fabs(t - (i == j)));
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) {
+      double s = 0;
+      for (int p = 0; p < 16; ++p) for (int q = 0; q < 16; ++q) s += O[256 + i * 16 + p] * B[p * 16 + q] * O[256 + j * 16 + q];
+      const double want = i == j ? 1.0 / O[512 + i] : 0.0;
+      e1 = fmax(e1, fabs(s - want));
+      if (j > i) e2 = fmax(e2, fabs(O[256 + i * 16 + j]));
     }
     printf("waves %d: %llu cycles per ldlt16 (err LDLt %.2e, Linv %.2e)\n", nw, c, e1, e2);
   }
