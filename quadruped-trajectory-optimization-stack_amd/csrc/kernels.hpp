@@ -691,11 +691,26 @@ __device__ __forceinline__ void assemble_stage(double *A, int F, const int *sbuf
     double acc = 0;
     for (int j = c0; j < c1; ++j) {
       const int code = cl[j], q = code >> 12, a = (code >> 6) & 63, c = code & 63;
-      const int qm = iqh[4 * q], qn = iqh[4 * q + 1];
-      const double *Gb = dbuf + iqh[4 * q + 2];
+      const int h = iqh[q], qm = h & 15, qn = (h >> 4) & 63;
+      const double *Gb = dbuf + (h >> 10);
       const double *sg = Gb + qm * qn, *wq = sg + qm;
-      if (c == 63) { for (int r = 0; r < qm; ++r) acc -= Gb[r * qn + a] * wq[r]; }
-      else { for (int r = 0; r < qm; ++r) acc += sg[r] * Gb[r * qn + a] * Gb[r * qn + c]; }
+      // blocks have at most five rows: fixed-length unrolled sums (all reads issued together), rows
+      // beyond the block read its last row and are weighted by zero
+      const bool rhs = c == 63;
+      const int cc = rhs ? a : c;
+      double ga[5], gc[5], sw[5];
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const int rr = min(r, qm - 1);
+        ga[r] = Gb[rr * qn + a];
+        gc[r] = Gb[rr * qn + cc];
+        sw[r] = rhs ? wq[rr] : sg[rr];
+      }
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const double term = rhs ? -(ga[r] * sw[r]) : sw[r] * ga[r] * gc[r];
+        acc += r < qm ? term : 0.0;
+      }
     }
     A[tv >> 12] += acc;
   }
@@ -715,53 +730,54 @@ __device__ __forceinline__ Mask128 load_mask(const unsigned *pm4, int lane) {
 __device__ __forceinline__ unsigned grp16(const Mask128 &m, int grp) {
   return ((unsigned)__builtin_amdgcn_readlane(m.v, grp >> 1) >> ((grp & 1) * 16)) & 0xffffu;
 }
-struct KktLds {
-  double *A, *PB, *Lib, *dvb, *dgb, *UF, *xs, *red, *dbuf;
-  int *sbuf, *soff, *doff, *psb, *hib, *hiall, *jm;
-  unsigned *pm;
+// LDS layout of k_kkt.  Everything whose size depends only on the front F sits at compile-time
+// offsets (small, hot arrays first so that they are reachable through the 16-bit offset field of the
+// ds instructions); the per-transcription arrays follow.  Offsets in doubles.
+template <int F>
+struct KktLayout {
+  static constexpr int PSZ = (F + 1) * PLD;
+  static constexpr int NTRI = (F + 1) * (F + 2) / 2;
+  static constexpr int LIB = 0;                          // 2 x 16 x PLD   L^-1 (current / next)
+  static constexpr int DVB = LIB + 2 * PIV * PLD;        // 2 x 16         1 / d
+  static constexpr int DGB = DVB + 2 * PIV;              // 3 x 16         pivot diagonals (ring)
+  static constexpr int UF = DGB + 3 * PIV;               // 128            accumulated rhs updates
+  static constexpr int XS = UF + 128;                    // 128            solution by slot (backward)
+  static constexpr int RED = XS + 128;                   // 256 + 64       partials / Y[piv] rows / dummy slots
+  static constexpr int PSB = RED + 2 * 8 * PIV + 64;     // 3 x 16 ints    pivot slots (ring)
+  static constexpr int HIB = PSB + 3 * PIV / 2;          // 4 ints
+  static constexpr int JM = HIB + 2;                     // 2 x 128 ints   slot -> pivot index
+  static constexpr int PM = JM + 128;                    // 8 ints         pivot-slot bit masks
+  static constexpr int PB = PM + 4;                      // 3 panels of (F+1) x PLD
+  static constexpr int AOFF = (PB + 3 * PSZ + 1) & ~1;   // lower triangle incl. rhs row
+  static constexpr int VAR = (AOFF + NTRI + 1) & ~1;     // dbuf, then (ints) sbuf, soff, doff, hiall
 };
-// LDS footprint in bytes (host and device agree through this one function)
-__host__ __device__ inline size_t kkt_lds_layout(int F, int NS, int max_srec, int max_drec, size_t *off /* 17 */) {
-  size_t o = 0;
-  auto take = [&](size_t n_doubles) { size_t r = o; o += (n_doubles + 1) & ~(size_t)1; return r; };
-  off[0] = take((size_t)((F + 1) * (F + 2) / 2));   // A
-  off[1] = take(3 * (size_t)(F + 1) * PLD);         // PB
-  off[2] = take(2 * PIV * PLD);                      // Lib
-  off[3] = take(2 * PIV);                            // dvb
-  off[4] = take(3 * PIV);                            // dgb
-  off[5] = take(128);                                // UF
-  off[6] = take(128);                                // xs
-  off[7] = take(2 * 8 * PIV);                        // red
-  off[8] = take((size_t)max_drec);                   // dbuf
-  size_t oi = o * 2;                                 // ints from here
-  auto takei = [&](size_t n) { size_t r = oi; oi += (n + 3) & ~(size_t)3; return r; };
-  off[9] = takei((size_t)max_srec);                  // sbuf
-  off[10] = takei((size_t)NS + 1);                   // soff
-  off[11] = takei((size_t)NS + 1);                   // doff
-  off[12] = takei(3 * PIV);                          // psb
-  off[13] = takei(4);                                // hib
-  off[14] = takei((size_t)NS + 1);                   // hiall
-  off[15] = takei(2 * 128);                          // jm
-  off[16] = takei(8);                                // pm
+__host__ __device__ inline size_t kkt_lds_bytes(int F, int NS, int max_srec, int max_drec) {
+  const int PSZ = (F + 1) * PLD, NTRI = (F + 1) * (F + 2) / 2;
+  const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 128 + 128 + 2 * 8 * PIV + 64 + 3 * PIV / 2 + 2 + 128 + 4;
+  size_t o = (fixed + 3 * (size_t)PSZ + 1) & ~(size_t)1;
+  o = (o + NTRI + 1) & ~(size_t)1;
+  o += ((size_t)max_drec + 1) & ~(size_t)1;
+  size_t oi = 2 * o + (((size_t)max_srec + 3) & ~(size_t)3) + 3 * ((((size_t)NS + 1) + 3) & ~(size_t)3);
   return oi * sizeof(int);
 }
 
+template <int F>
 __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
+
   const int b = blockIdx.x;
   if (b >= B || W.done[b]) return;
   extern __shared__ double lds[];
-  const int F = P.front, NT = F >> 4, tid = threadIdx.x, NS = P.n_stages, n = P.n_vars;
+  constexpr int NT = F >> 4;
+  const int tid = threadIdx.x, NS = P.n_stages, n = P.n_vars;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int ntri = ((F + 1) * (F + 2)) >> 1;
-  const int PSZ = (F + 1) * PLD;
-  size_t off[17];
-  kkt_lds_layout(F, NS, P.max_srec, P.max_drec, off);
-  double *A = lds + off[0], *PB = lds + off[1], *Lib = lds + off[2], *dvb = lds + off[3], *dgb = lds + off[4];
-  double *UF = lds + off[5], *xs = lds + off[6], *red = lds + off[7], *dbuf = lds + off[8];
-  int *ilds = (int *)lds;
-  int *sbuf = ilds + off[9], *soff = ilds + off[10], *doff = ilds + off[11], *psb = ilds + off[12], *hib = ilds + off[13];
-  int *hiall = ilds + off[14], *jm = ilds + off[15];
-  unsigned *pm = (unsigned *)(ilds + off[16]);
+  using LY = KktLayout<F>;
+  constexpr int ntri = LY::NTRI, PSZ = LY::PSZ;
+  double *Lib = lds + LY::LIB, *dvb = lds + LY::DVB, *dgb = lds + LY::DGB, *UF = lds + LY::UF, *xs = lds + LY::XS;
+  double *red = lds + LY::RED, *PB = lds + LY::PB, *A = lds + LY::AOFF, *dbuf = lds + LY::VAR;
+  int *psb = (int *)(lds + LY::PSB), *hib = (int *)(lds + LY::HIB), *jm = (int *)(lds + LY::JM);
+  unsigned *pm = (unsigned *)(lds + LY::PM);
+  int *sbuf = (int *)(dbuf + ((P.max_drec + 1) & ~1));
+  int *soff = sbuf + ((P.max_srec + 3) & ~3), *doff = soff + ((NS + 4) & ~3), *hiall = doff + ((NS + 4) & ~3);
   const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
   double *dx = W.dx + (size_t)b * n;
@@ -999,7 +1015,8 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     STAMPW(0, st0, 0);
     // ---- C(k) ---------------------------------------------------------------------------------------
     if (wv == 0) {
-#ifdef QTOS_EXP_TWICE
+#ifdef QTOS_EXP_NO_FACTOR
+#elif defined(QTOS_EXP_TWICE)
       { int reps = 2; asm volatile("" : "+s"(reps));
         for (int rep = 0; rep < reps; ++rep) if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV); }
 #else
@@ -1021,47 +1038,67 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       double dv4[4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) dv4[s4] = -dik[lk + 4 * s4];
+      // --- update: U(R,C) -= Y_R D^-1 Y_C^T for the six tiles of this wave; the operand reads of the next
+      //     tile are issued before the MFMAs of the current one (rows beyond the stage's range are zero
+      //     in Y, unused tile slots alias tile (0,0) and are never extracted: no tests in this loop)
+      int rcs[MAXT];
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) { rcs[t] = tRC[t]; asm volatile("" : "+s"(rcs[t])); }
+      double wa[2][4], pbv[2][4];
+      auto tile_loads = [&](int rc, double (&w)[4], double (&pq)[4]) __attribute__((always_inline)) {
+        const int R = rc < 0 ? 0 : rc >> 8, C = rc < 0 ? 0 : rc & 255;
+        const double *wrow = Yk + (16 * R + li) * PLD + lk, *prow2 = Yk + (16 * C + li) * PLD + lk;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { w[s4] = wrow[4 * s4]; pq[s4] = prow2[4 * s4]; }
+      };
+      tile_loads(rcs[0], wa[0], pbv[0]);
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
-        int rc = tRC[t];
-        asm volatile("" : "+s"(rc));   // keep the per-tile scalars out of the (spilled) loop-invariant set
-        if (rc < 0) continue;
-        const int R = rc >> 8, C = rc & 255;
-        // U(R,C) -= Y_R D^-1 Y_C^T  (rows beyond the stage's range are zero in Y: no test needed)
-        const double *wrow = Yk + (16 * R + li) * PLD + lk, *prow2 = Yk + (16 * C + li) * PLD + lk;
-        double wa[4], pbv[4];
+        if (t + 1 < MAXT) tile_loads(rcs[t + 1], wa[(t + 1) & 1], pbv[(t + 1) & 1]);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { wa[s4] = wrow[4 * s4] * dv4[s4]; pbv[s4] = prow2[4 * s4]; }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s4], pbv[s4], U[t], 0, 0, 0);
-        if (!extract) continue;
-        // columns / rows of the pivots of stage k+2 leave U (and are zeroed: later updates skip them)
-        const unsigned cw2 = grp16(m2, C), rw2 = grp16(m2, R);   // wave-uniform
-        if ((cw2 | rw2) == 0u) continue;
-        const unsigned cm = ((cw2 >> li) & 1u) ? (R > C ? 0xfu : ge4) : 0u;     // rows g this lane's column sends out
-        const unsigned rm = (rw2 >> lk) & 0x1111u;                                 // bit 4g: row lk + 4g is a pivot
-        const unsigned rmk = ((rm & 1u) | ((rm >> 3) & 2u) | ((rm >> 6) & 4u) | ((rm >> 9) & 8u)) & (R > C ? 0xfu : gt4);
-        if (rw2) {
-          double *xc = Xnn + (16 * C + li) * PLD;
-          const int *jr = jm2 + 16 * R + lk;
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            if ((rmk >> g) & 1u) xc[jr[4 * g]] = U[t][g];
-        }
-        if (cw2) {
-          double *xr = Xnn + (16 * R + lk) * PLD + jm2[16 * C + li];
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            if ((cm >> g) & 1u) xr[g * 4 * PLD] = U[t][g];
-        }
-        const unsigned zm = cm | rmk;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          if ((zm >> g) & 1u) U[t][g] = 0.0;
+        for (int s4 = 0; s4 < 4; ++s4)
+          U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[t & 1][s4] * dv4[s4], pbv[t & 1][s4], U[t], 0, 0, 0);
       }
+      STAMPW(1, st1, 2);
+      // --- extraction: columns / rows of the pivots of stage k+2 leave U for the panel under construction
+      //     (and are zeroed: later updates skip them).  Loops over the pivot slots of each tile's column
+      //     / row group are wave-uniform; a pivot column lives on the four lanes li == b, a pivot row on
+      //     the 16 lanes lk == b & 3 in register b >> 2.
+#ifndef QTOS_EXP_NO_EXTRACT
+      if (extract) {
+        // slot -> pivot index of every row / column this lane may send out, read in one batch
+        int jcs[MAXT], jrs[MAXT][4];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          const int rc = rcs[t] < 0 ? 0 : rcs[t];
+          jcs[t] = jm2[16 * (rc & 255) + li];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) jrs[t][g] = jm2[16 * (rc >> 8) + lk + 4 * g];
+        }
+        double *dummy = red + 2 * 8 * PIV + lane;   // per-lane scratch slot: unselected stores land here
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          const int rc = rcs[t];
+          if (rc < 0) continue;
+          const int R = rc >> 8, C = rc & 255;
+          const unsigned cw2 = grp16(m2, C), rw2 = grp16(m2, R);   // wave-uniform
+          if ((cw2 | rw2) == 0u) continue;
+          const unsigned cm = ((cw2 >> li) & 1u) ? (R > C ? 0xfu : ge4) : 0u;     // rows g this lane's column sends out
+          const unsigned rm = (rw2 >> lk) & 0x1111u;                                 // bit 4g: row lk + 4g is a pivot
+          const unsigned rmk = ((rm & 1u) | ((rm >> 3) & 2u) | ((rm >> 6) & 4u) | ((rm >> 9) & 8u)) & (R > C ? 0xfu : gt4);
+          double *xr = Xnn + (16 * R + lk) * PLD + jcs[t], *xc = Xnn + (16 * C + li) * PLD;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const bool cg = (cm >> g) & 1u, rg = (rmk >> g) & 1u;
+            const double uu = U[t][g];
+            if (cw2) *(cg ? xr + g * 4 * PLD : dummy) = uu;
+            if (rw2) *(rg ? xc + jrs[t][g] : dummy) = uu;
+            U[t][g] = (cg || rg) ? 0.0 : uu;
+          }
+        }
+      }
+#endif
       STAMPW(1, st1, 0);
-      if (extract) assemble_stage(A, F, sbuf, dbuf, tid - 64, 6 * 64);
-      STAMPW(1, st1, 1);
 #ifdef QTOS_EXP_ONLYW0
     } else if (wv > 100) {
 #else
@@ -1119,6 +1156,9 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       }
       STAMPW(7, st7, 0);
     }
+    // every wave ends the phase with its share of the assembly of stage k+2 (nobody else touches A here)
+    if (k + 2 < NS) assemble_stage(A, F, sbuf, dbuf, tid, KT);
+    STAMPW(1, st1, 1);
     lds_barrier();
     if (k + 2 < NS) prow_next = psb[((k + 2) % 3) * PIV + li];   // pivot slot li of the stage after next
     STAMPW(0, st0, 2);
@@ -1179,6 +1219,9 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       }
     }
   }
+#ifdef QTOS_EXP_NOEXTRACT
+  { double su = 0; for (int t = 0; t < MAXT; ++t) for (int g = 0; g < 4; ++g) su += U[t][g]; if (su == 1.2345e-300) dx[0] = su; }
+#endif
 #ifdef QTOS_STAMPS
   STAMPW(0, st0, 4);
   if (tid == 0 && W.trace) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 30) * 4 + i] = (double)st0[i];

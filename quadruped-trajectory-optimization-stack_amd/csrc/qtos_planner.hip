@@ -37,6 +37,7 @@ struct QtosPlanner {
   std::vector<hipEvent_t> ev;  // 2 per iteration (kkt begin/end) + 2 (total)
   int last_launches = 0, last_iters = 0;
   size_t kkt_lds = 0, eval_lds = 0;
+  void (*kkt_fn)(DevPlan, DevWork, int) = nullptr;   // k_kkt instantiated for this front size
   std::string err;
 
   template <class T>
@@ -59,6 +60,22 @@ struct QtosPlanner {
     return 0;
   }
 };
+
+// k_kkt is compiled once per front size (multiples of 16 up to 128): the LDS layout and every tile
+// loop bound are compile-time constants
+static void (*kkt_kernel(int F))(DevPlan, DevWork, int) {
+  switch (F) {
+    case 16: return k_kkt<16>;
+    case 32: return k_kkt<32>;
+    case 48: return k_kkt<48>;
+    case 64: return k_kkt<64>;
+    case 80: return k_kkt<80>;
+    case 96: return k_kkt<96>;
+    case 112: return k_kkt<112>;
+    case 128: return k_kkt<128>;
+    default: return nullptr;
+  }
+}
 
 static int upload_spline(QtosPlanner *p, const Spline &S, SampleSpline *out) {
   std::vector<double> tend(S.n_polys), dur(S.dur);
@@ -146,10 +163,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.panel_stride = (long long)S.n_stages * (S.front + 1) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  {
-    size_t off[17];
-    p->kkt_lds = kkt_lds_layout(F, S.n_stages, S.max_srec, S.max_drec, off);
-  }
+  p->kkt_lds = kkt_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec);
   if (S.max_drec > 2 * 2 * KT || S.max_srec > 2 * 4 * KT || F > 128 || (S.pack_src.size() & 1)) {
     p->err = "stage record exceeds the prefetch registers";
     fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints) or front %d > 128\n", S.max_drec, S.max_srec, F);
@@ -163,7 +177,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     return -4;
   }
   {
-    hipError_t e = hipFuncSetAttribute((const void *)k_kkt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
+    p->kkt_fn = kkt_kernel(F);
+    if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
+    hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
   }
   p->eval_lds = sizeof(double) * std::max((size_t)DYN_LOC * M.dyn.size(), (size_t)ROM_LOC * M.rom.size());
@@ -295,7 +311,7 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
     }
     if (*p->h_active <= 0) break;
     HIPCHK(p, hipEventRecord(p->ev[2 + 2 * launches], st));
-    hipLaunchKernelGGL(k_kkt, dim3(B), dim3(KT), p->kkt_lds, st, D, W, B);
+    hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(KT), p->kkt_lds, st, D, W, B);
     HIPCHK(p, hipEventRecord(p->ev[3 + 2 * launches], st));
     launches++;
     hipLaunchKernelGGL(k_step, dim3(B), dim3(256), p->eval_lds, st, D, W, B, it);
@@ -460,7 +476,7 @@ int qtos_debug_newton(QtosPlanner *p, int B, const double *start, const double *
   HIPCHK(p, hipMemcpy(W.sig, sig, (size_t)B * m * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(p, hipMemcpy(W.w, w, (size_t)B * m * sizeof(double), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_debug_pack, dim3(B), dim3(256), 0, 0, p->dp, W, B);
-  hipLaunchKernelGGL(k_kkt, dim3(B), dim3(KT), p->kkt_lds, 0, p->dp, W, B);
+  hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(KT), p->kkt_lds, 0, p->dp, W, B);
   HIPCHK(p, hipDeviceSynchronize());
   HIPCHK(p, hipMemcpy(dx_out, W.dx, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost));
   return 0;

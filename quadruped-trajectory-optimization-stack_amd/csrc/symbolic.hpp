@@ -60,8 +60,8 @@ struct Symbolic {
   int max_stage_g = 0;            // longest G slice of a stage
   // Packed per-stage records consumed by k_kkt (each is ONE contiguous, coalesced read):
   //   static  srec[srec_off[k] ..]: n_ent, n_rhs, n_iq, hi, gather offset, n_tgt, 0, 0, piv_slot[16],
-  //           tri index per equality entry, slot per rhs entry, {m, n, gloc, sloc} per inequality
-  //           block, slot lists, gather table (target, first contribution), contributions
+  //           tri index per equality entry, slot per rhs entry, one packed header int per inequality
+  //           block, gather table (target, first contribution), contributions
   //   dynamic stream (per problem), drec_off[k] ..: piv_diag[16], equality values, -g of the rhs
   //           rows, then per inequality block G (m x n), sig (m), w (m)
   // pack_src[i] says where stream element i comes from: (kind << 28) | index, kind 0 G, 1 g_static,
@@ -147,6 +147,7 @@ struct Symbolic {
     for (int j = 0; j < n_unknowns; ++j) enter[first[j] / PIV].push_back(j);
     std::vector<int> free_slots;  // kept sorted descending so pop_back gives the smallest
     std::vector<char> in_use;
+    std::vector<int> slot_stage;   // pivot stage of the unknown occupying a slot, -1 if free
     stage_hi.assign(n_stages, 0);
     int n_slots = 0;
     max_active = 0;
@@ -156,12 +157,32 @@ struct Symbolic {
     int active = 0;
     for (int k = 0; k < n_stages; ++k) {
       for (int j : enter[k]) {
-        int s;
-        if (!free_slots.empty()) { s = free_slots.back(); free_slots.pop_back(); }
-        else s = n_slots++;
+        // prefer a free slot in a 16-slot group that already hosts pivots of the same stage (the
+        // kernel extracts a stage's pivot columns tile by tile: fewer groups = fewer tiles to
+        // visit), then a completely free group, then the smallest free slot
+        int s = -1;
+        if (!free_slots.empty()) {
+          const int stage_j = j / PIV;
+          int best = -1, best_score = -1;
+          for (int fs : free_slots) {
+            const int grp = fs >> 4;
+            int same = 0, used = 0;
+            for (int t = grp * 16; t < grp * 16 + 16 && t < (int)slot_stage.size(); ++t)
+              if (slot_stage[t] >= 0) { used++; if (slot_stage[t] == stage_j) same++; }
+            const int score = same > 0 ? 1000 + same : (used == 0 ? 500 : 0);
+            if (score > best_score || (score == best_score && fs < best)) { best_score = score; best = fs; }
+          }
+          if (best_score >= 500 || true) {
+            s = best;
+            free_slots.erase(std::find(free_slots.begin(), free_slots.end(), s));
+          }
+        }
+        if (s < 0) s = n_slots++;
         slot_of[j] = s;
         if ((int)in_use.size() <= s) in_use.resize(s + 1, 0);
+        if ((int)slot_stage.size() <= s) slot_stage.resize(s + 1, -1);
         in_use[s] = 1;
+        slot_stage[s] = j / PIV;
         active++;
       }
       // dummy pivots of the (short) last stage need distinct unused slots
@@ -199,6 +220,7 @@ struct Symbolic {
       for (int i = lo; i < lo + PIV; ++i) {
         free_slots.push_back(piv_slot[(size_t)k * PIV + (i - lo)]);
         in_use[piv_slot[(size_t)k * PIV + (i - lo)]] = 0;
+        if ((int)slot_stage.size() > piv_slot[(size_t)k * PIV + (i - lo)]) slot_stage[piv_slot[(size_t)k * PIV + (i - lo)]] = -1;
       }
       std::sort(free_slots.begin(), free_slots.end(), std::greater<int>());
       active -= (hi - lo);
@@ -290,16 +312,14 @@ struct Symbolic {
         srec.push_back(eq_rhs[i].slot);
         pack_src.push_back((2 << 28) | eq_rhs[i].row);
       }
-      // inequality block headers, then their slot lists
+      // inequality block headers: ONE packed int per block, m | n << 4 | (offset of G inside the stage's
+      // dynamic record) << 10; followed in the dynamic record by G (m x n), sig (m), w (m)
       const int hdr = (int)srec.size();
-      srec.resize(srec.size() + 4 * (size_t)n_iq);
+      srec.resize(srec.size() + (size_t)n_iq);
       for (int q = 0; q < n_iq; ++q) {
         const IqBlock &Q = iq_blocks[S.iq_begin + q];
-        srec[hdr + 4 * q + 0] = Q.m;
-        srec[hdr + 4 * q + 1] = Q.n;
-        srec[hdr + 4 * q + 2] = (int)pack_src.size() - drec_off[k];
-        srec[hdr + 4 * q + 3] = (int)srec.size() - srec_off[k];
-        for (int a = 0; a < Q.n; ++a) srec.push_back(iq_slots[Q.slot_off + a]);
+        if (Q.m > 5 || Q.n > 63) { err = "inequality block too large for the packed gather records"; return -1; }
+        srec[hdr + q] = Q.m | (Q.n << 4) | (((int)pack_src.size() - drec_off[k]) << 10);
         for (int i = 0; i < Q.m * Q.n; ++i) pack_src.push_back(S.g_begin + Q.gloc + i);
         for (int r = 0; r < Q.m; ++r) pack_src.push_back((3 << 28) | (Q.row0 + r));
         for (int r = 0; r < Q.m; ++r) pack_src.push_back((4 << 28) | (Q.row0 + r));

@@ -19,5 +19,5 @@ NS = P.dims.n_stages
 print("per stage cycles (s_memtime = shader clock), mean of 3 problems:")
 for n, v in zip(names, tot / 3 / NS):
     print("  %-22s %8.0f" % (n, v))
-print("  wave1: tiles+extract %.0f, assembly %.0f | wave7 rhs %.0f" % (t1[0] / 3 / NS, t1[1] / 3 / NS, t7[0] / 3 / NS))
+print("  wave1: tile MFMA %.0f, extraction %.0f, assembly %.0f | wave7 rhs %.0f" % (t1[2] / 3 / NS, t1[0] / 3 / NS, t1[1] / 3 / NS, t7[0] / 3 / NS))
 print("sum per stage", tot.sum() / 3 / NS, "stages", NS, P.timing())
