@@ -673,6 +673,32 @@ __device__ __forceinline__ void ldlt16(double (&a)[PIV], double (&v)[PIV], doubl
 // sum_r sig_r G[r][a] G[r][c], or -sum_r G[r][a] w_r for the rhs, in a fixed order); no target of
 // one kind is a target of another (pivot diagonals are added when the pivot columns are gathered).
 constexpr int SHDR = 8;   // static record header ints
+// sum over the (at most five) rows of one inequality block for one target: code = offset of the
+// block's G in the dynamic record (12 bits) | a << 12 | c << 18 (63: right-hand side) | (n-1) << 24
+// | (m-1) << 29.  All reads are issued together; rows beyond the block re-read its last row and are
+// weighted by zero.
+__device__ __forceinline__ double gather_term(const double *dbuf, int code) {
+  const int a = (code >> 12) & 63, c = (code >> 18) & 63, qn = ((code >> 24) & 31) + 1, qm = (int)((unsigned)code >> 29) + 1;
+  const double *Gb = dbuf + (code & 4095);
+  const double *sg = Gb + qm * qn, *wq = sg + qm;
+  const bool rhs = c == 63;
+  const int cc = rhs ? a : c;
+  double ga[5], gc[5], sw[5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int rr = min(r, qm - 1);
+    ga[r] = Gb[rr * qn + a];
+    gc[r] = Gb[rr * qn + cc];
+    sw[r] = rhs ? wq[rr] : sg[rr];
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const double term = rhs ? -(ga[r] * sw[r]) : sw[r] * ga[r] * gc[r];
+    acc += r < qm ? term : 0.0;
+  }
+  return acc;
+}
 __device__ __forceinline__ void assemble_stage(double *A, int F, const int *sbuf, const double *dbuf, int t0, int nth) {
   const int n_ent = sbuf[0], n_rhs = sbuf[1], n_iq = sbuf[2];
   const int *eidx = sbuf + SHDR + PIV;
@@ -682,37 +708,15 @@ __device__ __forceinline__ void assemble_stage(double *A, int F, const int *sbuf
   const double *rval = eval + n_ent;
   for (int i = t0; i < n_rhs; i += nth) A[tri(F, rsl[i])] += rval[i];
   if (n_iq == 0) return;
-  const int *iqh = rsl + n_rhs;
   const int n_tgt = sbuf[5];
   const int *tg = sbuf + sbuf[4];                     // n_tgt + 1 ints: (tri << 12) | first contribution
-  const unsigned short *cl = (const unsigned short *)(tg + n_tgt + 1);
+  const int *cl = tg + n_tgt + 1;                     // one self-contained int per contribution
   for (int t = t0; t < n_tgt; t += nth) {
     const int tv = tg[t], c0 = tv & 4095, c1 = tg[t + 1] & 4095;
+    const double a_old = A[tv >> 12];                 // issued with the record reads, needed last
     double acc = 0;
-    for (int j = c0; j < c1; ++j) {
-      const int code = cl[j], q = code >> 12, a = (code >> 6) & 63, c = code & 63;
-      const int h = iqh[q], qm = h & 15, qn = (h >> 4) & 63;
-      const double *Gb = dbuf + (h >> 10);
-      const double *sg = Gb + qm * qn, *wq = sg + qm;
-      // blocks have at most five rows: fixed-length unrolled sums (all reads issued together), rows
-      // beyond the block read its last row and are weighted by zero
-      const bool rhs = c == 63;
-      const int cc = rhs ? a : c;
-      double ga[5], gc[5], sw[5];
-#pragma unroll
-      for (int r = 0; r < 5; ++r) {
-        const int rr = min(r, qm - 1);
-        ga[r] = Gb[rr * qn + a];
-        gc[r] = Gb[rr * qn + cc];
-        sw[r] = rhs ? wq[rr] : sg[rr];
-      }
-#pragma unroll
-      for (int r = 0; r < 5; ++r) {
-        const double term = rhs ? -(ga[r] * sw[r]) : sw[r] * ga[r] * gc[r];
-        acc += r < qm ? term : 0.0;
-      }
-    }
-    A[tv >> 12] += acc;
+    for (int j = c0; j < c1; ++j) acc += gather_term(dbuf, cl[j]);
+    A[tv >> 12] = a_old + acc;
   }
 }
 
@@ -883,7 +887,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   unsigned long long st7[4] = {0, 0, 0, 0}, tl_st7 = 0;
   if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st0) :: "memory");
 #endif
-  constexpr int PFD2 = 2, PFS4 = 2;   // per-thread prefetch registers: 128-bit loads of a stage's records
+  constexpr int PFD2 = 2, PFS4 = 3;   // per-thread prefetch registers: 128-bit loads of a stage's records
   d2_t pfd[PFD2];
   i4_t pfs[PFS4];
   int pf_nd2 = 0, pf_ns4 = 0;
@@ -1186,36 +1190,37 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       unkj = P.piv_unknown[kk * PIV + j];
     };
     auto bstep = [&](int k, const double (&v)[4], double wj, int psj, int unkj) __attribute__((always_inline)) {
-      const int nw = hiall[k] >> 4;
+      const bool valid = k >= 0;          // the stage count is padded to a multiple of DEPTH with no-op steps
+      const int kk = max(k, 0);
+      const int nw = valid ? hiall[kk] >> 4 : 0;
       double p = 0.0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) p = fma(v[i], xs[16 * wv + q + 4 * i], p);
       p += __shfl_xor(p, 16);
       p += __shfl_xor(p, 32);
-      if (lane < PIV) red[(k & 1) * 128 + wv * PIV + j] = wv < nw ? p : 0.0;   // rows beyond the stage's range: no contribution
+      if (lane < PIV) red[(kk & 1) * 128 + wv * PIV + j] = wv < nw ? p : 0.0;   // rows beyond the stage's range: no contribution
       lds_barrier();
       double r8[8];
 #pragma unroll
-      for (int w2 = 0; w2 < 8; ++w2) r8[w2] = red[(k & 1) * 128 + w2 * PIV + j];
+      for (int w2 = 0; w2 < 8; ++w2) r8[w2] = red[(kk & 1) * 128 + w2 * PIV + j];
       double s = 0.0;
 #pragma unroll
       for (int w2 = 0; w2 < 8; ++w2) s += r8[w2];
       const double x = wj - s;
-      if (lane < PIV) {
+      if (lane < PIV && valid) {
         xs[psj] = x;
         if (wv == 0 && unkj >= 0 && unkj < n) dx[unkj] = x;
       }
     };
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) bload(NS - 1 - d, bv[d], bw[d], bps[d], bun[d]);
+    // straight-line body (four steps, no stage-dependent branches) so that the compiler waits for each
+    // prefetched group with a partial vmcnt instead of draining the whole ring
     for (int k0 = NS - 1; k0 >= 0; k0 -= DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
-        const int k = k0 - d;
-        if (k >= 0) {
-          bstep(k, bv[d], bw[d], bps[d], bun[d]);
-          bload(k - DEPTH, bv[d], bw[d], bps[d], bun[d]);
-        }
+        bstep(k0 - d, bv[d], bw[d], bps[d], bun[d]);
+        bload(k0 - d - DEPTH, bv[d], bw[d], bps[d], bun[d]);
       }
     }
   }

@@ -164,7 +164,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   // LDS budget of k_kkt
   const int F = S.front;
   p->kkt_lds = kkt_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec);
-  if (S.max_drec > 2 * 2 * KT || S.max_srec > 2 * 4 * KT || F > 128 || (S.pack_src.size() & 1)) {
+  if (S.max_drec > 2 * 2 * KT || S.max_srec > 3 * 4 * KT || F > 128 || (S.pack_src.size() & 1)) {
     p->err = "stage record exceeds the prefetch registers";
     fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints) or front %d > 128\n", S.max_drec, S.max_srec, F);
     qtos_planner_destroy(p);

@@ -60,8 +60,8 @@ struct Symbolic {
   int max_stage_g = 0;            // longest G slice of a stage
   // Packed per-stage records consumed by k_kkt (each is ONE contiguous, coalesced read):
   //   static  srec[srec_off[k] ..]: n_ent, n_rhs, n_iq, hi, gather offset, n_tgt, 0, 0, piv_slot[16],
-  //           tri index per equality entry, slot per rhs entry, one packed header int per inequality
-  //           block, gather table (target, first contribution), contributions
+  //           tri index per equality entry, slot per rhs entry, gather table of the inequality blocks
+  //           (target, first contribution), one packed int per contribution
   //   dynamic stream (per problem), drec_off[k] ..: piv_diag[16], equality values, -g of the rhs
   //           rows, then per inequality block G (m x n), sig (m), w (m)
   // pack_src[i] says where stream element i comes from: (kind << 28) | index, kind 0 G, 1 g_static,
@@ -312,14 +312,12 @@ struct Symbolic {
         srec.push_back(eq_rhs[i].slot);
         pack_src.push_back((2 << 28) | eq_rhs[i].row);
       }
-      // inequality block headers: ONE packed int per block, m | n << 4 | (offset of G inside the stage's
-      // dynamic record) << 10; followed in the dynamic record by G (m x n), sig (m), w (m)
-      const int hdr = (int)srec.size();
-      srec.resize(srec.size() + (size_t)n_iq);
+      // dynamic record of the inequality blocks: per block G (m x n), sig (m), w (m)
+      std::vector<int> blk_goff(n_iq);
       for (int q = 0; q < n_iq; ++q) {
         const IqBlock &Q = iq_blocks[S.iq_begin + q];
-        if (Q.m > 5 || Q.n > 63) { err = "inequality block too large for the packed gather records"; return -1; }
-        srec[hdr + q] = Q.m | (Q.n << 4) | (((int)pack_src.size() - drec_off[k]) << 10);
+        blk_goff[q] = (int)pack_src.size() - drec_off[k];
+        if (Q.m > 5 || Q.n > 32 || blk_goff[q] >= 4096) { err = "inequality block too large for the packed gather records"; return -1; }
         for (int i = 0; i < Q.m * Q.n; ++i) pack_src.push_back(S.g_begin + Q.gloc + i);
         for (int r = 0; r < Q.m; ++r) pack_src.push_back((3 << 28) | (Q.row0 + r));
         for (int r = 0; r < Q.m; ++r) pack_src.push_back((4 << 28) | (Q.row0 + r));
@@ -339,8 +337,9 @@ struct Symbolic {
         }
         srec[srec_off[k] + 4] = (int)srec.size() - srec_off[k];
         srec[srec_off[k] + 5] = (int)tmap.size();
-        // packed: one int per target (tri << 12 | first contribution), contributions as 16-bit codes
-        // (q << 12 | a << 6 | c, c = 63: rhs), two per int
+        // one int per target (tri << 12 | first contribution), then one self-contained int per
+        // contribution: offset of the block's G in the dynamic record (12 bits) | a << 12 | c << 18
+        // (c = 63: right-hand side) | (n - 1) << 24 | (m - 1) << 29
         int cpos = 0;
         std::vector<int> codes;
         for (auto &kv : tmap) {
@@ -348,13 +347,13 @@ struct Symbolic {
           cpos += (int)kv.second.size();
           for (int code : kv.second) {
             const int q = code >> 16, a = (code >> 8) & 255, c = code & 255;
-            codes.push_back((q << 12) | (a << 6) | (c == 255 ? 63 : c));
+            const IqBlock &Q = iq_blocks[S.iq_begin + q];
+            codes.push_back(blk_goff[q] | (a << 12) | ((c == 255 ? 63 : c) << 18) | ((Q.n - 1) << 24) | (int)((unsigned)(Q.m - 1) << 29));
           }
         }
-        if (cpos >= 4096 || n_iq > 15) { err = "gather table overflow"; return -1; }
+        if (cpos >= 4096) { err = "gather table overflow"; return -1; }
         srec.push_back(cpos);   // sentinel: end of the last target's contributions
-        for (size_t i = 0; i < codes.size(); i += 2)
-          srec.push_back(codes[i] | ((i + 1 < codes.size() ? codes[i + 1] : 0) << 16));
+        srec.insert(srec.end(), codes.begin(), codes.end());
       }
       max_srec = std::max(max_srec, (int)srec.size() - srec_off[k]);
       max_drec = std::max(max_drec, (int)pack_src.size() - drec_off[k]);
