@@ -31,6 +31,8 @@ struct DevPlan {
   int n_dyn_cols, n_rom_cols;
   const Block *blocks;
   const int *block_cols;
+  const IqRow *iq_rows;   // rows of the inequality blocks (stream offsets)
+  int n_iq_rows;
   const double *g_static;
   const int *piv_slot, *piv_unknown;
   const double *piv_diag;
@@ -210,6 +212,9 @@ __device__ inline void terrain_basis(const Terr &t, int which, double b[3], doub
 constexpr int DYN_LOC = 54;  // A_th, A_thd, A_thdd (9 each), sum f (3), f_e (12), r - p_e (12)
 constexpr int ROM_LOC = 18;  // R (9), d/dtheta_j [R^T (p - r)] as columns (9)
 
+// Newton-Euler violation of one dynamics knot (values; with JAC also the force / lever-arm part of
+// the local Jacobian data).  The nine forward-mode passes for the Euler-angle columns are separate
+// work items (eval_dyn_pass) so that ten threads share one knot.
 template <bool JAC>
 __device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double *x, double *g, double *loc) {
   double r[3], a[3], th[3], thd[3], thdd[3];
@@ -219,24 +224,6 @@ __device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double
   dyn_angular<double>(P.Ib, th, thd, thdd, ga);
   gl[0] = P.mass * a[0]; gl[1] = P.mass * a[1]; gl[2] = P.mass * a[2] + P.mass * P.gravity;
   const bool jac = JAC && I.in_kkt;
-  if (jac) {
-    // angular rows wrt Euler angles / rates / accelerations: 9 forward-mode passes
-#pragma unroll
-    for (int what = 0; what < 3; ++what)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        D1 t0[3], t1[3], t2[3], o[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          t0[i] = {th[i], (what == 0 && i == j) ? 1.0 : 0.0};
-          t1[i] = {thd[i], (what == 1 && i == j) ? 1.0 : 0.0};
-          t2[i] = {thdd[i], (what == 2 && i == j) ? 1.0 : 0.0};
-        }
-        dyn_angular<D1>(P.Ib, t0, t1, t2, o);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) loc[9 * what + 3 * i + j] = o[i].d;
-      }
-  }
   double sf[3] = {0, 0, 0};
 #pragma unroll
   for (int e = 0; e < NEE; ++e) {
@@ -257,6 +244,27 @@ __device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double
   if (jac) { loc[27] = sf[0]; loc[28] = sf[1]; loc[29] = sf[2]; }
 #pragma unroll
   for (int i = 0; i < 3; ++i) { g[I.row0 + i] = ga[i]; g[I.row0 + 3 + i] = gl[i]; }
+}
+// three forward-mode passes: d(angular rows) / d(theta (WHAT = 0), theta-dot (1), theta-ddot (2)).
+// WHAT is a compile-time constant so that the zero tangents fold away.
+template <int WHAT>
+__device__ inline void eval_dyn_pass(const DevPlan &P, const DynInst &I, const double *x, double *loc) {
+  if (!I.in_kkt) return;
+  double th[3], thd[3], thdd[3];
+  vec_eval(I.th, x, th); vec_eval(I.thd, x, thd); vec_eval(I.thdd, x, thdd);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    D1 t0[3], t1[3], t2[3], o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      t0[i] = {th[i], (WHAT == 0 && i == j) ? 1.0 : 0.0};
+      t1[i] = {thd[i], (WHAT == 1 && i == j) ? 1.0 : 0.0};
+      t2[i] = {thdd[i], (WHAT == 2 && i == j) ? 1.0 : 0.0};
+    }
+    dyn_angular<D1>(P.Ib, t0, t1, t2, o);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) loc[9 * WHAT + 3 * i + j] = o[i].d;
+  }
 }
 
 // element (i, d) of the cross-product matrix [v]x
@@ -377,14 +385,29 @@ __device__ inline void eval_force(const DevPlan &P, const ForceInst &I, int map,
 
 // all constraint rows of one problem, by the whole workgroup; `loc` = LDS scratch of
 // max(DYN_LOC * n_dyn, ROM_LOC * n_rom) doubles (only used when JAC)
+// lds: n_vars doubles for a staged copy of the nodes (every spline evaluation then reads LDS instead
+// of chasing indices through global memory), followed by the local Jacobian data of the dynamics /
+// range-of-motion instances
+__device__ __forceinline__ int eval_loc_offset(int n_vars) { return (n_vars + 1) & ~1; }
 template <bool JAC>
-__device__ inline void eval_all(const DevPlan &P, int map, const double *x, double *g, double *G, double *loc) {
+__device__ inline void eval_all(const DevPlan &P, int map, const double *xg, double *g, double *G, double *lds) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int i = tid; i < P.n_dyn; i += nt) eval_dyn<JAC>(P, P.dyn[i], x, g, JAC ? loc + (size_t)i * DYN_LOC : nullptr);
+  double *x = lds, *loc = lds + eval_loc_offset(P.n_vars);
+  for (int v = tid; v < P.n_vars; v += nt) x[v] = xg[v];
+  __syncthreads();
   if (JAC) {
+    for (int i = tid; i < P.n_dyn; i += nt) {
+      double *li = loc + (size_t)i * DYN_LOC;
+      eval_dyn<true>(P, P.dyn[i], x, g, li);
+      eval_dyn_pass<0>(P, P.dyn[i], x, li);
+      eval_dyn_pass<1>(P, P.dyn[i], x, li);
+      eval_dyn_pass<2>(P, P.dyn[i], x, li);
+    }
     __syncthreads();
     for (int c = tid; c < P.n_dyn_cols; c += nt) dyn_column(P, P.dyn_cols[c], loc, G);
     __syncthreads();
+  } else {
+    for (int i = tid; i < P.n_dyn; i += nt) eval_dyn<false>(P, P.dyn[i], x, g, nullptr);
   }
   for (int i = tid; i < P.n_rom; i += nt) eval_rom<JAC>(P, P.rom[i], x, g, JAC ? loc + (size_t)i * ROM_LOC : nullptr);
   if (JAC) {
@@ -512,7 +535,7 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
     x[v] = val;
   }
   __syncthreads();
-  eval_all<false>(P, map, x, g, nullptr, nullptr);
+  eval_all<false>(P, map, x, g, nullptr, evl);
   __syncthreads();
   // slack initialisation: push strictly inside the bounds (Ipopt bound_push / bound_frac)
   for (int r = tid; r < m; r += blockDim.x) {
@@ -1250,19 +1273,33 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   const double *G = W.stream + (size_t)b * P.stream_len;
   const int map = W.map_id ? W.map_id[b] : 0;
   double mu = W.mu[b];
-  // ds = Ji dx + (g - s) through the inequality blocks
-  for (int bi = tid; bi < P.n_blocks; bi += blockDim.x) {
-    const Block blk = P.blocks[bi];
-    if (blk.kind != 1) continue;
-    const double *Gb = G + blk.goff;
-    for (int r = 0; r < blk.m; ++r) {
-      double acc = 0;
-      for (int a = 0; a < blk.n; ++a) acc += Gb[r * blk.n + a] * dx[P.block_cols[blk.col_off + a]];
-      const int row = blk.row0 + r;
-      ds[row] = acc + (g[row] - s[row]);
+#ifdef QTOS_STAMPS
+  unsigned long long ks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kt0 = 0;
+#define KSTAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ks[i] += t_ - kt0; kt0 = t_; } } while (0)
+  if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt0) :: "memory");
+#else
+#define KSTAMP(i) do {} while (0)
+#endif
+  // ds = Ji dx + (g - s): dx staged in LDS, one thread per inequality row, independent loads
+  for (int v = tid; v < n; v += blockDim.x) evl[v] = dx[v];
+  __syncthreads();
+  for (int i = tid; i < P.n_iq_rows; i += blockDim.x) {
+    const IqRow R = P.iq_rows[i];
+    const double *Gr = G + R.goff;
+    const int *cols = P.block_cols + R.col_off;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int a = 0;
+    for (; a + 4 <= R.n; a += 4) {
+      a0 = fma(Gr[a], evl[cols[a]], a0);
+      a1 = fma(Gr[a + 1], evl[cols[a + 1]], a1);
+      a2 = fma(Gr[a + 2], evl[cols[a + 2]], a2);
+      a3 = fma(Gr[a + 3], evl[cols[a + 3]], a3);
     }
+    for (; a < R.n; ++a) a0 = fma(Gr[a], evl[cols[a]], a0);
+    ds[R.row] = ((a0 + a1) + (a2 + a3)) + (g[R.row] - s[R.row]);
   }
   __syncthreads();
+  KSTAMP(0);
   const double tau = fmax(0.99, 1.0 - mu);
   double amax = 1.0, az = 1.0;
   for (int r = tid; r < m; r += blockDim.x) {
@@ -1283,17 +1320,19 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   amax = wg_reduce<2>(amax, scratch);
   az = wg_reduce<2>(az, scratch);
   const double th0 = l1_infeasibility(P, g, s, ds, 0.0, scratch);
+  KSTAMP(1);
   // backtracking on the l1 infeasibility of (c_E, c_I - s)
   double al = amax, th = 0;
   for (int ls = 0; ls < 6; ++ls) {
     for (int v = tid; v < n; v += blockDim.x) xt[v] = x[v] + al * dx[v];
     __syncthreads();
-    eval_all<false>(P, map, xt, gt, nullptr, nullptr);
+    eval_all<false>(P, map, xt, gt, nullptr, evl);
     __syncthreads();
     th = l1_infeasibility(P, gt, s, ds, al, scratch);
     if (th <= (1.0 - 1e-4 * al) * th0 || th < 1e-9) break;
     if (ls < 5) al *= 0.5;
   }
+  KSTAMP(2);
   for (int v = tid; v < n; v += blockDim.x) x[v] = xt[v];
   for (int r = tid; r < m; r += blockDim.x) {
     g[r] = gt[r];
@@ -1313,6 +1352,7 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   __syncthreads();
   double viol, theta;
   infeasibility(P, g, s, scratch, viol, theta);
+  KSTAMP(3);
   const bool conv = viol <= P.tol && theta <= P.tol;
   const bool bad = !(viol < INFINITY) || !(th < INFINITY);
   if (tid == 0) {
@@ -1330,7 +1370,12 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   __syncthreads();
   eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl);
   __syncthreads();
+  KSTAMP(4);
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
+  KSTAMP(5);
+#ifdef QTOS_STAMPS
+  if (tid == 0 && W.trace && it == 1) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 34) * 4 + i] = (double)ks[i];
+#endif
 }
 
 // =================================================================================================

@@ -65,6 +65,13 @@ struct Block {
   int kind;  // 0 equality, 1 inequality
   int m, n, row0, goff, gstatic, col_off, pad;
 };
+// one row of an inequality block, for the row-parallel product ds = Ji dx (k_step)
+struct IqRow {
+  int goff;     // stream offset of the row's first Jacobian entry
+  int n;        // entries
+  int col_off;  // into block_cols
+  int row;      // constraint row
+};
 // initial guess per variable (towr SetByLinearInterpolation): x = a + frac*(b-a) or (b-a)/T
 struct InitDesc {
   int set;  // 0 base-lin, 1 base-ang, 2+e ee-motion, 6+e ee-force

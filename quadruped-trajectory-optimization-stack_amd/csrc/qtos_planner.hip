@@ -138,6 +138,14 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(M.dyn_cols, &D.dyn_cols)); TRY(p->upload(M.rom_cols, &D.rom_cols));
   D.n_dyn_cols = (int)M.dyn_cols.size(); D.n_rom_cols = (int)M.rom_cols.size();
   TRY(p->upload(M.blocks, &D.blocks)); TRY(p->upload(M.block_cols, &D.block_cols));
+  {
+    std::vector<IqRow> rows;   // blocks carry their stream offsets once the symbolic analysis has run
+    for (const Block &b : M.blocks)
+      if (b.kind == 1)
+        for (int r = 0; r < b.m; ++r) rows.push_back({b.goff + r * b.n, b.n, b.col_off, b.row0 + r});
+    D.n_iq_rows = (int)rows.size();
+    TRY(p->upload(rows, &D.iq_rows));
+  }
   TRY(p->upload(M.g_static, &D.g_static));
   TRY(p->upload(S.piv_slot, &D.piv_slot)); TRY(p->upload(S.piv_unknown, &D.piv_unknown));
   TRY(p->upload(S.piv_diag, &D.piv_diag)); TRY(p->upload(S.stages, &D.stages));
@@ -182,7 +190,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
   }
-  p->eval_lds = sizeof(double) * std::max((size_t)DYN_LOC * M.dyn.size(), (size_t)ROM_LOC * M.rom.size());
+  p->eval_lds = sizeof(double) * (((size_t)M.n_vars + 1) / 2 * 2 + std::max((size_t)DYN_LOC * M.dyn.size(), (size_t)ROM_LOC * M.rom.size()));
   if (p->eval_lds > 150 * 1024) { p->err = "too many dynamics knots for the LDS scratch"; qtos_planner_destroy(p); return -4; }
   for (const void *fn : {(const void *)k_start, (const void *)k_step, (const void *)k_debug_eval})
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->eval_lds) != hipSuccess) { qtos_planner_destroy(p); return -2; }

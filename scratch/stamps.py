@@ -21,3 +21,9 @@ for n, v in zip(names, tot / 3 / NS):
     print("  %-22s %8.0f" % (n, v))
 print("  wave1: tile MFMA %.0f, extraction %.0f, assembly %.0f | wave7 rhs %.0f" % (t1[2] / 3 / NS, t1[0] / 3 / NS, t1[1] / 3 / NS, t7[0] / 3 / NS))
 print("sum per stage", tot.sum() / 3 / NS, "stages", NS, P.timing())
+ks = np.zeros(8)
+for b in (0, 5, NB - 1):
+    t = np.zeros((cfg.max_iter + 1, 4))
+    P.lib.qtos_debug_trace(P.h, b, t.ctypes.data_as(C.POINTER(C.c_double)))
+    ks += t[34:36].ravel()
+print("k_step (iteration 1) cycles: ds %.0f | dz+reductions %.0f | line search %.0f | update+infeasibility %.0f | linearise %.0f | barrier terms %.0f" % tuple(ks[:6] / 3))
