@@ -277,8 +277,7 @@ __device__ __forceinline__ double skew_el(const double *v, int i, int d) {
 
 __device__ inline void dyn_column(const DevPlan &P, const ColDesc &C, const double *loc_all, double *G) {
   const double *loc = loc_all + (size_t)C.inst * DYN_LOC;
-  const int *pos = P.eq_pos + C.gbase;   // the block's rows land at their own stream positions
-  const int d = C.dim, nc = C.ncol;
+  const int d = C.dim;
   double v[6];
   if (C.kind == 0) {        // base position / acceleration: d g_ang / d r = -[sum f]x ; d g_lin / d a = m I
     for (int i = 0; i < 3; ++i) v[i] = -skew_el(loc + 27, i, d) * C.w0;
@@ -297,7 +296,7 @@ __device__ inline void dyn_column(const DevPlan &P, const ColDesc &C, const doub
     for (int i = 0; i < 3; ++i) v[3 + i] = i == d ? -C.w0 : 0.0;
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) G[pos[i * nc]] = v[i];
+  for (int i = 0; i < 6; ++i) G[C.pos[i]] = v[i];   // the block's rows land at their own stream positions
 }
 
 template <bool JAC>
@@ -327,13 +326,12 @@ __device__ inline void eval_rom(const DevPlan &P, const RomInst &I, const double
 
 __device__ inline void rom_column(const ColDesc &C, const double *loc_all, double *G) {
   const double *loc = loc_all + (size_t)C.inst * ROM_LOC;
-  double *col = G + C.gbase;
-  const int d = C.dim, nc = C.ncol;
+  const int d = C.dim;
   if (C.kind == 1) {
-    for (int i = 0; i < 3; ++i) col[i * nc] = loc[9 + 3 * i + d] * C.w0;
+    for (int i = 0; i < 3; ++i) G[C.pos[i]] = loc[9 + 3 * i + d] * C.w0;
   } else {
     const double sgn = C.kind == 2 ? 1.0 : -1.0;   // d/dp = R^T, d/dr = -R^T ; (R^T)[i][d] = R[3d + i]
-    for (int i = 0; i < 3; ++i) col[i * nc] = sgn * loc[3 * d + i] * C.w0;
+    for (int i = 0; i < 3; ++i) G[C.pos[i]] = sgn * loc[3 * d + i] * C.w0;
   }
 }
 
@@ -390,11 +388,19 @@ __device__ inline void eval_force(const DevPlan &P, const ForceInst &I, int map,
 // range-of-motion instances
 __device__ __forceinline__ int eval_loc_offset(int n_vars) { return (n_vars + 1) & ~1; }
 template <bool JAC>
-__device__ inline void eval_all(const DevPlan &P, int map, const double *xg, double *g, double *G, double *lds) {
+__device__ inline void eval_all(const DevPlan &P, int map, const double *xg, double *g, double *G, double *lds, double *dbg = nullptr) {
   const int tid = threadIdx.x, nt = blockDim.x;
+#ifdef QTOS_STAMPS
+  unsigned long long et0 = 0; int ei = 0;
+#define ESTAMP() do { __syncthreads(); if (tid == 0 && dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dbg[ei++] = (double)(t_ - et0); et0 = t_; } } while (0)
+  if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(et0) :: "memory");
+#else
+#define ESTAMP() do {} while (0)
+#endif
   double *x = lds, *loc = lds + eval_loc_offset(P.n_vars);
   for (int v = tid; v < P.n_vars; v += nt) x[v] = xg[v];
   __syncthreads();
+  ESTAMP();
   if (JAC) {
     for (int i = tid; i < P.n_dyn; i += nt) {
       double *li = loc + (size_t)i * DYN_LOC;
@@ -404,15 +410,33 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
       eval_dyn_pass<2>(P, P.dyn[i], x, li);
     }
     __syncthreads();
-    for (int c = tid; c < P.n_dyn_cols; c += nt) dyn_column(P, P.dyn_cols[c], loc, G);
+    ESTAMP();
+    for (int c = tid; c < P.n_dyn_cols; c += 4 * nt) {   // four columns per round: all descriptors in flight
+      ColDesc C[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) C[u] = P.dyn_cols[min(c + u * nt, P.n_dyn_cols - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c + u * nt < P.n_dyn_cols) dyn_column(P, C[u], loc, G);
+    }
     __syncthreads();
+    ESTAMP();
   } else {
     for (int i = tid; i < P.n_dyn; i += nt) eval_dyn<false>(P, P.dyn[i], x, g, nullptr);
   }
   for (int i = tid; i < P.n_rom; i += nt) eval_rom<JAC>(P, P.rom[i], x, g, JAC ? loc + (size_t)i * ROM_LOC : nullptr);
   if (JAC) {
     __syncthreads();
-    for (int c = tid; c < P.n_rom_cols; c += nt) rom_column(P.rom_cols[c], loc, G);
+    ESTAMP();
+    for (int c = tid; c < P.n_rom_cols; c += 4 * nt) {
+      ColDesc C[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) C[u] = P.rom_cols[min(c + u * nt, P.n_rom_cols - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c + u * nt < P.n_rom_cols) rom_column(C[u], loc, G);
+    }
+    ESTAMP();
   }
   for (int i = tid; i < P.n_force; i += nt) eval_force<JAC>(P, P.force[i], map, x, g, G);
   for (int i = tid; i < P.n_terr; i += nt) eval_terr<JAC>(P, P.terr[i], map, x, g, G);
@@ -422,6 +446,7 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
     for (int k = 0; k < L.n; ++k) acc += L.coef[k] * x[L.var[k]];
     g[L.row] = acc;
   }
+  ESTAMP();
 }
 
 // ---- workgroup reductions (fixed tree => bitwise reproducible) --------------------------------
@@ -1368,7 +1393,7 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   }
   if (conv || bad) return;
   __syncthreads();
-  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl);
+  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, (W.trace && it == 1) ? W.trace + ((size_t)b * (P.max_iter + 1) + 36) * 4 : nullptr);
   __syncthreads();
   KSTAMP(4);
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);

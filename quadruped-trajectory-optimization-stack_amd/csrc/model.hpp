@@ -59,6 +59,7 @@ struct ColDesc {
   int inst, gbase, ncol;       // instance index, offset of G[0][col], row stride
   short kind, dim;             // dyn: 0 lin, 1 ang, 2+e foot e position, 6+e foot e force; rom: 0 lin, 1 ang, 2 foot
   double w0, w1, w2;
+  int pos[6];                  // stream positions of the column's entries (filled by the symbolic analysis)
 };
 // K2 assembly block: m consecutive constraint rows sharing one dense column list
 struct Block {

@@ -383,6 +383,10 @@ struct Symbolic {
     for (Block &b : M.blocks)
       if (b.kind == 1) b.goff = iq_first[b.goff];
     M.finalize_goff();
+    for (ColDesc &c : M.dyn_cols)
+      for (int i = 0; i < 6; ++i) c.pos[i] = eq_pos[c.gbase + i * c.ncol];
+    for (ColDesc &c : M.rom_cols)
+      for (int i = 0; i < 6; ++i) c.pos[i] = i < 3 ? c.gbase + i * c.ncol : 0;
     // bytes = w * [ sum_k (p + c_k) * p  +  2 M ]   (matrix once, rhs in, solution out)
     algorithmic_bytes = 0;
     flops = 0;

@@ -27,3 +27,6 @@ for b in (0, 5, NB - 1):
     P.lib.qtos_debug_trace(P.h, b, t.ctypes.data_as(C.POINTER(C.c_double)))
     ks += t[34:36].ravel()
 print("k_step (iteration 1) cycles: ds %.0f | dz+reductions %.0f | line search %.0f | update+infeasibility %.0f | linearise %.0f | barrier terms %.0f" % tuple(ks[:6] / 3))
+t = np.zeros((cfg.max_iter + 1, 4))
+P.lib.qtos_debug_trace(P.h, 0, t.ctypes.data_as(C.POINTER(C.c_double)))
+print("linearise phases (cycles): stage x %.0f | dynamics knots %.0f | dynamics columns %.0f | rom instances %.0f | rom columns %.0f | force/terrain/linear %.0f" % tuple(t[36:38].ravel()[:6]))
