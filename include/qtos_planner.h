@@ -41,6 +41,8 @@ typedef struct QtosParams {
   int max_iter;
   double tol, mu_init, mu_min, delta_x, eps_dual;
   double slack_push; /* cold-start slack push, fraction of the bound range (0.2); warm starts use 0.01 */
+  int stall_iters;   /* stop a problem (status 1, best iterate returned) after this many iterations
+                        without a new lowest violation; 0 = only the iteration limit stops it */
 } QtosParams;
 
 typedef struct QtosDims {

@@ -910,6 +910,7 @@ void qo_default_options(qo_options *o) {
   o->delta_x = 1e-2;
   o->eps_dual = 1e-8;
   o->slack_push = 0.2;
+  o->stall_iters = 5;
   o->warm_start = 0;
   o->verbose = 0;
 }
@@ -1123,6 +1124,11 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
   info->inf_pr0 = max_violation(M, g, cl, ch);
   int status = 1, it;
   double viol = 0;
+  /* stall detection: remember the iterate with the lowest violation; give up when it has not been
+   * improved for stall_iters iterations (cycling on a discontinuous terrain edge) and return it */
+  double best_viol = INFINITY;
+  int best_it = 0;
+  double *xbest = (double *)malloc(sizeof(double) * n);
   for (it = 0; it < o->max_iter; ++it) {
     double theta = 0;
     viol = 0;
@@ -1135,6 +1141,12 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     }
     if (o->verbose) fprintf(stderr, "oracle: it %2d viol %.3e theta %.3e mu %.1e\n", it, viol, theta, mu);
     if (viol <= o->tol && theta <= o->tol) { status = 0; break; }
+    if (viol < best_viol) { best_viol = viol; best_it = it; memcpy(xbest, x, sizeof(double) * n); }
+    else if (o->stall_iters > 0 && it - best_it >= o->stall_iters) {
+      memcpy(x, xbest, sizeof(double) * n);
+      eval_all(p, M, x, g, NULL);
+      break;
+    }
     t0 = now_s();
     eval_all(p, M, x, NULL, J);
     t_eval += now_s() - t0;
@@ -1239,6 +1251,6 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
   sky_free(&K);
   free(first); free(epos); free(ks); free(tv); free(tc); free(Er); free(Ir); free(ci); free(rp);
   free(rowtype); free(vpos); free(xt); free(J); free(gt); free(g); free(cl); free(xl); free(s);
-  free(rhs); free(dx); free(M);
+  free(rhs); free(dx); free(M); free(xbest);
   return status;
 }

@@ -98,6 +98,8 @@ typedef struct {
   double slack_push;   /* cold-start slack push as a fraction of the bound range */
   int warm_start;      /* 1: x_io holds the starting point                     */
   int verbose;
+  int stall_iters;     /* stop (status 1, best iterate returned) after this many iterations
+                          without a new lowest violation; 0 = never                */
 } qo_options;
 
 typedef struct {

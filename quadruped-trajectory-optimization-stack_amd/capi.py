@@ -27,6 +27,7 @@ class QtosParams(C.Structure):
         ("max_iter", C.c_int),
         ("tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
         ("delta_x", C.c_double), ("eps_dual", C.c_double), ("slack_push", C.c_double),
+        ("stall_iters", C.c_int),
     ]
 
 
@@ -120,6 +121,7 @@ def params_from_config(cfg):
     p.max_iter, p.tol = cfg.max_iter, cfg.tol
     p.mu_init, p.mu_min, p.delta_x, p.eps_dual = cfg.mu_init, cfg.mu_min, cfg.delta_x, cfg.eps_dual
     p.slack_push = cfg.slack_push
+    p.stall_iters = cfg.stall_iters
     return p
 
 

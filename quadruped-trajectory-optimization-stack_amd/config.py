@@ -82,6 +82,7 @@ class PlannerConfig:
     delta_x: float = 1e-2
     eps_dual: float = 1e-8
     slack_push: float = 0.2            # cold-start slack push (fraction of the bound range)
+    stall_iters: int = 5               # stop after this many iterations without a new lowest violation (0 = off)
     phase_durations: List[List[float]] = field(default=None)
 
     def __post_init__(self):

@@ -51,7 +51,7 @@ struct DevPlan {
   double mass, gravity, Ib[9], mu_fric, f_max, T;
   double nominal[NEE][3];
   double tol, mu_init, mu_min, delta_x, eps_dual, slack_push;
-  int max_iter;
+  int max_iter, stall_iters;
   const double *height;
   int n_maps, hnx, hny, terrain_mode;
   double hcell, hx0, hy0;
@@ -63,6 +63,8 @@ struct DevWork {
   const int *map_id;
   double *x, *xt, *g, *gt, *s, *zl, *zu, *ds, *dzl, *dzu, *sig, *w, *G, *panel, *dx, *stream;
   double *mu, *viol, *trace;
+  double *best_viol, *xbest;   // stall detection: lowest violation seen and the iterate that had it
+  int *best_it;
   int *status, *iters, *done, *n_active;
 };
 
@@ -558,6 +560,7 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
       val = I.is_vel ? (e - a) / P.T : a + I.frac * (e - a);
     }
     x[v] = val;
+    W.xbest[(size_t)b * n + v] = val;
   }
   __syncthreads();
   eval_all<false>(P, map, x, g, nullptr, evl);
@@ -592,6 +595,8 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
     W.iters[b] = 0;
     W.status[b] = conv ? 0 : (bad ? 2 : 1);
     W.done[b] = (conv || bad) ? 1 : 0;
+    W.best_viol[b] = viol;
+    W.best_it[b] = 0;
     if (!conv && !bad) atomicAdd(W.n_active, 1);
     record_trace(P, W, b, 0, viol, theta, 0.0, mu);
   }
@@ -1067,19 +1072,9 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     STAMPW(0, st0, 0);
     // ---- C(k) ---------------------------------------------------------------------------------------
     if (wv == 0) {
-#ifdef QTOS_EXP_NO_FACTOR
-#elif defined(QTOS_EXP_TWICE)
-      { int reps = 2; asm volatile("" : "+s"(reps));
-        for (int rep = 0; rep < reps; ++rep) if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV); }
-#else
       if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV);
-#endif
       STAMPW(0, st0, 1);
-#ifdef QTOS_EXP_ONLYW0
-    } else if (wv > 100) {
-#else
     } else if (wv <= 6) {
-#endif
 #ifdef QTOS_STAMPS
       if (tid == 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st1) :: "memory");
 #endif
@@ -1116,7 +1111,6 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       //     (and are zeroed: later updates skip them).  Loops over the pivot slots of each tile's column
       //     / row group are wave-uniform; a pivot column lives on the four lanes li == b, a pivot row on
       //     the 16 lanes lk == b & 3 in register b >> 2.
-#ifndef QTOS_EXP_NO_EXTRACT
       if (extract) {
         // slot -> pivot index of every row / column this lane may send out, read in one batch
         int jcs[MAXT], jrs[MAXT][4];
@@ -1149,13 +1143,8 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
           }
         }
       }
-#endif
       STAMPW(1, st1, 0);
-#ifdef QTOS_EXP_ONLYW0
-    } else if (wv > 100) {
-#else
     } else {
-#endif
       // wave 7: right-hand-side row.  y_F = p_F L^-T, w = L^-T D^-1 y_F (to HBM), the update of the
       // accumulated right-hand side, and the right-hand side of the next pivots
 #ifdef QTOS_STAMPS
@@ -1272,9 +1261,6 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       }
     }
   }
-#ifdef QTOS_EXP_NOEXTRACT
-  { double su = 0; for (int t = 0; t < MAXT; ++t) for (int g = 0; g < 4; ++g) su += U[t][g]; if (su == 1.2345e-300) dx[0] = su; }
-#endif
 #ifdef QTOS_STAMPS
   STAMPW(0, st0, 4);
   if (tid == 0 && W.trace) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 30) * 4 + i] = (double)st0[i];
@@ -1298,6 +1284,8 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   const double *G = W.stream + (size_t)b * P.stream_len;
   const int map = W.map_id ? W.map_id[b] : 0;
   double mu = W.mu[b];
+  const double best_viol = W.best_viol[b];   // read before anybody writes them (tid 0, end of the kernel)
+  const int best_it = W.best_it[b];
 #ifdef QTOS_STAMPS
   unsigned long long ks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kt0 = 0;
 #define KSTAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ks[i] += t_ - kt0; kt0 = t_; } } while (0)
@@ -1380,18 +1368,28 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   KSTAMP(3);
   const bool conv = viol <= P.tol && theta <= P.tol;
   const bool bad = !(viol < INFINITY) || !(th < INFINITY);
+  // stall detection: the iterate with the lowest violation is kept; a problem that has not improved
+  // it for stall_iters iterations (cycling on a discontinuous terrain edge) stops with status 1 and
+  // returns that iterate
+  const bool improved = !conv && !bad && viol < best_viol;
+  const bool stalled = !conv && !bad && !improved && P.stall_iters > 0 && it + 1 - best_it >= P.stall_iters;
+  if (improved)
+    for (int v = tid; v < n; v += blockDim.x) W.xbest[(size_t)b * n + v] = x[v];
+  if (stalled)
+    for (int v = tid; v < n; v += blockDim.x) x[v] = W.xbest[(size_t)b * n + v];
   if (tid == 0) {
     W.mu[b] = mu;
-    W.viol[b] = viol;
+    W.viol[b] = stalled ? best_viol : viol;
     W.iters[b] = it + 1;
+    if (improved) { W.best_viol[b] = viol; W.best_it[b] = it + 1; }
     record_trace(P, W, b, it + 1, viol, theta, al, mu);
-    if (conv || bad) {
-      W.status[b] = conv ? 0 : 2;
+    if (conv || bad || stalled) {
+      W.status[b] = conv ? 0 : (bad ? 2 : 1);
       W.done[b] = 1;
       atomicAdd(W.n_active, -1);
     }
   }
-  if (conv || bad) return;
+  if (conv || bad || stalled) return;
   __syncthreads();
   eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, (W.trace && it == 1) ? W.trace + ((size_t)b * (P.max_iter + 1) + 36) * 4 : nullptr);
   __syncthreads();

@@ -164,7 +164,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   for (int e = 0; e < NEE; ++e)
     for (int d = 0; d < 3; ++d) D.nominal[e][d] = M.P.nominal_stance[e][d];
   D.tol = M.P.tol; D.mu_init = M.P.mu_init; D.mu_min = M.P.mu_min; D.delta_x = M.P.delta_x;
-  D.eps_dual = M.P.eps_dual; D.max_iter = M.P.max_iter;
+  D.eps_dual = M.P.eps_dual; D.max_iter = M.P.max_iter; D.stall_iters = M.P.stall_iters;
   D.slack_push = M.P.slack_push > 0 ? M.P.slack_push : 0.01;
   D.terrain_mode = M.P.terrain_mode;
   D.g_doubles = S.g_doubles;
@@ -218,6 +218,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
       HIPCHK(p, hipMemcpy(W.stream + b * one.size(), one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   TRY(p->alloc(&W.mu, Bm)); TRY(p->alloc(&W.viol, Bm));
+  TRY(p->alloc(&W.best_viol, Bm)); TRY(p->alloc(&W.best_it, Bm)); TRY(p->alloc(&W.xbest, Bm * n));
   TRY(p->alloc(&W.trace, Bm * (size_t)(M.P.max_iter + 1) * 4));
   TRY(p->alloc(&W.status, Bm)); TRY(p->alloc(&W.iters, Bm)); TRY(p->alloc(&W.done, Bm));
   TRY(p->alloc(&W.n_active, 1));
