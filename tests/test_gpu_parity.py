@@ -456,3 +456,42 @@ def test_edge_cases_infeasible_nan_and_chunking(planner, cfg):
     st = lp.solve_batch(args + args[:2], sample=False)
     assert st == [0] * 10 and np.array_equal(lp.last["nodes"][:8], ref_nodes)
     lp.close()
+
+
+@pytest.mark.gpu
+def test_stall_detection_returns_best_iterate(cfg):
+    """A problem that stops lowering its violation (a foot cycling across a ledge edge of the
+    piecewise-constant exp_5 terrain) stops `stall_iters` iterations after its best iterate with
+    status 1 and returns that iterate; converged problems are untouched; with the rule switched
+    off the same problems run to the iteration limit.  The oracle applies the same rule."""
+    import dataclasses
+    from oracle.oracle import Oracle
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    hxy, cell = workloads.exp5_terrain()
+    start, goal = workloads.step_goals(256, seed=1, terrain=(hxy, cell))
+    P = Planner(cfg, max_batch=256)
+    P.set_heightfields(hxy, cell)
+    nodes, status, iters, viol = P.plan(start, goal)
+    stuck = np.nonzero(status == 1)[0]
+    assert 0 < len(stuck) <= 16 and (status != 2).all()
+    traces = {int(b): P.trace(int(b)) for b in stuck}
+    P.close()
+    for b in stuck:
+        tr = traces[int(b)]
+        best = int(np.argmin(tr[:, 0]))
+        assert iters[b] < cfg.max_iter and iters[b] == best + cfg.stall_iters
+        assert abs(viol[b] - tr[best, 0]) <= 1e-12
+    O = Oracle(cfg.oracle_dict(), height=hxy, hcell=cell)
+    assert all(O.max_violation(nodes[b]) <= viol[b] + 1e-9 for b in stuck[:4])
+    b = int(stuck[0])
+    s, g = start[b], goal[b]
+    xo, info = O.solve(O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g, (0, 0, 0), (0, 0, 0), 0.0))
+    assert info.status == 1 and info.iters < cfg.max_iter
+    P0 = Planner(dataclasses.replace(cfg, stall_iters=0), max_batch=256)
+    P0.set_heightfields(hxy, cell)
+    nodes0, status0, iters0, _ = P0.plan(start, goal)
+    P0.close()
+    ok = status == 0
+    assert np.array_equal(status0 == 0, ok) and np.array_equal(nodes0[ok], nodes[ok]) and np.array_equal(iters0[ok], iters[ok])
+    assert (iters0[stuck] == cfg.max_iter).all()

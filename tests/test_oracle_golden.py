@@ -172,3 +172,25 @@ def test_skyline_ldlt_against_numpy():
     assert rc == 0
     ref = np.linalg.solve(K, b)
     assert np.abs(sol - ref).max() <= 1e-8 * (1 + np.abs(ref).max())
+
+
+def test_oracle_stall_rule_stops_cycling_problems():
+    """exp_5 terrain (piecewise-constant heights): a foot that cycles across a ledge edge never meets
+    the tolerance.  With stall_iters = 5 (default) the solve stops five iterations after its best
+    iterate and returns it; with the rule off it runs to the iteration limit and ends no better."""
+    from oracle.oracle import Oracle
+    from qtos_amd import workloads
+    from qtos_amd.config import PlannerConfig
+    c = PlannerConfig.reference_compat()
+    hxy, cell = workloads.exp5_terrain()
+    start, goal = workloads.step_goals(256, seed=1, terrain=(hxy, cell))
+    O = Oracle(c.oracle_dict(), height=hxy, hcell=cell)
+    s, g = start[31], goal[31]
+    q = O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g, (0, 0, 0), (0, 0, 0), 0.0)
+    x5, i5 = O.solve(q)
+    o = O.default_options()
+    assert o.stall_iters == 5
+    o.stall_iters = 0
+    x0, i0 = O.solve(q, opts=o)
+    assert i5.status == 1 and i0.status == 1 and i5.iters < i0.iters == o.max_iter
+    assert i5.inf_pr <= i0.inf_pr + 1e-12 and abs(O.max_violation(x5) - i5.inf_pr) < 1e-12
