@@ -3,7 +3,8 @@
 //   k_start : initial guess (or warm start), constraint values, slack / barrier initialisation,
 //             first linearisation (per-instance dense Jacobian blocks G, barrier weights)
 //   k_kkt   : fused front assembly + block LDL^T (Schur-complement chain, 16 pivots per stage,
-//             front resident in LDS) + forward/backward substitution  -> Newton step dx
+//             assembled entries in LDS, Schur updates in MFMA accumulator registers) +
+//             forward/backward substitution  -> Newton step dx
 //   k_step  : slack/dual steps, fraction-to-the-boundary, backtracking on the l1 infeasibility,
 //             state update, convergence test, next linearisation
 //   k_sample: 1 kHz spline sampling into the 37-column CSV row layout
