@@ -939,6 +939,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   unsigned long long st0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_st0 = 0;
   unsigned long long st1[4] = {0, 0, 0, 0}, tl_st1 = 0;
   unsigned long long st7[4] = {0, 0, 0, 0}, tl_st7 = 0;
+  unsigned long long wcsum = 0;   // per wave: cycles from the start of phase C to its own arrival at the barrier
   if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st0) :: "memory");
 #endif
   constexpr int PFD2 = 2, PFS4 = 3;   // per-thread prefetch registers: 128-bit loads of a stage's records
@@ -1071,6 +1072,10 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     }
     lds_barrier();
     STAMPW(0, st0, 0);
+#ifdef QTOS_STAMPS
+    unsigned long long wc0 = 0;
+    if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wc0) :: "memory");
+#endif
     // ---- C(k) ---------------------------------------------------------------------------------------
     if (wv == 0) {
       if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV);
@@ -1199,8 +1204,17 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       STAMPW(7, st7, 0);
     }
     // every wave ends the phase with its share of the assembly of stage k+2 (nobody else touches A here)
-    if (k + 2 < NS) assemble_stage(A, F, sbuf, dbuf, tid, KT);
+    // (most stages have fewer items than threads, so the order of the waves matters: the waves with the
+    // most slack in this phase -- 7 right-hand side, 4 and 3 alone on their SIMD's matrix pipe, 0 --
+    // take the low item indices, the four update waves that share a matrix pipe come last)
+    if (k + 2 < NS) {
+      const int aslot = (0x07612543 >> (4 * wv)) & 7;   // wave -> position in the assembly order
+      assemble_stage(A, F, sbuf, dbuf, aslot * 64 + lane, KT);
+    }
     STAMPW(1, st1, 1);
+#ifdef QTOS_STAMPS
+    if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); wcsum += t_ - wc0; }
+#endif
     lds_barrier();
     if (k + 2 < NS) prow_next = psb[((k + 2) % 3) * PIV + li];   // pivot slot li of the stage after next
     STAMPW(0, st0, 2);
@@ -1267,6 +1281,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   if (tid == 0 && W.trace) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 30) * 4 + i] = (double)st0[i];
   if (tid == 64 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 32) * 4 + i] = (double)st1[i];
   if (tid == 448 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 33) * 4 + i] = (double)st7[i];
+  if (lane == 0 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 38) * 4 + wv] = (double)wcsum;
 #endif
 }
 

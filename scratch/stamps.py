@@ -30,3 +30,4 @@ print("k_step (iteration 1) cycles: ds %.0f | dz+reductions %.0f | line search %
 t = np.zeros((cfg.max_iter + 1, 4))
 P.lib.qtos_debug_trace(P.h, 0, t.ctypes.data_as(C.POINTER(C.c_double)))
 print("linearise phases (cycles): stage x %.0f | dynamics knots %.0f | dynamics columns %.0f | rom instances %.0f | rom columns %.0f | force/terrain/linear %.0f" % tuple(t[36:38].ravel()[:6]))
+print("phase C, cycles per stage until each wave reaches the barrier (waves 0..7):", (t[38:40].ravel() / NS).round(0))
