@@ -86,16 +86,32 @@ __device__ inline void sincos_t(D1 x, D1 &s, D1 &c) {
   s = {sv, cv * x.d};
   c = {cv, -sv * x.d};
 }
+// sines / cosines of the three Euler angles of one instance, computed once and shared by the value
+// pass and all forward-mode passes (sincos is by far the most expensive operation in them)
+struct Trig {
+  double s[3], c[3];
+};
+__device__ inline Trig trig_of(const double th[3]) {
+  Trig t;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sincos(th[i], &t.s[i], &t.c[i]);
+  return t;
+}
+__device__ inline void sincos_c(double, double sv, double cv, double &s, double &c) { s = sv; c = cv; }
+__device__ inline void sincos_c(D1 x, double sv, double cv, D1 &s, D1 &c) {
+  s = {sv, cv * x.d};
+  c = {cv, -sv * x.d};
+}
 __device__ inline double mk(double, double v) { return v; }
 __device__ inline D1 mk(D1, double v) { return {v, 0.0}; }
 
 // R = Rz(yaw) Ry(pitch) Rx(roll), th = (roll, pitch, yaw)
 template <class T>
-__device__ inline void rotation(const T th[3], T R[9]) {
+__device__ inline void rotation(const T th[3], const Trig &tg, T R[9]) {
   T sx, cx, sy, cy, sz, cz;
-  sincos_t(th[0], sx, cx);
-  sincos_t(th[1], sy, cy);
-  sincos_t(th[2], sz, cz);
+  sincos_c(th[0], tg.s[0], tg.c[0], sx, cx);
+  sincos_c(th[1], tg.s[1], tg.c[1], sy, cy);
+  sincos_c(th[2], tg.s[2], tg.c[2], sz, cz);
   R[0] = cy * cz; R[1] = cz * sx * sy - cx * sz; R[2] = sx * sz + cx * cz * sy;
   R[3] = cy * sz; R[4] = cx * cz + sx * sy * sz; R[5] = cx * sy * sz - cz * sx;
   R[6] = -sy;     R[7] = cy * sx;                R[8] = cx * cy;
@@ -104,10 +120,10 @@ __device__ inline void rotation(const T th[3], T R[9]) {
 // I_w wd + w x (I_w w) with I_w = R Ib R^T, w = M(th) thd, wd = Mdot thd + M thdd
 template <class T>
 __device__ inline void dyn_angular(const double *Ib, const T th[3], const T thd[3], const T thdd[3],
-                                   T out[3]) {
+                                   const Trig &tg, T out[3]) {
   T sy, cy, sz, cz;
-  sincos_t(th[1], sy, cy);
-  sincos_t(th[2], sz, cz);
+  sincos_c(th[1], tg.s[1], tg.c[1], sy, cy);
+  sincos_c(th[2], tg.s[2], tg.c[2], sz, cz);
   const T yd = thd[1], zd = thd[2];
   // w = M thd
   T w[3], wd[3];
@@ -122,7 +138,7 @@ __device__ inline void dyn_angular(const double *Ib, const T th[3], const T thd[
   wd[1] = m10 * thd[0] + m11 * thd[1] + cy * sz * thdd[0] + cz * thdd[1];
   wd[2] = m20 * thd[0] + thdd[2] - sy * thdd[0];
   T R[9];
-  rotation(th, R);
+  rotation(th, tg, R);
   // body-frame vectors u = R^T w, ud = R^T wd ; I_w v = R (Ib (R^T v))
   T u[3], ud[3];
   for (int i = 0; i < 3; ++i) {
@@ -219,12 +235,12 @@ constexpr int ROM_LOC = 18;  // R (9), d/dtheta_j [R^T (p - r)] as columns (9)
 // the local Jacobian data).  The nine forward-mode passes for the Euler-angle columns are separate
 // work items (eval_dyn_pass) so that ten threads share one knot.
 template <bool JAC>
-__device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double *x, double *g, double *loc) {
-  double r[3], a[3], th[3], thd[3], thdd[3];
+__device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double *x, double *g, double *loc,
+                                const double th[3], const double thd[3], const double thdd[3], const Trig &tg) {
+  double r[3], a[3];
   vec_eval(I.r, x, r); vec_eval(I.a, x, a);
-  vec_eval(I.th, x, th); vec_eval(I.thd, x, thd); vec_eval(I.thdd, x, thdd);
   double ga[3], gl[3];
-  dyn_angular<double>(P.Ib, th, thd, thdd, ga);
+  dyn_angular<double>(P.Ib, th, thd, thdd, tg, ga);
   gl[0] = P.mass * a[0]; gl[1] = P.mass * a[1]; gl[2] = P.mass * a[2] + P.mass * P.gravity;
   const bool jac = JAC && I.in_kkt;
   double sf[3] = {0, 0, 0};
@@ -251,10 +267,9 @@ __device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double
 // three forward-mode passes: d(angular rows) / d(theta (WHAT = 0), theta-dot (1), theta-ddot (2)).
 // WHAT is a compile-time constant so that the zero tangents fold away.
 template <int WHAT>
-__device__ inline void eval_dyn_pass(const DevPlan &P, const DynInst &I, const double *x, double *loc) {
+__device__ inline void eval_dyn_pass(const DevPlan &P, const DynInst &I, double *loc, const double th[3],
+                                     const double thd[3], const double thdd[3], const Trig &tg) {
   if (!I.in_kkt) return;
-  double th[3], thd[3], thdd[3];
-  vec_eval(I.th, x, th); vec_eval(I.thd, x, thd); vec_eval(I.thdd, x, thdd);
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     D1 t0[3], t1[3], t2[3], o[3];
@@ -264,7 +279,7 @@ __device__ inline void eval_dyn_pass(const DevPlan &P, const DynInst &I, const d
       t1[i] = {thd[i], (WHAT == 1 && i == j) ? 1.0 : 0.0};
       t2[i] = {thdd[i], (WHAT == 2 && i == j) ? 1.0 : 0.0};
     }
-    dyn_angular<D1>(P.Ib, t0, t1, t2, o);
+    dyn_angular<D1>(P.Ib, t0, t1, t2, tg, o);
 #pragma unroll
     for (int i = 0; i < 3; ++i) loc[9 * WHAT + 3 * i + j] = o[i].d;
   }
@@ -308,7 +323,8 @@ __device__ inline void eval_rom(const DevPlan &P, const RomInst &I, const double
   vec_eval(I.r, x, r); vec_eval(I.th, x, th); vec_eval(I.p, x, pe);
   const double d[3] = {pe[0] - r[0], pe[1] - r[1], pe[2] - r[2]};
   double R[9];
-  rotation<double>(th, R);
+  const Trig tg = trig_of(th);
+  rotation<double>(th, tg, R);
 #pragma unroll
   for (int i = 0; i < 3; ++i) g[I.row0 + i] = R[i] * d[0] + R[3 + i] * d[1] + R[6 + i] * d[2];
   if (JAC) {
@@ -320,7 +336,7 @@ __device__ inline void eval_rom(const DevPlan &P, const RomInst &I, const double
 #pragma unroll
       for (int i = 0; i < 3; ++i) t0[i] = {th[i], i == j ? 1.0 : 0.0};
       D1 Rd[9];
-      rotation<D1>(t0, Rd);
+      rotation<D1>(t0, tg, Rd);
 #pragma unroll
       for (int i = 0; i < 3; ++i) loc[9 + 3 * i + j] = Rd[i].d * d[0] + Rd[3 + i].d * d[1] + Rd[6 + i].d * d[2];
     }
@@ -407,10 +423,14 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
   if (JAC) {
     for (int i = tid; i < P.n_dyn; i += nt) {
       double *li = loc + (size_t)i * DYN_LOC;
-      eval_dyn<true>(P, P.dyn[i], x, g, li);
-      eval_dyn_pass<0>(P, P.dyn[i], x, li);
-      eval_dyn_pass<1>(P, P.dyn[i], x, li);
-      eval_dyn_pass<2>(P, P.dyn[i], x, li);
+      const DynInst &I = P.dyn[i];
+      double th[3], thd[3], thdd[3];
+      vec_eval(I.th, x, th); vec_eval(I.thd, x, thd); vec_eval(I.thdd, x, thdd);
+      const Trig tg = trig_of(th);   // shared by the value pass and the nine forward-mode passes
+      eval_dyn<true>(P, I, x, g, li, th, thd, thdd, tg);
+      eval_dyn_pass<0>(P, I, li, th, thd, thdd, tg);
+      eval_dyn_pass<1>(P, I, li, th, thd, thdd, tg);
+      eval_dyn_pass<2>(P, I, li, th, thd, thdd, tg);
     }
     __syncthreads();
     ESTAMP();
@@ -425,7 +445,12 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
     __syncthreads();
     ESTAMP();
   } else {
-    for (int i = tid; i < P.n_dyn; i += nt) eval_dyn<false>(P, P.dyn[i], x, g, nullptr);
+    for (int i = tid; i < P.n_dyn; i += nt) {
+      const DynInst &I = P.dyn[i];
+      double th[3], thd[3], thdd[3];
+      vec_eval(I.th, x, th); vec_eval(I.thd, x, thd); vec_eval(I.thdd, x, thdd);
+      eval_dyn<false>(P, I, x, g, nullptr, th, thd, thdd, trig_of(th));
+    }
   }
   for (int i = tid; i < P.n_rom; i += nt) eval_rom<JAC>(P, P.rom[i], x, g, JAC ? loc + (size_t)i * ROM_LOC : nullptr);
   if (JAC) {
@@ -472,8 +497,10 @@ __device__ inline double wg_reduce(double v, double *scratch) {
 }
 
 // barrier weights of every inequality row: sig = zl/(s-l) + zu/(u-s), w = sig (g - s) - mu/(s-l) + mu/(u-s)
-__device__ inline void barrier_terms(const DevPlan &P, const double *g, const double *s, const double *zl,
-                                     const double *zu, double mu, double *sig, double *w, double *stream) {
+__device__ inline void barrier_terms(const DevPlan &P, const double *__restrict__ g, const double *__restrict__ s,
+                                     const double *__restrict__ zl, const double *__restrict__ zu, double mu,
+                                     double *__restrict__ sig, double *__restrict__ w, double *__restrict__ stream) {
+#pragma unroll 3
   for (int r = threadIdx.x; r < P.n_cons; r += blockDim.x) {
     if (P.row_kind[r] == 1) { stream[P.rhs_pos[r]] = -g[r]; continue; }
     if (P.row_kind[r] != 2) continue;
@@ -1293,11 +1320,12 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   __shared__ double scratch[256];
   extern __shared__ double evl[];
   const int n = P.n_vars, m = P.n_cons, tid = threadIdx.x;
-  double *x = W.x + (size_t)b * n, *xt = W.xt + (size_t)b * n, *dx = W.dx + (size_t)b * n;
-  double *g = W.g + (size_t)b * m, *gt = W.gt + (size_t)b * m;
-  double *s = W.s + (size_t)b * m, *zl = W.zl + (size_t)b * m, *zu = W.zu + (size_t)b * m;
-  double *ds = W.ds + (size_t)b * m, *dzl = W.dzl + (size_t)b * m, *dzu = W.dzu + (size_t)b * m;
-  const double *G = W.stream + (size_t)b * P.stream_len;
+  // distinct buffers: __restrict__ lets the row loops below keep several rows' loads in flight
+  double *__restrict__ x = W.x + (size_t)b * n, *__restrict__ xt = W.xt + (size_t)b * n, *__restrict__ dx = W.dx + (size_t)b * n;
+  double *__restrict__ g = W.g + (size_t)b * m, *__restrict__ gt = W.gt + (size_t)b * m;
+  double *__restrict__ s = W.s + (size_t)b * m, *__restrict__ zl = W.zl + (size_t)b * m, *__restrict__ zu = W.zu + (size_t)b * m;
+  double *__restrict__ ds = W.ds + (size_t)b * m, *__restrict__ dzl = W.dzl + (size_t)b * m, *__restrict__ dzu = W.dzu + (size_t)b * m;
+  const double *__restrict__ G = W.stream + (size_t)b * P.stream_len;
   const int map = W.map_id ? W.map_id[b] : 0;
   double mu = W.mu[b];
   const double best_viol = W.best_viol[b];   // read before anybody writes them (tid 0, end of the kernel)
@@ -1331,6 +1359,7 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   KSTAMP(0);
   const double tau = fmax(0.99, 1.0 - mu);
   double amax = 1.0, az = 1.0;
+#pragma unroll 3
   for (int r = tid; r < m; r += blockDim.x) {
     if (P.row_kind[r] != 2) continue;
     const double l = P.con_lo[r], u = P.con_hi[r];
@@ -1363,6 +1392,7 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   }
   KSTAMP(2);
   for (int v = tid; v < n; v += blockDim.x) x[v] = xt[v];
+#pragma unroll 3
   for (int r = tid; r < m; r += blockDim.x) {
     g[r] = gt[r];
     if (P.row_kind[r] != 2) continue;
