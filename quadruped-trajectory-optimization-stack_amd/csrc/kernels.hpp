@@ -173,6 +173,36 @@ __device__ inline void vec_eval(const VecIn &in, const double *x, double out[3])
   }
 }
 
+// Pre-pass of the spline inputs: one work item per (instance, input vector, component), so that the
+// instance descriptors (about 1 KB per dynamics knot) are read coalesced by the whole workgroup
+// instead of being chased by one thread per instance.  The VecIn records are the leading members of
+// the instance structs.  Same summation order as vec_eval.
+__device__ inline void vec_prepass(const void *inst0, int inst_bytes, int n_inst, int n_vec, const double *x,
+                                   double *out) {
+  const int per = 3 * n_vec, total = n_inst * per, nt = blockDim.x;
+  constexpr int UN = 4;   // work items per thread and round: all descriptor reads of a round are in flight together
+  for (int base = threadIdx.x; base < total; base += UN * nt) {
+    int var[UN][4];
+    double w[UN][4];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int idx = min(base + u * nt, total - 1);
+      const int i = idx / per, rem = idx - i * per, v = rem / 3, d = rem - 3 * v;
+      const VecIn &in = *(const VecIn *)((const char *)inst0 + (size_t)i * inst_bytes + (size_t)v * sizeof(VecIn));
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { var[u][a] = in.var[3 * a + d]; w[u][a] = in.w[a]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      double acc = 0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        if (var[u][a] >= 0) acc += w[u][a] * x[var[u][a]];
+      if (base + u * nt < total) out[base + u * nt] = acc;
+    }
+  }
+}
+
 struct Terr {
   double h, hx, hy, hxy;
 };
@@ -235,10 +265,10 @@ constexpr int ROM_LOC = 18;  // R (9), d/dtheta_j [R^T (p - r)] as columns (9)
 // the local Jacobian data).  The nine forward-mode passes for the Euler-angle columns are separate
 // work items (eval_dyn_pass) so that ten threads share one knot.
 template <bool JAC>
-__device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double *x, double *g, double *loc,
+__device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double *vin, double *g, double *loc,
                                 const double th[3], const double thd[3], const double thdd[3], const Trig &tg) {
-  double r[3], a[3];
-  vec_eval(I.r, x, r); vec_eval(I.a, x, a);
+  // vin: the 13 spline inputs of the knot evaluated by the pre-pass: r a th thd thdd p[0..3] f[0..3]
+  const double r[3] = {vin[0], vin[1], vin[2]}, a[3] = {vin[3], vin[4], vin[5]};
   double ga[3], gl[3];
   dyn_angular<double>(P.Ib, th, thd, thdd, tg, ga);
   gl[0] = P.mass * a[0]; gl[1] = P.mass * a[1]; gl[2] = P.mass * a[2] + P.mass * P.gravity;
@@ -246,9 +276,7 @@ __device__ inline void eval_dyn(const DevPlan &P, const DynInst &I, const double
   double sf[3] = {0, 0, 0};
 #pragma unroll
   for (int e = 0; e < NEE; ++e) {
-    double pe[3], f[3];
-    vec_eval(I.p[e], x, pe);
-    vec_eval(I.f[e], x, f);
+    const double *pe = vin + 15 + 3 * e, *f = vin + 27 + 3 * e;
     const double d[3] = {r[0] - pe[0], r[1] - pe[1], r[2] - pe[2]};
     // tau_sum += f x (r - p)
     ga[0] -= f[1] * d[2] - f[2] * d[1];
@@ -318,9 +346,9 @@ __device__ inline void dyn_column(const DevPlan &P, const ColDesc &C, const doub
 }
 
 template <bool JAC>
-__device__ inline void eval_rom(const DevPlan &P, const RomInst &I, const double *x, double *g, double *loc) {
-  double r[3], th[3], pe[3];
-  vec_eval(I.r, x, r); vec_eval(I.th, x, th); vec_eval(I.p, x, pe);
+__device__ inline void eval_rom(const DevPlan &P, const RomInst &I, const double *vin, double *g, double *loc) {
+  // vin: r th p evaluated by the pre-pass
+  const double *r = vin, *th = vin + 3, *pe = vin + 6;
   const double d[3] = {pe[0] - r[0], pe[1] - r[1], pe[2] - r[2]};
   double R[9];
   const Trig tg = trig_of(th);
@@ -406,6 +434,7 @@ __device__ inline void eval_force(const DevPlan &P, const ForceInst &I, int map,
 // of chasing indices through global memory), followed by the local Jacobian data of the dynamics /
 // range-of-motion instances
 __device__ __forceinline__ int eval_loc_offset(int n_vars) { return (n_vars + 1) & ~1; }
+constexpr int DYN_VIN = 39, ROM_VIN = 9;   // pre-evaluated spline inputs per instance
 template <bool JAC>
 __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, double *g, double *G, double *lds, double *dbg = nullptr) {
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -417,17 +446,19 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
 #define ESTAMP() do {} while (0)
 #endif
   double *x = lds, *loc = lds + eval_loc_offset(P.n_vars);
+  double *vin = loc + max(DYN_LOC * P.n_dyn, ROM_LOC * P.n_rom);
   for (int v = tid; v < P.n_vars; v += nt) x[v] = xg[v];
+  __syncthreads();
+  vec_prepass(P.dyn, (int)sizeof(DynInst), P.n_dyn, 13, x, vin);
   __syncthreads();
   ESTAMP();
   if (JAC) {
     for (int i = tid; i < P.n_dyn; i += nt) {
       double *li = loc + (size_t)i * DYN_LOC;
       const DynInst &I = P.dyn[i];
-      double th[3], thd[3], thdd[3];
-      vec_eval(I.th, x, th); vec_eval(I.thd, x, thd); vec_eval(I.thdd, x, thdd);
+      const double *vi = vin + (size_t)i * DYN_VIN, *th = vi + 6, *thd = vi + 9, *thdd = vi + 12;
       const Trig tg = trig_of(th);   // shared by the value pass and the nine forward-mode passes
-      eval_dyn<true>(P, I, x, g, li, th, thd, thdd, tg);
+      eval_dyn<true>(P, I, vi, g, li, th, thd, thdd, tg);
       eval_dyn_pass<0>(P, I, li, th, thd, thdd, tg);
       eval_dyn_pass<1>(P, I, li, th, thd, thdd, tg);
       eval_dyn_pass<2>(P, I, li, th, thd, thdd, tg);
@@ -447,12 +478,16 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
   } else {
     for (int i = tid; i < P.n_dyn; i += nt) {
       const DynInst &I = P.dyn[i];
-      double th[3], thd[3], thdd[3];
-      vec_eval(I.th, x, th); vec_eval(I.thd, x, thd); vec_eval(I.thdd, x, thdd);
-      eval_dyn<false>(P, I, x, g, nullptr, th, thd, thdd, trig_of(th));
+      const double *vi = vin + (size_t)i * DYN_VIN, *th = vi + 6, *thd = vi + 9, *thdd = vi + 12;
+      eval_dyn<false>(P, I, vi, g, nullptr, th, thd, thdd, trig_of(th));
     }
+    ESTAMP();
   }
-  for (int i = tid; i < P.n_rom; i += nt) eval_rom<JAC>(P, P.rom[i], x, g, JAC ? loc + (size_t)i * ROM_LOC : nullptr);
+  __syncthreads();   // the dynamics knots are done with vin
+  vec_prepass(P.rom, (int)sizeof(RomInst), P.n_rom, 3, x, vin);
+  __syncthreads();
+  for (int i = tid; i < P.n_rom; i += nt) eval_rom<JAC>(P, P.rom[i], vin + (size_t)i * ROM_VIN, g, JAC ? loc + (size_t)i * ROM_LOC : nullptr);
+  if (!JAC) ESTAMP();
   if (JAC) {
     __syncthreads();
     ESTAMP();
@@ -1384,7 +1419,7 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   for (int ls = 0; ls < 6; ++ls) {
     for (int v = tid; v < n; v += blockDim.x) xt[v] = x[v] + al * dx[v];
     __syncthreads();
-    eval_all<false>(P, map, xt, gt, nullptr, evl);
+    eval_all<false>(P, map, xt, gt, nullptr, evl, (W.trace && it == 1 && ls == 0) ? W.trace + ((size_t)b * (P.max_iter + 1) + 40) * 4 : nullptr);
     __syncthreads();
     th = l1_infeasibility(P, gt, s, ds, al, scratch);
     if (th <= (1.0 - 1e-4 * al) * th0 || th < 1e-9) break;

@@ -190,7 +190,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
   }
-  p->eval_lds = sizeof(double) * (((size_t)M.n_vars + 1) / 2 * 2 + std::max((size_t)DYN_LOC * M.dyn.size(), (size_t)ROM_LOC * M.rom.size()));
+  p->eval_lds = sizeof(double) * (((size_t)M.n_vars + 1) / 2 * 2 + std::max((size_t)DYN_LOC * M.dyn.size(), (size_t)ROM_LOC * M.rom.size()) +
+                                  std::max((size_t)DYN_VIN * M.dyn.size(), (size_t)ROM_VIN * M.rom.size()));
   if (p->eval_lds > 150 * 1024) { p->err = "too many dynamics knots for the LDS scratch"; qtos_planner_destroy(p); return -4; }
   for (const void *fn : {(const void *)k_start, (const void *)k_step, (const void *)k_debug_eval})
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->eval_lds) != hipSuccess) { qtos_planner_destroy(p); return -2; }

@@ -31,3 +31,4 @@ t = np.zeros((cfg.max_iter + 1, 4))
 P.lib.qtos_debug_trace(P.h, 0, t.ctypes.data_as(C.POINTER(C.c_double)))
 print("linearise phases (cycles): stage x %.0f | dynamics knots %.0f | dynamics columns %.0f | rom instances %.0f | rom columns %.0f | force/terrain/linear %.0f" % tuple(t[36:38].ravel()[:6]))
 print("phase C, cycles per stage until each wave reaches the barrier (waves 0..7):", (t[38:40].ravel() / NS).round(0))
+print("line-search evaluation phases (cycles): stage x %.0f | dynamics knots %.0f | rom instances %.0f | force/terrain/linear %.0f" % tuple(t[40:42].ravel()[:4]))
