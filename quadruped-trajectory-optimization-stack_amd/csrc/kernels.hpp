@@ -1267,10 +1267,10 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     }
     // every wave ends the phase with its share of the assembly of stage k+2 (nobody else touches A here)
     // (most stages have fewer items than threads, so the order of the waves matters: the waves with the
-    // most slack in this phase -- 7 right-hand side, 4 and 3 alone on their SIMD's matrix pipe, 0 --
+    // most slack in this phase (measured per wave: 7, 3, 0, 2, then 1, 6, 4, 5)
     // take the low item indices, the four update waves that share a matrix pipe come last)
     if (k + 2 < NS) {
-      const int aslot = (0x07612543 >> (4 * wv)) & 7;   // wave -> position in the assembly order
+      const int aslot = (0x05761342 >> (4 * wv)) & 7;   // wave -> position in the assembly order
       assemble_stage(A, F, sbuf, dbuf, aslot * 64 + lane, KT);
     }
     STAMPW(1, st1, 1);
