@@ -34,6 +34,11 @@ struct DevPlan {
   const int *block_cols;
   const IqRow *iq_rows;   // rows of the inequality blocks (stream offsets)
   int n_iq_rows;
+  // compact row lists of the working set (the row loops of k_step run over these, branch-free):
+  // inequality rows with their bounds, equality rows
+  const int *iq_idx, *eq_idx;
+  const double *iq_lo, *iq_hi;
+  int n_iq, n_eqw;
   const double *g_static;
   const int *piv_slot, *piv_unknown;
   const double *piv_diag;
@@ -535,11 +540,15 @@ __device__ inline double wg_reduce(double v, double *scratch) {
 __device__ inline void barrier_terms(const DevPlan &P, const double *__restrict__ g, const double *__restrict__ s,
                                      const double *__restrict__ zl, const double *__restrict__ zu, double mu,
                                      double *__restrict__ sig, double *__restrict__ w, double *__restrict__ stream) {
-#pragma unroll 3
-  for (int r = threadIdx.x; r < P.n_cons; r += blockDim.x) {
-    if (P.row_kind[r] == 1) { stream[P.rhs_pos[r]] = -g[r]; continue; }
-    if (P.row_kind[r] != 2) continue;
-    const double l = P.con_lo[r], u = P.con_hi[r];
+#pragma unroll 4
+  for (int i = threadIdx.x; i < P.n_eqw; i += blockDim.x) {
+    const int r = P.eq_idx[i];
+    stream[P.rhs_pos[r]] = -g[r];
+  }
+#pragma unroll 4
+  for (int i = threadIdx.x; i < P.n_iq; i += blockDim.x) {
+    const int r = P.iq_idx[i];
+    const double l = P.iq_lo[i], u = P.iq_hi[i];
     const bool hl = l > -1e19, hu = u < 1e19;
     const double dl = hl ? s[r] - l : 1.0, du = hu ? u - s[r] : 1.0;
     const double sg = (hl ? zl[r] / dl : 0.0) + (hu ? zu[r] / du : 0.0);
@@ -553,31 +562,37 @@ __device__ inline void barrier_terms(const DevPlan &P, const double *__restrict_
 }
 
 // max violation of the working rows (viol) and of the slack form (theta)
-__device__ inline void infeasibility(const DevPlan &P, const double *g, const double *s, double *scratch,
-                                     double &viol, double &theta) {
+__device__ inline void infeasibility(const DevPlan &P, const double *__restrict__ g, const double *__restrict__ s,
+                                     double *scratch, double &viol, double &theta) {
   double v = 0, t = 0;
-  for (int r = threadIdx.x; r < P.n_cons; r += blockDim.x) {
-    const int k = P.row_kind[r];
-    if (k == 0) continue;
-    const double gr = g[r];
-    if (!(gr == gr) || !(s[r] == s[r])) { v = t = INFINITY; continue; }   // fmax would swallow a NaN
-    if (k == 1) { v = fmax(v, fabs(gr)); t = fmax(t, fabs(gr)); }
-    else {
-      v = fmax(v, fmax(P.con_lo[r] - gr, gr - P.con_hi[r]));
-      t = fmax(t, fabs(gr - s[r]));
-    }
+#pragma unroll 4
+  for (int i = threadIdx.x; i < P.n_eqw; i += blockDim.x) {
+    const double gr = g[P.eq_idx[i]];
+    if (!(gr == gr)) { v = t = INFINITY; continue; }   // fmax would swallow a NaN
+    v = fmax(v, fabs(gr));
+    t = fmax(t, fabs(gr));
+  }
+#pragma unroll 4
+  for (int i = threadIdx.x; i < P.n_iq; i += blockDim.x) {
+    const int r = P.iq_idx[i];
+    const double gr = g[r], sr = s[r];
+    if (!(gr == gr) || !(sr == sr)) { v = t = INFINITY; continue; }
+    v = fmax(v, fmax(P.iq_lo[i] - gr, gr - P.iq_hi[i]));
+    t = fmax(t, fabs(gr - sr));
   }
   viol = wg_reduce<1>(v, scratch);
   theta = wg_reduce<1>(t, scratch);
 }
 
-__device__ inline double l1_infeasibility(const DevPlan &P, const double *g, const double *s, const double *ds,
-                                          double al, double *scratch) {
+__device__ inline double l1_infeasibility(const DevPlan &P, const double *__restrict__ g, const double *__restrict__ s,
+                                          const double *__restrict__ ds, double al, double *scratch) {
   double t = 0;
-  for (int r = threadIdx.x; r < P.n_cons; r += blockDim.x) {
-    const int k = P.row_kind[r];
-    if (k == 1) t += fabs(g[r]);
-    else if (k == 2) t += fabs(g[r] - (s[r] + al * ds[r]));
+#pragma unroll 4
+  for (int i = threadIdx.x; i < P.n_eqw; i += blockDim.x) t += fabs(g[P.eq_idx[i]]);
+#pragma unroll 4
+  for (int i = threadIdx.x; i < P.n_iq; i += blockDim.x) {
+    const int r = P.iq_idx[i];
+    t += fabs(g[r] - (s[r] + al * ds[r]));
   }
   return wg_reduce<0>(t, scratch);
 }
@@ -1394,10 +1409,10 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   KSTAMP(0);
   const double tau = fmax(0.99, 1.0 - mu);
   double amax = 1.0, az = 1.0;
-#pragma unroll 3
-  for (int r = tid; r < m; r += blockDim.x) {
-    if (P.row_kind[r] != 2) continue;
-    const double l = P.con_lo[r], u = P.con_hi[r];
+#pragma unroll 4
+  for (int i = tid; i < P.n_iq; i += blockDim.x) {
+    const int r = P.iq_idx[i];
+    const double l = P.iq_lo[i], u = P.iq_hi[i];
     const bool hl = l > -1e19, hu = u < 1e19;
     const double dl = hl ? s[r] - l : 1.0, du = hu ? u - s[r] : 1.0;
     const double d = ds[r];
@@ -1427,11 +1442,12 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   }
   KSTAMP(2);
   for (int v = tid; v < n; v += blockDim.x) x[v] = xt[v];
-#pragma unroll 3
-  for (int r = tid; r < m; r += blockDim.x) {
-    g[r] = gt[r];
-    if (P.row_kind[r] != 2) continue;
-    const double l = P.con_lo[r], u = P.con_hi[r];
+#pragma unroll 4
+  for (int r = tid; r < m; r += blockDim.x) g[r] = gt[r];
+#pragma unroll 4
+  for (int i = tid; i < P.n_iq; i += blockDim.x) {
+    const int r = P.iq_idx[i];
+    const double l = P.iq_lo[i], u = P.iq_hi[i];
     const bool hl = l > -1e19, hu = u < 1e19;
     const double sn = s[r] + al * ds[r];
     s[r] = sn;

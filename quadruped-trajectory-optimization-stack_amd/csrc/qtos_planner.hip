@@ -146,6 +146,17 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     D.n_iq_rows = (int)rows.size();
     TRY(p->upload(rows, &D.iq_rows));
   }
+  {
+    std::vector<int> iq, eq;
+    std::vector<double> lo, hi;
+    for (int r = 0; r < M.n_cons; ++r) {
+      if (M.row_kind[r] == 2) { iq.push_back(r); lo.push_back(M.con_lo[r]); hi.push_back(M.con_hi[r]); }
+      else if (M.row_kind[r] == 1) eq.push_back(r);
+    }
+    D.n_iq = (int)iq.size(); D.n_eqw = (int)eq.size();
+    TRY(p->upload(iq, &D.iq_idx)); TRY(p->upload(eq, &D.eq_idx));
+    TRY(p->upload(lo, &D.iq_lo)); TRY(p->upload(hi, &D.iq_hi));
+  }
   TRY(p->upload(M.g_static, &D.g_static));
   TRY(p->upload(S.piv_slot, &D.piv_slot)); TRY(p->upload(S.piv_unknown, &D.piv_unknown));
   TRY(p->upload(S.piv_diag, &D.piv_diag)); TRY(p->upload(S.stages, &D.stages));
