@@ -136,7 +136,8 @@ int qtos_debug_newton(QtosPlanner *p, int B, const double *start, const double *
  * var_free[n_vars] (0/1), unknown order[n_unknowns] (var index, or n_vars + row for multipliers) */
 int qtos_debug_structure(const QtosPlanner *p, int *row_kind, int *var_free, int *order);
 /* factor panels of problem b after the last KKT solve (n_stages x (front + 1) x 16 doubles: per stage
- * w = L^-T D^-1 y_F (16) then V = Y D^-1 L^-1 by front slot) and the pivot slots (n_stages x 16) */
+ * w = L^-T D^-1 y_F (16) then V = Y D^-1 L^-1 by front slot, column c of a row stored at
+ * 4 (c & 3) + (c >> 2)) and the pivot slots (n_stages x 16) */
 int qtos_debug_factor(QtosPlanner *p, int b, double *panel_out, int *piv_slot_out);
 /* per-iteration trace of the last plan call for problem b: rows of (viol, theta, alpha, mu),
  * at most max_iter rows; returns the number of rows */

@@ -247,6 +247,9 @@ class Planner:
         pan = np.zeros((d.n_stages, d.front + 1, 16))
         ps = np.zeros((d.n_stages, 16), dtype=np.int32)
         self._chk(self.lib.qtos_debug_factor(self.h, b, _dp(pan), _ip(ps)), "qtos_debug_factor")
+        # in memory column c of a V row sits at 4 (c & 3) + (c >> 2) (32 contiguous bytes per lane on the store)
+        cols = np.array([4 * (c & 3) + (c >> 2) for c in range(16)])
+        pan[:, 1:, :] = pan[:, 1:, :][:, :, cols]
         return pan, ps
 
     def trace(self, b):

@@ -1094,12 +1094,10 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         av[s4] = A[aidx[s4]];
       }
       const double dgn = dgb[((k + 1) % 3) * PIV + li];
-      d4_t yt = {0.0, 0.0, 0.0, 0.0}, zt = {0.0, 0.0, 0.0, 0.0};
+      d4_t yt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
+      for (int s4 = 0; s4 < 4; ++s4)
         yt = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], pr[s4], yt, 0, 0, 0);   // yt[g] = Y[16R+li][lk+4g]
-        zt = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], pp[s4], zt, 0, 0, 0);   // zt[g] = Y[piv_li][lk+4g]
-      }
       STAMPW(0, st0, 6);
       // next pivot columns: assembled entries (read here, retired below), extracted Schur updates,
       // pivot diagonal; an entry between two pivots of stage k+1 is taken once, by the lane whose row
@@ -1116,19 +1114,21 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       double ya[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) ya[g] = yt[g] * dn[g];
+      // V^T = (D^-1 L^-1)^T Y^T in accumulator layout: vt[g] = V[16R+li][lk+4g], which is V itself as
+      // the A operand of the next product:  Y D^-1 Y[piv]^T = Y D^-1 L^-1 P[piv]^T = V P[piv]^T, so
+      // the raw rows of the next pivots serve as B operand (no Y[piv] to compute or to share)
       d4_t vt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        vt = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[s4], lb[s4], vt, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-ya[s4], zt[s4], acc, 0, 0, 0);
-      }
+      for (int s4 = 0; s4 < 4; ++s4) vt = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[s4], ya[s4], vt, 0, 0, 0);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-vt[s4], pp[s4], acc, 0, 0, 0);
       STAMPW(0, st0, 7);
       // Y rows of the next pivots are stored as zeros: their rows/columns of U were extracted (and
       // zeroed) one stage ago and must not be touched by this stage's update any more
       const bool myrowpiv = has_next && ((grp16(m1, R) >> li) & 1u);
       if (wv == 0 && has_next) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) red[(lk + 4 * g) * PIV + li] = zt[g];   // ZT[q][j] = Y[piv_j][q] for wave 7
+        for (int g = 0; g < 4; ++g) red[(lk + 4 * g) * PIV + li] = pp[g];   // PT[q][j] = P[piv_j][q] for wave 7
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       if (16 * R < hi16) {
         double *pv = panel + (size_t)k * pstride + PIV;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pv[(16 * R + lk + 4 * g) * PIV + li] = vt[g];
+        for (int g = 0; g < 4; ++g) pv[(16 * R + li) * PIV + 4 * lk + g] = vt[g];   // column c of a row sits at 4 (c & 3) + (c >> 2): 32 contiguous bytes per lane
       }
     }
     if (wv == 7 && lane < PIV && has_next) {   // assembled right-hand side of the next pivots (read and retired)
@@ -1269,9 +1269,11 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         UF[lane] = uf0 - a0;          // rows beyond the stage's range have Y = 0
         UF[lane + 64] = lane + 64 < F ? uf1 - a1 : 0.0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        double corr = 0.0;   // this stage's update of the next pivots' right-hand side (their Y rows are zero in LDS)
+        // this stage's update of the next pivots' right-hand side (their Y rows are zero in LDS):
+        // (y_F D^-1) Y[piv_j] = (y_F D^-1 L^-1) P[piv_j] = w . P[piv_j]
+        double corr = 0.0;
 #pragma unroll
-        for (int q = 0; q < PIV; ++q) corr = fma(ydq[q], red[q * PIV + li], corr);
+        for (int c = 0; c < PIV; ++c) corr = fma(__shfl(wsum, c), red[c * PIV + li], corr);
         if (lane < PIV) {
           const int c = prow_next;
           Xn[F * PLD + lane] += UF[c] - corr;
@@ -1313,7 +1315,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       const int kk = max(k, 0);
       const double *pk = panel + (size_t)kk * pstride;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = pk[PIV + min(16 * wv + q + 4 * i, F - 1) * PIV + j];
+      for (int i = 0; i < 4; ++i) v[i] = pk[PIV + min(16 * wv + q + 4 * i, F - 1) * PIV + 4 * (j & 3) + (j >> 2)];
       wj = pk[j];
       psj = P.piv_slot[kk * PIV + j];
       unkj = P.piv_unknown[kk * PIV + j];
