@@ -1138,8 +1138,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       }
       if (16 * R < hi16) {
         double *pv = panel + (size_t)k * pstride + PIV;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pv[(16 * R + li) * PIV + 4 * lk + g] = vt[g];   // column c of a row sits at 4 (c & 3) + (c >> 2): 32 contiguous bytes per lane
+        *(d4_t *)(pv + (16 * R + li) * PIV + 4 * lk) = vt;   // column c of a row sits at 4 (c & 3) + (c >> 2): 32 contiguous bytes per lane
       }
     }
     if (wv == 7 && lane < PIV && has_next) {   // assembled right-hand side of the next pivots (read and retired)
