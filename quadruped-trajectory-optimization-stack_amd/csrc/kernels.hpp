@@ -702,14 +702,15 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
 //   HBM   per stage V_k = Y_k D^-1 L^-1 (hi x 16) and w_k = L^-T D^-1 y_F: all the backward pass needs
 //
 // Two phases per stage, two LDS-only barriers:
-//   AB(k)  every wave owns one 16-row tile R of the panel: Y = P L^-T, the rows of the next pivots
-//          Y[piv_{k+1}] (recomputed by every wave: an MFMA accumulator IS a valid A/B operand, so no
-//          LDS round trip and no barrier between the products), the next pivot columns
-//          P_{k+1} = A[:, piv] + U[:, piv] - Y D^-1 Y[piv]^T, and V -> HBM.  16 MFMAs per wave.
+//   AB(k)  every wave owns one 16-row tile R of the panel, three chained products of 4 MFMAs (an MFMA
+//          accumulator IS a valid A/B operand of the next MFMA: no LDS round trip, no barrier between
+//          them): Y^T = L^-1 P^T;  V^T = (D^-1 L^-1)^T Y^T, which in accumulator layout is V as an A
+//          operand (and goes to HBM);  P_{k+1} = A[:, piv] + U[:, piv] - V P_k[piv]^T, because
+//          Y D^-1 Y[piv]^T = V P[piv]^T: the raw rows of the next pivots are the B operand.
 //   C(k)   wave 0: in-register LDL^T + L^-1 of the next 16 x 16 pivot block (DPP row broadcasts);
 //          waves 1..6: U -= Y D^-1 Y^T on the matrix cores, retire the next pivots' rows/columns,
-//          extract the columns of stage k+2, then assemble stage k+2's records into A;
-//          wave 7: right-hand-side row (y_F, w, updates).
+//          extract the columns of stage k+2;  wave 7: right-hand-side row (y_F, w, updates);
+//          every wave ends with its share of the assembly of stage k+2's records into A.
 // The backward pass is one barrier per stage: every wave reduces its 16 rows of V^T x against the
 // solution, partial sums meet in LDS, every wave forms the 16 new solution entries redundantly.
 constexpr int KT = 512;
@@ -1071,7 +1072,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     }
     STAMPW(0, st0, 5);
     // ---- AB(k): one 16-row panel tile per wave.  All LDS reads are issued up front (no lane-dependent
-    //      branches around loads), then the 16 MFMAs, then the stores. --------------------------------
+    //      branches around loads), then the 12 MFMAs, then the stores. --------------------------------
     const int hi16 = (hib[k % 3] + 15) & ~15;
     const Mask128 m1 = load_mask(pm + ((k + 1) & 1) * 4, lane);   // pivot slots of stage k+1
     if (wv < NT) {
