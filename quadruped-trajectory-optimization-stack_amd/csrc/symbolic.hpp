@@ -7,9 +7,10 @@
 // variable-band ("skyline") matrix: long-lived unknowns (a stance foothold is coupled to every base
 // node of its stance) sit at the END of their life so they only lengthen their own row.  The chain
 // is cut into stages of PIV consecutive pivots; stage k's front = its pivots + every later unknown
-// whose row reaches back into the eliminated range.  Each unknown is given ONE slot of the
-// LDS-resident front for its whole life, so Schur complements are applied in place and nothing is
-// ever copied between stages (slots of eliminated pivots are recycled).
+// whose row reaches back into the eliminated range.  Each unknown is given ONE slot of the front
+// (assembled entries in LDS, Schur updates in the MFMA accumulator registers of k_kkt) for its whole
+// life, so Schur complements are applied in place and nothing is ever copied between stages (slots
+// of eliminated pivots are recycled).
 #pragma once
 #include <algorithm>
 #include <map>
