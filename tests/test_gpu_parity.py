@@ -495,3 +495,68 @@ def test_stall_detection_returns_best_iterate(cfg):
     ok = status == 0
     assert np.array_equal(status0 == 0, ok) and np.array_equal(nodes0[ok], nodes[ok]) and np.array_equal(iters0[ok], iters[ok])
     assert (iters0[stuck] == cfg.max_iter).all()
+
+
+@pytest.mark.gpu
+def test_factor_panels_match_block_elimination(planner, oracle, gv1, cfg):
+    """The factor panels k_kkt leaves in HBM (per stage w = L^-T D^-1 y_F and V = Y D^-1 L^-1) against
+    an independent numpy block elimination of the same KKT matrix in the planner's elimination order
+    (16 pivots per stage, unpivoted LDL^T of the pivot block, explicit L^-1), stage by stage: this
+    pins the chain itself, not only the solution it produces.  Tolerance 1e-6 relative to the stage's
+    largest entry (the factors reach 1e8 where a multiplier is eliminated)."""
+    rng = np.random.default_rng(5)
+    inp = gv1["inputs"]
+    x = gv1["x"][None] + 0.01 * rng.standard_normal((1, planner.n))
+    lo, hi = oracle.var_bounds(oracle_problem(oracle, inp))
+    fx = lo == hi
+    x[:, fx] = lo[fx]
+    start, goal = start_vector(inp)[None], np.array(inp["g"])[None]
+    rk, _, order = planner.structure()
+    I = rk == 2
+    sig = np.zeros((1, planner.m)); w = np.zeros((1, planner.m))
+    sig[:, I] = 10.0 ** rng.uniform(-3, 3, (1, I.sum())); w[:, I] = rng.standard_normal((1, I.sum()))
+    dx = planner.debug_newton(start, goal, x, sig, w)
+    pan, ps = planner.factor(0)
+    free, E, Ii = np.nonzero(~fx)[0], np.nonzero(rk == 1)[0], np.nonzero(I)[0]
+    nf, nE = len(free), len(E)
+    Jo, go = oracle.jacobian(x[0]), oracle.constraints(x[0])
+    JE, JI = Jo[np.ix_(E, free)], Jo[np.ix_(Ii, free)]
+    K = np.zeros((nf + nE, nf + nE))
+    K[:nf, :nf] = cfg.delta_x * np.eye(nf) + JI.T @ (sig[0, Ii][:, None] * JI)
+    K[nf:, :nf] = JE; K[:nf, nf:] = JE.T; K[nf:, nf:] = -cfg.eps_dual * np.eye(nE)
+    rhs = np.concatenate([-JI.T @ w[0, Ii], -go[E]])
+    pos_of_var = {v: i for i, v in enumerate(free)}
+    pos_of_row = {r: nf + i for i, r in enumerate(E)}
+    perm = np.array([pos_of_var[u] if u < planner.n else pos_of_row[u - planner.n] for u in order])
+    N = len(perm); NS = (N + 15) // 16; Np = NS * 16
+    S = np.eye(Np); S[:N, :N] = K[np.ix_(perm, perm)]
+    y = np.zeros(Np); y[:N] = rhs[perm]
+    slot_of_pos = ps.ravel()
+    checked = 0
+    for k in range(NS):
+        p, r = slice(16 * k, 16 * k + 16), slice(16 * k + 16, Np)
+        L = np.eye(16); d = np.zeros(16); Aw = S[p, p].copy()
+        for i in range(16):
+            d[i] = Aw[i, i]
+            L[i + 1:, i] = Aw[i + 1:, i] / d[i]
+            Aw[i + 1:, i + 1:] -= np.outer(L[i + 1:, i], Aw[i, i + 1:])
+        Li = np.linalg.inv(L)
+        Y = S[r, p] @ Li.T
+        yF = Li @ y[p]
+        S[r, r] -= (Y / d) @ Y.T
+        y[r] -= (Y / d) @ yF
+        V, wk = (Y / d) @ Li, Li.T @ (yF / d)
+        if k % 9 == 0 or k == NS - 1:      # a dozen stages across the chain
+            nxt = {}
+            for pp in range(16 * (k + 1), N):
+                nxt.setdefault(int(slot_of_pos[pp]), pp)          # next occupant of every slot
+            rows = np.array(sorted(nxt.values()), dtype=int)
+            scale = max(1.0, np.abs(V).max(initial=0.0), np.abs(wk).max())
+            if len(rows):
+                Vg = pan[k, 1 + slot_of_pos[rows]]
+                assert np.abs(Vg - V[rows - 16 * (k + 1)]).max() <= 1e-6 * scale
+            assert np.abs(pan[k, 0] - wk).max() <= 1e-6 * scale
+            checked += 1
+    assert checked >= 10
+    ref = np.linalg.solve(K, rhs)[:nf]
+    assert np.abs(dx[0, free] - ref).max() <= 2e-5 * np.abs(ref).max()
