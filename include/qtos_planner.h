@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define QTOS_NEE 4
-#define QTOS_MAX_PHASES 16
+#define QTOS_MAX_PHASES 32
 #define QTOS_START_DOUBLES 24 /* CoM 3, Euler 3, feet FL FR HL HR 12, lin vel 3, Euler rates 3 */
 #define QTOS_CSV_COLS 37
 

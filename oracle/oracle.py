@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libqtos_oracle.so")
-NEE, MAX_PHASES = 4, 16
+NEE, MAX_PHASES = 4, 32
 
 
 class QoParams(C.Structure):

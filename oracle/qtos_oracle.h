@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define QO_NEE 4
-#define QO_MAX_PHASES 16
+#define QO_MAX_PHASES 32
 #define QO_MAX_POLYS 260
 #define QO_MAX_NODES (QO_MAX_POLYS + 1)
 

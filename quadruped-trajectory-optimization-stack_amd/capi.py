@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libqtos_planner.so")
-NEE, MAX_PHASES, START_DOUBLES, CSV_COLS = 4, 16, 24, 37
+NEE, MAX_PHASES, START_DOUBLES, CSV_COLS = 4, 32, 24, 37
 
 
 class QtosParams(C.Structure):

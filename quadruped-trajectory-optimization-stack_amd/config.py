@@ -102,6 +102,20 @@ class PlannerConfig:
         kw.setdefault("dt_dynamic", 0.05)
         return cls(**kw)
 
+    @classmethod
+    def knots200(cls, **kw):
+        """BASELINE.json configs[4]: 200 dynamics knots = a 10 s horizon at the knots100 spacing with the
+        walk schedule run twice (the final stance of the first cycle merges with the first stance of
+        the second: 17 phases per foot).  Scaling the one-cycle table to 10 s instead doubles every
+        phase and with it the elimination front (208 slots, over the 128 `k_kkt` is built for)."""
+        kw.setdefault("duration", 10.0)
+        kw.setdefault("dt_base", 0.05)
+        kw.setdefault("dt_dynamic", 0.05)
+        if "phase_durations" not in kw:
+            table = [list(f[:-1]) + [f[-1] + f[0]] + list(f[1:]) for f in REFERENCE_WALK_UNNORMALISED]
+            kw["phase_durations"] = scaled_phases(table, kw["duration"])
+        return cls(**kw)
+
     def oracle_dict(self):
         """The same numbers in the key names oracle/oracle.py expects (tests only)."""
         return dict(phase_durations=self.phase_durations, nominal_stance=self.nominal_stance,

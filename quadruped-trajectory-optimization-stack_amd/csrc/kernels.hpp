@@ -30,6 +30,8 @@ struct DevPlan {
   const LinRow *lin;
   const ColDesc *dyn_cols, *rom_cols;
   int n_dyn_cols, n_rom_cols;
+  int dyn_chunk;               // dynamics knots evaluated per pass of eval_all (LDS scratch bound)
+  const int *dyn_col_off;      // first dyn_cols entry of every chunk (+ end)
   const Block *blocks;
   const int *block_cols;
   const IqRow *iq_rows;   // rows of the inequality blocks (stream offsets)
@@ -451,42 +453,49 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
 #define ESTAMP() do {} while (0)
 #endif
   double *x = lds, *loc = lds + eval_loc_offset(P.n_vars);
-  double *vin = loc + max(DYN_LOC * P.n_dyn, ROM_LOC * P.n_rom);
+  double *vin = loc + max(DYN_LOC * P.dyn_chunk, ROM_LOC * P.n_rom);
   for (int v = tid; v < P.n_vars; v += nt) x[v] = xg[v];
   __syncthreads();
-  vec_prepass(P.dyn, (int)sizeof(DynInst), P.n_dyn, 13, x, vin);
-  __syncthreads();
-  ESTAMP();
-  if (JAC) {
-    for (int i = tid; i < P.n_dyn; i += nt) {
-      double *li = loc + (size_t)i * DYN_LOC;
-      const DynInst &I = P.dyn[i];
-      const double *vi = vin + (size_t)i * DYN_VIN, *th = vi + 6, *thd = vi + 9, *thdd = vi + 12;
-      const Trig tg = trig_of(th);   // shared by the value pass and the nine forward-mode passes
-      eval_dyn<true>(P, I, vi, g, li, th, thd, thdd, tg);
-      eval_dyn_pass<0>(P, I, li, th, thd, thdd, tg);
-      eval_dyn_pass<1>(P, I, li, th, thd, thdd, tg);
-      eval_dyn_pass<2>(P, I, li, th, thd, thdd, tg);
-    }
+  // the dynamics knots go through the LDS scratch in chunks of P.dyn_chunk (one chunk up to 128 knots)
+  for (int c0 = 0, ch = 0; c0 < P.n_dyn; c0 += P.dyn_chunk, ++ch) {
+    const int cnt = min(P.dyn_chunk, P.n_dyn - c0);
+    if (c0) __syncthreads();   // the previous chunk is done with vin / loc
+    vec_prepass(P.dyn + c0, (int)sizeof(DynInst), cnt, 13, x, vin);
     __syncthreads();
     ESTAMP();
-    for (int c = tid; c < P.n_dyn_cols; c += 4 * nt) {   // four columns per round: all descriptors in flight
-      ColDesc C[4];
+    if (JAC) {
+      for (int i = tid; i < cnt; i += nt) {
+        double *li = loc + (size_t)i * DYN_LOC;
+        const DynInst &I = P.dyn[c0 + i];
+        const double *vi = vin + (size_t)i * DYN_VIN, *th = vi + 6, *thd = vi + 9, *thdd = vi + 12;
+        const Trig tg = trig_of(th);   // shared by the value pass and the nine forward-mode passes
+        eval_dyn<true>(P, I, vi, g, li, th, thd, thdd, tg);
+        eval_dyn_pass<0>(P, I, li, th, thd, thdd, tg);
+        eval_dyn_pass<1>(P, I, li, th, thd, thdd, tg);
+        eval_dyn_pass<2>(P, I, li, th, thd, thdd, tg);
+      }
+      __syncthreads();
+      ESTAMP();
+      const int cend = P.dyn_col_off[ch + 1];
+      const double *loc0 = loc - (size_t)c0 * DYN_LOC;   // dyn_column indexes by the global knot number
+      for (int c = P.dyn_col_off[ch] + tid; c < cend; c += 4 * nt) {   // four columns per round: all descriptors in flight
+        ColDesc C[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) C[u] = P.dyn_cols[min(c + u * nt, P.n_dyn_cols - 1)];
+        for (int u = 0; u < 4; ++u) C[u] = P.dyn_cols[min(c + u * nt, cend - 1)];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (c + u * nt < P.n_dyn_cols) dyn_column(P, C[u], loc, G);
+        for (int u = 0; u < 4; ++u)
+          if (c + u * nt < cend) dyn_column(P, C[u], loc0, G);
+      }
+      __syncthreads();
+      ESTAMP();
+    } else {
+      for (int i = tid; i < cnt; i += nt) {
+        const DynInst &I = P.dyn[c0 + i];
+        const double *vi = vin + (size_t)i * DYN_VIN, *th = vi + 6, *thd = vi + 9, *thdd = vi + 12;
+        eval_dyn<false>(P, I, vi, g, nullptr, th, thd, thdd, trig_of(th));
+      }
+      ESTAMP();
     }
-    __syncthreads();
-    ESTAMP();
-  } else {
-    for (int i = tid; i < P.n_dyn; i += nt) {
-      const DynInst &I = P.dyn[i];
-      const double *vi = vin + (size_t)i * DYN_VIN, *th = vi + 6, *thd = vi + 9, *thdd = vi + 12;
-      eval_dyn<false>(P, I, vi, g, nullptr, th, thd, thdd, trig_of(th));
-    }
-    ESTAMP();
   }
   __syncthreads();   // the dynamics knots are done with vin
   vec_prepass(P.rom, (int)sizeof(RomInst), P.n_rom, 3, x, vin);
@@ -1017,6 +1026,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   unsigned long long st0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_st0 = 0;
   unsigned long long st1[4] = {0, 0, 0, 0}, tl_st1 = 0;
   unsigned long long st7[4] = {0, 0, 0, 0}, tl_st7 = 0;
+  unsigned long long wasum = 0;   // per wave: cycles from the top of a stage to its arrival at the AB barrier
   unsigned long long wcsum = 0;   // per wave: cycles from the start of phase C to its own arrival at the barrier
   if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st0) :: "memory");
 #endif
@@ -1037,27 +1047,18 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     const double *Lik = Lib + (k & 1) * PIV * PLD, *dik = dvb + (k & 1) * PIV;
     const int *psn = psb + ((k + 1) % 3) * PIV;
     const bool has_next = k + 1 < NS;
+#ifdef QTOS_STAMPS
+    unsigned long long wa0 = 0;
+    if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wa0) :: "memory");
+#endif
     // ---- install the records of stage k+2 (prefetched during stage k-1), prefetch stage k+3 --------
     if (k >= 1 && k + 2 < NS) {
-      const int s = k + 2;
 #pragma unroll
       for (int jj = 0; jj < PFD2; ++jj) { const int i = tid + jj * KT; if (i < pf_nd2) ((d2_t *)dbuf)[i] = pfd[jj]; }
 #pragma unroll
       for (int jj = 0; jj < PFS4; ++jj) { const int i = tid + jj * KT; if (i < pf_ns4) ((i4_t *)sbuf)[i] = pfs[jj]; }
-      // header straight from the registers: ints 0..7 on thread 0..1, pivot slots on threads 2..5,
-      // pivot diagonals (doubles 0..15) on threads 0..7
-      if (tid < 4) pm[(s & 1) * 4 + tid] = 0u;
-      if (tid == 0) { hib[s % 3] = pfs[0][3]; hiall[s] = (pfs[0][3] + 15) & ~15; }
-      if (tid < 8) { dgb[(s % 3) * PIV + 2 * tid] = pfd[0][0]; dgb[(s % 3) * PIV + 2 * tid + 1] = pfd[0][1]; }
-      if (tid >= 2 && tid < 6) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int slot = pfs[0][e], jidx = 4 * (tid - 2) + e;
-          psb[(s % 3) * PIV + jidx] = slot;
-          jm[(s & 1) * 128 + slot] = jidx;
-          atomicOr(&pm[(s & 1) * 4 + (slot >> 5)], 1u << (slot & 31));
-        }
-      }
+      // (the header of these records -- pivot slots, diagonals, slot map, masks -- was published one
+      //  stage ago by wave 7, off the critical path)
     }
     if (k + 3 < NS) {
       const int s = k + 3;
@@ -1147,6 +1148,9 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       Xn[F * PLD + lane] = A[idx];
       A[idx] = 0.0;
     }
+#ifdef QTOS_STAMPS
+    if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); wasum += t_ - wa0; }
+#endif
     lds_barrier();
     STAMPW(0, st0, 0);
 #ifdef QTOS_STAMPS
@@ -1233,6 +1237,17 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #ifdef QTOS_STAMPS
       if (tid == 448) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st7) :: "memory");
 #endif
+      // header of stage k+3 (static ints 0..23: counts, hi, pivot slots; dynamic doubles 0..15: pivot
+      // diagonals): read from global memory now, published to the LDS rings at the end of this phase.
+      // The ring slots it overwrites (stage k's pivot slots / diagonals, stage k+1's slot map and mask)
+      // have no reader left in this phase or later.
+      const int hs = k + 3;
+      int hv = 0;
+      double hd = 0.0;
+      if (hs < NS) {
+        if (lane < SHDR + PIV) hv = P.srec[soff[hs] + lane];
+        if (lane < PIV) hd = stream[doff[hs] + lane];
+      }
       double part = 0.0, lq[4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
@@ -1278,6 +1293,17 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
           const int c = prow_next;
           Xn[F * PLD + lane] += UF[c] - corr;
           UF[c] = 0.0;
+        }
+      }
+      if (hs < NS) {
+        if (lane < 4) pm[(hs & 1) * 4 + lane] = 0u;
+        if (lane == 3) { hib[hs % 3] = hv; hiall[hs] = (hv + 15) & ~15; }
+        if (lane < PIV) dgb[(hs % 3) * PIV + lane] = hd;
+        if (lane >= SHDR && lane < SHDR + PIV) {
+          const int jidx = lane - SHDR;
+          psb[(hs % 3) * PIV + jidx] = hv;
+          jm[(hs & 1) * 128 + hv] = jidx;
+          atomicOr(&pm[(hs & 1) * 4 + (hv >> 5)], 1u << (hv & 31));
         }
       }
       STAMPW(7, st7, 0);
@@ -1361,6 +1387,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   if (tid == 64 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 32) * 4 + i] = (double)st1[i];
   if (tid == 448 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 33) * 4 + i] = (double)st7[i];
   if (lane == 0 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 38) * 4 + wv] = (double)wcsum;
+  if (lane == 0 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 42) * 4 + wv] = (double)wasum;
 #endif
 }
 

@@ -282,7 +282,7 @@ struct HostModel {
     }
     for (int e = 0; e < NEE; ++e) {
       int n = P.n_phases[e];
-      if (n < 1 || n > QTOS_MAX_PHASES || n % 2 == 0) { err = "n_phases must be odd, <= 16"; return -1; }
+      if (n < 1 || n > QTOS_MAX_PHASES || n % 2 == 0) { err = "n_phases must be odd, <= QTOS_MAX_PHASES"; return -1; }
       double s = 0;
       for (int k = 0; k < n; ++k) s += P.phase_dur[e][k];
       if (std::fabs(s - T) > 1e-6) { err = "phase durations of all feet must sum to T"; return -1; }

@@ -137,6 +137,17 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(M.force, &D.force)); TRY(p->upload(M.linrow, &D.lin));
   TRY(p->upload(M.dyn_cols, &D.dyn_cols)); TRY(p->upload(M.rom_cols, &D.rom_cols));
   D.n_dyn_cols = (int)M.dyn_cols.size(); D.n_rom_cols = (int)M.rom_cols.size();
+  {  // dynamics knots per pass through the LDS scratch of the evaluation kernels: equal chunks of <= 128
+    const int n_dyn = (int)M.dyn.size(), n_ch = (n_dyn + 127) / 128;
+    D.dyn_chunk = n_ch ? (n_dyn + n_ch - 1) / n_ch : 1;
+    std::vector<int> off;
+    for (int c = 0, ch = 0; c <= (int)M.dyn_cols.size(); ++c) {
+      const int inst = c < (int)M.dyn_cols.size() ? M.dyn_cols[c].inst : n_dyn + D.dyn_chunk;
+      while (ch * D.dyn_chunk <= inst && ch <= n_ch) { off.push_back(c); ++ch; }
+    }
+    off.resize(n_ch + 1, (int)M.dyn_cols.size());
+    TRY(p->upload(off, &D.dyn_col_off));
+  }
   TRY(p->upload(M.blocks, &D.blocks)); TRY(p->upload(M.block_cols, &D.block_cols));
   {
     std::vector<IqRow> rows;   // blocks carry their stream offsets once the symbolic analysis has run
@@ -201,8 +212,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
   }
-  p->eval_lds = sizeof(double) * (((size_t)M.n_vars + 1) / 2 * 2 + std::max((size_t)DYN_LOC * M.dyn.size(), (size_t)ROM_LOC * M.rom.size()) +
-                                  std::max((size_t)DYN_VIN * M.dyn.size(), (size_t)ROM_VIN * M.rom.size()));
+  p->eval_lds = sizeof(double) * (((size_t)M.n_vars + 1) / 2 * 2 + std::max((size_t)DYN_LOC * D.dyn_chunk, (size_t)ROM_LOC * M.rom.size()) +
+                                  std::max((size_t)DYN_VIN * D.dyn_chunk, (size_t)ROM_VIN * M.rom.size()));
   if (p->eval_lds > 150 * 1024) { p->err = "too many dynamics knots for the LDS scratch"; qtos_planner_destroy(p); return -4; }
   for (const void *fn : {(const void *)k_start, (const void *)k_step, (const void *)k_debug_eval})
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->eval_lds) != hipSuccess) { qtos_planner_destroy(p); return -2; }

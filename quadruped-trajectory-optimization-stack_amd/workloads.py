@@ -108,3 +108,35 @@ def mixed_goals(batch, seed=2, terrains=None):
     map_id = np.concatenate([np.zeros(n1, np.int32), np.ones(n3, np.int32), np.full(n5, 2, np.int32)])
     perm = rng.permutation(batch)
     return start[perm], goal[perm], map_id[perm]
+
+
+def random_terrains(n_maps=8, seed=4, amplitude=0.02, nx=90, ny=46, cell=0.05):
+    """configs[4]: randomized heightfields -- smooth bumps (sum of 6 random Gaussian hills / dips per
+    map, |h| <= amplitude) on a 4.5 m x 2.3 m grid starting at (-1, -1), flattened (cosine ramp) around
+    x in [-0.5, 0.5] so that every start stance stands on level ground.  Returns (maps, cell)."""
+    rng = np.random.default_rng(seed)
+    x = -1.0 + cell * np.arange(nx)[:, None]
+    y = -1.0 + cell * np.arange(ny)[None, :]
+    maps = np.zeros((n_maps, nx, ny))
+    for m in range(n_maps):
+        h = np.zeros((nx, ny))
+        for _ in range(6):
+            cx, cy = rng.uniform(0.6, 3.0), rng.uniform(-0.5, 0.5)
+            w = rng.uniform(0.15, 0.4)
+            h += rng.uniform(-1.0, 1.0) * np.exp(-((x - cx) ** 2 + (y - cy) ** 2) / (2 * w * w))
+        h *= amplitude / max(np.abs(h).max(), 1e-12)
+        ramp = np.clip((x - 0.5) / 0.3, 0.0, 1.0)
+        maps[m] = h * (0.5 - 0.5 * np.cos(np.pi * ramp))
+    return maps, cell
+
+
+def mpc_goals(batch, seed=5, n_maps=8):
+    """configs[4]: long-horizon goals (0.9-1.4 m ahead over the 10 s / two-cycle horizon) from level
+    start stances, each problem on one of the randomized heightfields; returns (start, goal, map_id)."""
+    rng = np.random.default_rng(seed)
+    x0 = rng.uniform(0.0, 0.2, batch)
+    dx = rng.uniform(0.9, 1.4, batch)
+    dy = rng.uniform(-0.08, 0.08, batch)
+    start = np.stack([rest_start(x) for x in x0])
+    goal = np.stack([x0 + dx, dy, np.full(batch, 0.24)], axis=1)
+    return start, goal, rng.integers(0, n_maps, batch).astype(np.int32)

@@ -4,7 +4,7 @@ from qtos_amd import capi, workloads
 import os
 capi.LIB_PATH = capi.LIB_PATH.replace("libqtos_planner.so", os.environ.get("QTOS_LIB", "libqtos_planner_stamps.so"))
 from qtos_amd.config import PlannerConfig
-cfg = PlannerConfig.knots100(max_iter=40)
+cfg = PlannerConfig.knots100(max_iter=48)
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 P = capi.Planner(cfg, max_batch=NB)
 start, goal = workloads.flat_goals(NB, 0)
@@ -32,3 +32,4 @@ P.lib.qtos_debug_trace(P.h, 0, t.ctypes.data_as(C.POINTER(C.c_double)))
 print("linearise phases (cycles): stage x %.0f | dynamics knots %.0f | dynamics columns %.0f | rom instances %.0f | rom columns %.0f | force/terrain/linear %.0f" % tuple(t[36:38].ravel()[:6]))
 print("phase C, cycles per stage until each wave reaches the barrier (waves 0..7):", (t[38:40].ravel() / NS).round(0))
 print("line-search evaluation phases (cycles): stage x %.0f | dynamics knots %.0f | rom instances %.0f | force/terrain/linear %.0f" % tuple(t[40:42].ravel()[:4]))
+print("phase AB, cycles per stage until each wave reaches the barrier (waves 0..7):", (t[42:44].ravel() / NS).round(0))

@@ -102,6 +102,21 @@ def test_knots100_structure(hip_lib):
     assert act.max() <= d.front <= 128
 
 
+def test_knots200_structure(hip_lib):
+    """BASELINE configs[4]: two walk cycles over 10 s keep the elimination front at the 128 slots of the
+    100-knot problem (scaling the one-cycle schedule to 10 s would need 208)."""
+    from qtos_amd import capi
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig.knots200()
+    assert [len(f) for f in cfg.phase_durations] == [17] * 4
+    assert all(abs(sum(f) - 10.0) < 1e-12 for f in cfg.phase_durations)
+    d, act = capi.analyze(cfg)
+    assert (d.n_base_nodes, d.n_dyn_times, d.n_vars, d.n_cons) == (201, 202, 3160, 4558)
+    assert act.max() <= d.front == 128 and d.n_stages == 356
+    d2, _ = capi.analyze(PlannerConfig.knots100(duration=10.0))
+    assert d2.front > 128
+
+
 def test_bad_parameters_are_rejected(hip_lib, cfg):
     from qtos_amd import capi
     p = capi.params_from_config(cfg)

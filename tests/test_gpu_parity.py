@@ -560,3 +560,60 @@ def test_factor_panels_match_block_elimination(planner, oracle, gv1, cfg):
     assert checked >= 10
     ref = np.linalg.solve(K, rhs)[:nf]
     assert np.abs(dx[0, free] - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+def test_knots200_receding_window_on_random_heightfields():
+    """BASELINE configs[4]: 200 dynamics knots (10 s, two walk cycles), randomized heightfields, replans
+    at 50 Hz.  Cold solves and every warm-started replan are checked against the oracle run on the same
+    inputs (same start row, same warm nodes): nodes to 1e-5 when both took the same number of
+    iterations, CoM / feet of the sampled trajectory to the stated 1e-3 m otherwise."""
+    from oracle.oracle import Oracle
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig.knots200(honor_start_velocity=True)   # a replan continues the motion it starts in
+    B, NCHK = 64, 3
+    P = Planner(cfg, max_batch=B)
+    assert (P.dims.n_dyn_times, P.dims.front, P.dims.n_stages) == (202, 128, 356)
+    maps, cell = workloads.random_terrains()
+    P.set_heightfields(maps, cell)
+    start, goal, mid = workloads.mpc_goals(B)
+    oracles = [Oracle(cfg.oracle_dict(), height=maps[mid[b]], hcell=cell) for b in range(NCHK)]
+    assert oracles[0].n == P.n and oracles[0].m == P.m
+
+    def check(nodes, status, iters, start, warm):
+        exact = 0
+        for b in range(NCHK):
+            O, s = oracles[b], start[b]
+            q = O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), goal[b], s[18:21], s[21:24], 0.0)
+            xo, info = O.solve(q, x0=None if warm is None else warm[b])
+            assert info.status == 0 and status[b] == 0
+            assert O.max_violation(nodes[b]) <= cfg.tol + 1e-9
+            if info.iters == iters[b]:
+                assert np.abs(nodes[b] - xo).max() < 1e-5
+                exact += 1
+            ro = O.sample(xo, hz=100.0)
+            rg = P.sample(nodes[b:b + 1], 0.0, hz=100.0)[0]
+            assert np.abs(rg[:, 1:4] - ro[:, 1:4]).max() < 1e-3      # CoM
+            assert np.abs(rg[:, 7:19] - ro[:, 7:19]).max() < 1e-3    # feet
+        return exact
+
+    nodes, status, iters, viol = P.plan(start, goal, map_id=mid)
+    assert (status == 0).mean() >= 0.9 and viol[status == 0].max() <= cfg.tol   # nearest-cell terrain: a few stall on a cell edge
+    cold_iters = iters.copy()
+    assert check(nodes, status, iters, start, None) >= 2
+    # five replans of the receding window: the next start is the row 20 ms into the current plan, the
+    # current nodes are the warm start
+    for k in range(5):
+        row = P.sample(nodes, 0.0, hz=50.0, n_rows=2)[:, 1]
+        nstart = row[:, 1:25].copy()
+        assert np.abs(nstart[:, 0:3] - start[:, 0:3]).max() < 0.02     # 20 ms later: barely moved
+        warm = nodes
+        nodes, status, iters, viol = P.plan(nstart, goal, map_id=mid, warm=warm)
+        ok = status == 0
+        assert ok.mean() >= 0.9
+        assert iters[ok].mean() < cold_iters.mean()                    # the warm start pays
+        check(nodes, status, iters, nstart, warm)
+        start = nstart
+    P.close()

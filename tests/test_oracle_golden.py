@@ -194,3 +194,25 @@ def test_oracle_stall_rule_stops_cycling_problems():
     x0, i0 = O.solve(q, opts=o)
     assert i5.status == 1 and i0.status == 1 and i5.iters < i0.iters == o.max_iter
     assert i5.inf_pr <= i0.inf_pr + 1e-12 and abs(O.max_violation(x5) - i5.inf_pr) < 1e-12
+
+
+def test_oracle_knots200_on_random_heightfield():
+    """BASELINE configs[4] transcription in the oracle: cold solve, then the warm-started replan from the
+    row 20 ms into the plan converges in fewer iterations to a nearby plan."""
+    from oracle.oracle import Oracle
+    from qtos_amd import workloads
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig.knots200()
+    maps, cell = workloads.random_terrains()
+    assert np.abs(maps).max() <= 0.02 + 1e-12 and np.abs(maps[:, :30]).max() == 0.0   # level start area
+    start, goal, mid = workloads.mpc_goals(2)
+    O = Oracle(cfg.oracle_dict(), height=maps[mid[0]], hcell=cell)
+    assert (O.n, O.m) == (3160, 4558)
+    s = start[0]
+    x, info = O.solve(O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), goal[0]))
+    assert info.status == 0 and O.max_violation(x) <= 1e-4 + 1e-9
+    row = O.sample(x, hz=50.0, n_rows=2)[1]
+    x2, info2 = O.solve(O.problem(row[1:4], row[4:7], row[7:19].reshape(4, 3), goal[0], row[19:22], row[22:25]), x0=x)
+    assert info2.status == 0 and info2.iters < info.iters
+    # the gait schedule restarts with the replan: the new plan is the old one begun 20 ms further on
+    assert np.abs(O.sample(x2, hz=100.0)[:, 1:4] - O.sample(x, hz=100.0)[:, 1:4]).max() < 0.05
