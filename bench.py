@@ -38,8 +38,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="plans per GPU per step")
-    ap.add_argument("--transcription", default="knots100", choices=["knots100", "reference_compat"])
-    ap.add_argument("--workload", default="exp1_flat", choices=["exp1_flat", "exp5_step", "mixed"])
+    ap.add_argument("--transcription", default="knots100", choices=["knots100", "reference_compat", "knots200"])
+    ap.add_argument("--workload", default="exp1_flat", choices=["exp1_flat", "exp5_step", "mixed", "mpc_random"],
+                    help="mpc_random = BASELINE configs[4]: every step is one 50 Hz replan of all windows on randomized "
+                         "heightfields (next start = the row 20 ms into the current plan, warm start = the current nodes); "
+                         "use with --transcription knots200")
     ap.add_argument("--cpu-sample", type=int, default=96, help="plans timed on the CPU oracle (0 = skip)")
     ap.add_argument("--tol", type=float, default=None,
                     help="constraint-violation tolerance (default: the planner's 1e-4; the reference's Ipopt runs at ~1e-3)")
@@ -47,6 +50,10 @@ def main():
                     help="batches in flight per GPU (each on its own planner handle + HIP stream, driven by its own "
                          "host thread): 2 lets the next batch use the CUs idled by early-converged problems. "
                          "Default 1 = the configuration BASELINE.json names")
+    ap.add_argument("--episode", type=int, default=16,
+                    help="mpc_random: replans per window before it is replaced by a fresh patch (cold start). The NLP "
+                         "has no cost term, so a window replanned from its own 20 ms-ahead state drifts (base height) "
+                         "until the start state leaves the range-of-motion box; episodes bound that")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per k_kkt launch from a separate rocprofv3 --pmc pass "
                          "(default: the newest profiles/*_pmc_hbm.json, collected with this same command)")
@@ -71,13 +78,21 @@ def main():
     from qtos_amd.config import PlannerConfig
     from qtos_amd.dist import gather_plans
     tol_kw = {} if args.tol is None else {"tol": args.tol}
-    cfg = PlannerConfig.knots100(**tol_kw) if args.transcription == "knots100" else PlannerConfig.reference_compat(**tol_kw)
+    mpc = args.workload == "mpc_random"
+    if mpc:
+        tol_kw["honor_start_velocity"] = True    # a replan continues the motion it starts in
+    cfg = {"knots100": PlannerConfig.knots100, "knots200": PlannerConfig.knots200,
+           "reference_compat": PlannerConfig.reference_compat}[args.transcription](**tol_kw)
     B = args.batch
     P = Planner(cfg, max_batch=B, device=local_rank)
     d = P.dims
     terrain = None
     map_id_np = None
-    if args.workload == "mixed":     # BASELINE configs[3] shard: exp_1 / exp_3 / exp_5 patches, one map index per problem
+    if mpc:                          # BASELINE configs[4] shard: randomized heightfields, long-horizon goals
+        maps, cell = workloads.random_terrains()
+        P.set_heightfields(maps, cell)
+        start_np, goal_np, map_id_np = workloads.mpc_goals(B, seed=5 + rank)
+    elif args.workload == "mixed":   # BASELINE configs[3] shard: exp_1 / exp_3 / exp_5 patches, one map index per problem
         maps, cell = workloads.mixed_terrains()
         P.set_heightfields(maps, cell)
         start_np, goal_np, map_id_np = workloads.mixed_goals(B, seed=2 + rank, terrains=(maps, cell))
@@ -99,14 +114,39 @@ def main():
     viol = torch.empty((B,), dtype=torch.float64, device=dev)
     map_id = None if map_id_np is None else torch.as_tensor(map_id_np, dtype=torch.int32, device=dev).contiguous()
     stream = torch.cuda.current_stream(dev)
+    # receding window (mpc_random): ping-pong node buffers (solution k is the warm start of k+1), the two
+    # CSV rows the next start state is read from, and the number of converged replans
+    nodes_prev = torch.empty_like(nodes) if mpc else None
+    rows2 = torch.empty((B, 2, 37), dtype=torch.float64, device=dev) if mpc else None
+    t0_dev = torch.zeros((B,), dtype=torch.float64, device=dev) if mpc else None
+    mpc_state = {"have_warm": False, "solved": torch.zeros((), dtype=torch.int64, device=dev), "k": 0, "cold": 0}
+    start0 = start.clone() if mpc else None
 
     def step():
+        nonlocal nodes, nodes_prev
+        warm_ptr = None
+        if mpc and mpc_state["k"] % max(args.episode, 1) == 0:   # new episode: fresh patches, cold start
+            start.copy_(start0)
+            mpc_state["have_warm"] = False
+            mpc_state["cold"] += 1
+        if mpc and mpc_state["have_warm"]:
+            nodes, nodes_prev = nodes_prev, nodes
+            warm_ptr = nodes_prev.data_ptr()
         rc = P.lib.qtos_plan_batch_device(P.h, B, start.data_ptr(), goal.data_ptr(),
-                                          None if map_id is None else map_id.data_ptr(), None,
+                                          None if map_id is None else map_id.data_ptr(), warm_ptr,
                                           nodes.data_ptr(), status.data_ptr(), iters.data_ptr(),
                                           viol.data_ptr(), C.c_void_p(stream.cuda_stream))
         if rc != 0:
             raise RuntimeError("qtos_plan_batch_device failed: %d %s" % (rc, P.lib.qtos_last_error(P.h)))
+        if mpc:   # the window moves on by 20 ms: CSV row 1 at 50 Hz, columns 1..24 = the next start vector
+            rc = P.lib.qtos_sample_csv_device(P.h, B, nodes.data_ptr(), t0_dev.data_ptr(), C.c_double(50.0), 2,
+                                              rows2.data_ptr(), C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError("qtos_sample_csv_device failed: %d" % rc)
+            start.copy_(rows2[:, 1, 1:25])
+            mpc_state["solved"] += (status == 0).sum()
+            mpc_state["have_warm"] = True
+            mpc_state["k"] += 1
         if world > 1:
             return gather_plans(nodes, status, B * world)
         return nodes, status
@@ -145,6 +185,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    mpc_state["solved"].zero_()
+    mpc_state["cold"] = 0
     kkt_s, kkt_n, tot_s, it_sum = 0.0, 0, 0.0, 0
     solved_inflight = None
     if lanes:
@@ -183,11 +225,17 @@ def main():
     value = n_solved * args.steps / elapsed
     if solved_inflight is not None:
         value = solved_inflight / elapsed
+    if mpc:
+        ms = mpc_state["solved"].to(torch.float64).reshape(1)
+        if world > 1:
+            dist.all_reduce(ms)
+        value = float(ms.item()) / elapsed
     st = status.cpu().numpy()
     itn = iters.cpu().numpy()
 
     out = {
-        "metric": "NLP solves/sec (100-knot SOLO12 gait, 5 s horizon, converged to %s)" % ("%.0e" % cfg.tol).replace("e-0", "e-"),
+        "metric": "NLP solves/sec (%d-knot SOLO12 gait, %g s horizon, converged to %s)" %
+                  (d.n_dyn_times - 2, cfg.duration, ("%.0e" % cfg.tol).replace("e-0", "e-")),
         "value": round(value, 2), "unit": "plans/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
@@ -196,7 +244,8 @@ def main():
             "workload": "batch=%d/GPU %s goals, %s transcription (%d base polynomials, %d vars, %d "
                         "constraint rows), walk gait of the reference's golden plans" %
                         (B, {"exp1_flat": "exp_1 flat-ground", "exp5_step": "exp_5 step-climb",
-                             "mixed": "mixed exp_1/exp_3/exp_5"}[args.workload],
+                             "mixed": "mixed exp_1/exp_3/exp_5",
+                             "mpc_random": "receding-window replans (20 ms shift, warm-started) on randomized heightfields,"}[args.workload],
                          args.transcription, d.n_base_nodes - 1, d.n_vars, d.n_cons),
             "global_batch": total_plans, "converged": n_solved, "iterations_max": int(itn.max()),
             "iterations_mean": round(float(itn.mean()), 2), "parallelism": "batch-shard x%d + 1 all-gather" % world,
@@ -204,6 +253,12 @@ def main():
             "batches_in_flight": args.inflight,
         },
     }
+    if mpc:
+        out["config"]["replan_hz_per_window"] = round(args.steps / elapsed, 2)
+        out["config"]["window_shift_s"] = 0.02
+        out["config"]["replans_per_episode"] = args.episode
+        out["config"]["cold_steps"] = mpc_state["cold"]
+        out["config"]["warm_steps"] = args.steps - mpc_state["cold"]
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
     if traffic is None and args.transcription == "knots100" and args.workload == "exp1_flat" and B == 256:
         import glob
@@ -227,7 +282,7 @@ def main():
             "fp64_tflops": round(B * d.kkt_flops / avg / 1e12, 3), "fp64_peak_tflops": 78.6,
             "kkt_share_of_device_time": round(kkt_s / max(tot_s, 1e-12), 3),
         }
-    if rank == 0 and world == 1 and args.cpu_sample > 0 and args.workload != "mixed":
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and args.workload not in ("mixed", "mpc_random"):
         from oracle.oracle import Oracle
         O = Oracle(cfg.oracle_dict(), height=None if terrain is None else terrain[0],
                    hcell=0.1 if terrain is None else terrain[1])

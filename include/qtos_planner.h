@@ -94,7 +94,8 @@ int qtos_set_heightfields(QtosPlanner *p, int n_maps, const double *height, int 
  *   nodes_out  B x n_vars  solution in the reference NLP's variable order
  *                          (logs/towr_log.out:99-110)
  *   status_out B   0 = solved (the reference's exit code / "status -> 0"), 1 = iteration limit,
- *                  2 = numerical failure
+ *                  2 = numerical failure (non-finite inputs; or a non-finite step, nodes_out is
+ *                  then the best finite iterate)
  *   iters_out B, viol_out B (max constraint violation), either may be NULL
  * Returns 0 or a negative error code; never throws. */
 int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *goal,

@@ -688,6 +688,7 @@ __global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
     record_trace(P, W, b, 0, viol, theta, 0.0, mu);
   }
   if (conv || bad) return;
+  for (int v = tid; v < n; v += blockDim.x) W.xbest[(size_t)b * n + v] = x[v];   // best iterate so far: the starting point
   __syncthreads();
   eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl);
   __syncthreads();
@@ -1501,11 +1502,13 @@ __global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int i
   const bool stalled = !conv && !bad && !improved && P.stall_iters > 0 && it + 1 - best_it >= P.stall_iters;
   if (improved)
     for (int v = tid; v < n; v += blockDim.x) W.xbest[(size_t)b * n + v] = x[v];
-  if (stalled)
+  // a numerical failure (NaN / inf after a step from a finite iterate) hands back that best iterate too
+  const bool restore = stalled || (bad && best_viol < INFINITY);
+  if (restore)
     for (int v = tid; v < n; v += blockDim.x) x[v] = W.xbest[(size_t)b * n + v];
   if (tid == 0) {
     W.mu[b] = mu;
-    W.viol[b] = stalled ? best_viol : viol;
+    W.viol[b] = restore ? best_viol : viol;
     W.iters[b] = it + 1;
     if (improved) { W.best_viol[b] = viol; W.best_it[b] = it + 1; }
     record_trace(P, W, b, it + 1, viol, theta, al, mu);

@@ -616,4 +616,13 @@ def test_knots200_receding_window_on_random_heightfields():
         assert iters[ok].mean() < cold_iters.mean()                    # the warm start pays
         check(nodes, status, iters, nstart, warm)
         start = nstart
+    # the NLP has no cost: replanned from its own trajectory a window drifts (base height) until its
+    # start state leaves the range-of-motion box and the solves fail -- as statuses, never as NaNs
+    failed = 0
+    for k in range(30):
+        row = P.sample(nodes, 0.0, hz=50.0, n_rows=2)[:, 1]
+        nodes, status, iters, viol = P.plan(row[:, 1:25].copy(), goal, map_id=mid, warm=nodes)
+        assert np.isfinite(nodes).all()
+        failed += int((status != 0).sum())
+    assert failed > 0
     P.close()
