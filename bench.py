@@ -50,6 +50,10 @@ def main():
                     help="batches in flight per GPU (each on its own planner handle + HIP stream, driven by its own "
                          "host thread): 2 lets the next batch use the CUs idled by early-converged problems. "
                          "Default 1 = the configuration BASELINE.json names")
+    ap.add_argument("--max-iter", type=int, default=None,
+                    help="Newton iteration limit per solve (default: the planner's 24). A fixed small budget is the "
+                         "usual real-time setting for mpc_random: windows that need more come back with status 1 and "
+                         "are not counted as solves")
     ap.add_argument("--episode", type=int, default=16,
                     help="mpc_random: replans per window before it is replaced by a fresh patch (cold start). The NLP "
                          "has no cost term, so a window replanned from its own 20 ms-ahead state drifts (base height) "
@@ -79,6 +83,8 @@ def main():
     from qtos_amd.dist import gather_plans
     tol_kw = {} if args.tol is None else {"tol": args.tol}
     mpc = args.workload == "mpc_random"
+    if args.max_iter is not None:
+        tol_kw["max_iter"] = args.max_iter
     if mpc:
         tol_kw["honor_start_velocity"] = True    # a replan continues the motion it starts in
     cfg = {"knots100": PlannerConfig.knots100, "knots200": PlannerConfig.knots200,
@@ -91,7 +97,7 @@ def main():
     if mpc:                          # BASELINE configs[4] shard: randomized heightfields, long-horizon goals
         maps, cell = workloads.random_terrains()
         P.set_heightfields(maps, cell)
-        start_np, goal_np, map_id_np = workloads.mpc_goals(B, seed=5 + rank)
+        start_np, goal_np, map_id_np = workloads.mpc_goals(B, seed=5 + rank, terrains=(maps, cell))
     elif args.workload == "mixed":   # BASELINE configs[3] shard: exp_1 / exp_3 / exp_5 patches, one map index per problem
         maps, cell = workloads.mixed_terrains()
         P.set_heightfields(maps, cell)
@@ -245,12 +251,12 @@ def main():
                         "constraint rows), walk gait of the reference's golden plans" %
                         (B, {"exp1_flat": "exp_1 flat-ground", "exp5_step": "exp_5 step-climb",
                              "mixed": "mixed exp_1/exp_3/exp_5",
-                             "mpc_random": "receding-window replans (20 ms shift, warm-started) on randomized heightfields,"}[args.workload],
+                             "mpc_random": "receding-window replans (20 ms shift, warm-started) on randomized exp_5 heightfields: ledge"}[args.workload],
                          args.transcription, d.n_base_nodes - 1, d.n_vars, d.n_cons),
             "global_batch": total_plans, "converged": n_solved, "iterations_max": int(itn.max()),
             "iterations_mean": round(float(itn.mean()), 2), "parallelism": "batch-shard x%d + 1 all-gather" % world,
             "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front,
-            "batches_in_flight": args.inflight,
+            "batches_in_flight": args.inflight, "max_iter": cfg.max_iter,
         },
     }
     if mpc:

@@ -3,7 +3,8 @@
 Counterpart of QTOS/generateHeightField.py: tile reader (:100-118, tiles are read transposed),
 nearest-neighbour upsampling (:39-56), tile concatenation along x (:470-484), the solver's copy
 (transpose, shifted one row toward +x: :568,620-631) and the text format
-(``"v, v, ..., v,"`` per line, no final newline: :590-605).
+(``"v, v, ..., v,"`` per line, no final newline: :590-605), and the height-level randomiser
+(:692-730).
 World frame: map index (row = y, col = x), cell = 2 / rows metres, origin shift 1.0 in x and y
 (QTOS/planner.py:61-62), i.e. x in [-1, 2*tiles - 1], y in [-1, 1].
 """
@@ -38,6 +39,31 @@ def towr_map(map_yx):
     m = np.transpose(np.array(map_yx, dtype=float))
     out = np.zeros_like(m)
     out[1:] = m[:-1]
+    return out
+
+
+def random_height(map_yx, rng, height_delta=0.005):
+    """One pass of the reference's terrain randomiser (QTOS/generateHeightField.py:708-730): every
+    distinct non-zero height level (ascending) moves as a whole by +d, -d or not at all, d uniform
+    in [-height_delta, height_delta].  `rng` is a `random.Random`; seeded like the module-level
+    generator the reference uses it reproduces the reference's maps (tests/golden/random_height.json)."""
+    out = np.array(map_yx, dtype=float)
+    for h in np.unique(out[out != 0]):
+        d = rng.uniform(-height_delta, height_delta)
+        n = rng.choice((0, 1, 2))
+        if n == 0:
+            out[out == h] += d
+        elif n == 1:
+            out[out == h] -= d
+    return out
+
+
+def random_height_shift(map_yx, shift, rng):
+    """`shift` cumulative passes of random_height (QTOS/generateHeightField.py:692-706; the
+    reference's randomize_env applies 10)."""
+    out = np.array(map_yx, dtype=float)
+    for _ in range(shift):
+        out = random_height(out, rng)
     return out
 
 

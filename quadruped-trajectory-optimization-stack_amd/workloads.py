@@ -110,33 +110,32 @@ def mixed_goals(batch, seed=2, terrains=None):
     return start[perm], goal[perm], map_id[perm]
 
 
-def random_terrains(n_maps=8, seed=4, amplitude=0.02, nx=90, ny=46, cell=0.05):
-    """configs[4]: randomized heightfields -- smooth bumps (sum of 6 random Gaussian hills / dips per
-    map, |h| <= amplitude) on a 4.5 m x 2.3 m grid starting at (-1, -1), flattened (cosine ramp) around
-    x in [-0.5, 0.5] so that every start stance stands on level ground.  Returns (maps, cell)."""
-    rng = np.random.default_rng(seed)
-    x = -1.0 + cell * np.arange(nx)[:, None]
-    y = -1.0 + cell * np.arange(ny)[None, :]
-    maps = np.zeros((n_maps, nx, ny))
-    for m in range(n_maps):
-        h = np.zeros((nx, ny))
-        for _ in range(6):
-            cx, cy = rng.uniform(0.6, 3.0), rng.uniform(-0.5, 0.5)
-            w = rng.uniform(0.15, 0.4)
-            h += rng.uniform(-1.0, 1.0) * np.exp(-((x - cx) ** 2 + (y - cy) ** 2) / (2 * w * w))
-        h *= amplitude / max(np.abs(h).max(), 1e-12)
-        ramp = np.clip((x - 0.5) / 0.3, 0.0, 1.0)
-        maps[m] = h * (0.5 - 0.5 * np.cos(np.pi * ramp))
-    return maps, cell
+def random_terrains(n_maps=8, seed=4, mesh_scale=11, shift=10):
+    """configs[4]: randomized heightfields -- the exp_5 map with every height level jittered by the
+    reference's own randomiser (`random_height_shift`, 10 cumulative passes of +-0.005 m per level as in
+    its `randomize_env`, QTOS/generateHeightField.py:560-567,692-730), one `random.Random(seed + m)`
+    stream per map, in the solver file's orientation.  Returns (maps[n_maps][nx][ny], cell)."""
+    import random
+    base = heightfield.build_map([tile("climb_2"), tile("climb_1")], mesh_scale)
+    maps = [heightfield.towr_map(heightfield.random_height_shift(base, shift, random.Random(seed + m)))
+            for m in range(n_maps)]
+    return np.stack(maps), heightfield.cell_size(base)
 
 
-def mpc_goals(batch, seed=5, n_maps=8):
-    """configs[4]: long-horizon goals (0.9-1.4 m ahead over the 10 s / two-cycle horizon) from level
-    start stances, each problem on one of the randomized heightfields; returns (start, goal, map_id)."""
+def mpc_goals(batch, seed=5, terrains=None, mode=1):
+    """configs[4]: long-horizon goals (0.45-0.7 m ahead over the 10 s / two-cycle horizon: up the
+    randomized ledges) from start stances at x in [0, 0.2] standing on the surface of their map, each
+    problem on one of the randomized heightfields; returns (start, goal, map_id)."""
+    maps, cell = terrains if terrains is not None else random_terrains()
     rng = np.random.default_rng(seed)
     x0 = rng.uniform(0.0, 0.2, batch)
-    dx = rng.uniform(0.9, 1.4, batch)
-    dy = rng.uniform(-0.08, 0.08, batch)
-    start = np.stack([rest_start(x) for x in x0])
+    dx = rng.uniform(0.45, 0.7, batch)
+    dy = rng.uniform(-0.03, 0.03, batch)
+    map_id = rng.integers(0, len(maps), batch).astype(np.int32)
+    start = []
+    for x, m in zip(x0, map_id):
+        feet = NOMINAL_FEET + np.array([x, 0.0, 0.0])
+        fz = heightfield.height_at(maps[m], cell, feet[:, 0], feet[:, 1], mode=mode)
+        start.append(rest_start(x, 0.0, 0.24 + float(heightfield.height_at(maps[m], cell, x, 0.0, mode=mode)), fz))
     goal = np.stack([x0 + dx, dy, np.full(batch, 0.24)], axis=1)
-    return start, goal, rng.integers(0, n_maps, batch).astype(np.int32)
+    return np.stack(start), goal, map_id

@@ -6,7 +6,7 @@ cfg = PlannerConfig.knots200(honor_start_velocity=True)
 B = 64
 P = capi.Planner(cfg, max_batch=B)
 maps, cell = workloads.random_terrains(); P.set_heightfields(maps, cell)
-start, goal, mid = workloads.mpc_goals(B)
+start, goal, mid = workloads.mpc_goals(B, terrains=(maps, cell))
 nodes, status, iters, viol = P.plan(start, goal, map_id=mid)
 print(0, np.bincount(status, minlength=3), iters.mean())
 for k in range(1, 70):

@@ -6,9 +6,10 @@ cfg = PlannerConfig.knots200()
 NB = 256
 P = capi.Planner(cfg, max_batch=NB)
 print("dims", P.dims.n_vars, P.dims.n_stages, P.dims.front)
-start, goal, mid = workloads.mpc_goals(NB)
+terr0 = workloads.random_terrains()
+start, goal, mid = workloads.mpc_goals(NB, terrains=terr0)
 goal_flat = goal.copy()
-for tag, terr in (("flat", None), ("random", workloads.random_terrains())):
+for tag, terr in (("random", terr0),):
     if terr is not None:
         P.set_heightfields(terr[0], terr[1])
     for rep in range(2):

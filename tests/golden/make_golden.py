@@ -311,6 +311,30 @@ def planner_fixtures():
         os.chdir(cwd)
 
 
+def random_height_fixtures():
+    """Outputs of the reference's terrain randomiser (`Height_Map_Generator.random_height_shift`,
+    QTOS/generateHeightField.py:692-730) on the exp_5 map at mesh_scale 1, python `random` seeded."""
+    import random
+    import types
+    sys.modules.setdefault("pybullet", types.ModuleType("pybullet"))
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from QTOS import generateHeightField as ghf
+        obj = object.__new__(ghf.Height_Map_Generator)
+        ghf.Maps.__init__(obj, ["climb_2", "climb_1"], 20, 1)
+        base = np.array(obj.map, dtype=float)
+        out = {"tiles": ["climb_2", "climb_1"], "mesh_scale": 1, "base": base.tolist(), "cases": []}
+        for seed, shift in ((0, 1), (1, 10), (2, 10)):
+            random.seed(seed)
+            m = obj.random_height_shift(base.copy(), shift)
+            out["cases"].append({"seed": seed, "shift": shift, "map": np.asarray(m).tolist()})
+        return out
+    finally:
+        os.chdir(cwd)
+
+
 def main():
     gait = np.loadtxt(os.path.join(REF, "test/data/traj/gait.csv"), delimiter=",")
     towr = np.loadtxt(os.path.join(REF, "data/traj/towr.csv"), delimiter=",")
@@ -337,6 +361,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "gv3_partial.npz"), rows=gv3[::10], row_idx=np.arange(0, 1254, 10))
     json.dump(boundary_fixtures(), open(os.path.join(OUT, "boundary.json"), "w"), indent=1)
     json.dump(planner_fixtures(), open(os.path.join(OUT, "planner.json"), "w"))
+    json.dump(random_height_fixtures(), open(os.path.join(OUT, "random_height.json"), "w"))
     dims = parse_log(os.path.join(REF, "logs/towr_log.out"))
     json.dump(dims, open(os.path.join(OUT, "nlp_dims.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in dims.items() if not k.endswith("_sets")}))

@@ -125,3 +125,18 @@ def test_bad_parameters_are_rejected(hip_lib, cfg):
     assert hip_lib.qtos_analyze(C.byref(p), C.byref(d), None, 0) == -1
     h = C.c_void_p()
     assert hip_lib.qtos_planner_create(C.byref(p), 1, 0, C.byref(h)) < 0 and not h
+
+
+def test_random_height_equals_reference():
+    """Terrain randomiser vs the reference's own `random_height_shift` outputs (python `random` seeded;
+    fixture generated by tests/golden/make_golden.py from QTOS/generateHeightField.py:692-730)."""
+    import json
+    import random
+    from qtos_amd import heightfield, workloads
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "random_height.json")))
+    base = heightfield.build_map([workloads.tile(t) for t in d["tiles"]], d["mesh_scale"])
+    assert np.array_equal(base, np.array(d["base"]))
+    for c in d["cases"]:
+        m = heightfield.random_height_shift(base, c["shift"], random.Random(c["seed"]))
+        assert np.array_equal(m, np.array(c["map"]))
+    assert np.array_equal(base, np.array(d["base"]))   # the input is not modified

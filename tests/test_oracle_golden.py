@@ -204,8 +204,9 @@ def test_oracle_knots200_on_random_heightfield():
     from qtos_amd.config import PlannerConfig
     cfg = PlannerConfig.knots200()
     maps, cell = workloads.random_terrains()
-    assert np.abs(maps).max() <= 0.02 + 1e-12 and np.abs(maps[:, :30]).max() == 0.0   # level start area
-    start, goal, mid = workloads.mpc_goals(2)
+    assert maps.shape[0] == 8 and maps.min() == 0.0 and 0.1 < maps.max() < 0.2
+    assert np.abs(maps[:, :140]).max() == 0.0 and np.ptp(maps, axis=0).max() > 0.01   # level start area, maps differ
+    start, goal, mid = workloads.mpc_goals(2, terrains=(maps, cell))
     O = Oracle(cfg.oracle_dict(), height=maps[mid[0]], hcell=cell)
     assert (O.n, O.m) == (3160, 4558)
     s = start[0]
