@@ -6,7 +6,10 @@ G = "gpurun_out/"
 pairs = {"bench_%s.json": "r01_final_bench.json", "bench_%s_compat.json": "r01_final_bench_reference_compat.json",
          "bench_%s_exp5.json": "r01_final_bench_exp5.json", "bench_%s_mixed.json": "r01_final_bench_mixed.json",
          "bench_%s_mixed_inflight3.json": "r01_final_bench_mixed_inflight3.json",
-         "bench_%s_flat_inflight2.json": "r01_final_bench_flat_inflight2.json"}
+         "bench_%s_flat_inflight2.json": "r01_final_bench_flat_inflight2.json",
+         "bench_%s_knots200.json": "r01_final_bench_knots200.json",
+         "bench_%s_mpc200_iter6.json": "r01_final_bench_knots200_mpc_random_maxiter6.json",
+         "bench_%s_mpc200.json": "r01_final_bench_knots200_mpc_random.json"}
 for src, dst in pairs.items():
     line = open(G + src % tag).read().strip().splitlines()[-1]
     json.loads(line)
