@@ -28,10 +28,13 @@ struct DevPlan {
   const TerrInst *terr;
   const ForceInst *force;
   const LinRow *lin;
-  const ColDesc *dyn_cols, *rom_cols;
-  int n_dyn_cols, n_rom_cols;
+  // iterate-dependent Jacobian entries of the dynamics / range-of-motion columns as linear forms over
+  // the local Jacobians in LDS, in stream order (model.hpp: LinTerm1 / LinTerm3)
+  const LinTerm1 *dyn_t1, *rom_t1;
+  const LinTerm3 *dyn_t3;
+  const int *dyn_t1_off, *dyn_t3_off;   // first entry of every knot chunk (+ end)
+  int n_rom_t1;
   int dyn_chunk;               // dynamics knots evaluated per pass of eval_all (LDS scratch bound)
-  const int *dyn_col_off;      // first dyn_cols entry of every chunk (+ end)
   const Block *blocks;
   const int *block_cols;
   const IqRow *iq_rows;   // rows of the inequality blocks (stream offsets)
@@ -264,9 +267,7 @@ __device__ inline void terrain_basis(const Terr &t, int which, double b[3], doub
 // written exactly once and all threads of the workgroup share the work:
 //   phase A (thread per instance): constraint values + the small local Jacobians -> LDS
 //   phase B (thread per block column): the 6 (3) entries of that column from the local Jacobians
-//                                      and the column's combined Hermite weights (ColDesc)
-constexpr int DYN_LOC = 54;  // A_th, A_thd, A_thdd (9 each), sum f (3), f_e (12), r - p_e (12)
-constexpr int ROM_LOC = 18;  // R (9), d/dtheta_j [R^T (p - r)] as columns (9)
+//                                      and the column's combined Hermite weights (LinTerm1 / LinTerm3)
 
 // Newton-Euler violation of one dynamics knot (values; with JAC also the force / lever-arm part of
 // the local Jacobian data).  The nine forward-mode passes for the Euler-angle columns are separate
@@ -328,28 +329,37 @@ __device__ __forceinline__ double skew_el(const double *v, int i, int d) {
   return sgn * v[k];
 }
 
-__device__ inline void dyn_column(const DevPlan &P, const ColDesc &C, const double *loc_all, double *G) {
-  const double *loc = loc_all + (size_t)C.inst * DYN_LOC;
-  const int d = C.dim;
-  double v[6];
-  if (C.kind == 0) {        // base position / acceleration: d g_ang / d r = -[sum f]x ; d g_lin / d a = m I
-    for (int i = 0; i < 3; ++i) v[i] = -skew_el(loc + 27, i, d) * C.w0;
-    for (int i = 0; i < 3; ++i) v[3 + i] = i == d ? P.mass * C.w1 : 0.0;
-  } else if (C.kind == 1) { // Euler angles / rates / accelerations
-    for (int i = 0; i < 3; ++i)
-      v[i] = loc[3 * i + d] * C.w0 + loc[9 + 3 * i + d] * C.w1 + loc[18 + 3 * i + d] * C.w2;
-    for (int i = 0; i < 3; ++i) v[3 + i] = 0.0;
-  } else if (C.kind < 6) {  // foot position: d g_ang / d p = [f]x
-    const double *f = loc + 30 + 3 * (C.kind - 2);
-    for (int i = 0; i < 3; ++i) v[i] = skew_el(f, i, d) * C.w0;
-    for (int i = 0; i < 3; ++i) v[3 + i] = 0.0;
-  } else {                  // foot force: d g_ang / d f = [r - p]x ; d g_lin / d f = -I
-    const double *dd = loc + 42 + 3 * (C.kind - 6);
-    for (int i = 0; i < 3; ++i) v[i] = skew_el(dd, i, d) * C.w0;
-    for (int i = 0; i < 3; ++i) v[3 + i] = i == d ? -C.w0 : 0.0;
-  }
+#ifndef TERM1_UNROLL
+#define TERM1_UNROLL 12
+#endif
+#ifndef TERM3_UNROLL
+#define TERM3_UNROLL 4
+#endif
+// G[pos] = a * loc[off] for the entries [i0, i1) of a LinTerm1 list, TERM1_UNROLL per thread and round (all
+// descriptor reads of a round in flight together); consecutive threads write consecutive positions
+__device__ inline void write_terms1(const LinTerm1 *T, int i0, int i1, const double *loc, double *G) {
+  const int nt = blockDim.x;
+  constexpr int UN = TERM1_UNROLL;   // descriptor reads in flight per thread: the lists are read at memory latency
+  for (int i = i0 + threadIdx.x; i < i1; i += UN * nt) {
+    LinTerm1 t[UN];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) G[C.pos[i]] = v[i];   // the block's rows land at their own stream positions
+    for (int u = 0; u < UN; ++u) t[u] = T[min(i + u * nt, i1 - 1)];
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      if (i + u * nt < i1) G[t[u].pos] = t[u].a * loc[t[u].off];
+  }
+}
+__device__ inline void write_terms3(const LinTerm3 *T, int i0, int i1, const double *loc, double *G) {
+  const int nt = blockDim.x;
+  constexpr int UN = TERM3_UNROLL;
+  for (int i = i0 + threadIdx.x; i < i1; i += UN * nt) {
+    LinTerm3 t[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) t[u] = T[min(i + u * nt, i1 - 1)];
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      if (i + u * nt < i1) G[t[u].pos] = loc[t[u].off[0]] * t[u].a[0] + loc[t[u].off[1]] * t[u].a[1] + loc[t[u].off[2]] * t[u].a[2];
+  }
 }
 
 template <bool JAC>
@@ -375,17 +385,6 @@ __device__ inline void eval_rom(const DevPlan &P, const RomInst &I, const double
 #pragma unroll
       for (int i = 0; i < 3; ++i) loc[9 + 3 * i + j] = Rd[i].d * d[0] + Rd[3 + i].d * d[1] + Rd[6 + i].d * d[2];
     }
-  }
-}
-
-__device__ inline void rom_column(const ColDesc &C, const double *loc_all, double *G) {
-  const double *loc = loc_all + (size_t)C.inst * ROM_LOC;
-  const int d = C.dim;
-  if (C.kind == 1) {
-    for (int i = 0; i < 3; ++i) G[C.pos[i]] = loc[9 + 3 * i + d] * C.w0;
-  } else {
-    const double sgn = C.kind == 2 ? 1.0 : -1.0;   // d/dp = R^T, d/dr = -R^T ; (R^T)[i][d] = R[3d + i]
-    for (int i = 0; i < 3; ++i) G[C.pos[i]] = sgn * loc[3 * d + i] * C.w0;
   }
 }
 
@@ -476,16 +475,8 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
       }
       __syncthreads();
       ESTAMP();
-      const int cend = P.dyn_col_off[ch + 1];
-      const double *loc0 = loc - (size_t)c0 * DYN_LOC;   // dyn_column indexes by the global knot number
-      for (int c = P.dyn_col_off[ch] + tid; c < cend; c += 4 * nt) {   // four columns per round: all descriptors in flight
-        ColDesc C[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) C[u] = P.dyn_cols[min(c + u * nt, cend - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (c + u * nt < cend) dyn_column(P, C[u], loc0, G);
-      }
+      write_terms1(P.dyn_t1, P.dyn_t1_off[ch], P.dyn_t1_off[ch + 1], loc, G);
+      write_terms3(P.dyn_t3, P.dyn_t3_off[ch], P.dyn_t3_off[ch + 1], loc, G);
       __syncthreads();
       ESTAMP();
     } else {
@@ -505,14 +496,7 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
   if (JAC) {
     __syncthreads();
     ESTAMP();
-    for (int c = tid; c < P.n_rom_cols; c += 4 * nt) {
-      ColDesc C[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) C[u] = P.rom_cols[min(c + u * nt, P.n_rom_cols - 1)];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (c + u * nt < P.n_rom_cols) rom_column(C[u], loc, G);
-    }
+    write_terms1(P.rom_t1, 0, P.n_rom_t1, loc, G);
     ESTAMP();
   }
   for (int i = tid; i < P.n_force; i += nt) eval_force<JAC>(P, P.force[i], map, x, g, G);
@@ -526,6 +510,10 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
   ESTAMP();
 }
 
+#ifndef QTOS_ET
+#define QTOS_ET 512
+#endif
+constexpr int ET = QTOS_ET;   // threads of the evaluation kernels (k_start, k_step): one workgroup per problem
 // ---- workgroup reductions (fixed tree => bitwise reproducible) --------------------------------
 template <int OP>  // 0 sum, 1 max, 2 min
 __device__ inline double wg_reduce(double v, double *scratch) {
@@ -615,10 +603,10 @@ __device__ inline void record_trace(const DevPlan &P, const DevWork &W, int b, i
 }
 
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_start(DevPlan P, DevWork W, int B) {
+__global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
   if (b >= B) return;
-  __shared__ double scratch[256];
+  __shared__ double scratch[ET];
   extern __shared__ double evl[];
   const int n = P.n_vars, m = P.n_cons, tid = threadIdx.x;
   double *x = W.x + (size_t)b * n, *g = W.g + (size_t)b * m;
@@ -1394,10 +1382,10 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 
 
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_step(DevPlan P, DevWork W, int B, int it) {
+__global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it) {
   const int b = blockIdx.x;
   if (b >= B || W.done[b]) return;
-  __shared__ double scratch[256];
+  __shared__ double scratch[ET];
   extern __shared__ double evl[];
   const int n = P.n_vars, m = P.n_cons, tid = threadIdx.x;
   // distinct buffers: __restrict__ lets the row loops below keep several rows' loads in flight

@@ -53,14 +53,23 @@ struct LinRow {  // 1 row with constant coefficients (acceleration continuity, s
   int var[8];
   double coef[8];
 };
-// One column of a dynamics / range-of-motion Jacobian block: which local Jacobian feeds it and the
-// combined Hermite weights of the node slots that map onto this variable (written exactly once).
+// Local Jacobians of one instance, kept in LDS between the instance pass and the entry pass:
+constexpr int DYN_LOC = 54;  // A_th, A_thd, A_thdd (9 each), sum f (3), f_e (12), r - p_e (12)
+constexpr int ROM_LOC = 18;  // R (9), d/dtheta_j [R^T (p - r)] as columns (9)
+// One column of a dynamics / range-of-motion Jacobian block (host only): which local Jacobian feeds
+// it and the combined Hermite weights of the node slots that map onto this variable.
 struct ColDesc {
   int inst, gbase, ncol;       // instance index, offset of G[0][col], row stride
   short kind, dim;             // dyn: 0 lin, 1 ang, 2+e foot e position, 6+e foot e force; rom: 0 lin, 1 ang, 2 foot
   double w0, w1, w2;
-  int pos[6];                  // stream positions of the column's entries (filled by the symbolic analysis)
 };
+// What the device sees of those columns: every Jacobian entry that depends on the iterate is a linear
+// form over the per-instance local Jacobians in LDS (`loc`), G[pos] = sum_t a_t * loc[off_t], listed in
+// stream order so that neighbouring threads write neighbouring stream positions.  Entries that do
+// not depend on the iterate (structural zeros of the 6-row columns, m*w, -w) are written into the
+// stream once, with the other constants, when the planner is created.
+struct LinTerm1 { int pos, off; double a; };
+struct LinTerm3 { int pos, off[3]; double a[3]; };
 // K2 assembly block: m consecutive constraint rows sharing one dense column list
 struct Block {
   int kind;  // 0 equality, 1 inequality
@@ -220,6 +229,7 @@ struct HostModel {
     return (int)blocks.size() - 1;
   }
   std::vector<ColDesc> dyn_cols, rom_cols;
+  int dyn_chunk = 1;   // dynamics knots per pass through the LDS scratch of the evaluation kernels (<= 128)
   // instances hold a block id in .goff until the offsets are final
   void finalize_goff() {
     auto fix = [&](int &goff) { if (goff >= 0) goff = blocks[goff].goff; };

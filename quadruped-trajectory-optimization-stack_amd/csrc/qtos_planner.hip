@@ -135,19 +135,10 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.n_force = (int)M.force.size(); D.n_lin = (int)M.linrow.size(); D.n_blocks = (int)M.blocks.size();
   TRY(p->upload(M.dyn, &D.dyn)); TRY(p->upload(M.rom, &D.rom)); TRY(p->upload(M.terr, &D.terr));
   TRY(p->upload(M.force, &D.force)); TRY(p->upload(M.linrow, &D.lin));
-  TRY(p->upload(M.dyn_cols, &D.dyn_cols)); TRY(p->upload(M.rom_cols, &D.rom_cols));
-  D.n_dyn_cols = (int)M.dyn_cols.size(); D.n_rom_cols = (int)M.rom_cols.size();
-  {  // dynamics knots per pass through the LDS scratch of the evaluation kernels: equal chunks of <= 128
-    const int n_dyn = (int)M.dyn.size(), n_ch = (n_dyn + 127) / 128;
-    D.dyn_chunk = n_ch ? (n_dyn + n_ch - 1) / n_ch : 1;
-    std::vector<int> off;
-    for (int c = 0, ch = 0; c <= (int)M.dyn_cols.size(); ++c) {
-      const int inst = c < (int)M.dyn_cols.size() ? M.dyn_cols[c].inst : n_dyn + D.dyn_chunk;
-      while (ch * D.dyn_chunk <= inst && ch <= n_ch) { off.push_back(c); ++ch; }
-    }
-    off.resize(n_ch + 1, (int)M.dyn_cols.size());
-    TRY(p->upload(off, &D.dyn_col_off));
-  }
+  TRY(p->upload(S.dyn_t1, &D.dyn_t1)); TRY(p->upload(S.dyn_t3, &D.dyn_t3)); TRY(p->upload(S.rom_t1, &D.rom_t1));
+  TRY(p->upload(S.dyn_t1_off, &D.dyn_t1_off)); TRY(p->upload(S.dyn_t3_off, &D.dyn_t3_off));
+  D.n_rom_t1 = (int)S.rom_t1.size();
+  D.dyn_chunk = M.dyn_chunk;
   TRY(p->upload(M.blocks, &D.blocks)); TRY(p->upload(M.block_cols, &D.block_cols));
   {
     std::vector<IqRow> rows;   // blocks carry their stream offsets once the symbolic analysis has run
@@ -330,7 +321,7 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
   const DevPlan &D = p->dp;
   HIPCHK(p, hipMemsetAsync(W.n_active, 0, sizeof(int), st));
   HIPCHK(p, hipEventRecord(p->ev[0], st));
-  hipLaunchKernelGGL(k_start, dim3(B), dim3(256), p->eval_lds, st, D, W, B);
+  hipLaunchKernelGGL(k_start, dim3(B), dim3(ET), p->eval_lds, st, D, W, B);
   int launches = 0, it = 0;
   for (it = 0; it < D.max_iter; ++it) {
     HIPCHK(p, hipMemcpyAsync(p->h_active, W.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -346,7 +337,7 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
     hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(KT), p->kkt_lds, st, D, W, B);
     HIPCHK(p, hipEventRecord(p->ev[3 + 2 * launches], st));
     launches++;
-    hipLaunchKernelGGL(k_step, dim3(B), dim3(256), p->eval_lds, st, D, W, B, it);
+    hipLaunchKernelGGL(k_step, dim3(B), dim3(ET), p->eval_lds, st, D, W, B, it);
   }
   HIPCHK(p, hipMemcpyAsync(d_nodes_out, W.x, (size_t)B * D.n_vars * sizeof(double), hipMemcpyDeviceToDevice, st));
   if (d_status_out) HIPCHK(p, hipMemcpyAsync(d_status_out, W.status, B * sizeof(int), hipMemcpyDeviceToDevice, st));

@@ -80,6 +80,72 @@ struct Symbolic {
   int max_active = 0;
   std::string err;
 
+  // Jacobian entries of the dynamics / range-of-motion columns as linear forms over the local
+  // Jacobians (see LinTerm1); the formulas are those of one 6-row (3-row) column:
+  //   dyn  lin   : d g_ang / d r = -[sum f]x w0 ; d g_lin / d a = m w1 I          (loc 27..29 = sum f)
+  //        ang   : rows 0-2 = A_th w0 + A_thd w1 + A_thdd w2 (loc 0.., 9.., 18..), rows 3-5 = 0
+  //        foot e: d g_ang / d p_e = [f_e]x w0 (loc 30+3e), rows 3-5 = 0
+  //        force e: d g_ang / d f_e = [r - p_e]x w0 (loc 42+3e) ; d g_lin / d f_e = -w0 I
+  //   rom  lin / foot: -/+ R^T w0 ((R^T)[i][d] = loc[3d+i]) ; ang: loc[9+3i+d] w0
+  std::vector<LinTerm1> dyn_t1, rom_t1;
+  std::vector<LinTerm3> dyn_t3;
+  std::vector<int> dyn_t1_off, dyn_t3_off;   // first entry of every knot chunk (+ end)
+  void build_linear_terms(HostModel &M) {
+    const int n_dyn = (int)M.dyn.size(), n_ch = std::max(1, (n_dyn + 127) / 128);
+    M.dyn_chunk = std::max(1, (n_dyn + n_ch - 1) / n_ch);
+    std::vector<std::vector<LinTerm1>> t1(n_ch);
+    std::vector<std::vector<LinTerm3>> t3(n_ch);
+    auto skew = [](int i, int d, int &k, double &sgn) {   // [v]x[i][d] = sgn * v[k] (i != d)
+      k = 3 - i - d;
+      sgn = ((d - i + 3) % 3 == 1) ? -1.0 : 1.0;
+    };
+    for (const ColDesc &c : M.dyn_cols) {
+      const int ch = c.inst / M.dyn_chunk, base = (c.inst - ch * M.dyn_chunk) * DYN_LOC, d = c.dim;
+      for (int i = 0; i < 6; ++i) {
+        const int pos = eq_pos[c.gbase + i * c.ncol];
+        double cst = 0.0;
+        bool is_const = true;
+        if (i < 3 && c.kind == 1) {
+          LinTerm3 t;
+          t.pos = pos;
+          t.off[0] = base + 3 * i + d; t.off[1] = base + 9 + 3 * i + d; t.off[2] = base + 18 + 3 * i + d;
+          t.a[0] = c.w0; t.a[1] = c.w1; t.a[2] = c.w2;
+          t3[ch].push_back(t);
+          is_const = false;
+        } else if (i < 3 && i != d) {
+          int k; double sgn;
+          skew(i, d, k, sgn);
+          const int vec = c.kind == 0 ? 27 : (c.kind < 6 ? 30 + 3 * (c.kind - 2) : 42 + 3 * (c.kind - 6));
+          t1[ch].push_back({pos, base + vec + k, (c.kind == 0 ? -sgn : sgn) * c.w0});
+          is_const = false;
+        } else if (i >= 3 && i - 3 == d) {
+          if (c.kind == 0) cst = M.P.mass * c.w1;
+          else if (c.kind >= 6) cst = -c.w0;
+        }
+        if (is_const) { const_pos.push_back(pos); const_val.push_back(cst); }
+      }
+    }
+    dyn_t1.clear(); dyn_t3.clear(); dyn_t1_off.assign(1, 0); dyn_t3_off.assign(1, 0);
+    for (int ch = 0; ch < n_ch; ++ch) {
+      std::sort(t1[ch].begin(), t1[ch].end(), [](const LinTerm1 &a, const LinTerm1 &b) { return a.pos < b.pos; });
+      std::sort(t3[ch].begin(), t3[ch].end(), [](const LinTerm3 &a, const LinTerm3 &b) { return a.pos < b.pos; });
+      dyn_t1.insert(dyn_t1.end(), t1[ch].begin(), t1[ch].end());
+      dyn_t3.insert(dyn_t3.end(), t3[ch].begin(), t3[ch].end());
+      dyn_t1_off.push_back((int)dyn_t1.size());
+      dyn_t3_off.push_back((int)dyn_t3.size());
+    }
+    rom_t1.clear();
+    for (const ColDesc &c : M.rom_cols) {
+      const int base = c.inst * ROM_LOC, d = c.dim;
+      for (int i = 0; i < 3; ++i) {
+        const int pos = c.gbase + i * c.ncol;   // inequality block: contiguous in the stream
+        if (c.kind == 1) rom_t1.push_back({pos, base + 9 + 3 * i + d, c.w0});
+        else rom_t1.push_back({pos, base + 3 * d + i, (c.kind == 2 ? 1.0 : -1.0) * c.w0});
+      }
+    }
+    std::sort(rom_t1.begin(), rom_t1.end(), [](const LinTerm1 &a, const LinTerm1 &b) { return a.pos < b.pos; });
+  }
+
   int build(HostModel &M) {
     const int n = M.n_vars, m = M.n_cons;
     struct Key { double t; int id; };
@@ -384,10 +450,7 @@ struct Symbolic {
     for (Block &b : M.blocks)
       if (b.kind == 1) b.goff = iq_first[b.goff];
     M.finalize_goff();
-    for (ColDesc &c : M.dyn_cols)
-      for (int i = 0; i < 6; ++i) c.pos[i] = eq_pos[c.gbase + i * c.ncol];
-    for (ColDesc &c : M.rom_cols)
-      for (int i = 0; i < 6; ++i) c.pos[i] = i < 3 ? c.gbase + i * c.ncol : 0;
+    build_linear_terms(M);
     // bytes = w * [ sum_k (p + c_k) * p  +  2 M ]   (matrix once, rhs in, solution out)
     algorithmic_bytes = 0;
     flops = 0;
