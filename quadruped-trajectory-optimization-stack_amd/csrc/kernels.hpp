@@ -35,6 +35,7 @@ struct DevPlan {
   const int *dyn_t1_off, *dyn_t3_off;   // first entry of every knot chunk (+ end)
   int n_rom_t1;
   int dyn_chunk;               // dynamics knots evaluated per pass of eval_all (LDS scratch bound)
+  const unsigned *amask;       // n_stages x 4: rows of the factor panel that are stored / read back (Symbolic::amask)
   const Block *blocks;
   const int *block_cols;
   const IqRow *iq_rows;   // rows of the inequality blocks (stream offsets)
@@ -1127,7 +1128,9 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         if (take[g]) A[aidx[g]] = 0.0;
         if (has_next) Xn[(16 * R + lk + 4 * g) * PLD + li] = acc[g];
       }
-      if (16 * R < hi16) {
+      // only the rows of live, non-pivot slots are kept (the others are zero and never read back)
+      const unsigned am16 = (P.amask[k * 4 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu;
+      if ((am16 >> li) & 1u) {
         double *pv = panel + (size_t)k * pstride + PIV;
         *(d4_t *)(pv + (16 * R + li) * PIV + 4 * lk) = vt;   // column c of a row sits at 4 (c & 3) + (c >> 2): 32 contiguous bytes per lane
       }
@@ -1324,27 +1327,38 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     constexpr int DEPTH = 4;
     double bv[DEPTH][4], bw[DEPTH];
     int bps[DEPTH], bun[DEPTH];
+    unsigned bam[DEPTH];
+    // the rows this wave reads of a stage: 16 bits of the stage's row mask, fetched one stage ahead of
+    // the panel loads that depend on it
+    auto amask16 = [&](int k) __attribute__((always_inline)) {
+      return (P.amask[max(k, 0) * 4 + (wv >> 1)] >> ((wv & 1) * 16)) & 0xffffu;
+    };
+    unsigned am_next = amask16(NS - 1);
     // loads are unconditional (clamped indices) so that the compiler can wait with partial vmcnt
     // counts instead of draining the whole prefetch ring at every stage
-    auto bload = [&](int k, double (&v)[4], double &wj, int &psj, int &unkj) __attribute__((always_inline)) {
+    auto bload = [&](int k, double (&v)[4], double &wj, int &psj, int &unkj, unsigned &am) __attribute__((always_inline)) {
       const int kk = max(k, 0);
       const double *pk = panel + (size_t)kk * pstride;
+      am = am_next;
+      am_next = amask16(k - 1);
+      // rows that were not stored are not fetched either: their lanes re-read w (finite, multiplied by 0 below)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = pk[PIV + min(16 * wv + q + 4 * i, F - 1) * PIV + 4 * (j & 3) + (j >> 2)];
+      for (int i = 0; i < 4; ++i)
+        v[i] = pk[((am >> (q + 4 * i)) & 1u) ? PIV + (16 * wv + q + 4 * i) * PIV + 4 * (j & 3) + (j >> 2) : j];
       wj = pk[j];
       psj = P.piv_slot[kk * PIV + j];
       unkj = P.piv_unknown[kk * PIV + j];
     };
-    auto bstep = [&](int k, const double (&v)[4], double wj, int psj, int unkj) __attribute__((always_inline)) {
+    auto bstep = [&](int k, const double (&v)[4], double wj, int psj, int unkj, unsigned am) __attribute__((always_inline)) {
       const bool valid = k >= 0;          // the stage count is padded to a multiple of DEPTH with no-op steps
       const int kk = max(k, 0);
       const int nw = valid ? hiall[kk] >> 4 : 0;
       double p = 0.0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) p = fma(v[i], xs[16 * wv + q + 4 * i], p);
+      for (int i = 0; i < 4; ++i) p = fma(v[i], ((am >> (q + 4 * i)) & 1u) ? xs[16 * wv + q + 4 * i] : 0.0, p);
       p += __shfl_xor(p, 16);
       p += __shfl_xor(p, 32);
-      if (lane < PIV) red[(kk & 1) * 128 + wv * PIV + j] = wv < nw ? p : 0.0;   // rows beyond the stage's range: no contribution
+      if (lane < PIV) red[(kk & 1) * 128 + wv * PIV + j] = (valid && wv < nw) ? p : 0.0;   // rows beyond the stage's range: no contribution
       lds_barrier();
       double r8[8];
 #pragma unroll
@@ -1359,14 +1373,14 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       }
     };
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) bload(NS - 1 - d, bv[d], bw[d], bps[d], bun[d]);
+    for (int d = 0; d < DEPTH; ++d) bload(NS - 1 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
     // straight-line body (four steps, no stage-dependent branches) so that the compiler waits for each
     // prefetched group with a partial vmcnt instead of draining the whole ring
     for (int k0 = NS - 1; k0 >= 0; k0 -= DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
-        bstep(k0 - d, bv[d], bw[d], bps[d], bun[d]);
-        bload(k0 - d - DEPTH, bv[d], bw[d], bps[d], bun[d]);
+        bstep(k0 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
+        bload(k0 - d - DEPTH, bv[d], bw[d], bps[d], bun[d], bam[d]);
       }
     }
   }

@@ -139,6 +139,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(S.dyn_t1_off, &D.dyn_t1_off)); TRY(p->upload(S.dyn_t3_off, &D.dyn_t3_off));
   D.n_rom_t1 = (int)S.rom_t1.size();
   D.dyn_chunk = M.dyn_chunk;
+  TRY(p->upload(S.amask, &D.amask));
   TRY(p->upload(M.blocks, &D.blocks)); TRY(p->upload(M.block_cols, &D.block_cols));
   {
     std::vector<IqRow> rows;   // blocks carry their stream offsets once the symbolic analysis has run
@@ -519,6 +520,13 @@ int qtos_debug_factor(QtosPlanner *p, int b, double *panel_out, int *piv_slot_ou
   HIPCHK(p, hipSetDevice(p->device));
   if (panel_out)
     HIPCHK(p, hipMemcpy(panel_out, p->wk.panel + (size_t)b * p->dp.panel_stride, (size_t)p->dp.panel_stride * sizeof(double), hipMemcpyDeviceToHost));
+  if (panel_out) {   // rows the kernel does not store (dead slots, the stage's own pivots) are zero by definition
+    const int F = p->S.front, NS = p->S.n_stages;
+    for (int k = 0; k < NS; ++k)
+      for (int r = 0; r < F; ++r)
+        if (!((p->S.amask[(size_t)k * 4 + (r >> 5)] >> (r & 31)) & 1u))
+          std::memset(panel_out + ((size_t)k * (F + 1) + 1 + r) * PIV, 0, PIV * sizeof(double));
+  }
   if (piv_slot_out) std::memcpy(piv_slot_out, p->S.piv_slot.data(), p->S.piv_slot.size() * sizeof(int));
   return 0;
 }

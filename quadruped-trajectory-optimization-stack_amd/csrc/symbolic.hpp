@@ -68,6 +68,7 @@ struct Symbolic {
   // pack_src[i] says where stream element i comes from: (kind << 28) | index, kind 0 G, 1 g_static,
   // 2 -g[row], 3 sig[row], 4 w[row], 5 piv_diag, 6 alignment padding
   std::vector<int> srec, srec_off, pack_src, drec_off, stage_hi;
+  std::vector<unsigned> amask;   // per stage 128 bits: front slots whose row of the factor panel V is stored (live, not a pivot of the stage)
   // The linearisation kernels write straight into the stream: eq_pos maps the (virtual) G offset of
   // an equality-block entry to its stream position; inequality blocks are contiguous in the stream
   // (Block::goff = stream offset); rhs/sig/w positions per constraint row; constants (static
@@ -216,6 +217,7 @@ struct Symbolic {
     std::vector<char> in_use;
     std::vector<int> slot_stage;   // pivot stage of the unknown occupying a slot, -1 if free
     stage_hi.assign(n_stages, 0);
+    amask.assign((size_t)n_stages * 4, 0u);
     int n_slots = 0;
     max_active = 0;
     envelope = 0;
@@ -282,6 +284,13 @@ struct Symbolic {
           piv_unknown[q] = -1;
           piv_diag[q] = 1.0;
         }
+      }
+      // rows of the stage's factor panel that can be non-zero: the slots in use, without its own pivots
+      for (int t = 0; t < (int)in_use.size() && t < 128; ++t)
+        if (in_use[t]) amask[(size_t)k * 4 + (t >> 5)] |= 1u << (t & 31);
+      for (int i = 0; i < PIV; ++i) {
+        const int t = piv_slot[(size_t)k * PIV + i];
+        if (t < 128) amask[(size_t)k * 4 + (t >> 5)] &= ~(1u << (t & 31));
       }
       // release pivots and dummies
       for (int i = lo; i < lo + PIV; ++i) {
