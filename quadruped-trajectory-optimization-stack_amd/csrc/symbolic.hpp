@@ -224,27 +224,47 @@ struct Symbolic {
     for (int j = 0; j < n_unknowns; ++j) envelope += j - first[j] + 1;
     std::vector<int> active_count(n_stages, 0);
     int active = 0;
+    // The front size is the largest number of simultaneously live unknowns whatever the placement rule
+    // (a free slot is always reused), so it is known up front and ALL its slots are on offer from the
+    // first stage on: that lets the rule below keep the pivots of a stage together.
+    {
+      int live = 0, peak = 0;
+      for (int k = 0; k < n_stages; ++k) {
+        live += (int)enter[k].size();
+        const int members = std::min(n_unknowns, (k + 1) * PIV) - k * PIV;
+        peak = std::max(peak, live + (PIV - members));   // + the dummy pivots of a short last stage
+        live -= members;
+      }
+      n_slots = ((peak + PIV - 1) / PIV) * PIV;
+      for (int t = n_slots - 1; t >= 0; --t) free_slots.push_back(t);
+      in_use.assign(n_slots, 0);
+      slot_stage.assign(n_slots, -1);
+    }
     for (int k = 0; k < n_stages; ++k) {
       for (int j : enter[k]) {
-        // prefer a free slot in a 16-slot group that already hosts pivots of the same stage (the
-        // kernel extracts a stage's pivot columns tile by tile: fewer groups = fewer tiles to
-        // visit), then a completely free group, then the smallest free slot
+        // The kernel moves a stage's pivot columns out of the Schur tiles tile by tile: the fewer 16-slot
+        // groups its pivots are spread over, the fewer tiles to visit.  Placement of an entering unknown:
+        // a group that already hosts unknowns of its pivot stage (the one with most of them); else a
+        // completely free group; else the group with the most free slots (room for the siblings still
+        // to come); ties to the lower group, lowest free slot of the group.  (1.9 groups per stage on
+        // the 100-knot problem; lowest-free-slot placement gives 3.7, same-stage preference alone 2.6.)
         int s = -1;
         if (!free_slots.empty()) {
-          const int stage_j = j / PIV;
-          int best = -1, best_score = -1;
-          for (int fs : free_slots) {
-            const int grp = fs >> 4;
-            int same = 0, used = 0;
-            for (int t = grp * 16; t < grp * 16 + 16 && t < (int)slot_stage.size(); ++t)
-              if (slot_stage[t] >= 0) { used++; if (slot_stage[t] == stage_j) same++; }
-            const int score = same > 0 ? 1000 + same : (used == 0 ? 500 : 0);
-            if (score > best_score || (score == best_score && fs < best)) { best_score = score; best = fs; }
+          const int stage_j = j / PIV, n_grp = (n_slots + 15) / 16;
+          int best_grp = -1, best_score = -1;
+          for (int grp = 0; grp < n_grp; ++grp) {
+            int same = 0, used = 0, nfree = 0;
+            for (int t = grp * 16; t < grp * 16 + 16 && t < n_slots; ++t) {
+              if (in_use[t]) { used++; if (slot_stage[t] == stage_j) same++; }
+              else nfree++;
+            }
+            if (!nfree) continue;
+            const int score = same > 0 ? 2000 + same : (used == 0 ? 1000 : nfree);
+            if (score > best_score) { best_score = score; best_grp = grp; }
           }
-          if (best_score >= 500 || true) {
-            s = best;
-            free_slots.erase(std::find(free_slots.begin(), free_slots.end(), s));
-          }
+          for (int t = best_grp * 16; t < best_grp * 16 + 16; ++t)
+            if (!in_use[t]) { s = t; break; }
+          free_slots.erase(std::find(free_slots.begin(), free_slots.end(), s));
         }
         if (s < 0) s = n_slots++;
         slot_of[j] = s;
