@@ -35,6 +35,8 @@ struct DevPlan {
   const int *dyn_t1_off, *dyn_t3_off;   // first entry of every knot chunk (+ end)
   int n_rom_t1;
   int dyn_chunk;               // dynamics knots evaluated per pass of eval_all (LDS scratch bound)
+  const int *cont;             // continuation records of heavy stages: {srec offset, ints, stream offset, doubles} each
+  int n_cont;                  // how many there are in the whole plan (0 for the standard transcriptions)
   const unsigned *amask;       // n_stages x 4: rows of the factor panel that are stored / read back (Symbolic::amask)
   const Block *blocks;
   const int *block_cols;
@@ -984,10 +986,27 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   // ---- prologue: assemble stages 0 and 1, gather and factor the pivot block of stage 0, leave the
   //      records of stage 2 in LDS ----------------------------------------------------------------
   //      (stage 1 may reuse the slots of stage 0's pivots: it is assembled after they were gathered)
+  // continuation records of the stage whose record sits in sbuf / dbuf (a stage that owns more
+  // inequality blocks than one record holds -- long stance phases): fetched and assembled one by one
+  auto assemble_continuations = [&]() __attribute__((always_inline)) {
+    if (P.n_cont == 0) return;
+    const int n_cont = __builtin_amdgcn_readfirstlane(sbuf[6]), c_first = __builtin_amdgcn_readfirstlane(sbuf[7]);
+    for (int c = 0; c < n_cont; ++c) {
+      lds_barrier();   // everybody is done with the current contents of sbuf / dbuf
+      const int *co = P.cont + 4 * (c_first + c);
+      const int so = co[0], sl = co[1], dof = co[2], dl = co[3];
+      for (int i = threadIdx.x; i < dl; i += KT) dbuf[i] = stream[dof + i];
+      for (int i = threadIdx.x; i < sl; i += KT) sbuf[i] = P.srec[so + i];
+      lds_barrier();
+      assemble_stage(A, F, sbuf, dbuf, threadIdx.x, KT);
+    }
+  };
   load_records(0);
   __syncthreads();
   header_from_lds(0);
+  __syncthreads();
   assemble_stage(A, F, sbuf, dbuf, tid, KT);
+  assemble_continuations();
   __syncthreads();
   {
     double *P0 = PB;   // stage 0 lives in panel 0
@@ -1008,7 +1027,8 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     load_records(s);
     __syncthreads();
     header_from_lds(s);
-    if (s == 1) assemble_stage(A, F, sbuf, dbuf, tid, KT);
+    __syncthreads();
+    if (s == 1) { assemble_stage(A, F, sbuf, dbuf, tid, KT); assemble_continuations(); }
     __syncthreads();
   }
 
@@ -1307,6 +1327,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     if (k + 2 < NS) {
       const int aslot = (0x05761342 >> (4 * wv)) & 7;   // wave -> position in the assembly order
       assemble_stage(A, F, sbuf, dbuf, aslot * 64 + lane, KT);
+      assemble_continuations();
     }
     STAMPW(1, st1, 1);
 #ifdef QTOS_STAMPS

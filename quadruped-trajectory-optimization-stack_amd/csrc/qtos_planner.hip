@@ -113,7 +113,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   p->device = device;
   p->max_batch = max_batch;
   if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
-  if (p->S.build(p->M)) { delete p; return -1; }
+  if (p->S.build(p->M)) { fprintf(stderr, "qtos: %s\n", p->S.err.c_str()); delete p; return -1; }
   const HostModel &M = p->M;
   const Symbolic &S = p->S;
   int ndev = 0;
@@ -140,6 +140,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.n_rom_t1 = (int)S.rom_t1.size();
   D.dyn_chunk = M.dyn_chunk;
   TRY(p->upload(S.amask, &D.amask));
+  D.n_cont = 0;
+  for (int k = 0; k < S.n_stages; ++k) D.n_cont += S.srec[S.srec_off[k] + 6];
+  TRY(p->upload(S.cont, &D.cont));
   TRY(p->upload(M.blocks, &D.blocks)); TRY(p->upload(M.block_cols, &D.block_cols));
   {
     std::vector<IqRow> rows;   // blocks carry their stream offsets once the symbolic analysis has run
@@ -282,8 +285,8 @@ int qtos_analyze(const QtosParams *params, QtosDims *d, int *stage_active, int m
   if (!params || !d) return -1;
   HostModel M;
   Symbolic S;
-  if (M.build(*params)) return -1;
-  if (S.build(M)) return -1;
+  if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
+  if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
   fill_dims(M, S, d);
   if (stage_active)
     for (int k = 0; k < S.n_stages && k < max_stages; ++k) stage_active[k] = S.stages[k].n_active;

@@ -13,7 +13,10 @@
 // of eliminated pivots are recycled).
 #pragma once
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
+#include <set>
 #include <numeric>
 #include <vector>
 
@@ -60,7 +63,8 @@ struct Symbolic {
   std::vector<short> iq_slots;    // front slot of every column of every inequality block
   int max_stage_g = 0;            // longest G slice of a stage
   // Packed per-stage records consumed by k_kkt (each is ONE contiguous, coalesced read):
-  //   static  srec[srec_off[k] ..]: n_ent, n_rhs, n_iq, hi, gather offset, n_tgt, 0, 0, piv_slot[16],
+  //   static  srec[srec_off[k] ..]: n_ent, n_rhs, n_iq, hi, gather offset, n_tgt, number of continuation
+  //           records, index of the first one in `cont`, piv_slot[16],
   //           tri index per equality entry, slot per rhs entry, gather table of the inequality blocks
   //           (target, first contribution), one packed int per contribution
   //   dynamic stream (per problem), drec_off[k] ..: piv_diag[16], equality values, -g of the rhs
@@ -145,6 +149,81 @@ struct Symbolic {
       }
     }
     std::sort(rom_t1.begin(), rom_t1.end(), [](const LinTerm1 &a, const LinTerm1 &b) { return a.pos < b.pos; });
+  }
+
+  // record limits: a stage record travels through the prefetch registers of k_kkt (2 x 16 B of doubles
+  // and 3 x 16 B of ints per thread, 512 threads) and its gather codes address 4096 doubles
+  static constexpr int REC_MAX_DOUBLES = 2048, REC_MAX_INTS = 6144, SHDR_INTS = 8;
+  std::vector<int> cont;   // continuation records: {srec offset, ints, stream offset, doubles} each
+  // dynamic part (per block G, sig, w) and gather table of the blocks `blks` of stage k, appended to the
+  // record that starts at srec[s0] / pack_src[d0]; patches the record's header ints [4], [5]
+  // the longest prefix of `blks` that fits a record which already holds `dyn` doubles and `fixed` ints
+  template <class TRS>
+  int split_blocks(const StageDesc &S, const std::vector<int> &blks, int dyn, int fixed, TRS trs,
+                   std::vector<int> &mine, std::vector<int> &rest) {
+    std::set<int> targets;
+    int contrib = 0;
+    for (int q : blks) {
+      const IqBlock &Q = iq_blocks[S.iq_begin + q];
+      if (Q.m > 5 || Q.n > 32) { err = "inequality block too large for the packed gather records"; return -1; }
+      const int d = Q.m * Q.n + 2 * Q.m, c = Q.n * (Q.n + 1) / 2 + Q.n;
+      std::set<int> t2 = targets;
+      for (int a = 0; a < Q.n; ++a) {
+        const int sa = iq_slots[Q.slot_off + a];
+        for (int cc = 0; cc <= a; ++cc) t2.insert(trs(sa, iq_slots[Q.slot_off + cc]));
+        t2.insert(front * (front + 1) / 2 + sa);
+      }
+      const bool fits = rest.empty() && dyn < 4096 && dyn + d <= REC_MAX_DOUBLES - 2 && contrib + c < 4096 &&
+                        fixed + (int)t2.size() + 1 + contrib + c <= REC_MAX_INTS - 8;
+      if (fits) { mine.push_back(q); dyn += d; contrib += c; targets.swap(t2); }
+      else rest.push_back(q);
+    }
+    return 0;
+  }
+  template <class TRS>
+  int emit_blocks(int k, const StageDesc &S, const std::vector<int> &blks, int s0, int d0, TRS trs) {
+    (void)k;
+    std::vector<int> blk_goff(blks.size());
+    for (size_t bi = 0; bi < blks.size(); ++bi) {
+      const IqBlock &Q = iq_blocks[S.iq_begin + blks[bi]];
+      blk_goff[bi] = (int)pack_src.size() - d0;
+      if (blk_goff[bi] >= 4096) { err = "inequality block beyond the reach of the packed gather records"; return -1; }
+      for (int i = 0; i < Q.m * Q.n; ++i) pack_src.push_back(S.g_begin + Q.gloc + i);
+      for (int r = 0; r < Q.m; ++r) pack_src.push_back((3 << 28) | (Q.row0 + r));
+      for (int r = 0; r < Q.m; ++r) pack_src.push_back((4 << 28) | (Q.row0 + r));
+    }
+    // gather table: target entry -> contributions (bi << 16 | a << 8 | c; c = 255: right-hand-side
+    // contribution of column a).  One thread owns one target, so the blocks of a record are assembled
+    // in ONE pass without conflicts and in a fixed order.
+    std::map<int, std::vector<int>> tmap;
+    for (size_t bi = 0; bi < blks.size(); ++bi) {
+      const IqBlock &Q = iq_blocks[S.iq_begin + blks[bi]];
+      for (int a = 0; a < Q.n; ++a) {
+        const int sa = iq_slots[Q.slot_off + a];
+        for (int c = 0; c <= a; ++c) tmap[trs(sa, iq_slots[Q.slot_off + c])].push_back(((int)bi << 16) | (a << 8) | c);
+        tmap[front * (front + 1) / 2 + sa].push_back(((int)bi << 16) | (a << 8) | 255);
+      }
+    }
+    srec[s0 + 4] = (int)srec.size() - s0;
+    srec[s0 + 5] = (int)tmap.size();
+    // one int per target (tri << 12 | first contribution), then one self-contained int per
+    // contribution: offset of the block's G in the dynamic record (12 bits) | a << 12 | c << 18
+    // (c = 63: right-hand side) | (n - 1) << 24 | (m - 1) << 29
+    int cpos = 0;
+    std::vector<int> codes;
+    for (auto &kv : tmap) {
+      srec.push_back((kv.first << 12) | cpos);
+      cpos += (int)kv.second.size();
+      for (int code : kv.second) {
+        const int bi = code >> 16, a = (code >> 8) & 255, c = code & 255;
+        const IqBlock &Q = iq_blocks[S.iq_begin + blks[bi]];
+        codes.push_back(blk_goff[bi] | (a << 12) | ((c == 255 ? 63 : c) << 18) | ((Q.n - 1) << 24) | (int)((unsigned)(Q.m - 1) << 29));
+      }
+    }
+    if (cpos >= 4096) { err = "gather table overflow"; return -1; }
+    srec.push_back(cpos);   // sentinel: end of the last target's contributions
+    srec.insert(srec.end(), codes.begin(), codes.end());
+    return 0;
   }
 
   int build(HostModel &M) {
@@ -385,6 +464,7 @@ struct Symbolic {
     auto trs = [](int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
     srec_off.assign(n_stages + 1, 0);
     drec_off.assign(n_stages + 1, 0);
+    std::vector<std::vector<int>> pending;   // per stage: inequality blocks left for continuation records
     for (int k = 0; k < n_stages; ++k) {
       const StageDesc &S = stages[k];
       // 16-byte aligned records: k_kkt moves them with 128-bit loads
@@ -408,58 +488,60 @@ struct Symbolic {
         srec.push_back(eq_rhs[i].slot);
         pack_src.push_back((2 << 28) | eq_rhs[i].row);
       }
-      // dynamic record of the inequality blocks: per block G (m x n), sig (m), w (m)
-      std::vector<int> blk_goff(n_iq);
-      for (int q = 0; q < n_iq; ++q) {
-        const IqBlock &Q = iq_blocks[S.iq_begin + q];
-        blk_goff[q] = (int)pack_src.size() - drec_off[k];
-        if (Q.m > 5 || Q.n > 32 || blk_goff[q] >= 4096) { err = "inequality block too large for the packed gather records"; return -1; }
-        for (int i = 0; i < Q.m * Q.n; ++i) pack_src.push_back(S.g_begin + Q.gloc + i);
-        for (int r = 0; r < Q.m; ++r) pack_src.push_back((3 << 28) | (Q.row0 + r));
-        for (int r = 0; r < Q.m; ++r) pack_src.push_back((4 << 28) | (Q.row0 + r));
-      }
-      // gather table of the inequality blocks: target entry -> contributions (q << 16 | a << 8 | c;
-      // c = 255: right-hand-side contribution of column a).  One thread owns one target, so the
-      // blocks of a stage are assembled in ONE pass without conflicts and in a fixed order.
+      // inequality blocks of the stage: as many as the record limits allow go into the stage's own
+      // record, the rest into continuation records (same layout, no equality part) that the kernel
+      // fetches and assembles one after the other; they are emitted behind all stage records
+      std::vector<int> mine, rest;
       {
-        std::map<int, std::vector<int>> tmap;
-        for (int q = 0; q < n_iq; ++q) {
-          const IqBlock &Q = iq_blocks[S.iq_begin + q];
-          for (int a = 0; a < Q.n; ++a) {
-            const int sa = iq_slots[Q.slot_off + a];
-            for (int c = 0; c <= a; ++c) tmap[trs(sa, iq_slots[Q.slot_off + c])].push_back((q << 16) | (a << 8) | c);
-            tmap[front * (front + 1) / 2 + sa].push_back((q << 16) | (a << 8) | 255);
-          }
-        }
-        srec[srec_off[k] + 4] = (int)srec.size() - srec_off[k];
-        srec[srec_off[k] + 5] = (int)tmap.size();
-        // one int per target (tri << 12 | first contribution), then one self-contained int per
-        // contribution: offset of the block's G in the dynamic record (12 bits) | a << 12 | c << 18
-        // (c = 63: right-hand side) | (n - 1) << 24 | (m - 1) << 29
-        int cpos = 0;
-        std::vector<int> codes;
-        for (auto &kv : tmap) {
-          srec.push_back((kv.first << 12) | cpos);
-          cpos += (int)kv.second.size();
-          for (int code : kv.second) {
-            const int q = code >> 16, a = (code >> 8) & 255, c = code & 255;
-            const IqBlock &Q = iq_blocks[S.iq_begin + q];
-            codes.push_back(blk_goff[q] | (a << 12) | ((c == 255 ? 63 : c) << 18) | ((Q.n - 1) << 24) | (int)((unsigned)(Q.m - 1) << 29));
-          }
-        }
-        if (cpos >= 4096) { err = "gather table overflow"; return -1; }
-        srec.push_back(cpos);   // sentinel: end of the last target's contributions
-        srec.insert(srec.end(), codes.begin(), codes.end());
+        std::vector<int> all(n_iq);
+        std::iota(all.begin(), all.end(), 0);
+        if (split_blocks(S, all, (int)pack_src.size() - drec_off[k], (int)srec.size() - srec_off[k], trs, mine, rest)) return -1;
       }
+      if (emit_blocks(k, S, mine, srec_off[k], drec_off[k], trs)) return -1;
+      srec[srec_off[k] + 2] = (int)mine.size();
+      pending.push_back(rest);
       max_srec = std::max(max_srec, (int)srec.size() - srec_off[k]);
       max_drec = std::max(max_drec, (int)pack_src.size() - drec_off[k]);
     }
     while (srec.size() & 3) srec.push_back(0);
     while (pack_src.size() & 1) pack_src.push_back(6 << 28);
-    max_srec = (max_srec + 7) & ~3;   // a stage's record may end with alignment padding
-    max_drec = (max_drec + 3) & ~1;
     srec_off[n_stages] = (int)srec.size();
     drec_off[n_stages] = (int)pack_src.size();
+    // continuation records
+    cont.clear();
+    for (int k = 0; k < n_stages; ++k) {
+      const StageDesc &S = stages[k];
+      std::vector<int> rest = pending[k];
+      int first_cont = (int)cont.size() / 4, n_cont = 0;
+      while (!rest.empty()) {
+        while (srec.size() & 3) srec.push_back(0);
+        while (pack_src.size() & 1) pack_src.push_back(6 << 28);
+        const int s0 = (int)srec.size(), d0 = (int)pack_src.size();
+        srec.push_back(0); srec.push_back(0); srec.push_back(0); srec.push_back(stage_hi[k]);
+        srec.push_back(0); srec.push_back(0); srec.push_back(0); srec.push_back(0);
+        for (int i = 0; i < PIV; ++i) { srec.push_back(0); pack_src.push_back(6 << 28); }
+        std::vector<int> mine, later;
+        if (split_blocks(S, rest, PIV, SHDR_INTS + PIV, trs, mine, later)) return -1;
+        if (mine.empty()) { err = "inequality block does not fit a record"; return -1; }
+        if (emit_blocks(k, S, mine, s0, d0, trs)) return -1;
+        srec[s0 + 2] = (int)mine.size();
+        while (srec.size() & 3) srec.push_back(0);
+        while (pack_src.size() & 1) pack_src.push_back(6 << 28);
+        cont.push_back(s0); cont.push_back((int)srec.size() - s0); cont.push_back(d0); cont.push_back((int)pack_src.size() - d0);
+        max_srec = std::max(max_srec, (int)srec.size() - s0);
+        max_drec = std::max(max_drec, (int)pack_src.size() - d0);
+        rest = later;
+        ++n_cont;
+      }
+      srec[srec_off[k] + 6] = n_cont;
+      srec[srec_off[k] + 7] = first_cont;
+    }
+    if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: %d stages, %d continuation records, max record %d ints / %d doubles\n", n_stages, (int)cont.size() / 4, max_srec, max_drec);
+    if (cont.empty()) cont.assign(4, 0);
+    while (srec.size() & 3) srec.push_back(0);
+    while (pack_src.size() & 1) pack_src.push_back(6 << 28);
+    max_srec = (max_srec + 7) & ~3;   // a stage's record may end with alignment padding
+    max_drec = (max_drec + 3) & ~1;
     // ---- direct-write maps derived from the stream layout ----
     eq_pos.assign((size_t)std::max<long long>(g_doubles, 1), -1);
     rhs_pos.assign(m, -1);

@@ -634,3 +634,35 @@ def test_knots200_receding_window_on_random_heightfields():
         failed += int((status != 0).sum())
     assert failed > 0
     P.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,front,heavy", [
+    (dict(duration=8.0), 112, True),                                   # `-duration 8`: stance phases of 1.7 s own more
+                                                                       # inequality blocks than one stage record holds
+    (dict(duration=2.5), 96, False),                                   # `-duration 2.5` (scripts/main.py:119-120)
+    (dict(duration=2.5, dt_dynamic=0.2, dt_base=0.2), 96, True),
+    (dict(duration=1.5, dt_dynamic=0.25, dt_base=0.25, dt_range_of_motion=0.25), 96, False),
+])
+def test_other_horizons_match_oracle(kw, front, heavy):
+    """Horizons other than 5 s (the reference's `-duration` flag rescales the gait schedule): other
+    front sizes (other `k_kkt<F>` instantiations) and, for long stance phases, stages whose inequality
+    blocks spill into continuation records.  GPU vs oracle, same iterates."""
+    from oracle.oracle import Oracle
+    from qtos_amd import capi, workloads
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig.reference_compat(**kw)
+    d, _ = capi.analyze(cfg)
+    assert d.front == front
+    P = capi.Planner(cfg, max_batch=8)
+    O = Oracle(cfg.oracle_dict())
+    assert (P.n, P.m) == (O.n, O.m)
+    start, goal = workloads.flat_goals(8, seed=11)
+    goal[:, 0] = start[:, 0] + (goal[:, 0] - start[:, 0]) * cfg.duration / 5.0   # same average speed
+    nodes, status, iters, viol = P.plan(start, goal)
+    assert (status == 0).all() and viol.max() <= cfg.tol
+    xo, infos = _oracle_solve(O, start[:4], goal[:4])
+    assert [i[0] for i in infos] == [0] * 4
+    assert [int(i) for i in iters[:4]] == [i[1] for i in infos]
+    assert np.abs(nodes[:4] - xo).max() < 1e-6
+    P.close()
