@@ -43,6 +43,11 @@ typedef struct QtosParams {
   double slack_push; /* cold-start slack push, fraction of the bound range (0.2); warm starts use 0.01 */
   int stall_iters;   /* stop a problem (status 1, best iterate returned) after this many iterations
                         without a new lowest violation; 0 = only the iteration limit stops it */
+  int hold_from;     /* two-phase solve: once an iterate (number >= hold_from) has brought the constraint
+                        violation down to hold_tol, the stance footholds stay where they are (their x, y
+                        get the proximal weight hold_weight instead of delta_x): the first iterations
+                        place the feet, the rest of the solve is a fixed-foothold problem; 0 = never */
+  double hold_weight, hold_tol;
 } QtosParams;
 
 typedef struct QtosDims {

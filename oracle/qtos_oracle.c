@@ -911,6 +911,9 @@ void qo_default_options(qo_options *o) {
   o->eps_dual = 1e-8;
   o->slack_push = 0.2;
   o->stall_iters = 5;
+  o->hold_from = 2;
+  o->hold_weight = 1e6;
+  o->hold_tol = 0.25;
   o->warm_start = 0;
   o->verbose = 0;
 }
@@ -1122,7 +1125,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     zu[i] = ch[r] < 1e19 ? mu / (ch[r] - s[i]) : 0.0;
   }
   info->inf_pr0 = max_violation(M, g, cl, ch);
-  int status = 1, it;
+  int status = 1, it, held = 0;
   double viol = 0;
   /* stall detection: remember the iterate with the lowest violation; give up when it has not been
    * improved for stall_iters iterations (cycling on a discontinuous terrain edge) and return it */
@@ -1155,6 +1158,15 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     memset(rhs, 0, sizeof(double) * N);
     for (int i = 0; i < n; ++i)
       if (vpos[i] >= 0) *sky_at(&K, vpos[i], vpos[i]) = o->delta_x;
+    /* two-phase solve: once the first iterations have placed the feet, the stance footholds stay */
+    if (o->hold_from > 0 && it >= o->hold_from && viol <= o->hold_tol) held = 1;
+    if (held)
+      for (int e = 0; e < QO_NEE; ++e)
+        for (int sn = 0; sn < M->n_stance[e]; ++sn)
+          for (int d = 0; d < 2; ++d) {
+            const int v = stance_var(M, e, sn) + d;
+            if (vpos[v] >= 0) *sky_at(&K, vpos[v], vpos[v]) = o->hold_weight;
+          }
     for (int i = 0; i < nI; ++i) {
       int r = Ir[i];
       double l = cl[r], u = ch[r];

@@ -100,6 +100,10 @@ typedef struct {
   int verbose;
   int stall_iters;     /* stop (status 1, best iterate returned) after this many iterations
                           without a new lowest violation; 0 = never                */
+  int hold_from;       /* once an iterate (number >= hold_from) has violation <= hold_tol the stance
+                          footholds (x, y) carry the proximal weight hold_weight instead of
+                          delta_x for the rest of the solve; 0 = never              */
+  double hold_weight, hold_tol;
 } qo_options;
 
 typedef struct {

@@ -27,7 +27,7 @@ class QtosParams(C.Structure):
         ("max_iter", C.c_int),
         ("tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
         ("delta_x", C.c_double), ("eps_dual", C.c_double), ("slack_push", C.c_double),
-        ("stall_iters", C.c_int),
+        ("stall_iters", C.c_int), ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double),
     ]
 
 
@@ -122,6 +122,7 @@ def params_from_config(cfg):
     p.mu_init, p.mu_min, p.delta_x, p.eps_dual = cfg.mu_init, cfg.mu_min, cfg.delta_x, cfg.eps_dual
     p.slack_push = cfg.slack_push
     p.stall_iters = cfg.stall_iters
+    p.hold_from, p.hold_weight, p.hold_tol = cfg.foothold_hold_from, cfg.foothold_hold_weight, cfg.foothold_hold_tol
     return p
 
 

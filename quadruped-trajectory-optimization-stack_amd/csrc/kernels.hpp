@@ -37,6 +37,9 @@ struct DevPlan {
   int dyn_chunk;               // dynamics knots evaluated per pass of eval_all (LDS scratch bound)
   const int *cont;             // continuation records of heavy stages: {srec offset, ints, stream offset, doubles} each
   int n_cont;                  // how many there are in the whole plan (0 for the standard transcriptions)
+  const int *terr_dpos;        // n_terr x 2: stream positions of the pivot diagonals of a foot node's x and y (-1: none)
+  int hold_from;               // two-phase solve: stance footholds are held once an iterate >= hold_from has violation <= hold_tol (0: never)
+  double hold_weight, hold_tol;
   const unsigned *amask;       // n_stages x 4: rows of the factor panel that are stored / read back (Symbolic::amask)
   const Block *blocks;
   const int *block_cols;
@@ -78,6 +81,7 @@ struct DevWork {
   double *x, *xt, *g, *gt, *s, *zl, *zu, *ds, *dzl, *dzu, *sig, *w, *G, *panel, *dx, *stream;
   double *mu, *viol, *trace;
   double *best_viol, *xbest;   // stall detection: lowest violation seen and the iterate that had it
+  int *held;                   // two-phase solve: 1 once the problem's footholds are held
   int *best_it;
   int *status, *iters, *done, *n_active;
 };
@@ -392,10 +396,19 @@ __device__ inline void eval_rom(const DevPlan &P, const RomInst &I, const double
 }
 
 template <bool JAC>
-__device__ inline void eval_terr(const DevPlan &P, const TerrInst &I, int map, const double *x, double *g, double *Gp) {
+__device__ inline void eval_terr(const DevPlan &P, const TerrInst &I, int map, const double *x, double *g, double *Gp,
+                                 int hold = -1, const int *dpos = nullptr) {
   const Terr t = terrain_at(P, map, x[I.vx], x[I.vy]);
   g[I.row] = x[I.vz] - t.h;
   if (JAC && I.in_kkt) {
+    if (P.hold_from > 0 && P.row_kind[I.row] == 1 && dpos) {
+      // two-phase solve (QtosParams.hold_from): the proximal weight of a stance foothold's x, y for the
+      // KKT system of this iterate -- delta_x while the feet are being placed, hold_weight afterwards
+      // (hold = -1, the introspection calls: delta_x)
+      const double wgt = hold > 0 ? P.hold_weight : P.delta_x;
+      if (dpos[0] >= 0) Gp[dpos[0]] = wgt;
+      if (dpos[1] >= 0) Gp[dpos[1]] = wgt;
+    }
     if (P.row_kind[I.row] == 1) {   // stance row: equality block, entries at their stream positions
       const int *pos = P.eq_pos + I.goff;
       if (I.cx >= 0) Gp[pos[I.cx]] = -t.hx;
@@ -445,7 +458,8 @@ __device__ inline void eval_force(const DevPlan &P, const ForceInst &I, int map,
 __device__ __forceinline__ int eval_loc_offset(int n_vars) { return (n_vars + 1) & ~1; }
 constexpr int DYN_VIN = 39, ROM_VIN = 9;   // pre-evaluated spline inputs per instance
 template <bool JAC>
-__device__ inline void eval_all(const DevPlan &P, int map, const double *xg, double *g, double *G, double *lds, double *dbg = nullptr) {
+__device__ inline void eval_all(const DevPlan &P, int map, const double *xg, double *g, double *G, double *lds, double *dbg = nullptr,
+                                int hold = -1) {
   const int tid = threadIdx.x, nt = blockDim.x;
 #ifdef QTOS_STAMPS
   unsigned long long et0 = 0; int ei = 0;
@@ -503,7 +517,7 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
     ESTAMP();
   }
   for (int i = tid; i < P.n_force; i += nt) eval_force<JAC>(P, P.force[i], map, x, g, G);
-  for (int i = tid; i < P.n_terr; i += nt) eval_terr<JAC>(P, P.terr[i], map, x, g, G);
+  for (int i = tid; i < P.n_terr; i += nt) eval_terr<JAC>(P, P.terr[i], map, x, g, G, hold, P.terr_dpos + 2 * i);
   for (int i = tid; i < P.n_lin; i += nt) {
     const LinRow &L = P.lin[i];
     double acc = 0;
@@ -675,13 +689,14 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     W.done[b] = (conv || bad) ? 1 : 0;
     W.best_viol[b] = viol;
     W.best_it[b] = 0;
+    W.held[b] = 0;
     if (!conv && !bad) atomicAdd(W.n_active, 1);
     record_trace(P, W, b, 0, viol, theta, 0.0, mu);
   }
   if (conv || bad) return;
   for (int v = tid; v < n; v += blockDim.x) W.xbest[(size_t)b * n + v] = x[v];   // best iterate so far: the starting point
   __syncthreads();
-  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl);
+  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, nullptr, 0);
   __syncthreads();
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
 }
@@ -1542,8 +1557,12 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     }
   }
   if (conv || bad || stalled) return;
+  // two-phase solve: latch the hold once this iterate is close enough
+  const int held = (W.held[b] || (P.hold_from > 0 && it + 1 >= P.hold_from && viol <= P.hold_tol)) ? 1 : 0;
   __syncthreads();
-  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, (W.trace && it == 1) ? W.trace + ((size_t)b * (P.max_iter + 1) + 36) * 4 : nullptr);
+  if (tid == 0) W.held[b] = held;
+  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, (W.trace && it == 1) ? W.trace + ((size_t)b * (P.max_iter + 1) + 36) * 4 : nullptr,
+                 held);
   __syncthreads();
   KSTAMP(4);
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);

@@ -143,6 +143,20 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.n_cont = 0;
   for (int k = 0; k < S.n_stages; ++k) D.n_cont += S.srec[S.srec_off[k] + 6];
   TRY(p->upload(S.cont, &D.cont));
+  {  // stream positions of the pivot diagonals of every foot node's x and y (two-phase solve)
+    std::vector<int> dpos_of_var(M.n_vars, -1), td;
+    for (int i = 0; i < (int)S.pack_src.size(); ++i)
+      if ((S.pack_src[i] >> 28) == 5) {
+        const int u = S.piv_unknown[S.pack_src[i] & 0x0fffffff];
+        if (u >= 0 && u < M.n_vars) dpos_of_var[u] = i;
+      }
+    for (const TerrInst &t : M.terr) { td.push_back(dpos_of_var[t.vx]); td.push_back(dpos_of_var[t.vy]); }
+    if (td.empty()) td.assign(2, -1);
+    TRY(p->upload(td, &D.terr_dpos));
+    D.hold_from = M.P.hold_from;
+    D.hold_weight = M.P.hold_weight > 0 ? M.P.hold_weight : 1e6;
+    D.hold_tol = M.P.hold_tol;
+  }
   TRY(p->upload(M.blocks, &D.blocks)); TRY(p->upload(M.block_cols, &D.block_cols));
   {
     std::vector<IqRow> rows;   // blocks carry their stream offsets once the symbolic analysis has run
@@ -237,6 +251,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   }
   TRY(p->alloc(&W.mu, Bm)); TRY(p->alloc(&W.viol, Bm));
   TRY(p->alloc(&W.best_viol, Bm)); TRY(p->alloc(&W.best_it, Bm)); TRY(p->alloc(&W.xbest, Bm * n));
+  TRY(p->alloc(&W.held, Bm));
   TRY(p->alloc(&W.trace, Bm * (size_t)(M.P.max_iter + 1) * 4));
   TRY(p->alloc(&W.status, Bm)); TRY(p->alloc(&W.iters, Bm)); TRY(p->alloc(&W.done, Bm));
   TRY(p->alloc(&W.n_active, 1));

@@ -463,13 +463,15 @@ def test_stall_detection_returns_best_iterate(cfg):
     """A problem that stops lowering its violation (a foot cycling across a ledge edge of the
     piecewise-constant exp_5 terrain) stops `stall_iters` iterations after its best iterate with
     status 1 and returns that iterate; converged problems are untouched; with the rule switched
-    off the same problems run to the iteration limit.  The oracle applies the same rule."""
+    off the same problems run to the iteration limit.  The oracle applies the same rule.
+    (Footholds left free for the whole solve, `foothold_hold_from` = 0.)"""
     import dataclasses
     from oracle.oracle import Oracle
     from qtos_amd import workloads
     from qtos_amd.capi import Planner
     hxy, cell = workloads.exp5_terrain()
     start, goal = workloads.step_goals(256, seed=1, terrain=(hxy, cell))
+    cfg = dataclasses.replace(cfg, foothold_hold_from=0)
     P = Planner(cfg, max_batch=256)
     P.set_heightfields(hxy, cell)
     nodes, status, iters, viol = P.plan(start, goal)
@@ -486,7 +488,9 @@ def test_stall_detection_returns_best_iterate(cfg):
     assert all(O.max_violation(nodes[b]) <= viol[b] + 1e-9 for b in stuck[:4])
     b = int(stuck[0])
     s, g = start[b], goal[b]
-    xo, info = O.solve(O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g, (0, 0, 0), (0, 0, 0), 0.0))
+    oo = O.default_options()
+    oo.hold_from = 0
+    xo, info = O.solve(O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g, (0, 0, 0), (0, 0, 0), 0.0), opts=oo)
     assert info.status == 1 and info.iters < cfg.max_iter
     P0 = Planner(dataclasses.replace(cfg, stall_iters=0), max_batch=256)
     P0.set_heightfields(hxy, cell)
@@ -665,4 +669,61 @@ def test_other_horizons_match_oracle(kw, front, heavy):
     assert [i[0] for i in infos] == [0] * 4
     assert [int(i) for i in iters[:4]] == [i[1] for i in infos]
     assert np.abs(nodes[:4] - xo).max() < 1e-6
+    P.close()
+
+
+@pytest.mark.gpu
+def test_two_phase_solve_holds_the_footholds():
+    """Two-phase solve (default): the first Newton iterations place the feet; once an iterate (the second
+    or a later one) is within `foothold_hold_tol` of feasibility the stance footholds stay put and
+    the solve finishes as a fixed-foothold problem.  On the exp_5 ledges every
+    problem of the batch then converges within a handful of iterations (with free footholds a few
+    cycle across a ledge edge until the stall rule stops them), the footholds of iterate 2 are the
+    footholds of the solution, the solution is feasible on the true terrain, and the oracle -- same
+    rule -- takes the same iterations to the same nodes."""
+    import dataclasses
+    from oracle.oracle import Oracle
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig.knots100()
+    assert (cfg.foothold_hold_from, cfg.foothold_hold_weight, cfg.foothold_hold_tol) == (2, 1e6, 0.25)
+    hxy, cell = workloads.exp5_terrain()
+    start, goal = workloads.step_goals(256, seed=1, terrain=(hxy, cell))
+    P = Planner(cfg, max_batch=256)
+    P.set_heightfields(hxy, cell)
+    nodes, status, iters, viol = P.plan(start, goal)
+    assert (status == 0).all() and iters.max() <= 6 and viol.max() <= cfg.tol
+    P2 = Planner(dataclasses.replace(cfg, max_iter=2, stall_iters=0), max_batch=256)
+    P2.set_heightfields(hxy, cell)
+    nodes2, _, it2, viol2 = P2.plan(start, goal)
+    P2.close()
+    assert (it2 == 2).all()
+    early = viol2 <= cfg.foothold_hold_tol   # held from iterate 2 on
+    assert early.sum() >= 200
+    d = P.dims
+    off = 2 * 6 * d.n_base_nodes            # ee-motion sets follow the two base sets (logs/towr_log.out:99-110)
+    for e in range(4):
+        for s in range(1, 5):               # stance nodes 1..4 (node 0 is the fixed start stance)
+            xy, xy2 = nodes[:, off + 35 * e + 8 * s: off + 35 * e + 8 * s + 2], nodes2[:, off + 35 * e + 8 * s: off + 35 * e + 8 * s + 2]
+            assert np.abs(xy - xy2)[early].max() < 1e-5
+    O = Oracle(cfg.oracle_dict(), height=hxy, hcell=cell)
+    same = 0
+    for b in range(6):
+        assert O.max_violation(nodes[b]) <= cfg.tol + 1e-9
+        s, g = start[b], goal[b]
+        xo, info = O.solve(O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g, (0, 0, 0), (0, 0, 0), 0.0))
+        assert info.status == 0
+        if info.iters == iters[b]:
+            assert np.abs(nodes[b] - xo).max() < 1e-5
+            same += 1
+    assert same >= 4
+    # flat ground: same iteration count with and without the hold
+    Pf = Planner(dataclasses.replace(cfg, foothold_hold_from=0), max_batch=64)
+    sf, gf = workloads.flat_goals(64, seed=0)
+    _, st_f, it_f, _ = Pf.plan(sf, gf)
+    Pf.close()
+    P.set_heightfields(np.zeros((40, 20)), 0.1)
+    _, st_h, it_h, _ = P.plan(sf, gf)
+    assert (st_f == 0).all() and (st_h == 0).all() and np.array_equal(it_f, it_h)
     P.close()

@@ -177,7 +177,9 @@ def test_skyline_ldlt_against_numpy():
 def test_oracle_stall_rule_stops_cycling_problems():
     """exp_5 terrain (piecewise-constant heights): a foot that cycles across a ledge edge never meets
     the tolerance.  With stall_iters = 5 (default) the solve stops five iterations after its best
-    iterate and returns it; with the rule off it runs to the iteration limit and ends no better."""
+    iterate and returns it; with the rule off it runs to the iteration limit and ends no better.
+    (Footholds left free for the whole solve, hold_from = 0: with the default two-phase solve the
+    foot is held after the second iteration and the same problem converges.)"""
     from oracle.oracle import Oracle
     from qtos_amd import workloads
     from qtos_amd.config import PlannerConfig
@@ -187,9 +189,14 @@ def test_oracle_stall_rule_stops_cycling_problems():
     O = Oracle(c.oracle_dict(), height=hxy, hcell=cell)
     s, g = start[31], goal[31]
     q = O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g, (0, 0, 0), (0, 0, 0), 0.0)
-    x5, i5 = O.solve(q)
+    xh, ih = O.solve(q)
     o = O.default_options()
-    assert o.stall_iters == 5
+    assert (o.stall_iters, o.hold_from, o.hold_weight, o.hold_tol) == (5, 2, 1e6, 0.25)
+    assert ih.status == 0 and ih.iters <= 6 and O.max_violation(xh) <= 1e-4 + 1e-9
+    o.hold_from = 0
+    x5, i5 = O.solve(q, opts=o)
+    o = O.default_options()
+    o.hold_from = 0
     o.stall_iters = 0
     x0, i0 = O.solve(q, opts=o)
     assert i5.status == 1 and i0.status == 1 and i5.iters < i0.iters == o.max_iter
