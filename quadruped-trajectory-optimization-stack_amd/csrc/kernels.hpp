@@ -913,7 +913,8 @@ __host__ __device__ inline size_t kkt_lds_bytes(int F, int NS, int max_srec, int
   return oi * sizeof(int);
 }
 
-template <int F>
+// CONT: the plan has continuation records (compiled out of the standard transcriptions' kernel)
+template <int F, bool CONT>
 __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 
   const int b = blockIdx.x;
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   // continuation records of the stage whose record sits in sbuf / dbuf (a stage that owns more
   // inequality blocks than one record holds -- long stance phases): fetched and assembled one by one
   auto assemble_continuations = [&]() __attribute__((always_inline)) {
-    if (P.n_cont == 0) return;
+    if constexpr (!CONT) return;
     const int n_cont = __builtin_amdgcn_readfirstlane(sbuf[6]), c_first = __builtin_amdgcn_readfirstlane(sbuf[7]);
     for (int c = 0; c < n_cont; ++c) {
       lds_barrier();   // everybody is done with the current contents of sbuf / dbuf

@@ -63,18 +63,13 @@ struct QtosPlanner {
 
 // k_kkt is compiled once per front size (multiples of 16 up to 128): the LDS layout and every tile
 // loop bound are compile-time constants
-static void (*kkt_kernel(int F))(DevPlan, DevWork, int) {
+static void (*kkt_kernel(int F, bool cont))(DevPlan, DevWork, int) {
+#define QTOS_KKT(f) case f: return cont ? k_kkt<f, true> : k_kkt<f, false>;
   switch (F) {
-    case 16: return k_kkt<16>;
-    case 32: return k_kkt<32>;
-    case 48: return k_kkt<48>;
-    case 64: return k_kkt<64>;
-    case 80: return k_kkt<80>;
-    case 96: return k_kkt<96>;
-    case 112: return k_kkt<112>;
-    case 128: return k_kkt<128>;
-    default: return nullptr;
+    QTOS_KKT(16) QTOS_KKT(32) QTOS_KKT(48) QTOS_KKT(64) QTOS_KKT(80) QTOS_KKT(96) QTOS_KKT(112) QTOS_KKT(128)
   }
+#undef QTOS_KKT
+  return nullptr;
 }
 
 static int upload_spline(QtosPlanner *p, const Spline &S, SampleSpline *out) {
@@ -216,7 +211,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     return -4;
   }
   {
-    p->kkt_fn = kkt_kernel(F);
+    p->kkt_fn = kkt_kernel(F, D.n_cont > 0);
     if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
