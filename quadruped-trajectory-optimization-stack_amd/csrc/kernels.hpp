@@ -328,14 +328,6 @@ __device__ inline void eval_dyn_pass(const DevPlan &P, const DynInst &I, double 
   }
 }
 
-// element (i, d) of the cross-product matrix [v]x
-__device__ __forceinline__ double skew_el(const double *v, int i, int d) {
-  if (i == d) return 0.0;
-  const int k = 3 - i - d;                       // the remaining axis
-  const double sgn = ((d - i + 3) % 3 == 1) ? -1.0 : 1.0;   // [v]x[0][1] = -v2, [0][2] = +v1, ...
-  return sgn * v[k];
-}
-
 #ifndef TERM1_UNROLL
 #define TERM1_UNROLL 12
 #endif
