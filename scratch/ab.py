@@ -14,5 +14,5 @@ for i in range(12):
 print(os.environ["QTOS_LIB"], "kkt ms: median %.4f min %.4f" % (1e3 * np.median(ts[2:]), 1e3 * min(ts[2:])))
 '''
 for rep in range(3):
-    for lib in ("libqtos_planner_A.so", "libqtos_planner_B.so"):
+    for lib in sys.argv[1:]:
         subprocess.run([sys.executable, "-c", code], env=dict(os.environ, QTOS_LIB=lib))
