@@ -89,6 +89,16 @@ int qtos_analyze(const QtosParams *params, QtosDims *dims, int *stage_active, in
 int qtos_set_heightfields(QtosPlanner *p, int n_maps, const double *height, int hnx, int hny,
                           double cell, double x0, double y0);
 
+/* Optional table of nominal plans for the starting point of cold solves (no reference counterpart: the
+ * reference's solver always starts from towr's straight-line guess, and so does this planner
+ * unless a table is set).  nodes[(j * ndx + i) * n_vars ..] = a solved plan from the rest start at the
+ * origin (nominal stance) to the goal (dx[i], dy[j]); grids strictly increasing.  A solve without
+ * `warm` then starts from the bilinear interpolation of the table over its goal displacement,
+ * shifted to its own start state, and is treated like a warm start.  ndx = 0 removes the table.
+ * Host pointers. */
+int qtos_set_init_table(QtosPlanner *p, int ndx, const double *dx, int ndy, const double *dy,
+                        const double *nodes);
+
 /* One batched solve = B invocations of `./main -g .. -s .. -s_ang .. -e1..-e4 .. [s_vel ..]
  * [s_ang_vel ..]`.  Host-pointer form: copies in, solves on the GPU, copies out.
  *   start   B x 24   CoM, Euler, feet FL FR HL HR (world), CoM velocity, Euler rates
@@ -145,6 +155,9 @@ int qtos_debug_structure(const QtosPlanner *p, int *row_kind, int *var_free, int
  * w = L^-T D^-1 y_F (16) then V = Y D^-1 L^-1 by front slot, column c of a row stored at
  * 4 (c & 3) + (c >> 2)) and the pivot slots (n_stages x 16) */
 int qtos_debug_factor(QtosPlanner *p, int b, double *panel_out, int *piv_slot_out);
+/* the starting point a solve without `warm` would use (straight-line guess or table guess), B x n_vars */
+int qtos_debug_initial_guess(QtosPlanner *p, int B, const double *start, const double *goal,
+                             const int *map_id, double *nodes_out);
 /* per-iteration trace of the last plan call for problem b: rows of (viol, theta, alpha, mu),
  * at most max_iter rows; returns the number of rows */
 int qtos_debug_trace(QtosPlanner *p, int b, double *trace_out);

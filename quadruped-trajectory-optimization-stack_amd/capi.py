@@ -52,6 +52,7 @@ EXPORTS = [
     "qtos_set_heightfields", "qtos_plan_batch", "qtos_plan_batch_device", "qtos_sample_csv",
     "qtos_sample_csv_device", "qtos_last_timing", "qtos_debug_eval", "qtos_debug_newton",
     "qtos_debug_structure", "qtos_debug_trace", "qtos_debug_factor", "qtos_analyze",
+    "qtos_set_init_table", "qtos_debug_initial_guess",
 ]
 
 _lib = None
@@ -85,6 +86,8 @@ def load():
     lib.qtos_debug_trace.argtypes = [vp, C.c_int, dp]
     lib.qtos_debug_factor.argtypes = [vp, C.c_int, dp, ip]
     lib.qtos_analyze.argtypes = [C.POINTER(QtosParams), C.POINTER(QtosDims), ip, C.c_int]
+    lib.qtos_set_init_table.argtypes = [vp, C.c_int, dp, C.c_int, dp, dp]
+    lib.qtos_debug_initial_guess.argtypes = [vp, C.c_int, dp, dp, ip, dp]
     _lib = lib
     return lib
 
@@ -151,6 +154,7 @@ class Planner:
             raise RuntimeError("qtos_planner_create failed (%d): -2 = no HIP device, -3 = out of "
                                "memory, -4 = front too large" % rc)
         self.max_batch, self.device = max_batch, device
+        self.init_table = None
         self.dims = QtosDims()
         self.lib.qtos_planner_dims(self.h, C.byref(self.dims))
         self.n, self.m = self.dims.n_vars, self.dims.n_cons
@@ -204,6 +208,50 @@ class Planner:
         rows = np.empty((B, n_rows, CSV_COLS))
         self._chk(self.lib.qtos_sample_csv(self.h, B, _dp(nodes), _dp(t0), hz, n_rows, _dp(rows)), "sample_csv")
         return rows
+
+    # ---- optional: nominal-plan table for the starting point of cold solves ----
+    def set_init_table(self, dx=None, dy=None, nodes=None):
+        """Install (or, without arguments, remove) a table of nominal plans: nodes[j][i] = the plan from the
+        rest start at the origin to the goal (dx[i], dy[j])."""
+        if dx is None:
+            self._chk(self.lib.qtos_set_init_table(self.h, 0, None, 0, None, None), "set_init_table")
+            self.init_table = None
+            return
+        dx = np.ascontiguousarray(dx, np.float64)
+        dy = np.ascontiguousarray(dy, np.float64)
+        nodes = np.ascontiguousarray(nodes, np.float64).reshape(len(dy), len(dx), self.n)
+        self._chk(self.lib.qtos_set_init_table(self.h, len(dx), _dp(dx), len(dy), _dp(dy), _dp(nodes)), "set_init_table")
+        self.init_table = (dx, dy, nodes)
+
+    def build_init_table(self, dx=None, dy=None, z=0.24):
+        """Solve the nominal problems (rest start at the origin, nominal stance, current heightfields,
+        straight-line guess) on a grid of goal displacements and install them as the table.  Default
+        grid: 0.1 .. 0.16 m per second of horizon ahead in five steps, -0.1 .. 0.1 m sideways in three."""
+        from . import workloads
+        T = self.dims.duration
+        dx = np.asarray(dx if dx is not None else np.linspace(0.03, 0.15, 5) * T, np.float64)
+        dy = np.asarray(dy if dy is not None else [-0.1, 0.0, 0.1], np.float64)
+        self.set_init_table()
+        start = np.repeat(workloads.rest_start(0.0, 0.0, z)[None], len(dx) * len(dy), 0)
+        goal = np.array([[x, y, z] for y in dy for x in dx])
+        nodes = np.empty((len(goal), self.n))
+        for i in range(0, len(goal), self.max_batch):
+            sl = slice(i, i + self.max_batch)
+            nodes[sl], status, _, _ = self.plan(start[sl], goal[sl])
+            if (status != 0).any():
+                raise RuntimeError("a nominal plan of the table did not converge")
+        self.set_init_table(dx, dy, nodes)
+        return dx, dy
+
+    def initial_guess(self, start, goal, map_id=None):
+        """The starting point a solve without `warm` uses for these problems (tests: the oracle is started
+        from the same point)."""
+        start = np.ascontiguousarray(start, np.float64).reshape(-1, START_DOUBLES)
+        goal = np.ascontiguousarray(goal, np.float64).reshape(-1, 3)
+        out = np.empty((start.shape[0], self.n))
+        mid = None if map_id is None else np.ascontiguousarray(map_id, np.int32)
+        self._chk(self.lib.qtos_debug_initial_guess(self.h, start.shape[0], _dp(start), _dp(goal), _ip(mid), _dp(out)), "initial_guess")
+        return out
 
     def timing(self):
         k, t = C.c_double(), C.c_double()

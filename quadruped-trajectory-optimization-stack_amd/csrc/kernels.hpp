@@ -35,6 +35,11 @@ struct DevPlan {
   const int *dyn_t1_off, *dyn_t3_off;   // first entry of every knot chunk (+ end)
   int n_rom_t1;
   int dyn_chunk;               // dynamics knots evaluated per pass of eval_all (LDS scratch bound)
+  // optional table of nominal plans (rest start at the origin, goals on a dx x dy grid) for the initial
+  // guess: table[(j * tab_ndx + i) * n_vars + v]; null = towr's straight-line guess
+  const double *table, *tab_dx, *tab_dy;
+  int tab_ndx, tab_ndy;
+  int off_lin, off_ang, off_eem[NEE];   // first variable of the base / foot motion node sets
   const int *cont;             // continuation records of heavy stages: {srec offset, ints, stream offset, doubles} each
   int n_cont;                  // how many there are in the whole plan (0 for the standard transcriptions)
   const int *terr_dpos;        // n_terr x 2: stream positions of the pivot diagonals of a foot node's x and y (-1: none)
@@ -611,6 +616,62 @@ __device__ inline void record_trace(const DevPlan &P, const DevWork &W, int b, i
   }
 }
 
+// ---- starting point of a solve ---------------------------------------------------------------------
+// With a table of nominal plans: bilinear interpolation over the goal displacement (clamped to the
+// grid), then every position-like variable is shifted by the difference between the problem's start
+// state and the interpolated plan's own (the flat-ground problem is translation invariant; the start
+// stance / height / attitude of the problem need not be the nominal one).
+struct TableCell {
+  int i0, i1, j0, j1;
+  double wx, wy;
+};
+__device__ inline TableCell table_cell(const DevPlan &P, const double *st, const double *gl) {
+  TableCell c = {0, 0, 0, 0, 0.0, 0.0};
+  if (!P.table) return c;
+  const double dx = gl[0] - st[0], dy = gl[1] - st[1];
+  int i = 0, j = 0;
+  while (i + 2 < P.tab_ndx && dx >= P.tab_dx[i + 1]) ++i;
+  while (j + 2 < P.tab_ndy && dy >= P.tab_dy[j + 1]) ++j;
+  c.i0 = i; c.i1 = min(i + 1, P.tab_ndx - 1);
+  c.j0 = j; c.j1 = min(j + 1, P.tab_ndy - 1);
+  c.wx = c.i1 > c.i0 ? fmin(fmax((dx - P.tab_dx[c.i0]) / (P.tab_dx[c.i1] - P.tab_dx[c.i0]), 0.0), 1.0) : 0.0;
+  c.wy = c.j1 > c.j0 ? fmin(fmax((dy - P.tab_dy[c.j0]) / (P.tab_dy[c.j1] - P.tab_dy[c.j0]), 0.0), 1.0) : 0.0;
+  return c;
+}
+__device__ inline double table_value(const DevPlan &P, const TableCell &c, int v) {
+  const size_t n = P.n_vars;
+  const double a = P.table[((size_t)c.j0 * P.tab_ndx + c.i0) * n + v], b = P.table[((size_t)c.j0 * P.tab_ndx + c.i1) * n + v];
+  const double d = P.table[((size_t)c.j1 * P.tab_ndx + c.i0) * n + v], e = P.table[((size_t)c.j1 * P.tab_ndx + c.i1) * n + v];
+  return (1.0 - c.wy) * ((1.0 - c.wx) * a + c.wx * b) + c.wy * ((1.0 - c.wx) * d + c.wx * e);
+}
+__device__ inline double initial_value(const DevPlan &P, const DevWork &W, int b, int v, const double *st, const double *gl,
+                                       int map, const TableCell &tc) {
+  const InitDesc I = P.init[v];
+  if (I.fix_src >= 0) return I.fix_src < 24 ? st[I.fix_src] : (I.fix_src < 26 ? gl[I.fix_src - 24] : 0.0);
+  if (W.warm) return W.warm[(size_t)b * P.n_vars + v];
+  if (P.table) {
+    double val = table_value(P, tc, v);
+    if (!I.is_vel && I.set < 6) {
+      const int ref = (I.set == 0 ? P.off_lin : (I.set == 1 ? P.off_ang : P.off_eem[I.set - 2])) + I.dim;
+      const int src = I.set == 0 ? I.dim : (I.set == 1 ? 3 + I.dim : 6 + 3 * (I.set - 2) + I.dim);
+      val += st[src] - table_value(P, tc, ref);
+    }
+    return val;
+  }
+  // towr's straight-line guess (nlp_formulation.cc Make*Variables)
+  const double fin[3] = {gl[0], gl[1], terrain_at(P, map, gl[0], gl[1]).h - P.nominal[0][2]};
+  double a, e;
+  if (I.set == 0) { a = st[I.dim]; e = fin[I.dim]; }
+  else if (I.set == 1) { a = st[3 + I.dim]; e = 0.0; }
+  else if (I.set < 6) {
+    const int ee = I.set - 2;
+    a = st[6 + 3 * ee + I.dim];
+    const double fx = fin[0] + P.nominal[ee][0], fy = fin[1] + P.nominal[ee][1];
+    e = I.dim == 0 ? fx : (I.dim == 1 ? fy : terrain_at(P, map, fx, fy).h);
+  } else { a = e = I.dim == 2 ? P.mass * P.gravity / NEE : 0.0; }
+  return I.is_vel ? (e - a) / P.T : a + I.frac * (e - a);
+}
+
 // =================================================================================================
 __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
@@ -622,27 +683,9 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
   double *s = W.s + (size_t)b * m, *zl = W.zl + (size_t)b * m, *zu = W.zu + (size_t)b * m;
   const double *st = W.start + (size_t)b * QTOS_START_DOUBLES, *gl = W.goal + (size_t)b * 3;
   const int map = W.map_id ? W.map_id[b] : 0;
-  // end points of the linear-interpolation guess (towr nlp_formulation.cc Make*Variables)
-  const double fin[3] = {gl[0], gl[1], terrain_at(P, map, gl[0], gl[1]).h - P.nominal[0][2]};
+  const TableCell tc = table_cell(P, st, gl);
   for (int v = tid; v < n; v += blockDim.x) {
-    const InitDesc I = P.init[v];
-    double val;
-    if (I.fix_src >= 0) {
-      val = I.fix_src < 24 ? st[I.fix_src] : (I.fix_src < 26 ? gl[I.fix_src - 24] : 0.0);
-    } else if (W.warm) {
-      val = W.warm[(size_t)b * n + v];
-    } else {
-      double a, e;
-      if (I.set == 0) { a = st[I.dim]; e = fin[I.dim]; }
-      else if (I.set == 1) { a = st[3 + I.dim]; e = 0.0; }
-      else if (I.set < 6) {
-        const int ee = I.set - 2;
-        a = st[6 + 3 * ee + I.dim];
-        const double fx = fin[0] + P.nominal[ee][0], fy = fin[1] + P.nominal[ee][1];
-        e = I.dim == 0 ? fx : (I.dim == 1 ? fy : terrain_at(P, map, fx, fy).h);
-      } else { a = e = I.dim == 2 ? P.mass * P.gravity / NEE : 0.0; }
-      val = I.is_vel ? (e - a) / P.T : a + I.frac * (e - a);
-    }
+    const double val = initial_value(P, W, b, v, st, gl, map, tc);
     x[v] = val;
     W.xbest[(size_t)b * n + v] = val;
   }
@@ -654,7 +697,7 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     if (P.row_kind[r] != 2) { s[r] = 0; zl[r] = 0; zu[r] = 0; continue; }
     const double l = P.con_lo[r], u = P.con_hi[r];
     const bool hl = l > -1e19, hu = u < 1e19;
-    const double kp = W.warm ? 0.01 : P.slack_push;   // large push on cold starts, Ipopt's 0.01 on warm starts
+    const double kp = (W.warm || P.table) ? 0.01 : P.slack_push;   // large push on cold starts, Ipopt's 0.01 on warm starts (a table guess is one)
     double pl = hl ? kp * fmax(1.0, fabs(l)) : 0.0, pu = hu ? kp * fmax(1.0, fabs(u)) : 0.0;
     if (hl && hu) { pl = fmin(pl, kp * (u - l)); pu = fmin(pu, kp * (u - l)); }
     double si = g[r];

@@ -33,6 +33,7 @@ struct QtosPlanner {
   double *d_start = nullptr, *d_goal = nullptr, *d_nodes = nullptr, *d_warm = nullptr;
   int *d_map = nullptr;
   double *d_height = nullptr;
+  double *d_table = nullptr, *d_tab_dx = nullptr, *d_tab_dy = nullptr;   // nominal-plan table (qtos_set_init_table)
   int *h_active = nullptr;  // pinned
   std::vector<hipEvent_t> ev;  // 2 per iteration (kkt begin/end) + 2 (total)
   int last_launches = 0, last_iters = 0;
@@ -97,6 +98,8 @@ void qtos_planner_destroy(QtosPlanner *p) {
   (void)hipSetDevice(p->device);
   for (void *a : p->allocs) (void)hipFree(a);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+  for (void *q : {(void *)p->d_table, (void *)p->d_tab_dx, (void *)p->d_tab_dy, (void *)p->d_height})
+    if (q) (void)hipFree(q);
   if (p->h_active) (void)hipHostFree(p->h_active);
   delete p;
 }
@@ -137,6 +140,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(S.amask, &D.amask));
   D.n_cont = 0;
   for (int k = 0; k < S.n_stages; ++k) D.n_cont += S.srec[S.srec_off[k] + 6];
+  D.table = nullptr; D.tab_dx = D.tab_dy = nullptr; D.tab_ndx = D.tab_ndy = 0;
+  D.off_lin = M.off_lin; D.off_ang = M.off_ang;
+  for (int e = 0; e < NEE; ++e) D.off_eem[e] = M.off_eem[e];
   TRY(p->upload(S.cont, &D.cont));
   {  // stream positions of the pivot diagonals of every foot node's x and y (two-phase solve)
     std::vector<int> dpos_of_var(M.n_vars, -1), td;
@@ -432,7 +438,53 @@ int qtos_sample_csv(QtosPlanner *p, int B, const double *nodes, const double *t0
   return rc;
 }
 
+int qtos_set_init_table(QtosPlanner *p, int ndx, const double *dx, int ndy, const double *dy, const double *nodes) {
+  if (!p) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  for (void *q : {(void *)p->d_table, (void *)p->d_tab_dx, (void *)p->d_tab_dy})
+    if (q) (void)hipFree(q);
+  p->d_table = p->d_tab_dx = p->d_tab_dy = nullptr;
+  p->dp.table = p->dp.tab_dx = p->dp.tab_dy = nullptr;
+  p->dp.tab_ndx = p->dp.tab_ndy = 0;
+  if (ndx <= 0 || ndy <= 0 || !dx || !dy || !nodes) return 0;
+  for (int i = 1; i < ndx; ++i) if (!(dx[i] > dx[i - 1])) return -1;
+  for (int j = 1; j < ndy; ++j) if (!(dy[j] > dy[j - 1])) return -1;
+  const size_t cnt = (size_t)ndx * ndy * p->M.n_vars;
+  HIPCHK(p, hipMalloc((void **)&p->d_table, cnt * sizeof(double)));
+  HIPCHK(p, hipMalloc((void **)&p->d_tab_dx, ndx * sizeof(double)));
+  HIPCHK(p, hipMalloc((void **)&p->d_tab_dy, ndy * sizeof(double)));
+  HIPCHK(p, hipMemcpy(p->d_table, nodes, cnt * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(p, hipMemcpy(p->d_tab_dx, dx, ndx * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(p, hipMemcpy(p->d_tab_dy, dy, ndy * sizeof(double), hipMemcpyHostToDevice));
+  p->dp.table = p->d_table; p->dp.tab_dx = p->d_tab_dx; p->dp.tab_dy = p->d_tab_dy;
+  p->dp.tab_ndx = ndx; p->dp.tab_ndy = ndy;
+  return 0;
+}
+
 // ---- introspection -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_debug_guess(DevPlan P, DevWork W, int B, double *out) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const double *st = W.start + (size_t)b * QTOS_START_DOUBLES, *gl = W.goal + (size_t)b * 3;
+  const int map = W.map_id ? W.map_id[b] : 0;
+  const TableCell tc = table_cell(P, st, gl);
+  for (int v = threadIdx.x; v < P.n_vars; v += blockDim.x) out[(size_t)b * P.n_vars + v] = initial_value(P, W, b, v, st, gl, map, tc);
+}
+
+int qtos_debug_initial_guess(QtosPlanner *p, int B, const double *start, const double *goal, const int *map_id, double *nodes_out) {
+  if (!p || B < 1 || B > p->max_batch || !start || !goal || !nodes_out) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  HIPCHK(p, hipMemcpy(p->d_start, start, (size_t)B * QTOS_START_DOUBLES * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(p, hipMemcpy(p->d_goal, goal, (size_t)B * 3 * sizeof(double), hipMemcpyHostToDevice));
+  if (map_id) HIPCHK(p, hipMemcpy(p->d_map, map_id, (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+  DevWork W = p->wk;
+  W.start = p->d_start; W.goal = p->d_goal; W.map_id = map_id ? p->d_map : nullptr; W.warm = nullptr;
+  hipLaunchKernelGGL(k_debug_guess, dim3(B), dim3(256), 0, 0, p->dp, W, B, p->d_nodes);
+  HIPCHK(p, hipDeviceSynchronize());
+  HIPCHK(p, hipMemcpy(nodes_out, p->d_nodes, (size_t)B * p->M.n_vars * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void k_debug_eval(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
   if (b >= B) return;

@@ -727,3 +727,49 @@ def test_two_phase_solve_holds_the_footholds():
     _, st_h, it_h, _ = P.plan(sf, gf)
     assert (st_f == 0).all() and (st_h == 0).all() and np.array_equal(it_f, it_h)
     P.close()
+
+
+@pytest.mark.gpu
+def test_nominal_plan_table_as_starting_point(oracle):
+    """Optional starting point for cold solves: the bilinear interpolation of a small table of nominal
+    plans (rest start at the origin, 5 x 3 goals, solved once) shifted to the problem's start state.
+    On flat ground the interpolated plan is so close that ONE Newton iteration reaches 1e-4 for the
+    whole seeded batch (four from towr's straight line); the oracle started from the same point takes
+    the same iteration to the same nodes; without a table nothing changes; non-nominal start stances
+    and goals outside the grid still converge."""
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig.reference_compat()
+    P = Planner(cfg, max_batch=64)
+    start, goal = workloads.flat_goals(64, seed=0)
+    cold_nodes, cold_status, cold_iters, _ = P.plan(start, goal)
+    guess0 = P.initial_guess(start[:2], goal[:2])
+    lo, hi = oracle.var_bounds(oracle.problem(start[0][0:3], start[0][3:6], start[0][6:18].reshape(4, 3), goal[0]))
+    assert np.abs(guess0[0] - oracle.initial_guess(oracle.problem(start[0][0:3], start[0][3:6], start[0][6:18].reshape(4, 3), goal[0]))).max() < 1e-12
+    dx, dy = P.build_init_table()
+    assert (len(dx), len(dy)) == (5, 3) and P.init_table[2].shape == (3, 5, P.n)
+    nodes, status, iters, viol = P.plan(start, goal)
+    assert (status == 0).all() and viol.max() <= cfg.tol
+    assert iters.max() <= 2 and iters.mean() < 0.5 * cold_iters.mean()
+    guess = P.initial_guess(start, goal)
+    fx = lo == hi
+    assert np.abs(guess[0, fx] - lo[fx]).max() == 0.0            # fixed variables carry the problem's own data
+    for b in range(3):
+        s, g = start[b], goal[b]
+        xo, info = oracle.solve(oracle.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g), x0=guess[b])
+        assert info.status == 0 and info.iters == iters[b]
+        assert np.abs(nodes[b] - xo).max() < 1e-6
+    # plans from the table guess are plans of the same problems: close to the cold-start ones
+    assert np.abs(P.sample(nodes[:4], 0.0, hz=100.0)[:, :, 1:4] - P.sample(cold_nodes[:4], 0.0, hz=100.0)[:, :, 1:4]).max() < 0.05
+    # a start stance that is not the nominal one, a yawed start, a goal outside the grid
+    s2, g2 = start[:3].copy(), goal[:3].copy()
+    s2[0, 6:18] += np.tile([0.02, -0.015, 0.0], 4)
+    s2[1, 5] = 0.1
+    g2[2, 0] = s2[2, 0] + 0.9
+    n2, st2, it2, v2 = P.plan(s2, g2)
+    assert (st2[:2] == 0).all() and it2[:2].max() <= 4
+    P.set_init_table()
+    n3, st3, it3, _ = P.plan(start, goal)
+    assert np.array_equal(n3, cold_nodes) and np.array_equal(it3, cold_iters)
+    P.close()
