@@ -9,7 +9,10 @@ pairs = {"bench_%s.json": "r01_final_bench.json", "bench_%s_compat.json": "r01_f
          "bench_%s_flat_inflight2.json": "r01_final_bench_flat_inflight2.json",
          "bench_%s_knots200.json": "r01_final_bench_knots200.json",
          "bench_%s_mpc200_iter6.json": "r01_final_bench_knots200_mpc_random_maxiter6.json",
-         "bench_%s_mpc200.json": "r01_final_bench_knots200_mpc_random.json"}
+         "bench_%s_mpc200.json": "r01_final_bench_knots200_mpc_random.json",
+         "bench_%s_table.json": "r01_final_bench_init_table.json",
+         "bench_%s_table_compat.json": "r01_final_bench_init_table_reference_compat.json",
+         "bench_%s_table_knots200.json": "r01_final_bench_init_table_knots200.json"}
 for src, dst in pairs.items():
     line = open(G + src % tag).read().strip().splitlines()[-1]
     json.loads(line)

@@ -12,6 +12,9 @@ python bench.py --cpu-sample 0 --inflight 2 > $O/bench_${T}_flat_inflight2.json 
 python bench.py --cpu-sample 8 --transcription knots200 > $O/bench_${T}_knots200.json 2>/dev/null
 python bench.py --cpu-sample 0 --transcription knots200 --workload mpc_random --steps 64 --max-iter 6 > $O/bench_${T}_mpc200_iter6.json 2>/dev/null
 python bench.py --cpu-sample 0 --transcription knots200 --workload mpc_random --steps 64 > $O/bench_${T}_mpc200.json 2>/dev/null
+python bench.py --cpu-sample 0 --init table > $O/bench_${T}_table.json 2>/dev/null
+python bench.py --cpu-sample 0 --init table --transcription reference_compat > $O/bench_${T}_table_compat.json 2>/dev/null
+python bench.py --cpu-sample 0 --init table --transcription knots200 > $O/bench_${T}_table_knots200.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o runc -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $O/prof_$T.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$T -o runc -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $O/pmc_fetch_$T.log 2>&1
