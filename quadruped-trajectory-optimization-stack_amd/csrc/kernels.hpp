@@ -1283,14 +1283,17 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
           const unsigned rm = (rw2 >> lk) & 0x1111u;                                 // bit 4g: row lk + 4g is a pivot
           const unsigned rmk = ((rm & 1u) | ((rm >> 3) & 2u) | ((rm >> 6) & 4u) | ((rm >> 9) & 8u)) & (R > C ? 0xfu : gt4);
           double *xr = Xnn + (16 * R + lk) * PLD + jcs[t], *xc = Xnn + (16 * C + li) * PLD;
+          // (one wave-uniform branch per direction, not one per entry)
+          if (cw2) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const bool cg = (cm >> g) & 1u, rg = (rmk >> g) & 1u;
-            const double uu = U[t][g];
-            if (cw2) *(cg ? xr + g * 4 * PLD : dummy) = uu;
-            if (rw2) *(rg ? xc + jrs[t][g] : dummy) = uu;
-            U[t][g] = (cg || rg) ? 0.0 : uu;
+            for (int g = 0; g < 4; ++g) *(((cm >> g) & 1u) ? xr + g * 4 * PLD : dummy) = U[t][g];
           }
+          if (rw2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(((rmk >> g) & 1u) ? xc + jrs[t][g] : dummy) = U[t][g];
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) U[t][g] = (((cm | rmk) >> g) & 1u) ? 0.0 : U[t][g];
         }
       }
       STAMPW(1, st1, 0);
