@@ -1139,6 +1139,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     const Mask128 m1 = load_mask(pm + ((k + 1) & 1) * 4, lane);   // pivot slots of stage k+1
     if (wv < NT) {
       const int R = wv;
+      const unsigned am_word = P.amask[k * 4 + (R >> 1)];   // row mask of this stage's panel: fetched now, used at the end of the phase
       const int prow = has_next ? prow_next : 0;
       const int *jmn = jm + ((k + 1) & 1) * 128;
       double la[4], pr[4], pp[4], dn[4], lb[4], xv[4], av[4];
@@ -1171,12 +1172,12 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       for (int g = 0; g < 4; ++g) {
         const int r = 16 * R + lk + 4 * g;
         const bool rp = (grp16(m1, R) >> (lk + 4 * g)) & 1u;
-        take[g] = has_next && !(rp && jr[g] < li);
+        take[g] = (int)has_next & (int)!(rp & (jr[g] < li));   // bitwise on purpose: no wave-uniform branch per entry
         acc[g] = xv[g] + (take[g] ? av[g] : 0.0) + (r == prow ? dgn : 0.0);
       }
-      double ya[4];
+      double ya[4], npp[4];   // (the sign of the last product sits on its B operand, off the MFMA chain)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) ya[g] = yt[g] * dn[g];
+      for (int g = 0; g < 4; ++g) { ya[g] = yt[g] * dn[g]; npp[g] = -pp[g]; }
       // V^T = (D^-1 L^-1)^T Y^T in accumulator layout: vt[g] = V[16R+li][lk+4g], which is V itself as
       // the A operand of the next product:  Y D^-1 Y[piv]^T = Y D^-1 L^-1 P[piv]^T = V P[piv]^T, so
       // the raw rows of the next pivots serve as B operand (no Y[piv] to compute or to share)
@@ -1184,7 +1185,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) vt = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[s4], ya[s4], vt, 0, 0, 0);
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-vt[s4], pp[s4], acc, 0, 0, 0);
+      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[s4], npp[s4], acc, 0, 0, 0);   // acc -= V P[piv]^T
       STAMPW(0, st0, 7);
       // Y rows of the next pivots are stored as zeros: their rows/columns of U were extracted (and
       // zeroed) one stage ago and must not be touched by this stage's update any more
@@ -1197,10 +1198,13 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       for (int g = 0; g < 4; ++g) {
         Yk[(16 * R + li) * PLD + lk + 4 * g] = myrowpiv ? 0.0 : yt[g];
         if (take[g]) A[aidx[g]] = 0.0;
-        if (has_next) Xn[(16 * R + lk + 4 * g) * PLD + li] = acc[g];
+      }
+      if (has_next) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Xn[(16 * R + lk + 4 * g) * PLD + li] = acc[g];
       }
       // only the rows of live, non-pivot slots are kept (the others are zero and never read back)
-      const unsigned am16 = (P.amask[k * 4 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu;
+      const unsigned am16 = (am_word >> ((R & 1) * 16)) & 0xffffu;
       if ((am16 >> li) & 1u) {
         double *pv = panel + (size_t)k * pstride + PIV;
         *(d4_t *)(pv + (16 * R + li) * PIV + 4 * lk) = vt;   // column c of a row sits at 4 (c & 3) + (c >> 2): 32 contiguous bytes per lane
