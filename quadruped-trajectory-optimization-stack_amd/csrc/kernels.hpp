@@ -1115,9 +1115,11 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     // ---- install the records of stage k+2 (prefetched during stage k-1), prefetch stage k+3 --------
     if (k >= 1 && k + 2 < NS) {
 #pragma unroll
-      for (int jj = 0; jj < PFD2; ++jj) { const int i = tid + jj * KT; if (i < pf_nd2) ((d2_t *)dbuf)[i] = pfd[jj]; }
+      // (no lane-dependent branches: threads beyond the record write the spare element behind it,
+      //  and below re-read its last element)
+      for (int jj = 0; jj < PFD2; ++jj) ((d2_t *)dbuf)[min(tid + jj * KT, pf_nd2)] = pfd[jj];
 #pragma unroll
-      for (int jj = 0; jj < PFS4; ++jj) { const int i = tid + jj * KT; if (i < pf_ns4) ((i4_t *)sbuf)[i] = pfs[jj]; }
+      for (int jj = 0; jj < PFS4; ++jj) ((i4_t *)sbuf)[min(tid + jj * KT, pf_ns4)] = pfs[jj];
       // (the header of these records -- pivot slots, diagonals, slot map, masks -- was published one
       //  stage ago by wave 7, off the critical path)
     }
@@ -1128,9 +1130,9 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       const d2_t *dsrc = (const d2_t *)(stream + doff[s]);
       const i4_t *ssrc = (const i4_t *)(P.srec + soff[s]);
 #pragma unroll
-      for (int jj = 0; jj < PFD2; ++jj) { const int i = tid + jj * KT; if (i < pf_nd2) pfd[jj] = dsrc[i]; }
+      for (int jj = 0; jj < PFD2; ++jj) pfd[jj] = dsrc[min(tid + jj * KT, pf_nd2 - 1)];
 #pragma unroll
-      for (int jj = 0; jj < PFS4; ++jj) { const int i = tid + jj * KT; if (i < pf_ns4) pfs[jj] = ssrc[i]; }
+      for (int jj = 0; jj < PFS4; ++jj) pfs[jj] = ssrc[min(tid + jj * KT, pf_ns4 - 1)];
     }
     STAMPW(0, st0, 5);
     // ---- AB(k): one 16-row panel tile per wave.  All LDS reads are issued up front (no lane-dependent
