@@ -1087,6 +1087,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   unsigned long long st0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_st0 = 0;
   unsigned long long st1[4] = {0, 0, 0, 0}, tl_st1 = 0;
   unsigned long long st7[4] = {0, 0, 0, 0}, tl_st7 = 0;
+  unsigned long long st4[5] = {0, 0, 0, 0, 0}, tl_st4 = 0;   // wave 4: the AB phase of a second wave of a SIMD
   unsigned long long wasum = 0;   // per wave: cycles from the top of a stage to its arrival at the AB barrier
   unsigned long long wcsum = 0;   // per wave: cycles from the start of phase C to its own arrival at the barrier
   if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st0) :: "memory");
@@ -1135,6 +1136,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       for (int jj = 0; jj < PFS4; ++jj) pfs[jj] = ssrc[min(tid + jj * KT, pf_ns4 - 1)];
     }
     STAMPW(0, st0, 5);
+    STAMPW(4, st4, 0);
     // ---- AB(k): one 16-row panel tile per wave.  All LDS reads are issued up front (no lane-dependent
     //      branches around loads), then the 12 MFMAs, then the stores. --------------------------------
     const int hi16 = (hib[k % 3] + 15) & ~15;
@@ -1165,6 +1167,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       for (int s4 = 0; s4 < 4; ++s4)
         yt = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], pr[s4], yt, 0, 0, 0);   // yt[g] = Y[16R+li][lk+4g]
       STAMPW(0, st0, 6);
+      STAMPW(4, st4, 1);
       // next pivot columns: assembled entries (read here, retired below), extracted Schur updates,
       // pivot diagonal; an entry between two pivots of stage k+1 is taken once, by the lane whose row
       // has the larger pivot index
@@ -1189,6 +1192,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[s4], npp[s4], acc, 0, 0, 0);   // acc -= V P[piv]^T
       STAMPW(0, st0, 7);
+      STAMPW(4, st4, 2);
       // Y rows of the next pivots are stored as zeros: their rows/columns of U were extracted (and
       // zeroed) one stage ago and must not be touched by this stage's update any more
       const bool myrowpiv = has_next && ((grp16(m1, R) >> li) & 1u);
@@ -1222,6 +1226,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #endif
     lds_barrier();
     STAMPW(0, st0, 0);
+    STAMPW(4, st4, 3);
 #ifdef QTOS_STAMPS
     unsigned long long wc0 = 0;
     if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wc0) :: "memory");
@@ -1396,6 +1401,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     lds_barrier();
     if (k + 2 < NS) prow_next = psb[((k + 2) % 3) * PIV + li];   // pivot slot li of the stage after next
     STAMPW(0, st0, 2);
+    STAMPW(4, st4, 4);
   }
   // ---- backward substitution: x_piv = w - V^T x, one barrier per stage.  Wave w owns rows 16w..16w+15
   //      of every panel (prefetched four stages ahead into registers), partial sums meet in LDS and
@@ -1470,6 +1476,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   if (tid == 0 && W.trace) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 30) * 4 + i] = (double)st0[i];
   if (tid == 64 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 32) * 4 + i] = (double)st1[i];
   if (tid == 448 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 33) * 4 + i] = (double)st7[i];
+  if (tid == 256 && W.trace) for (int i = 0; i < 5; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 44) * 4 + i] = (double)st4[i];
   if (lane == 0 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 38) * 4 + wv] = (double)wcsum;
   if (lane == 0 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 42) * 4 + wv] = (double)wasum;
 #endif
