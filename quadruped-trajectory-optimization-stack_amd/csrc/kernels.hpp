@@ -1282,6 +1282,10 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) jrs[t][g] = jm2[16 * (rc >> 8) + lk + 4 * g];
         }
+        // (pinned here: left alone the compiler sinks each read into its tile's branch, where its latency is exposed)
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+          asm volatile("" : "+v"(jcs[t]), "+v"(jrs[t][0]), "+v"(jrs[t][1]), "+v"(jrs[t][2]), "+v"(jrs[t][3]));
         double *dummy = red + 2 * 8 * PIV + lane;   // per-lane scratch slot: unselected stores land here
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
