@@ -1087,7 +1087,8 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   unsigned long long st0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_st0 = 0;
   unsigned long long st1[4] = {0, 0, 0, 0}, tl_st1 = 0;
   unsigned long long st7[4] = {0, 0, 0, 0}, tl_st7 = 0;
-  unsigned long long st4[5] = {0, 0, 0, 0, 0}, tl_st4 = 0;   // wave 4: the AB phase of a second wave of a SIMD
+  unsigned long long st4[5] = {0, 0, 0, 0, 0}, tl_st4 = 0;
+  unsigned long long st5[4] = {0, 0, 0, 0}, tl_st5 = 0;   // wave 5: phase C of a second update wave   // wave 4: the AB phase of a second wave of a SIMD
   unsigned long long wasum = 0;   // per wave: cycles from the top of a stage to its arrival at the AB barrier
   unsigned long long wcsum = 0;   // per wave: cycles from the start of phase C to its own arrival at the barrier
   if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st0) :: "memory");
@@ -1238,6 +1239,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     } else if (wv <= 6) {
 #ifdef QTOS_STAMPS
       if (tid == 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st1) :: "memory");
+      if (tid == 320) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st5) :: "memory");
 #endif
       const Mask128 m2 = load_mask(pm + (k & 1) * 4, lane);   // pivot slots of stage k+2
       const bool extract = k + 2 < NS;
@@ -1268,6 +1270,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
           U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[t & 1][s4] * dv4[s4], pbv[t & 1][s4], U[t], 0, 0, 0);
       }
       STAMPW(1, st1, 2);
+      STAMPW(5, st5, 2);
       // --- extraction: columns / rows of the pivots of stage k+2 leave U for the panel under construction
       //     (and are zeroed: later updates skip them).  Loops over the pivot slots of each tile's column
       //     / row group are wave-uniform; a pivot column lives on the four lanes li == b, a pivot row on
@@ -1312,6 +1315,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         }
       }
       STAMPW(1, st1, 0);
+      STAMPW(5, st5, 0);
     } else {
       // wave 7: right-hand-side row.  y_F = p_F L^-T, w = L^-T D^-1 y_F (to HBM), the update of the
       // accumulated right-hand side, and the right-hand side of the next pivots
@@ -1399,6 +1403,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       assemble_continuations();
     }
     STAMPW(1, st1, 1);
+    STAMPW(5, st5, 1);
 #ifdef QTOS_STAMPS
     if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); wcsum += t_ - wc0; }
 #endif
@@ -1480,6 +1485,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   if (tid == 0 && W.trace) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 30) * 4 + i] = (double)st0[i];
   if (tid == 64 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 32) * 4 + i] = (double)st1[i];
   if (tid == 448 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 33) * 4 + i] = (double)st7[i];
+  if (tid == 320 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 46) * 4 + i] = (double)st5[i];
   if (tid == 256 && W.trace) for (int i = 0; i < 5; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 44) * 4 + i] = (double)st4[i];
   if (lane == 0 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 38) * 4 + wv] = (double)wcsum;
   if (lane == 0 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 42) * 4 + wv] = (double)wasum;

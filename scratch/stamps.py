@@ -4,7 +4,7 @@ from qtos_amd import capi, workloads
 import os
 capi.LIB_PATH = capi.LIB_PATH.replace("libqtos_planner.so", os.environ.get("QTOS_LIB", "libqtos_planner_stamps.so"))
 from qtos_amd.config import PlannerConfig
-cfg = PlannerConfig.knots100(max_iter=52)
+cfg = PlannerConfig.knots100(max_iter=56)
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 P = capi.Planner(cfg, max_batch=NB)
 start, goal = workloads.flat_goals(NB, 0)
@@ -35,3 +35,4 @@ print("line-search evaluation phases (cycles): stage x %.0f | dynamics knots %.0
 print("phase AB, cycles per stage until each wave reaches the barrier (waves 0..7):", (t[42:44].ravel() / NS).round(0))
 s4 = t[44:46].ravel()[:5] / NS
 print("wave 4 (second wave of SIMD 0), AB per stage: top %.0f | loads + yt %.0f | vt + acc %.0f | stores + barrier wait %.0f | (phase C to barrier %.0f)" % tuple(s4))
+print("wave 5 (second update wave of SIMD 1), phase C per stage: tile MFMA %.0f, extraction %.0f, assembly + wait for its start %.0f" % (t[46][2] / NS, t[46][0] / NS, t[46][1] / NS))
