@@ -987,7 +987,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   // bit g of ge4 / gt4: row lk + 4g of a diagonal tile lies on or below / strictly below column li
   unsigned ge4 = 0u, gt4 = 0u;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) { ge4 |= (lk + 4 * g >= li ? 1u : 0u) << g; gt4 |= (lk + 4 * g > li ? 1u : 0u) << g; }
+  for (int g = 0; g < 4; ++g) { ge4 |= (lk + 4 * g >= li ? 1u : 0u) << (4 * g); gt4 |= (lk + 4 * g > li ? 1u : 0u) << (4 * g); }   // (bit 4g: the layout of (mask >> lk) & 0x1111)
 
   for (int i = tid; i < ntri; i += KT) A[i] = 0.0;
   for (int i = tid; i < 3 * PSZ; i += KT) PB[i] = 0.0;
@@ -1297,21 +1297,21 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
           const int R = rc >> 8, C = rc & 255;
           const unsigned cw2 = grp16(m2, C), rw2 = grp16(m2, R);   // wave-uniform
           if ((cw2 | rw2) == 0u) continue;
-          const unsigned cm = ((cw2 >> li) & 1u) ? (R > C ? 0xfu : ge4) : 0u;     // rows g this lane's column sends out
-          const unsigned rm = (rw2 >> lk) & 0x1111u;                                 // bit 4g: row lk + 4g is a pivot
-          const unsigned rmk = ((rm & 1u) | ((rm >> 3) & 2u) | ((rm >> 6) & 4u) | ((rm >> 9) & 8u)) & (R > C ? 0xfu : gt4);
+          // bit 4g of cm / rmk: entry g of this lane leaves with its column / with its row
+          const unsigned cm = ((cw2 >> li) & 1u) ? (R > C ? 0x1111u : ge4) : 0u;
+          const unsigned rmk = (rw2 >> lk) & (R > C ? 0x1111u : gt4);
           double *xr = Xnn + (16 * R + lk) * PLD + jcs[t], *xc = Xnn + (16 * C + li) * PLD;
           // (one wave-uniform branch per direction, not one per entry)
           if (cw2) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *(((cm >> g) & 1u) ? xr + g * 4 * PLD : dummy) = U[t][g];
+            for (int g = 0; g < 4; ++g) *(((cm >> (4 * g)) & 1u) ? xr + g * 4 * PLD : dummy) = U[t][g];
           }
           if (rw2) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *(((rmk >> g) & 1u) ? xc + jrs[t][g] : dummy) = U[t][g];
+            for (int g = 0; g < 4; ++g) *(((rmk >> (4 * g)) & 1u) ? xc + jrs[t][g] : dummy) = U[t][g];
           }
 #pragma unroll
-          for (int g = 0; g < 4; ++g) U[t][g] = (((cm | rmk) >> g) & 1u) ? 0.0 : U[t][g];
+          for (int g = 0; g < 4; ++g) U[t][g] = (((cm | rmk) >> (4 * g)) & 1u) ? 0.0 : U[t][g];
         }
       }
       STAMPW(1, st1, 0);
