@@ -1394,11 +1394,11 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       STAMPW(7, st7, 0);
     }
     // every wave ends the phase with its share of the assembly of stage k+2 (nobody else touches A here)
-    // (most stages have fewer items than threads, so the order of the waves matters: the waves with the
-    // most slack in this phase (measured per wave: 7, 3, 0, 2, then 1, 6, 4, 5)
-    // take the low item indices, the four update waves that share a matrix pipe come last)
+    // (most stages have fewer items than threads, so the order of the waves matters: the low item
+    // indices go to the waves with the most slack in this phase -- measured order 3, 0, 2, 7, 1, 4, 6, 5:
+    // the two update waves that come second on a shared matrix pipe are last)
     if (k + 2 < NS) {
-      const int aslot = (0x05761342 >> (4 * wv)) & 7;   // wave -> position in the assembly order
+      const int aslot = (0x36750241 >> (4 * wv)) & 7;   // wave -> position in the assembly order
       assemble_stage(A, F, sbuf, dbuf, aslot * 64 + lane, KT);
       assemble_continuations();
     }
