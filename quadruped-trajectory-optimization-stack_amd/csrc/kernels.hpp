@@ -1093,7 +1093,9 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   unsigned long long wcsum = 0;   // per wave: cycles from the start of phase C to its own arrival at the barrier
   if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st0) :: "memory");
 #endif
-  constexpr int PFD2 = 2, PFS4 = 3;   // per-thread prefetch registers: 128-bit loads of a stage's records
+  // per-thread prefetch registers: 128-bit loads of a stage's records.  Only the first wave of every SIMD
+  // (waves 0..3) moves records: in the AB phase it reaches the barrier ~1 k cycles before its partner anyway
+  constexpr int XW = 4, XT = 64 * XW, PFD2 = 2 * KT / XT, PFS4 = 3 * KT / XT;
   d2_t pfd[PFD2];
   i4_t pfs[PFS4];
   int pf_nd2 = 0, pf_ns4 = 0;
@@ -1115,26 +1117,26 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wa0) :: "memory");
 #endif
     // ---- install the records of stage k+2 (prefetched during stage k-1), prefetch stage k+3 --------
-    if (k >= 1 && k + 2 < NS) {
+    if (wv < XW && k >= 1 && k + 2 < NS) {
 #pragma unroll
       // (no lane-dependent branches: threads beyond the record write the spare element behind it,
       //  and below re-read its last element)
-      for (int jj = 0; jj < PFD2; ++jj) ((d2_t *)dbuf)[min(tid + jj * KT, pf_nd2)] = pfd[jj];
+      for (int jj = 0; jj < PFD2; ++jj) ((d2_t *)dbuf)[min(tid + jj * XT, pf_nd2)] = pfd[jj];
 #pragma unroll
-      for (int jj = 0; jj < PFS4; ++jj) ((i4_t *)sbuf)[min(tid + jj * KT, pf_ns4)] = pfs[jj];
+      for (int jj = 0; jj < PFS4; ++jj) ((i4_t *)sbuf)[min(tid + jj * XT, pf_ns4)] = pfs[jj];
       // (the header of these records -- pivot slots, diagonals, slot map, masks -- was published one
       //  stage ago by wave 7, off the critical path)
     }
-    if (k + 3 < NS) {
+    if (wv < XW && k + 3 < NS) {
       const int s = k + 3;
       pf_nd2 = (doff[s + 1] - doff[s]) >> 1;
       pf_ns4 = (soff[s + 1] - soff[s]) >> 2;
       const d2_t *dsrc = (const d2_t *)(stream + doff[s]);
       const i4_t *ssrc = (const i4_t *)(P.srec + soff[s]);
 #pragma unroll
-      for (int jj = 0; jj < PFD2; ++jj) pfd[jj] = dsrc[min(tid + jj * KT, pf_nd2 - 1)];
+      for (int jj = 0; jj < PFD2; ++jj) pfd[jj] = dsrc[min(tid + jj * XT, pf_nd2 - 1)];
 #pragma unroll
-      for (int jj = 0; jj < PFS4; ++jj) pfs[jj] = ssrc[min(tid + jj * KT, pf_ns4 - 1)];
+      for (int jj = 0; jj < PFS4; ++jj) pfs[jj] = ssrc[min(tid + jj * XT, pf_ns4 - 1)];
     }
     STAMPW(0, st0, 5);
     STAMPW(4, st4, 0);
