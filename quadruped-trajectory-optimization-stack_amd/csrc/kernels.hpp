@@ -845,7 +845,8 @@ __device__ __forceinline__ void ldlt16(double (&a)[PIV], double (&v)[PIV], doubl
 }
 
 #ifdef QTOS_STAMPS
-#define STAMPW(w, arr, i) do { if (tid == 64 * (w)) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); arr[i] += t_ - tl_##arr; tl_##arr = t_; } } while (0)
+// (accumulators in LDS, not in registers: the diagnostic build must not spill where the production build does not)
+#define STAMPW(w, arr, i) do { if (tid == 64 * (w)) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); arr[i] += t_ - tl_##arr[0]; tl_##arr[0] = t_; } } while (0)
 #else
 #define STAMPW(w, arr, i) do {} while (0)
 #endif
@@ -1084,14 +1085,14 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   }
 
 #ifdef QTOS_STAMPS
-  unsigned long long st0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_st0 = 0;
-  unsigned long long st1[4] = {0, 0, 0, 0}, tl_st1 = 0;
-  unsigned long long st7[4] = {0, 0, 0, 0}, tl_st7 = 0;
-  unsigned long long st4[5] = {0, 0, 0, 0, 0}, tl_st4 = 0;
-  unsigned long long st5[4] = {0, 0, 0, 0}, tl_st5 = 0;   // wave 5: phase C of a second update wave   // wave 4: the AB phase of a second wave of a SIMD
-  unsigned long long wasum = 0;   // per wave: cycles from the top of a stage to its arrival at the AB barrier
-  unsigned long long wcsum = 0;   // per wave: cycles from the start of phase C to its own arrival at the barrier
-  if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st0) :: "memory");
+  __shared__ unsigned long long stamp_lds[8 * 4 + 3 + 16];
+  unsigned long long *st0 = stamp_lds, *st1 = stamp_lds + 8, *st7 = stamp_lds + 12, *tl_st0 = stamp_lds + 16, *tl_st1 = stamp_lds + 17,
+                     *tl_st7 = stamp_lds + 18;
+  unsigned long long &wasum = stamp_lds[19 + wv];        // per wave: cycles from the top of a stage to its arrival at the AB barrier
+  unsigned long long &wcsum = stamp_lds[19 + 8 + wv];    // per wave: cycles from the start of phase C to its own arrival at the barrier
+  if (tid < 8 * 4 + 3 + 16) stamp_lds[tid] = 0;
+  __syncthreads();
+  if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tl_st0[0] = t_; }
 #endif
   // per-thread prefetch registers: 128-bit loads of a stage's records.  Only the first wave of every SIMD
   // (waves 0..3) moves records: in the AB phase it reaches the barrier ~1 k cycles before its partner anyway
@@ -1139,7 +1140,6 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       for (int jj = 0; jj < PFS4; ++jj) pfs[jj] = ssrc[min(tid + jj * XT, pf_ns4 - 1)];
     }
     STAMPW(0, st0, 5);
-    STAMPW(4, st4, 0);
     // ---- AB(k): one 16-row panel tile per wave.  All LDS reads are issued up front (no lane-dependent
     //      branches around loads), then the 12 MFMAs, then the stores. --------------------------------
     const int hi16 = (hib[k % 3] + 15) & ~15;
@@ -1170,7 +1170,6 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       for (int s4 = 0; s4 < 4; ++s4)
         yt = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], pr[s4], yt, 0, 0, 0);   // yt[g] = Y[16R+li][lk+4g]
       STAMPW(0, st0, 6);
-      STAMPW(4, st4, 1);
       // next pivot columns: assembled entries (read here, retired below), extracted Schur updates,
       // pivot diagonal; an entry between two pivots of stage k+1 is taken once, by the lane whose row
       // has the larger pivot index
@@ -1195,7 +1194,6 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[s4], npp[s4], acc, 0, 0, 0);   // acc -= V P[piv]^T
       STAMPW(0, st0, 7);
-      STAMPW(4, st4, 2);
       // Y rows of the next pivots are stored as zeros: their rows/columns of U were extracted (and
       // zeroed) one stage ago and must not be touched by this stage's update any more
       const bool myrowpiv = has_next && ((grp16(m1, R) >> li) & 1u);
@@ -1229,7 +1227,6 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #endif
     lds_barrier();
     STAMPW(0, st0, 0);
-    STAMPW(4, st4, 3);
 #ifdef QTOS_STAMPS
     unsigned long long wc0 = 0;
     if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wc0) :: "memory");
@@ -1240,8 +1237,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       STAMPW(0, st0, 1);
     } else if (wv <= 6) {
 #ifdef QTOS_STAMPS
-      if (tid == 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st1) :: "memory");
-      if (tid == 320) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st5) :: "memory");
+      if (tid == 64) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tl_st1[0] = t_; }
 #endif
       const Mask128 m2 = load_mask(pm + (k & 1) * 4, lane);   // pivot slots of stage k+2
       const bool extract = k + 2 < NS;
@@ -1272,7 +1268,6 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
           U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[t & 1][s4] * dv4[s4], pbv[t & 1][s4], U[t], 0, 0, 0);
       }
       STAMPW(1, st1, 2);
-      STAMPW(5, st5, 2);
       // --- extraction: columns / rows of the pivots of stage k+2 leave U for the panel under construction
       //     (and are zeroed: later updates skip them).  Loops over the pivot slots of each tile's column
       //     / row group are wave-uniform; a pivot column lives on the four lanes li == b, a pivot row on
@@ -1317,12 +1312,11 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         }
       }
       STAMPW(1, st1, 0);
-      STAMPW(5, st5, 0);
     } else {
       // wave 7: right-hand-side row.  y_F = p_F L^-T, w = L^-T D^-1 y_F (to HBM), the update of the
       // accumulated right-hand side, and the right-hand side of the next pivots
 #ifdef QTOS_STAMPS
-      if (tid == 448) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_st7) :: "memory");
+      if (tid == 448) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tl_st7[0] = t_; }
 #endif
       // header of stage k+3 (static ints 0..23: counts, hi, pivot slots; dynamic doubles 0..15: pivot
       // diagonals): read from global memory now, published to the LDS rings at the end of this phase.
@@ -1405,14 +1399,12 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       assemble_continuations();
     }
     STAMPW(1, st1, 1);
-    STAMPW(5, st5, 1);
 #ifdef QTOS_STAMPS
     if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); wcsum += t_ - wc0; }
 #endif
     lds_barrier();
     if (k + 2 < NS) prow_next = psb[((k + 2) % 3) * PIV + li];   // pivot slot li of the stage after next
     STAMPW(0, st0, 2);
-    STAMPW(4, st4, 4);
   }
   // ---- backward substitution: x_piv = w - V^T x, one barrier per stage.  Wave w owns rows 16w..16w+15
   //      of every panel (prefetched four stages ahead into registers), partial sums meet in LDS and
@@ -1487,8 +1479,6 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   if (tid == 0 && W.trace) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 30) * 4 + i] = (double)st0[i];
   if (tid == 64 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 32) * 4 + i] = (double)st1[i];
   if (tid == 448 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 33) * 4 + i] = (double)st7[i];
-  if (tid == 320 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 46) * 4 + i] = (double)st5[i];
-  if (tid == 256 && W.trace) for (int i = 0; i < 5; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 44) * 4 + i] = (double)st4[i];
   if (lane == 0 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 38) * 4 + wv] = (double)wcsum;
   if (lane == 0 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 42) * 4 + wv] = (double)wasum;
 #endif

@@ -33,6 +33,3 @@ print("linearise phases (cycles): stage x %.0f | dynamics knots %.0f | dynamics 
 print("phase C, cycles per stage until each wave reaches the barrier (waves 0..7):", (t[38:40].ravel() / NS).round(0))
 print("line-search evaluation phases (cycles): stage x %.0f | dynamics knots %.0f | rom instances %.0f | force/terrain/linear %.0f" % tuple(t[40:42].ravel()[:4]))
 print("phase AB, cycles per stage until each wave reaches the barrier (waves 0..7):", (t[42:44].ravel() / NS).round(0))
-s4 = t[44:46].ravel()[:5] / NS
-print("wave 4 (second wave of SIMD 0), AB per stage: top %.0f | loads + yt %.0f | vt + acc %.0f | stores + barrier wait %.0f | (phase C to barrier %.0f)" % tuple(s4))
-print("wave 5 (second update wave of SIMD 1), phase C per stage: tile MFMA %.0f, extraction %.0f, assembly + wait for its start %.0f" % (t[46][2] / NS, t[46][0] / NS, t[46][1] / NS))
