@@ -690,7 +690,9 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     W.xbest[(size_t)b * n + v] = val;
   }
   __syncthreads();
-  eval_all<false>(P, map, x, g, nullptr, evl);
+  // values and linearisation of the starting point in ONE pass (the Jacobian does not depend on the slack
+  // initialisation below; a problem that turns out converged or invalid has merely written a stream nobody reads)
+  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, nullptr, 0);
   __syncthreads();
   // slack initialisation: push strictly inside the bounds (Ipopt bound_push / bound_frac)
   for (int r = tid; r < m; r += blockDim.x) {
@@ -730,8 +732,6 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
   }
   if (conv || bad) return;
   for (int v = tid; v < n; v += blockDim.x) W.xbest[(size_t)b * n + v] = x[v];   // best iterate so far: the starting point
-  __syncthreads();
-  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, nullptr, 0);
   __syncthreads();
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
 }
