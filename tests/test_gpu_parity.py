@@ -647,6 +647,8 @@ def test_knots200_receding_window_on_random_heightfields():
     (dict(duration=2.5), 96, False),                                   # `-duration 2.5` (scripts/main.py:119-120)
     (dict(duration=2.5, dt_dynamic=0.2, dt_base=0.2), 96, True),
     (dict(duration=1.5, dt_dynamic=0.25, dt_base=0.25, dt_range_of_motion=0.25), 96, False),
+    (dict(duration=1.0, dt_dynamic=0.5, dt_base=0.5, dt_range_of_motion=0.5), 64, False),              # a 64-slot front: `k_kkt<64>`, four
+                                                                       # of the eight waves without a panel tile
 ])
 def test_other_horizons_match_oracle(kw, front, heavy):
     """Horizons other than 5 s (the reference's `-duration` flag rescales the gait schedule): other
