@@ -935,13 +935,14 @@ struct KktLayout {
   static constexpr int HIB = PSB + 3 * PIV / 2;          // 4 ints
   static constexpr int JM = HIB + 2;                     // 2 x 128 ints   slot -> pivot index
   static constexpr int PM = JM + 128;                    // 8 ints         pivot-slot bit masks
-  static constexpr int PB = PM + 4;                      // 3 panels of (F+1) x PLD
+  static constexpr int MIV = PM + 4;                     // 16 x PLD        (L D L^T)^-1 of the current pivot block
+  static constexpr int PB = MIV + PIV * PLD;             // 3 panels of (F+1) x PLD
   static constexpr int AOFF = (PB + 3 * PSZ + 1) & ~1;   // lower triangle incl. rhs row
   static constexpr int VAR = (AOFF + NTRI + 1) & ~1;     // dbuf, then (ints) sbuf, soff, doff, hiall
 };
 __host__ __device__ inline size_t kkt_lds_bytes(int F, int NS, int max_srec, int max_drec) {
   const int PSZ = (F + 1) * PLD, NTRI = (F + 1) * (F + 2) / 2;
-  const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 128 + 128 + 2 * 8 * PIV + 64 + 3 * PIV / 2 + 2 + 128 + 4;
+  const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 128 + 128 + 2 * 8 * PIV + 64 + 3 * PIV / 2 + 2 + 128 + 4 + PIV * PLD;
   size_t o = (fixed + 3 * (size_t)PSZ + 1) & ~(size_t)1;
   o = (o + NTRI + 1) & ~(size_t)1;
   o += ((size_t)max_drec + 1) & ~(size_t)1;
@@ -965,6 +966,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   double *red = lds + LY::RED, *PB = lds + LY::PB, *A = lds + LY::AOFF, *dbuf = lds + LY::VAR;
   int *psb = (int *)(lds + LY::PSB), *hib = (int *)(lds + LY::HIB), *jm = (int *)(lds + LY::JM);
   unsigned *pm = (unsigned *)(lds + LY::PM);
+  double *Minv = lds + LY::MIV;
   int *sbuf = (int *)(dbuf + ((P.max_drec + 1) & ~1));
   int *soff = sbuf + ((P.max_srec + 3) & ~3), *doff = soff + ((NS + 4) & ~3), *hiall = doff + ((NS + 4) & ~3);
   const double *stream = W.stream + (size_t)b * P.stream_len;
@@ -1032,6 +1034,18 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       dvn[li] = myinv;
 #pragma unroll
       for (int j = 0; j < PIV; ++j) Pn[myps * PLD + j] = 0.0;
+    }
+    // inverse of the whole pivot block, (L D L^T)^-1 = L^-T D^-1 L^-1, on the matrix core: with it the
+    // panel product V = P (L D L^T)^-1 of the next AB phase does not have to wait for Y = P L^-T
+    {
+      d4_t mi = {0.0, 0.0, 0.0, 0.0};
+      double lt[4], ld[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { lt[s4] = Lin[(lk + 4 * s4) * PLD + li]; ld[s4] = dvn[lk + 4 * s4]; }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) mi = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[s4], lt[s4] * ld[s4], mi, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Minv[(lk + 4 * g) * PLD + li] = mi[g];
     }
   };
 
@@ -1149,7 +1163,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       const unsigned am_word = P.amask[k * 4 + (R >> 1)];   // row mask of this stage's panel: fetched now, used at the end of the phase
       const int prow = has_next ? prow_next : 0;
       const int *jmn = jm + ((k + 1) & 1) * 128;
-      double la[4], pr[4], pp[4], dn[4], lb[4], xv[4], av[4];
+      double la[4], pr[4], pp[4], lm[4], xv[4], av[4];
       int jr[4], aidx[4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
@@ -1157,18 +1171,19 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         la[s4] = Lik[li * PLD + lk + 4 * s4];
         pr[s4] = Pk[(16 * R + li) * PLD + lk + 4 * s4];
         pp[s4] = Pk[prow * PLD + lk + 4 * s4];
-        dn[s4] = dik[lk + 4 * s4];
-        lb[s4] = Lik[(lk + 4 * s4) * PLD + li];
+        lm[s4] = Minv[li * PLD + lk + 4 * s4];
         xv[s4] = Xn[r * PLD + li];
         jr[s4] = jmn[r];
         aidx[s4] = trs(r, prow);
         av[s4] = A[aidx[s4]];
       }
       const double dgn = dgb[((k + 1) % 3) * PIV + li];
-      d4_t yt = {0.0, 0.0, 0.0, 0.0};
+      // V = P (L D L^T)^-1 in accumulator layout: vt[g] = V[16R+li][lk+4g] -- which is V itself as the A
+      // operand of the next product.  It heads the chain; Y = P L^-T (kept for the Schur updates of phase C)
+      // follows on the side.
+      d4_t vt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-        yt = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], pr[s4], yt, 0, 0, 0);   // yt[g] = Y[16R+li][lk+4g]
+      for (int s4 = 0; s4 < 4; ++s4) vt = __builtin_amdgcn_mfma_f64_16x16x4f64(lm[s4], pr[s4], vt, 0, 0, 0);
       STAMPW(0, st0, 6);
       // next pivot columns: assembled entries (read here, retired below), extracted Schur updates,
       // pivot diagonal; an entry between two pivots of stage k+1 is taken once, by the lane whose row
@@ -1182,17 +1197,17 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         take[g] = (int)has_next & (int)!(rp & (jr[g] < li));   // bitwise on purpose: no wave-uniform branch per entry
         acc[g] = xv[g] + (take[g] ? av[g] : 0.0) + (r == prow ? dgn : 0.0);
       }
-      double ya[4], npp[4];   // (the sign of the last product sits on its B operand, off the MFMA chain)
+      double npp[4];   // (the sign of the last product sits on its B operand, off the MFMA chain)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) { ya[g] = yt[g] * dn[g]; npp[g] = -pp[g]; }
-      // V^T = (D^-1 L^-1)^T Y^T in accumulator layout: vt[g] = V[16R+li][lk+4g], which is V itself as
-      // the A operand of the next product:  Y D^-1 Y[piv]^T = Y D^-1 L^-1 P[piv]^T = V P[piv]^T, so
-      // the raw rows of the next pivots serve as B operand (no Y[piv] to compute or to share)
-      d4_t vt = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) vt = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[s4], ya[s4], vt, 0, 0, 0);
+      for (int g = 0; g < 4; ++g) npp[g] = -pp[g];
+      // Y D^-1 Y[piv]^T = V P[piv]^T: the raw rows of the next pivots serve as B operand (no Y[piv] to
+      // compute or to share)
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[s4], npp[s4], acc, 0, 0, 0);   // acc -= V P[piv]^T
+      d4_t yt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        yt = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], pr[s4], yt, 0, 0, 0);   // yt[g] = Y[16R+li][lk+4g]
       STAMPW(0, st0, 7);
       // Y rows of the next pivots are stored as zeros: their rows/columns of U were extracted (and
       // zeroed) one stage ago and must not be touched by this stage's update any more
