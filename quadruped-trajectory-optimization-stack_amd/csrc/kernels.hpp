@@ -1323,7 +1323,10 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
             for (int g = 0; g < 4; ++g) *(((rmk >> (4 * g)) & 1u) ? xc + jrs[t][g] : dummy) = U[t][g];
           }
 #pragma unroll
-          for (int g = 0; g < 4; ++g) U[t][g] = (((cm | rmk) >> (4 * g)) & 1u) ? 0.0 : U[t][g];
+          for (int g = 0; g < 4; ++g) {   // sign-extended bit -> all-ones mask -> and-not on both halves
+            const int z = ~__builtin_amdgcn_sbfe((int)(cm | rmk), 4 * g, 1);
+            U[t][g] = __hiloint2double(__double2hiint(U[t][g]) & z, __double2loint(U[t][g]) & z);
+          }
         }
       }
       STAMPW(1, st1, 0);
