@@ -16,7 +16,7 @@ python bench.py --cpu-sample 0 --init table > $O/bench_${T}_table.json 2>/dev/nu
 python bench.py --cpu-sample 0 --init table --transcription reference_compat > $O/bench_${T}_table_compat.json 2>/dev/null
 python bench.py --cpu-sample 0 --init table --transcription knots200 > $O/bench_${T}_table_knots200.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o runc -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $O/prof_$T.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o runc -- python3 $R/bench.py --cpu-sample 0 > $O/prof_$T.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$T -o runc -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $O/pmc_fetch_$T.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$T -o runc -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $O/pmc_write_$T.log 2>&1
 cd $R; for f in $O/bench_$T*.json; do echo $f; tail -1 $f | cut -c1-160; done
