@@ -33,6 +33,8 @@ struct QtosPlanner {
   double *d_start = nullptr, *d_goal = nullptr, *d_nodes = nullptr, *d_warm = nullptr;
   int *d_map = nullptr;
   double *d_height = nullptr;
+  int sure_iters = 0;   // iterations the next batch is launched for without looking (previous batch's count - 1)
+  int prev_iters = -1;
   double *d_table = nullptr, *d_tab_dx = nullptr, *d_tab_dy = nullptr;   // nominal-plan table (qtos_set_init_table)
   int *h_active = nullptr;  // pinned
   std::vector<hipEvent_t> ev;  // 2 per iteration (kkt begin/end) + 2 (total)
@@ -343,16 +345,20 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
   HIPCHK(p, hipEventRecord(p->ev[0], st));
   hipLaunchKernelGGL(k_start, dim3(B), dim3(ET), p->eval_lds, st, D, W, B);
   int launches = 0, it = 0;
+  // The host only has to look at the number of unfinished problems when the batch may be done: the
+  // iterations the previous batch certainly needed are launched back to back (a batch that finishes
+  // earlier runs kernels whose workgroups exit at once), then one check per iteration as before.
+  const int no_check_before = p->sure_iters;
   for (it = 0; it < D.max_iter; ++it) {
-    HIPCHK(p, hipMemcpyAsync(p->h_active, W.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
-    // spin on the stream instead of a blocking wait: the wake-up latency of a blocking
-    // hipStreamSynchronize is paid once per Newton iteration otherwise
-    {
+    if (it >= no_check_before) {
+      HIPCHK(p, hipMemcpyAsync(p->h_active, W.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+      // spin on the stream instead of a blocking wait: the wake-up latency of a blocking
+      // hipStreamSynchronize is paid once per Newton iteration otherwise
       hipError_t q;
       while ((q = hipStreamQuery(st)) == hipErrorNotReady) {}
       if (q != hipSuccess) { p->err = std::string("hipStreamQuery: ") + hipGetErrorString(q); return -2; }
+      if (*p->h_active <= 0) break;
     }
-    if (*p->h_active <= 0) break;
     HIPCHK(p, hipEventRecord(p->ev[2 + 2 * launches], st));
     hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(KT), p->kkt_lds, st, D, W, B);
     HIPCHK(p, hipEventRecord(p->ev[3 + 2 * launches], st));
@@ -366,6 +372,10 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
   HIPCHK(p, hipEventRecord(p->ev[1], st));
   p->last_launches = launches;
   p->last_iters = it;
+  // (only in a steady state -- two batches in a row with the same count, e.g. a stream of like batches --,
+  //  and never the last iteration: a batch that needs fewer would run, and time, empty launches)
+  p->sure_iters = (it == p->prev_iters && it > 1) ? it - 1 : 0;
+  p->prev_iters = it;
   HIPCHK(p, hipGetLastError());
   return 0;
 }
