@@ -46,6 +46,8 @@ struct DevPlan {
   int hold_from;               // two-phase solve: stance footholds are held once an iterate >= hold_from has violation <= hold_tol (0: never)
   double hold_weight, hold_tol;
   const unsigned *amask;       // n_stages x 4: rows of the factor panel that are stored / read back (Symbolic::amask)
+  const unsigned short *ctab;  // n_stages x (front/16) x 64 x 4: cell of every entry of a stage's pivot columns (Symbolic::ctab)
+  int n_cells;                 // cells of the assembled entries: [0] zero, [1 + slot] right-hand side, then the entries
   const Block *blocks;
   const int *block_cols;
   const IqRow *iq_rows;   // rows of the inequality blocks (stream offsets)
@@ -232,6 +234,7 @@ struct Terr {
 __device__ inline Terr terrain_at(const DevPlan &P, int map, double x, double y) {
   Terr t = {0, 0, 0, 0};
   if (!P.height || P.n_maps <= 0) return t;
+  map = min(max(map, 0), P.n_maps - 1);   // a stale / out-of-range map id must not read outside the maps
   const double *H = P.height + (size_t)map * P.hnx * P.hny;
   double fx = (x - P.hx0) / P.hcell, fy = (y - P.hy0) / P.hcell;
   const double mx = P.hnx - 1, my = P.hny - 1;
@@ -707,6 +710,7 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     if (hu) si = fmin(si, u - pu);
     s[r] = si;
   }
+  __syncthreads();   // infeasibility() reads s through the compact row lists: another thread-to-row mapping
   double viol, theta;
   infeasibility(P, g, s, scratch, viol, theta);
   const double mu = fmax(P.mu_min, fmin(P.mu_init, 0.01 * theta * theta));
@@ -890,7 +894,7 @@ __device__ __forceinline__ void assemble_stage(double *A, int F, const int *sbuf
   for (int i = t0; i < n_ent; i += nth) A[eidx[i]] += eval[i];
   const int *rsl = eidx + n_ent;
   const double *rval = eval + n_ent;
-  for (int i = t0; i < n_rhs; i += nth) A[tri(F, rsl[i])] += rval[i];
+  for (int i = t0; i < n_rhs; i += nth) A[rsl[i]] += rval[i];
   if (n_iq == 0) return;
   const int n_tgt = sbuf[5];
   const int *tg = sbuf + sbuf[4];                     // n_tgt + 1 ints: (tri << 12) | first contribution
@@ -937,16 +941,15 @@ struct KktLayout {
   static constexpr int PM = JM + 128;                    // 8 ints         pivot-slot bit masks
   static constexpr int MIV = PM + 4;                     // 16 x PLD        (L D L^T)^-1 of the current pivot block
   static constexpr int PB = MIV + PIV * PLD;             // 3 panels of (F+1) x PLD
-  static constexpr int AOFF = (PB + 3 * PSZ + 1) & ~1;   // lower triangle incl. rhs row
-  static constexpr int VAR = (AOFF + NTRI + 1) & ~1;     // dbuf, then (ints) sbuf, soff, doff, hiall
+  static constexpr int VAR = (PB + 3 * PSZ + 1) & ~1;    // dbuf, then (ints) sbuf, soff, doff, hiall, then the cells A
 };
-__host__ __device__ inline size_t kkt_lds_bytes(int F, int NS, int max_srec, int max_drec) {
-  const int PSZ = (F + 1) * PLD, NTRI = (F + 1) * (F + 2) / 2;
+__host__ __device__ inline size_t kkt_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells) {
+  const int PSZ = (F + 1) * PLD;
   const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 128 + 128 + 2 * 8 * PIV + 64 + 3 * PIV / 2 + 2 + 128 + 4 + PIV * PLD;
   size_t o = (fixed + 3 * (size_t)PSZ + 1) & ~(size_t)1;
-  o = (o + NTRI + 1) & ~(size_t)1;
   o += ((size_t)max_drec + 1) & ~(size_t)1;
   size_t oi = 2 * o + (((size_t)max_srec + 3) & ~(size_t)3) + 3 * ((((size_t)NS + 1) + 3) & ~(size_t)3);
+  oi += 2 * (((size_t)n_cells + 1) & ~(size_t)1);
   return oi * sizeof(int);
 }
 
@@ -961,14 +964,15 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   const int tid = threadIdx.x, NS = P.n_stages, n = P.n_vars;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
   using LY = KktLayout<F>;
-  constexpr int ntri = LY::NTRI, PSZ = LY::PSZ;
+  constexpr int PSZ = LY::PSZ;
   double *Lib = lds + LY::LIB, *dvb = lds + LY::DVB, *dgb = lds + LY::DGB, *UF = lds + LY::UF, *xs = lds + LY::XS;
-  double *red = lds + LY::RED, *PB = lds + LY::PB, *A = lds + LY::AOFF, *dbuf = lds + LY::VAR;
+  double *red = lds + LY::RED, *PB = lds + LY::PB, *dbuf = lds + LY::VAR;
   int *psb = (int *)(lds + LY::PSB), *hib = (int *)(lds + LY::HIB), *jm = (int *)(lds + LY::JM);
   unsigned *pm = (unsigned *)(lds + LY::PM);
   double *Minv = lds + LY::MIV;
   int *sbuf = (int *)(dbuf + ((P.max_drec + 1) & ~1));
   int *soff = sbuf + ((P.max_srec + 3) & ~3), *doff = soff + ((NS + 4) & ~3), *hiall = doff + ((NS + 4) & ~3);
+  double *A = (double *)(hiall + ((NS + 4) & ~3));   // cells of the assembled entries (Symbolic::compact_cells)
   const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
   double *dx = W.dx + (size_t)b * n;
@@ -992,7 +996,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) { ge4 |= (lk + 4 * g >= li ? 1u : 0u) << (4 * g); gt4 |= (lk + 4 * g > li ? 1u : 0u) << (4 * g); }   // (bit 4g: the layout of (mask >> lk) & 0x1111)
 
-  for (int i = tid; i < ntri; i += KT) A[i] = 0.0;
+  for (int i = tid; i < P.n_cells; i += KT) A[i] = 0.0;
   for (int i = tid; i < 3 * PSZ; i += KT) PB[i] = 0.0;
   for (int i = tid; i < 128; i += KT) { UF[i] = 0.0; xs[i] = 0.0; }
   for (int v = tid; v < n; v += KT) dx[v] = 0.0;
@@ -1077,14 +1081,18 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   {
     double *P0 = PB;   // stage 0 lives in panel 0
     const int *ps0 = psb;
+    // cell of panel entry (row r, pivot column j) of stage 0: P.ctab, laid out for the AB phase's lanes
+    auto cell0 = [&](int r, int j, int c) __attribute__((always_inline)) {
+      return r < F ? (int)P.ctab[(((r >> 4) * 64) + (r & 3) * 16 + j) * 4 + ((r & 15) >> 2)] : 1 + c;
+    };
     for (int i = tid; i < (F + 1) * PIV; i += KT) {
       const int r = i >> 4, j = i & 15, c = ps0[j];
-      P0[r * PLD + j] = (r < F ? A[trs(r, c)] : A[tri(F, c)]) + (r == c ? dgb[j] : 0.0);
+      P0[r * PLD + j] = A[cell0(r, j, c)] + (r == c ? dgb[j] : 0.0);
     }
     __syncthreads();
     for (int i = tid; i < (F + 1) * PIV; i += KT) {
       const int r = i >> 4, j = i & 15, c = ps0[j];
-      A[r < F ? trs(r, c) : tri(F, c)] = 0.0;
+      A[cell0(r, j, c)] = 0.0;
     }
     __syncthreads();
     if (wv == 0) factor_block(P0, ps0[li], Lib, dvb);
@@ -1115,6 +1123,11 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
   i4_t pfs[PFS4];
   int pf_nd2 = 0, pf_ns4 = 0;
   int prow_next = NS > 1 ? psb[PIV + li] : 0;   // pivot slot li of stage k+1
+  // cells that feed this lane's four entries of the next stage's pivot columns (row tile = wave): one 8-byte
+  // load per lane and stage from the static table, fetched a stage ahead
+  typedef unsigned short us4_t __attribute__((ext_vector_type(4)));
+  const us4_t *ctab4 = (const us4_t *)P.ctab;
+  us4_t ct_cur = ctab4[((size_t)min(1, NS - 1) * NT + min(wv, NT - 1)) * 64 + lane];
   const int tid_outer = tid, lane_outer = lane;
   for (int k = 0; k < NS; ++k) {
     // per-iteration opaque copies of the thread / lane index: everything derived from them is
@@ -1153,6 +1166,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #pragma unroll
       for (int jj = 0; jj < PFS4; ++jj) pfs[jj] = ssrc[min(tid + jj * XT, pf_ns4 - 1)];
     }
+    const us4_t ct_nxt = ctab4[((size_t)min(k + 2, NS - 1) * NT + min(wv, NT - 1)) * 64 + lane];
     STAMPW(0, st0, 5);
     // ---- AB(k): one 16-row panel tile per wave.  All LDS reads are issued up front (no lane-dependent
     //      branches around loads), then the 12 MFMAs, then the stores. --------------------------------
@@ -1162,9 +1176,8 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       const int R = wv;
       const unsigned am_word = P.amask[k * 4 + (R >> 1)];   // row mask of this stage's panel: fetched now, used at the end of the phase
       const int prow = has_next ? prow_next : 0;
-      const int *jmn = jm + ((k + 1) & 1) * 128;
       double la[4], pr[4], pp[4], lm[4], xv[4], av[4];
-      int jr[4], aidx[4];
+      int aidx[4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int r = 16 * R + lk + 4 * s4;
@@ -1173,8 +1186,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
         pp[s4] = Pk[prow * PLD + lk + 4 * s4];
         lm[s4] = Minv[li * PLD + lk + 4 * s4];
         xv[s4] = Xn[r * PLD + li];
-        jr[s4] = jmn[r];
-        aidx[s4] = trs(r, prow);
+        aidx[s4] = ct_cur[s4];   // 0 (the zero cell) where K has no entry or the entry belongs to the mirrored position
         av[s4] = A[aidx[s4]];
       }
       const double dgn = dgb[((k + 1) % 3) * PIV + li];
@@ -1186,16 +1198,13 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       for (int s4 = 0; s4 < 4; ++s4) vt = __builtin_amdgcn_mfma_f64_16x16x4f64(lm[s4], pr[s4], vt, 0, 0, 0);
       STAMPW(0, st0, 6);
       // next pivot columns: assembled entries (read here, retired below), extracted Schur updates,
-      // pivot diagonal; an entry between two pivots of stage k+1 is taken once, by the lane whose row
-      // has the larger pivot index
+      // pivot diagonal; an entry between two pivots of stage k+1 is delivered once, to the row with the
+      // larger pivot index (the cell table says so)
       d4_t acc;
-      bool take[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int r = 16 * R + lk + 4 * g;
-        const bool rp = (grp16(m1, R) >> (lk + 4 * g)) & 1u;
-        take[g] = (int)has_next & (int)!(rp & (jr[g] < li));   // bitwise on purpose: no wave-uniform branch per entry
-        acc[g] = xv[g] + (take[g] ? av[g] : 0.0) + (r == prow ? dgn : 0.0);
+        acc[g] = xv[g] + av[g] + (r == prow ? dgn : 0.0);
       }
       double npp[4];   // (the sign of the last product sits on its B operand, off the MFMA chain)
 #pragma unroll
@@ -1219,7 +1228,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         Yk[(16 * R + li) * PLD + lk + 4 * g] = myrowpiv ? 0.0 : yt[g];
-        if (take[g]) A[aidx[g]] = 0.0;
+        A[aidx[g]] = 0.0;   // retired (the zero cell stays zero)
       }
       if (has_next) {
 #pragma unroll
@@ -1233,7 +1242,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
       }
     }
     if (wv == 7 && lane < PIV && has_next) {   // assembled right-hand side of the next pivots (read and retired)
-      const int idx = tri(F, prow_next);
+      const int idx = 1 + prow_next;
       Xn[F * PLD + lane] = A[idx];
       A[idx] = 0.0;
     }
@@ -1422,6 +1431,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
 #endif
     lds_barrier();
     if (k + 2 < NS) prow_next = psb[((k + 2) % 3) * PIV + li];   // pivot slot li of the stage after next
+    ct_cur = ct_nxt;
     STAMPW(0, st0, 2);
   }
   // ---- backward substitution: x_piv = w - V^T x, one barrier per stage.  Wave w owns rows 16w..16w+15

@@ -33,11 +33,10 @@ struct QtosPlanner {
   double *d_start = nullptr, *d_goal = nullptr, *d_nodes = nullptr, *d_warm = nullptr;
   int *d_map = nullptr;
   double *d_height = nullptr;
-  int sure_iters = 0;   // iterations the next batch is launched for without looking (previous batch's count - 1)
-  int prev_iters = -1;
+  hipStream_t own_stream = nullptr;   // stream of the host-pointer entry points (non-blocking: other handles / streams are not synchronised)
   double *d_table = nullptr, *d_tab_dx = nullptr, *d_tab_dy = nullptr;   // nominal-plan table (qtos_set_init_table)
-  int *h_active = nullptr;  // pinned
-  std::vector<hipEvent_t> ev;  // 2 per iteration (kkt begin/end) + 2 (total)
+  int *h_active = nullptr;  // pinned, one word per Newton iteration: unfinished problems after it
+  std::vector<hipEvent_t> ev;  // 3 per iteration (kkt begin / end, count read back) + 2 (total)
   int last_launches = 0, last_iters = 0;
   size_t kkt_lds = 0, eval_lds = 0;
   void (*kkt_fn)(DevPlan, DevWork, int) = nullptr;   // k_kkt instantiated for this front size
@@ -103,6 +102,7 @@ void qtos_planner_destroy(QtosPlanner *p) {
   for (void *q : {(void *)p->d_table, (void *)p->d_tab_dx, (void *)p->d_tab_dy, (void *)p->d_height})
     if (q) (void)hipFree(q);
   if (p->h_active) (void)hipHostFree(p->h_active);
+  if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
   delete p;
 }
 
@@ -140,6 +140,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.n_rom_t1 = (int)S.rom_t1.size();
   D.dyn_chunk = M.dyn_chunk;
   TRY(p->upload(S.amask, &D.amask));
+  TRY(p->upload(S.ctab, &D.ctab));
+  D.n_cells = S.n_cells;
   D.n_cont = 0;
   for (int k = 0; k < S.n_stages; ++k) D.n_cont += S.srec[S.srec_off[k] + 6];
   D.table = nullptr; D.tab_dx = D.tab_dy = nullptr; D.tab_ndx = D.tab_ndy = 0;
@@ -205,7 +207,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.panel_stride = (long long)S.n_stages * (S.front + 1) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  p->kkt_lds = kkt_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec);
+  p->kkt_lds = kkt_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
   if (S.max_drec > 2 * 2 * KT || S.max_srec > 3 * 4 * KT || F > 128 || (S.pack_src.size() & 1)) {
     p->err = "stage record exceeds the prefetch registers";
     fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints) or front %d > 128\n", S.max_drec, S.max_srec, F);
@@ -260,8 +262,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.n_active, 1));
   TRY(p->alloc(&p->d_start, Bm * QTOS_START_DOUBLES)); TRY(p->alloc(&p->d_goal, Bm * 3));
   TRY(p->alloc(&p->d_nodes, Bm * n)); TRY(p->alloc(&p->d_warm, Bm * n)); TRY(p->alloc(&p->d_map, Bm));
-  if (hipHostMalloc((void **)&p->h_active, sizeof(int)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
-  p->ev.resize(2 * (size_t)M.P.max_iter + 2);
+  if (hipHostMalloc((void **)&p->h_active, sizeof(int) * ((size_t)M.P.max_iter + 1)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
+  if (hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+  p->ev.resize(3 * (size_t)M.P.max_iter + 3);
   for (auto &e : p->ev)
     if (hipEventCreate(&e) != hipSuccess) { qtos_planner_destroy(p); return -2; }
 #undef TRY
@@ -344,38 +347,39 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
   HIPCHK(p, hipMemsetAsync(W.n_active, 0, sizeof(int), st));
   HIPCHK(p, hipEventRecord(p->ev[0], st));
   hipLaunchKernelGGL(k_start, dim3(B), dim3(ET), p->eval_lds, st, D, W, B);
-  int launches = 0, it = 0;
-  // The host only has to look at the number of unfinished problems when the batch may be done: the
-  // iterations the previous batch certainly needed are launched back to back (a batch that finishes
-  // earlier runs kernels whose workgroups exit at once), then one check per iteration as before.
-  const int no_check_before = p->sure_iters;
-  for (it = 0; it < D.max_iter; ++it) {
-    if (it >= no_check_before) {
-      HIPCHK(p, hipMemcpyAsync(p->h_active, W.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
-      // spin on the stream instead of a blocking wait: the wake-up latency of a blocking
-      // hipStreamSynchronize is paid once per Newton iteration otherwise
-      hipError_t q;
-      while ((q = hipStreamQuery(st)) == hipErrorNotReady) {}
-      if (q != hipSuccess) { p->err = std::string("hipStreamQuery: ") + hipGetErrorString(q); return -2; }
-      if (*p->h_active <= 0) break;
-    }
-    HIPCHK(p, hipEventRecord(p->ev[2 + 2 * launches], st));
+  // Newton iterations, one launch ahead of the host: iteration `it` is queued before the count of
+  // unfinished problems after iteration it - 1 has come back, so the device never waits for the host.
+  // When that count turns out to be zero the iteration already queued is empty (its workgroups exit
+  // at once); it is neither counted nor timed.  No state is kept between calls.
+  const int ev_start = 2 + 3 * D.max_iter;   // event behind the read-back of k_start's count
+  auto count_after = [&](int it, int *n) -> int {   // it = -1: after k_start.  Spin instead of a blocking wait (wake-up latency once per iteration)
+    hipError_t q;
+    while ((q = hipEventQuery(p->ev[it < 0 ? ev_start : 4 + 3 * it])) == hipErrorNotReady) {}
+    if (q != hipSuccess) { p->err = std::string("hipEventQuery: ") + hipGetErrorString(q); return -2; }
+    *n = p->h_active[it < 0 ? D.max_iter : it];
+    return 0;
+  };
+  HIPCHK(p, hipMemcpyAsync(p->h_active + D.max_iter, W.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(p, hipEventRecord(p->ev[ev_start], st));
+  int iters = D.max_iter;   // real (non-empty) iterations
+  for (int it = 0; it < D.max_iter; ++it) {
+    HIPCHK(p, hipEventRecord(p->ev[2 + 3 * it], st));
     hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(KT), p->kkt_lds, st, D, W, B);
-    HIPCHK(p, hipEventRecord(p->ev[3 + 2 * launches], st));
-    launches++;
+    HIPCHK(p, hipEventRecord(p->ev[3 + 3 * it], st));
     hipLaunchKernelGGL(k_step, dim3(B), dim3(ET), p->eval_lds, st, D, W, B, it);
+    HIPCHK(p, hipMemcpyAsync(p->h_active + it, W.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(p, hipEventRecord(p->ev[4 + 3 * it], st));
+    int n = 0;
+    if (int rc = count_after(it - 1, &n)) return rc;
+    if (n <= 0) { iters = it; break; }   // nothing was left to do: the iteration just queued is the empty one
   }
   HIPCHK(p, hipMemcpyAsync(d_nodes_out, W.x, (size_t)B * D.n_vars * sizeof(double), hipMemcpyDeviceToDevice, st));
   if (d_status_out) HIPCHK(p, hipMemcpyAsync(d_status_out, W.status, B * sizeof(int), hipMemcpyDeviceToDevice, st));
   if (d_iters_out) HIPCHK(p, hipMemcpyAsync(d_iters_out, W.iters, B * sizeof(int), hipMemcpyDeviceToDevice, st));
   if (d_viol_out) HIPCHK(p, hipMemcpyAsync(d_viol_out, W.viol, B * sizeof(double), hipMemcpyDeviceToDevice, st));
   HIPCHK(p, hipEventRecord(p->ev[1], st));
-  p->last_launches = launches;
-  p->last_iters = it;
-  // (only in a steady state -- two batches in a row with the same count, e.g. a stream of like batches --,
-  //  and never the last iteration: a batch that needs fewer would run, and time, empty launches)
-  p->sure_iters = (it == p->prev_iters && it > 1) ? it - 1 : 0;
-  p->prev_iters = it;
+  p->last_launches = iters;   // real (non-empty) k_kkt launches: the ones qtos_last_timing sums
+  p->last_iters = iters;
   HIPCHK(p, hipGetLastError());
   return 0;
 }
@@ -385,18 +389,22 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
   if (!p || B < 1 || B > p->max_batch || !start || !goal || !nodes_out) return -1;
   HIPCHK(p, hipSetDevice(p->device));
   const size_t n = p->M.n_vars;
-  HIPCHK(p, hipMemcpy(p->d_start, start, (size_t)B * QTOS_START_DOUBLES * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(p, hipMemcpy(p->d_goal, goal, (size_t)B * 3 * sizeof(double), hipMemcpyHostToDevice));
-  if (map_id) HIPCHK(p, hipMemcpy(p->d_map, map_id, B * sizeof(int), hipMemcpyHostToDevice));
-  if (warm) HIPCHK(p, hipMemcpy(p->d_warm, warm, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice));
+  if (map_id)   // (the kernels clamp too; a wrong id is the caller's bug and is reported)
+    for (int b = 0; b < B; ++b)
+      if (map_id[b] < 0 || map_id[b] >= std::max(p->dp.n_maps, 1)) { p->err = "map_id out of range"; return -1; }
+  hipStream_t st = p->own_stream;   // stream-scoped: no device-wide synchronisation
+  HIPCHK(p, hipMemcpyAsync(p->d_start, start, (size_t)B * QTOS_START_DOUBLES * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(p, hipMemcpyAsync(p->d_goal, goal, (size_t)B * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+  if (map_id) HIPCHK(p, hipMemcpyAsync(p->d_map, map_id, B * sizeof(int), hipMemcpyHostToDevice, st));
+  if (warm) HIPCHK(p, hipMemcpyAsync(p->d_warm, warm, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, st));
   int rc = qtos_plan_batch_device(p, B, p->d_start, p->d_goal, map_id ? p->d_map : nullptr,
-                                  warm ? p->d_warm : nullptr, p->d_nodes, nullptr, nullptr, nullptr, nullptr);
+                                  warm ? p->d_warm : nullptr, p->d_nodes, nullptr, nullptr, nullptr, (void *)st);
   if (rc) return rc;
-  HIPCHK(p, hipDeviceSynchronize());
-  HIPCHK(p, hipMemcpy(nodes_out, p->d_nodes, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost));
-  if (status_out) HIPCHK(p, hipMemcpy(status_out, p->wk.status, B * sizeof(int), hipMemcpyDeviceToHost));
-  if (iters_out) HIPCHK(p, hipMemcpy(iters_out, p->wk.iters, B * sizeof(int), hipMemcpyDeviceToHost));
-  if (viol_out) HIPCHK(p, hipMemcpy(viol_out, p->wk.viol, B * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(p, hipMemcpyAsync(nodes_out, p->d_nodes, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (status_out) HIPCHK(p, hipMemcpyAsync(status_out, p->wk.status, B * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (iters_out) HIPCHK(p, hipMemcpyAsync(iters_out, p->wk.iters, B * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (viol_out) HIPCHK(p, hipMemcpyAsync(viol_out, p->wk.viol, B * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(p, hipStreamSynchronize(st));
   return 0;
 }
 
@@ -407,7 +415,7 @@ int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, dou
   double kkt = 0;
   for (int i = 0; i < p->last_launches; ++i) {
     float ms = 0;
-    HIPCHK(p, hipEventElapsedTime(&ms, p->ev[2 + 2 * i], p->ev[3 + 2 * i]));
+    HIPCHK(p, hipEventElapsedTime(&ms, p->ev[2 + 3 * i], p->ev[3 + 3 * i]));
     kkt += ms * 1e-3;
   }
   float tot = 0;

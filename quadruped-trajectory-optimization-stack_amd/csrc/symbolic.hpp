@@ -72,6 +72,11 @@ struct Symbolic {
   // pack_src[i] says where stream element i comes from: (kind << 28) | index, kind 0 G, 1 g_static,
   // 2 -g[row], 3 sig[row], 4 w[row], 5 piv_diag, 6 alignment padding
   std::vector<int> srec, srec_off, pack_src, drec_off, stage_hi;
+  // Compact storage of the assembled entries (see compact_cells): cell 0 is a constant zero, cells
+  // 1..front hold the assembled right-hand side by slot, the rest are handed out to the structural
+  // entries of K for the stages between their assembly and the gathering of their pivot column.
+  std::vector<unsigned short> ctab;   // n_stages x (front/16) x 64 lanes x 4: cell of panel entry (row 16R + lk + 4g, pivot column li), 0 = none
+  int n_cells = 0;                    // length of the cell array (zero cell + rhs + entries)
   std::vector<unsigned> amask;   // per stage 128 bits: front slots whose row of the factor panel V is stored (live, not a pivot of the stage)
   // The linearisation kernels write straight into the stream: eq_pos maps the (virtual) G offset of
   // an equality-block entry to its stream position; inequality blocks are contiguous in the stream
@@ -223,6 +228,77 @@ struct Symbolic {
     if (cpos >= 4096) { err = "gather table overflow"; return -1; }
     srec.push_back(cpos);   // sentinel: end of the last target's contributions
     srec.insert(srec.end(), codes.begin(), codes.end());
+    return 0;
+  }
+
+
+  // The assembled (original) entries of K waiting in LDS for their pivot column used to live in a dense
+  // lower triangle over the front's slots ((F+1)(F+2)/2 doubles: 67 KB at F = 128), of which only a few
+  // thousand are structurally non-zero at any time.  Here every structural entry (u, v) gets a cell for
+  // the stages between its first assembly (record k <= stage of u) and the gathering of the pivot columns
+  // of its earlier unknown u (AB phase of stage(u) - 1, which comes before the assembly of record
+  // stage(u) + 1: cells are recycled from then on).  The records' targets are rewritten to cell numbers
+  // and a per-stage table tells every lane of the panel construction which cell (if any) feeds its entry.
+  // An entry between two pivots of one stage is delivered once, to the row with the larger pivot index.
+  int compact_cells(const std::vector<int> &first, const std::vector<int> &slot_of) {
+    const int F = front, ntri_rhs = F * (F + 1) / 2;
+    std::vector<int> occ((size_t)n_stages * F, -1);
+    for (int j = 0; j < n_unknowns; ++j)
+      for (int k = first[j] / PIV; k <= j / PIV; ++k) occ[(size_t)k * F + slot_of[j]] = j;
+    std::map<std::pair<int, int>, int> cell;
+    std::vector<std::vector<int>> retire(n_stages);
+    std::vector<int> free_cells;
+    n_cells = 1 + F;
+    auto target = [&](int k, int t) -> int {
+      if (t >= ntri_rhs) return 1 + (t - ntri_rhs);
+      int r = 0;
+      while ((r + 1) * (r + 2) / 2 <= t) ++r;
+      const int c = t - r * (r + 1) / 2;
+      int u = occ[(size_t)k * F + r], v = occ[(size_t)k * F + c];
+      if (u < 0 || v < 0) { err = "assembled entry on a free slot"; return -1; }
+      if (u > v) std::swap(u, v);
+      if (u / PIV < k) { err = "entry assembled after its pivot column was gathered"; return -1; }
+      auto it = cell.find({u, v});
+      if (it != cell.end()) return it->second;
+      int id;
+      if (!free_cells.empty()) { id = free_cells.back(); free_cells.pop_back(); }
+      else id = n_cells++;
+      cell[{u, v}] = id;
+      retire[u / PIV].push_back(id);
+      return id;
+    };
+    auto rewrite = [&](int k, int s0) -> int {
+      const int n_ent = srec[s0], n_rhs = srec[s0 + 1];
+      int *e = &srec[s0 + SHDR_INTS + PIV];
+      for (int i = 0; i < n_ent; ++i) if ((e[i] = target(k, e[i])) < 0) return -1;
+      for (int i = 0; i < n_rhs; ++i) e[n_ent + i] = 1 + e[n_ent + i];
+      if (srec[s0 + 2] == 0) return 0;
+      int *tg = &srec[s0 + srec[s0 + 4]];
+      for (int t = 0; t < srec[s0 + 5]; ++t) {
+        const int c = target(k, tg[t] >> 12);
+        if (c < 0) return -1;
+        tg[t] = (c << 12) | (tg[t] & 4095);
+      }
+      return 0;
+    };
+    ctab.assign((size_t)n_stages * F * PIV, 0);
+    for (int k = 0; k < n_stages; ++k) {
+      if (k >= 1) { for (int id : retire[k - 1]) free_cells.push_back(id); }
+      std::sort(free_cells.begin(), free_cells.end(), std::greater<int>());   // lowest cell first
+      if (rewrite(k, srec_off[k])) return -1;
+      const int n_cont = srec[srec_off[k] + 6], c_first = srec[srec_off[k] + 7];
+      for (int c = 0; c < n_cont; ++c)
+        if (rewrite(k, cont[4 * (c_first + c)])) return -1;
+    }
+    if (n_cells >= 65536) { err = "too many live entries for the 16-bit cell table"; return -1; }
+    const int NT = F / 16;
+    for (auto &kv : cell) {
+      const int u = kv.first.first, v = kv.first.second, k = u / PIV, col = u - k * PIV, r = slot_of[v];
+      const int R = r >> 4, rr = r & 15, lk = rr & 3, g = rr >> 2;
+      ctab[((((size_t)k * NT + R) * 64) + lk * 16 + col) * 4 + g] = (unsigned short)kv.second;
+    }
+    n_cells = (n_cells + 1) & ~1;
+    if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: %d cells for the assembled entries (dense triangle: %d)\n", n_cells, (F + 1) * (F + 2) / 2);
     return 0;
   }
 
@@ -537,11 +613,33 @@ struct Symbolic {
       srec[srec_off[k] + 7] = first_cont;
     }
     if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: %d stages, %d continuation records, max record %d ints / %d doubles\n", n_stages, (int)cont.size() / 4, max_srec, max_drec);
+    if (getenv("QTOS_DEBUG_SYMBOLIC2")) {
+      // lifetimes
+      std::map<int,int> hist;
+      for (int j = 0; j < n_unknowns; ++j) hist[j / PIV - first[j] / PIV]++;
+      fprintf(stderr, "lifetime(stages) histogram:");
+      for (auto &kv : hist) fprintf(stderr, " %d:%d", kv.first, kv.second);
+      fprintf(stderr, "\n");
+      // live original entries in A per stage: target tri index -> (assembly stage, retire stage)
+      // an entry (r,c) is assembled at stage s_a (record of that stage) and retired when min(pivot stage of slot r, of slot c)
+      // here: count distinct targets per record and total
+      long long tot_t = 0; int max_t = 0;
+      for (int k = 0; k < n_stages; ++k) { int nt = srec[srec_off[k] + 5] + srec[srec_off[k]] ; tot_t += nt; max_t = std::max(max_t, nt); }
+      fprintf(stderr, "targets total %lld max/stage %d ; srec ints %zu, stream doubles %zu\n", tot_t, max_t, srec.size(), pack_src.size());
+      fprintf(stderr, "active per stage:");
+      for (int k = 0; k < n_stages; ++k) fprintf(stderr, " %d", active_count[k]);
+      fprintf(stderr, "\nhi per stage:");
+      for (int k = 0; k < n_stages; ++k) fprintf(stderr, " %d", stage_hi[k]);
+      fprintf(stderr, "\nenter per stage:");
+      for (int k = 0; k < n_stages; ++k) fprintf(stderr, " %d", (int)enter[k].size());
+      fprintf(stderr, "\n");
+    }
     if (cont.empty()) cont.assign(4, 0);
     while (srec.size() & 3) srec.push_back(0);
     while (pack_src.size() & 1) pack_src.push_back(6 << 28);
     max_srec = (max_srec + 7) & ~3;   // a stage's record may end with alignment padding
     max_drec = (max_drec + 3) & ~1;
+    if (compact_cells(first, slot_of)) return -1;
     // ---- direct-write maps derived from the stream layout ----
     eq_pos.assign((size_t)std::max<long long>(g_doubles, 1), -1);
     rhs_pos.assign(m, -1);
