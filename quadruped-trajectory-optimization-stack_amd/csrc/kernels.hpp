@@ -45,9 +45,11 @@ struct DevPlan {
   const int *terr_dpos;        // n_terr x 2: stream positions of the pivot diagonals of a foot node's x and y (-1: none)
   int hold_from;               // two-phase solve: stance footholds are held once an iterate >= hold_from has violation <= hold_tol (0: never)
   double hold_weight, hold_tol;
-  const unsigned *amask;       // n_stages x 4: rows of the factor panel that are stored / read back (Symbolic::amask)
+  const unsigned *amask;       // n_stages x 8: rows of the factor panel that are stored / read back (Symbolic::amask)
   const unsigned short *ctab;  // n_stages x (front/16) x 64 x 4: cell of every entry of a stage's pivot columns (Symbolic::ctab)
   int n_cells;                 // cells of the assembled entries: [0] zero, [1 + slot] right-hand side, then the entries
+  int max_part_con;            // most contributions in one assembly part (k_kkt2 scratch, Symbolic::max_part_con)
+  const int *rtab;             // n_stages x 16: cell of the assembled right-hand side of every pivot (k_kkt2, Symbolic::rtab)
   const Block *blocks;
   const int *block_cols;
   const IqRow *iq_rows;   // rows of the inequality blocks (stream offsets)
@@ -896,6 +898,9 @@ __device__ __forceinline__ void assemble_stage(double *A, int F, const int *sbuf
   const double *rval = eval + n_ent;
   for (int i = t0; i < n_rhs; i += nth) A[rsl[i]] += rval[i];
   if (n_iq == 0) return;
+#ifdef QTOS_EXP_NOASM
+  return;   // ablation build (timing only): the inequality blocks are not assembled
+#endif
   const int n_tgt = sbuf[5];
   const int *tg = sbuf + sbuf[4];                     // n_tgt + 1 ints: (tri << 12) | first contribution
   const int *cl = tg + n_tgt + 1;                     // one self-contained int per contribution
@@ -1174,7 +1179,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     const Mask128 m1 = load_mask(pm + ((k + 1) & 1) * 4, lane);   // pivot slots of stage k+1
     if (wv < NT) {
       const int R = wv;
-      const unsigned am_word = P.amask[k * 4 + (R >> 1)];   // row mask of this stage's panel: fetched now, used at the end of the phase
+      const unsigned am_word = P.amask[k * 8 + (R >> 1)];   // row mask of this stage's panel: fetched now, used at the end of the phase
       const int prow = has_next ? prow_next : 0;
       double la[4], pr[4], pp[4], lm[4], xv[4], av[4];
       int aidx[4];
@@ -1449,7 +1454,7 @@ __global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
     // the rows this wave reads of a stage: 16 bits of the stage's row mask, fetched one stage ahead of
     // the panel loads that depend on it
     auto amask16 = [&](int k) __attribute__((always_inline)) {
-      return (P.amask[max(k, 0) * 4 + (wv >> 1)] >> ((wv & 1) * 16)) & 0xffffu;
+      return (P.amask[max(k, 0) * 8 + (wv >> 1)] >> ((wv & 1) * 16)) & 0xffffu;
     };
     unsigned am_next = amask16(NS - 1);
     // loads are unconditional (clamped indices) so that the compiler can wait with partial vmcnt

@@ -1,0 +1,713 @@
+// kkt2.hpp -- k_kkt2: the KKT factor + solve kernel with 16 waves per problem (1024 threads).
+//
+// Same mathematics and the same data structures as k_kkt (kernels.hpp: chain of fronts, 16 pivots per
+// stage, Schur updates in MFMA accumulator registers, assembled entries in LDS cells, factor panels to
+// HBM for the backward pass), re-cut so that no wave carries two jobs in a row:
+//
+//   AB(k)  waves 0 .. NT-1   one 16-row tile of the panel each (V = P (L D L^T)^-1, next pivot columns,
+//                             Y = P L^-T), as before
+//          service waves      (the other 16 - NT): assembly of stage k+2's records into the cells -- it used
+//                             to close phase C on every wave --, and, on the first of them, the whole
+//                             right-hand-side row: w = (L D L^T)^-1 p_F (to HBM), rhs -= P w, the right-hand
+//                             side of the next pivots.  (y_F D^-1 Y[r]^T = P[r] w, so the row needs nothing
+//                             this phase produces.)
+//   C(k)   wave 0             LDL^T + inverses of the next pivot block (nothing else)
+//          update waves       (those not on the factor wave's SIMD: the f64 matrix and vector pipes are one)
+//                             U -= Y D^-1 Y^T on MAXT tiles each,
+//                             extraction of stage k+2's columns
+//          wave 12            header of stage k+3 (pivot slots, slot map, masks, diagonals)
+//          all                install the records of stage k+3 (prefetched into 12 registers per thread
+//                             at the top of the stage)
+//
+// Fronts up to 208 slots: 13 row tiles, 91 Schur tiles = 7 per update wave (56 registers); the LDS
+// budget holds because the assembled entries live in cells (Symbolic::compact_cells, cell_mode 2).
+#pragma once
+#include "kernels.hpp"
+
+namespace qtos {
+
+constexpr int KT2 = 1024;
+
+template <int F>
+struct Kkt2Cfg {
+  static constexpr int NT = F / 16;
+  static constexpr int NTILE = NT * (NT + 1) / 2;
+  // Update waves: the f64 matrix instructions and the f64 vector instructions of a SIMD share one pipe, and
+  // waves w, w+4, w+8, w+12 of a workgroup share a SIMD: the twelve waves that do not sit on the factor wave's
+  // SIMD come first (update index u -> wave u + 1 + u / 3), waves 4 and 8 join only when a large front needs
+  // them (u = 12, 13); wave 12 publishes headers.  As many update waves as divide the tiles evenly.
+  static constexpr int pick_nu() {
+    int best = 14, best_t = (NTILE + 13) / 14;
+    for (int nu = 14; nu >= 8; --nu) {
+      const int t = (NTILE + nu - 1) / nu;
+      if (t < best_t || (t == best_t && nu * t - NTILE <= best * best_t - NTILE)) { best = nu; best_t = t; }
+    }
+    return NTILE < 8 ? (NTILE < 1 ? 1 : NTILE) : best;
+  }
+  static constexpr int NU = pick_nu();
+  static constexpr int MAXT = (NTILE + NU - 1) / NU;
+  static constexpr int NSV = 16 - NT;            // service waves of the AB phase
+  static constexpr int NH = NT <= 8 ? 2 : 1;     // backward pass: waves per row tile
+  static constexpr int FR = (F + 63) & ~63;      // by-slot arrays padded to whole waves
+};
+
+// LDS layout (doubles)
+template <int F>
+struct Kkt2Layout {
+  using CF = Kkt2Cfg<F>;
+  static constexpr int PSZ = (F + 1) * PLD;
+  static constexpr int LIB = 0;                          // 2 x 16 x PLD   L^-1 (current / next)
+  static constexpr int DVB = LIB + 2 * PIV * PLD;        // 2 x 16         1 / d
+  static constexpr int DGB = DVB + 2 * PIV;              // 3 x 16         pivot diagonals (ring)
+  static constexpr int UF = DGB + 3 * PIV;               // FR             accumulated rhs updates
+  static constexpr int XS = UF + CF::FR;                 // FR             solution by slot (backward)
+  static constexpr int RED = XS + CF::FR;                // 2 x 16 x 16 partial sums + 64 dummy slots
+  static constexpr int PSB = RED + 2 * 16 * PIV + 64;    // 3 x 16 ints    pivot slots (ring)
+  static constexpr int HIB = PSB + 3 * PIV / 2;          // 4 ints
+  static constexpr int JM = HIB + 2;                     // 2 x FR ints    slot -> pivot index
+  static constexpr int PM = JM + CF::FR;                 // 2 x 8 ints     pivot-slot bit masks
+  static constexpr int MIV = PM + 8;                     // 16 x PLD       (L D L^T)^-1 of the current pivot block
+  static constexpr int PB = MIV + PIV * PLD;             // 3 panels of (F+1) x PLD
+  static constexpr int VAR = (PB + 3 * PSZ + 1) & ~1;    // dbuf, then (ints) sbuf, soff, doff, hiall, then the cells A
+};
+inline size_t kkt2_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells, int max_part_con) {
+  const int FR = (F + 63) & ~63, PSZ = (F + 1) * PLD;
+  const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 2 * (size_t)FR + 2 * 16 * PIV + 64 + 3 * PIV / 2 + 2 + FR + 8 + PIV * PLD;
+  size_t o = (fixed + 3 * (size_t)PSZ + 1) & ~(size_t)1;
+  o += ((size_t)max_drec + 1) & ~(size_t)1;
+  size_t oi = 2 * o + (((size_t)max_srec + 3) & ~(size_t)3) + 3 * ((((size_t)NS + 1) + 3) & ~(size_t)3);
+  oi += 2 * (((size_t)n_cells + 1) & ~(size_t)1);
+  oi += 2 * 16 * (size_t)max_part_con;
+  return oi * sizeof(int);
+}
+
+// pivot-slot mask of up to 256 bits: lane l holds word l & 7
+struct Mask256 {
+  int v;
+};
+__device__ __forceinline__ Mask256 load_mask8(const unsigned *pm8, int lane) {
+  Mask256 m;
+  m.v = (int)pm8[lane & 7];
+  return m;
+}
+__device__ __forceinline__ unsigned grp16(const Mask256 &m, int grp) {
+  return ((unsigned)__builtin_amdgcn_readlane(m.v, grp >> 1) >> ((grp & 1) * 16)) & 0xffffu;
+}
+// acc += bcast_K(w) * b : the K-th lane of every 16-lane row of w, one DP-ALU DPP instruction
+template <int K>
+__device__ __forceinline__ void fma_bc(double &acc, double w, double b) {
+  asm volatile("v_fmac_f64 %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(b), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void dot16_steps(double &acc, double w, const double (&p)[PIV]) {
+  if constexpr (K < PIV) {
+    fma_bc<K>(acc, w, p[K]);
+    dot16_steps<K + 1>(acc, w, p);
+  }
+}
+
+// two consecutive ints by a scalar load (the compiler reads plan arrays reached through the by-value DevPlan
+// with vector loads and a full vmcnt(0) drain: it cannot prove them read-only)
+__device__ __forceinline__ void sload2(const int *p, int &a, int &b) {
+  typedef int i2_t __attribute__((ext_vector_type(2)));
+  i2_t r;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+  a = r[0];
+  b = r[1];
+}
+
+// Assembly of one stage's records (in LDS) into the cells.  Equality entries and multiplier right-hand sides
+// are distinct targets: one item per thread.  The inequality blocks come in NPART parts (Symbolic::emit_blocks),
+// one wave each and no barrier: first every contribution  sum_r sig_r G[r][a] G[r][c]  (or  -sum_r G[r][a] w_r)
+// is formed by its own lane and parked in the wave's scratch array, then every target of the part sums its
+// run of contributions in list order (fixed order => bitwise reproducible) and adds it to its cell.
+constexpr int NPART = Symbolic::NPART;
+constexpr int APW = 4;   // parts a wave without Schur tiles takes in phase C (merged into one run)
+__device__ __forceinline__ void assemble_eq(double *A, const int *sbuf, const double *dbuf, int t0, int nth) {
+  const int n_ent = sbuf[0], n_rhs = sbuf[1];
+  const int *eidx = sbuf + SHDR + PIV;
+  const double *eval = dbuf + PIV;
+  for (int i = t0; i < n_ent + n_rhs; i += nth) A[eidx[i]] += eval[i];   // (rhs targets and values follow the entries)
+}
+// parts [p0, p1) as one run (consecutive parts are consecutive targets / contributions); scr0 = scratch of part 0
+__device__ __forceinline__ void assemble_part(double *A, const int *sbuf, const double *dbuf, double *scr0, int mpc, int lane, int p0, int p1) {
+  if (sbuf[2] == 0 || p0 >= p1) return;
+  double *scr = scr0 + p0 * mpc;
+  const int *tg = sbuf + sbuf[4];
+  const int *pt = tg - 2 * (NPART + 1), *pc = pt + (NPART + 1);
+  const int *cl = tg + sbuf[5] + 1;
+  const int t0 = pt[p0], t1 = pt[p1], c0 = pc[p0], c1 = pc[p1];
+#ifdef QTOS_EXP_NOASM
+  return;
+#endif
+  for (int j = c0 + lane; j < c1; j += 64) scr[j - c0] = gather_term(dbuf, cl[j]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the LDS operations of one wave complete in order)
+  for (int t = t0 + lane; t < t1; t += 64) {
+    const int tv = tg[t], b = (tv & 4095) - c0, e = (tg[t + 1] & 4095) - c0;
+    const double a_old = A[tv >> 12];
+    double acc = 0.0;
+    for (int j = b; j < e; j += 4) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = scr[min(j + u, e - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += j + u < e ? v[u] : 0.0;
+    }
+    A[tv >> 12] = a_old + acc;
+  }
+}
+
+template <int F, bool CONT>
+__global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
+  const int b = blockIdx.x;
+  if (b >= B || W.done[b]) return;
+  extern __shared__ double lds[];
+  using CF = Kkt2Cfg<F>;
+  using LY = Kkt2Layout<F>;
+  constexpr int NT = CF::NT, NU = CF::NU, MAXT2 = CF::MAXT, NSV = CF::NSV, NH = CF::NH, FR = CF::FR, PSZ = LY::PSZ;
+  const int tid = threadIdx.x, NS = P.n_stages, n = P.n_vars;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  double *Lib = lds + LY::LIB, *dvb = lds + LY::DVB, *dgb = lds + LY::DGB, *UF = lds + LY::UF, *xs = lds + LY::XS;
+  double *red = lds + LY::RED, *PB = lds + LY::PB, *dbuf = lds + LY::VAR;
+  int *psb = (int *)(lds + LY::PSB), *hib = (int *)(lds + LY::HIB), *jm = (int *)(lds + LY::JM);
+  unsigned *pm = (unsigned *)(lds + LY::PM);
+  double *Minv = lds + LY::MIV;
+  int *sbuf = (int *)(dbuf + ((P.max_drec + 1) & ~1));
+  int *soff = sbuf + ((P.max_srec + 3) & ~3), *doff = soff + ((NS + 4) & ~3), *hiall = doff + ((NS + 4) & ~3);
+  double *A = (double *)(hiall + ((NS + 4) & ~3));   // cells of the assembled entries
+  double *scr0 = A + ((P.n_cells + 1) & ~1);   // assembly scratch: max_part_con doubles per part
+  const double *stream = W.stream + (size_t)b * P.stream_len;
+  double *panel = W.panel + (size_t)b * P.panel_stride;
+  double *dx = W.dx + (size_t)b * n;
+  const int pstride = (F + 1) * PIV;   // per stage: w (16), V (F x 16)
+
+  // ---- U tiles of this wave: update index uw (Kkt2Cfg), tile t = uw + NU i of the lower triangle ---------
+  const int uw = (wv & 3) ? wv - 1 - (wv >> 2) : (wv == 4 ? 12 : (wv == 8 ? 13 : (wv == 12 ? 14 : 99)));
+  const bool is_upd = uw < NU;
+  d4_t U[MAXT2];
+  int tRC[MAXT2];   // (R << 8) | C, or -1
+#pragma unroll
+  for (int i = 0; i < MAXT2; ++i) {
+    U[i] = d4_t{0.0, 0.0, 0.0, 0.0};
+    const int t = uw + NU * i;
+    int R = 0;
+    while (is_upd && ((R + 1) * (R + 2)) >> 1 <= t) ++R;
+    const bool valid = is_upd && t < CF::NTILE;
+    tRC[i] = valid ? (R << 8) | (t - ((R * (R + 1)) >> 1)) : -1;
+  }
+
+  for (int i = tid; i < P.n_cells; i += KT2) A[i] = 0.0;
+  for (int i = tid; i < 3 * PSZ; i += KT2) PB[i] = 0.0;
+  for (int i = tid; i < FR; i += KT2) { UF[i] = 0.0; xs[i] = 0.0; }
+  for (int v = tid; v < n; v += KT2) dx[v] = 0.0;
+  for (int i = tid; i <= NS; i += KT2) { soff[i] = P.srec_off[i]; doff[i] = P.drec_off[i]; }
+  __syncthreads();
+
+  auto header_from_lds = [&](int s) __attribute__((always_inline)) {
+    if (tid < 8) pm[(s & 1) * 8 + tid] = 0u;
+    if (tid < PIV) {
+      const int slot = sbuf[SHDR + tid];
+      psb[(s % 3) * PIV + tid] = slot;
+      jm[(s & 1) * FR + slot] = tid;
+      dgb[(s % 3) * PIV + tid] = dbuf[tid];
+      atomicOr(&pm[(s & 1) * 8 + (slot >> 5)], 1u << (slot & 31));
+    }
+    if (tid == 0) { hib[s % 3] = sbuf[3]; hiall[s] = (sbuf[3] + 15) & ~15; }
+  };
+  auto load_records = [&](int s) __attribute__((always_inline)) {
+    for (int i = tid; i < soff[s + 1] - soff[s]; i += KT2) sbuf[i] = P.srec[soff[s] + i];
+    for (int i = tid; i < doff[s + 1] - doff[s]; i += KT2) dbuf[i] = stream[doff[s] + i];
+  };
+  // wave 0: LDL^T + L^-1 + (L D L^T)^-1 of the pivot block of the panel Pn, then the pivot rows leave the panel
+  auto factor_block = [&](double *Pn, const int myps, double *Lin, double *dvn) __attribute__((always_inline)) {
+    double a[PIV], v[PIV], myinv;
+#pragma unroll
+    for (int j = 0; j < PIV; ++j) {
+      const int pj = __builtin_amdgcn_readlane(myps, j);
+      a[j] = Pn[li >= j ? myps * PLD + j : pj * PLD + li];
+    }
+    ldlt16(a, v, myinv, li);
+    if (lane >= PIV && lane < 2 * PIV) {
+#pragma unroll
+      for (int j = 0; j < PIV; ++j) Lin[li * PLD + j] = j == li ? 1.0 : v[j];
+    }
+    if (lane < PIV) {
+      dvn[li] = myinv;
+#pragma unroll
+      for (int j = 0; j < PIV; ++j) Pn[myps * PLD + j] = 0.0;
+    }
+    {
+      double zero = 0.0;
+      asm volatile("" : "+v"(zero));
+      d4_t mi = {zero, zero, zero, zero};
+      double lt[4], ld[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { lt[s4] = Lin[(lk + 4 * s4) * PLD + li]; ld[s4] = dvn[lk + 4 * s4]; }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) mi = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[s4], lt[s4] * ld[s4], mi, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Minv[(lk + 4 * g) * PLD + li] = mi[g];
+    }
+  };
+  auto assemble_continuations = [&](int t0, int nth) __attribute__((always_inline)) {
+    if constexpr (!CONT) return;
+    // (continuation records are fetched by the whole workgroup: only used from the prologue and from
+    //  a phase in which every wave takes part in the assembly)
+    const int n_cont = __builtin_amdgcn_readfirstlane(sbuf[6]), c_first = __builtin_amdgcn_readfirstlane(sbuf[7]);
+    for (int c = 0; c < n_cont; ++c) {
+      lds_barrier();
+      const int *co = P.cont + 4 * (c_first + c);
+      const int so = co[0], sl = co[1], dof = co[2], dl = co[3];
+      for (int i = threadIdx.x; i < dl; i += KT2) dbuf[i] = stream[dof + i];
+      for (int i = threadIdx.x; i < sl; i += KT2) sbuf[i] = P.srec[so + i];
+      lds_barrier();
+      if (t0 >= 0) {
+        for (int p = t0 >> 6; p < NPART; p += nth >> 6) assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, p, p + 1);
+      }
+    }
+  };
+
+  // ---- prologue: assemble stages 0 and 1, gather and factor the pivot block of stage 0, leave the
+  //      records of stage 2 in LDS ----------------------------------------------------------------
+  load_records(0);
+  __syncthreads();
+  header_from_lds(0);
+  __syncthreads();
+  assemble_eq(A, sbuf, dbuf, tid, KT2);
+  assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, wv, wv + 1);
+  assemble_continuations(tid, KT2);
+  __syncthreads();
+  {
+    double *P0 = PB;
+    const int *ps0 = psb;
+    auto cell0 = [&](int r, int j) __attribute__((always_inline)) {
+      return r < F ? (int)P.ctab[(((r >> 4) * 64) + (r & 3) * 16 + j) * 4 + ((r & 15) >> 2)] : P.rtab[j];
+    };
+    for (int i = tid; i < (F + 1) * PIV; i += KT2) {
+      const int r = i >> 4, j = i & 15, c = ps0[j];
+      P0[r * PLD + j] = A[cell0(r, j)] + (r == c ? dgb[j] : 0.0);
+    }
+    __syncthreads();
+    for (int i = tid; i < (F + 1) * PIV; i += KT2) {
+      const int r = i >> 4, j = i & 15;
+      A[cell0(r, j)] = 0.0;
+    }
+    __syncthreads();
+    if (wv == 0) factor_block(P0, ps0[li], Lib, dvb);
+  }
+  for (int s = 1; s < 3 && s < NS; ++s) {
+    load_records(s);
+    __syncthreads();
+    header_from_lds(s);
+    __syncthreads();
+    if (s == 1) { assemble_eq(A, sbuf, dbuf, tid, KT2); assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, wv, wv + 1); assemble_continuations(tid, KT2); }
+    __syncthreads();
+  }
+
+#ifdef QTOS_STAMPS
+  // diagnostic build: per wave, cycles spent in each part of a stage (accumulated in LDS by lane 0)
+  __shared__ unsigned long long st2[16][12];
+  unsigned long long ts_ = 0;
+  if (tid < 192) st2[tid / 12][tid % 12] = 0;
+  __syncthreads();
+#define KS2_START() do { if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) :: "memory"); } while (0)
+#define KS2(i) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st2[wv][i] += t_ - ts_; ts_ = t_; } } while (0)
+  KS2_START();
+#else
+#define KS2_START() do {} while (0)
+#define KS2(i) do {} while (0)
+#endif
+  // per-thread prefetch registers: one 128-bit load of doubles and two of ints cover the longest record
+  d2_t pfd;
+  i4_t pfs0, pfs1;
+  int pf_nd2 = 0, pf_ns4 = 0;
+  int prow_next = NS > 1 ? psb[PIV + li] : 0;   // pivot slot li of stage k+1
+  typedef unsigned short us4_t __attribute__((ext_vector_type(4)));
+  const us4_t *ctab4 = (const us4_t *)P.ctab;
+  us4_t ct_cur = ctab4[((size_t)min(1, NS - 1) * NT + min(wv, NT - 1)) * 64 + lane];
+  int rc_cur = P.rtab[min(1, NS - 1) * PIV + li];   // cell of the assembled rhs of pivot li of stage k+1
+  const int tid_outer = tid, lane_outer = lane;
+  for (int k = 0; k < NS; ++k) {
+    int tid = tid_outer, lane = lane_outer;
+    asm volatile("" : "+v"(tid), "+v"(lane));
+    const int li = lane & 15, lk = lane >> 4;
+    const int pb = (k & 1) ? 2 : 0;
+    double *Pk = PB + pb * PSZ, *Yk = PB + PSZ, *Xn = PB + (2 - pb) * PSZ;
+    const double *Lik = Lib + (k & 1) * PIV * PLD, *dik = dvb + (k & 1) * PIV;
+    const bool has_next = k + 1 < NS;
+    KS2(7);
+    // ---- install the records of stage k+2 (prefetched during phase C of the previous stage; the records of
+    //      stage 2 are in LDS since the prologue).  Thread t holds element (t + 256) mod 1024: the record's
+    //      header sits in the registers of wave 12, which publishes it. ------------------------------------
+    const int pidx = (tid + 256) & (KT2 - 1);
+    if (k >= 1 && k + 2 < NS) {
+      const int wbase = __builtin_amdgcn_readfirstlane(pidx);
+      if (wbase < pf_nd2) ((d2_t *)dbuf)[min(pidx, pf_nd2)] = pfd;
+      if (wbase < pf_ns4) ((i4_t *)sbuf)[min(pidx, pf_ns4)] = pfs0;
+      if (wbase + KT2 < pf_ns4) ((i4_t *)sbuf)[min(pidx + KT2, pf_ns4)] = pfs1;
+    }
+    const us4_t ct_nxt = ctab4[((size_t)min(k + 2, NS - 1) * NT + min(wv, NT - 1)) * 64 + lane];
+    const int rc_nxt = P.rtab[min(k + 2, NS - 1) * PIV + li];
+    // ---- AB(k) ----------------------------------------------------------------------------------------
+    const Mask256 m1 = load_mask8(pm + ((k + 1) & 1) * 8, lane);   // pivot slots of stage k+1
+    if (wv < NT) {
+      const int R = wv;
+      const unsigned am_word = P.amask[k * 8 + (R >> 1)];
+      const int prow = has_next ? prow_next : 0;
+      // operands in the order they are needed (register budget: 128 per lane with sixteen waves)
+      double pr[4], lm[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        pr[s4] = Pk[(16 * R + li) * PLD + lk + 4 * s4];
+        lm[s4] = Minv[li * PLD + lk + 4 * s4];
+      }
+      double zero = 0.0;
+      asm volatile("" : "+v"(zero));   // (a loop-invariant zero pair would be kept across the loop -- and spilled)
+      // V = P (L D L^T)^-1 in accumulator layout: vt[g] = V[16R+li][lk+4g] -- V itself as the A operand of the next product
+      d4_t vt = {zero, zero, zero, zero};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) vt = __builtin_amdgcn_mfma_f64_16x16x4f64(lm[s4], pr[s4], vt, 0, 0, 0);
+      // next pivot columns: assembled entries (cell table: 0 = the zero cell), extracted Schur updates, pivot
+      // diagonal, minus V P[piv]^T (= Y D^-1 Y[piv]^T: the raw rows of the next pivots are the B operand)
+      double npp[4], xv[4], av[4];
+      int aidx[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int r = 16 * R + lk + 4 * s4;
+        npp[s4] = Pk[prow * PLD + lk + 4 * s4];
+        xv[s4] = Xn[r * PLD + li];
+        aidx[s4] = ct_cur[s4];
+        av[s4] = A[aidx[s4]];
+      }
+      const double dgn = dgb[((k + 1) % 3) * PIV + li];
+      d4_t acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = 16 * R + lk + 4 * g;
+        acc[g] = xv[g] + av[g] + (r == prow ? dgn : 0.0);
+        npp[g] = -npp[g];
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[s4], npp[s4], acc, 0, 0, 0);   // acc -= V P[piv]^T
+#pragma unroll
+      for (int g = 0; g < 4; ++g) A[aidx[g]] = 0.0;   // retired (the zero cell stays zero)
+      // Y = P L^-T of this tile: here for the tiles without a partner wave, else on service wave R (below)
+      if (R == 0 || R >= NSV) {
+        double la[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) la[s4] = Lik[li * PLD + lk + 4 * s4];
+        d4_t yt = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          yt = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], pr[s4], yt, 0, 0, 0);   // yt[g] = Y[16R+li][lk+4g]
+        const bool myrowpiv = has_next && ((grp16(m1, R) >> li) & 1u);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Yk[(16 * R + li) * PLD + lk + 4 * g] = myrowpiv ? 0.0 : yt[g];
+      }
+      if (has_next) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Xn[(16 * R + lk + 4 * g) * PLD + li] = acc[g];
+      }
+      const unsigned am16 = (am_word >> ((R & 1) * 16)) & 0xffffu;
+      if ((am16 >> li) & 1u) {
+        double *pv = panel + (size_t)k * pstride + PIV;
+        *(d4_t *)(pv + (16 * R + li) * PIV + 4 * lk) = vt;
+      }
+    } else {
+      // ---- service waves ------------------------------------------------------------------------------
+      const int sv = wv - NT;
+#ifdef QTOS_EXP_NORHS
+      if (false) {
+#else
+      if (sv == 0) {
+#endif
+        // right-hand-side row: w = (L D L^T)^-1 p_F; rhs -= P w; right-hand side of the next pivots
+        double part = 0.0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) part = fma(Minv[li * PLD + lk + 4 * s4], Pk[F * PLD + lk + 4 * s4], part);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);            // w[li] on every lane
+        if (lane < PIV) panel[(size_t)k * pstride + lane] = part;
+        if (has_next) {
+          asm volatile("s_nop 4" : "+v"(part));    // DPP hazard distance for the broadcast reads below
+#pragma unroll
+          for (int c = 0; c < FR / 64; ++c) {
+            const int r = c * 64 + lane;
+            const int rr = min(r, F - 1);
+            double pq[PIV];
+#pragma unroll
+            for (int q = 0; q < PIV; ++q) pq[q] = Pk[rr * PLD + q];
+            const double uf = UF[r];
+            double a0 = 0.0;
+            dot16_steps<0>(a0, part, pq);
+            UF[r] = r < F ? uf - a0 : 0.0;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane < PIV) {
+            const int c = prow_next;
+            Xn[F * PLD + lane] = A[rc_cur] + UF[c];
+            A[rc_cur] = 0.0;
+            UF[c] = 0.0;
+          }
+        }
+      }
+      else if (sv < NT) {
+        // Y = P L^-T of row tile R = sv for its tile wave
+        const int R = sv;
+        double la[4], pr[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          la[s4] = Lik[li * PLD + lk + 4 * s4];
+          pr[s4] = Pk[(16 * R + li) * PLD + lk + 4 * s4];
+        }
+        double zero = 0.0;
+        asm volatile("" : "+v"(zero));
+        d4_t yt = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) yt = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], pr[s4], yt, 0, 0, 0);
+        const bool myrowpiv = has_next && ((grp16(m1, R) >> li) & 1u);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Yk[(16 * R + li) * PLD + lk + 4 * g] = myrowpiv ? 0.0 : yt[g];
+      }
+    }
+    KS2(0);
+    lds_barrier();
+    KS2(1);
+    // ---- C(k) ---------------------------------------------------------------------------------------
+    // prefetch of the records of stage k+3 (installed at the top of the next stage): issued by every wave when
+    // its urgent work of the phase is done (48 KB-wide loads at once keep the CU's memory pipe busy for ~800 cycles);
+    // a wave skips the loads that lie wholly behind the record's end
+    auto prefetch_records = [&]() __attribute__((always_inline)) {
+      if (k + 3 < NS) {
+        const int s = k + 3;
+        int d0, d1, s0, s1;
+        sload2(P.drec_off + s, d0, d1);
+        sload2(P.srec_off + s, s0, s1);
+        pf_nd2 = (d1 - d0) >> 1;
+        pf_ns4 = (s1 - s0) >> 2;
+        const d2_t *dsrc = (const d2_t *)(stream + d0);
+        const i4_t *ssrc = (const i4_t *)(P.srec + s0);
+        const int wbase = __builtin_amdgcn_readfirstlane(pidx);   // first element of this wave
+        if (wbase < pf_nd2) pfd = dsrc[min(pidx, pf_nd2 - 1)];
+        if (wbase < pf_ns4) pfs0 = ssrc[min(pidx, pf_ns4 - 1)];
+        if (wbase + KT2 < pf_ns4) pfs1 = ssrc[min(pidx + KT2, pf_ns4 - 1)];
+      }
+    };
+#ifndef QTOS_PF_LATE
+    prefetch_records();
+    KS2(8);
+#endif
+    if (wv == 0) {
+      __builtin_amdgcn_s_setprio(3);
+      if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV);
+      __builtin_amdgcn_s_setprio(0);
+#ifdef QTOS_PF_LATE
+      prefetch_records();
+#endif
+    } else if (is_upd) {
+      const Mask256 m2 = load_mask8(pm + (k & 1) * 8, lane);   // pivot slots of stage k+2
+      const bool extract = k + 2 < NS;
+      const int *jm2 = jm + (k & 1) * FR;
+      double *Xnn = Pk;   // the panel of stage k is dead: it receives the columns of stage k+2
+      double dv4[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) dv4[s4] = -dik[lk + 4 * s4];
+      int rcs[MAXT2];
+#pragma unroll
+      for (int t = 0; t < MAXT2; ++t) { rcs[t] = tRC[t]; asm volatile("" : "+s"(rcs[t])); }
+      double wa[2][4], pbv[2][4];
+      auto tile_loads = [&](int rc, double (&w)[4], double (&pq)[4]) __attribute__((always_inline)) {
+        const int R = rc < 0 ? 0 : rc >> 8, C = rc < 0 ? 0 : rc & 255;
+        const double *wrow = Yk + (16 * R + li) * PLD + lk, *prow2 = Yk + (16 * C + li) * PLD + lk;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { w[s4] = wrow[4 * s4]; pq[s4] = prow2[4 * s4]; }
+      };
+      tile_loads(rcs[0], wa[0], pbv[0]);
+#pragma unroll
+      for (int t = 0; t < MAXT2; ++t) {
+        if (t + 1 < MAXT2) tile_loads(rcs[t + 1], wa[(t + 1) & 1], pbv[(t + 1) & 1]);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[t & 1][s4] * dv4[s4], pbv[t & 1][s4], U[t], 0, 0, 0);
+      }
+      KS2(5);
+#ifdef QTOS_PF_LATE
+      prefetch_records();
+      KS2(8);
+#endif
+#ifdef QTOS_EXP_NOEXTRACT
+      if (false) {
+#else
+      if (extract) {
+#endif
+        int jcs[MAXT2], jrs[MAXT2][4];
+#pragma unroll
+        for (int t = 0; t < MAXT2; ++t) {
+          const int rc = rcs[t] < 0 ? 0 : rcs[t];
+          jcs[t] = jm2[16 * (rc & 255) + li];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) jrs[t][g] = jm2[16 * (rc >> 8) + lk + 4 * g];
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT2; ++t)
+          asm volatile("" : "+v"(jcs[t]), "+v"(jrs[t][0]), "+v"(jrs[t][1]), "+v"(jrs[t][2]), "+v"(jrs[t][3]));
+        double *dummy = red + 2 * 16 * PIV + lane;
+        // bit 4g of ge4 / gt4: row lk + 4g of a diagonal tile lies on or below / strictly below column li
+        // (recomputed every stage: two registers less across the loop)
+        unsigned ge4 = 0u, gt4 = 0u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { ge4 |= (lk + 4 * g >= li ? 1u : 0u) << (4 * g); gt4 |= (lk + 4 * g > li ? 1u : 0u) << (4 * g); }
+#pragma unroll
+        for (int t = 0; t < MAXT2; ++t) {
+          const int rc = rcs[t];
+          if (rc < 0) continue;
+          const int R = rc >> 8, C = rc & 255;
+          const unsigned cw2 = grp16(m2, C), rw2 = grp16(m2, R);
+          if ((cw2 | rw2) == 0u) continue;
+          const unsigned cm = ((cw2 >> li) & 1u) ? (R > C ? 0x1111u : ge4) : 0u;
+          const unsigned rmk = (rw2 >> lk) & (R > C ? 0x1111u : gt4);
+          double *xr = Xnn + (16 * R + lk) * PLD + jcs[t], *xc = Xnn + (16 * C + li) * PLD;
+          if (cw2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(((cm >> (4 * g)) & 1u) ? xr + g * 4 * PLD : dummy) = U[t][g];
+          }
+          if (rw2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(((rmk >> (4 * g)) & 1u) ? xc + jrs[t][g] : dummy) = U[t][g];
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int z = ~__builtin_amdgcn_sbfe((int)(cm | rmk), 4 * g, 1);
+            U[t][g] = __hiloint2double(__double2hiint(U[t][g]) & z, __double2loint(U[t][g]) & z);
+          }
+        }
+      }
+    } else if (wv == 12) {
+#ifdef QTOS_PF_LATE
+      prefetch_records();
+#endif
+      // header of stage k+3, published to the LDS rings (their slots have no reader left in this phase:
+      // stage k's pivot slots / diagonals, stage k+1's slot map and mask) from this wave's share of the
+      // prefetched record: lane l holds ints 4l .. 4l+3 (static header 0..7, pivot slots 8..23) and doubles
+      // 2l, 2l+1 (pivot diagonals 0..15)
+      const int hs = k + 3;
+      if (hs < NS) {
+        if (lane < 8) pm[(hs & 1) * 8 + lane] = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) { hib[hs % 3] = pfs0[3]; hiall[hs] = (pfs0[3] + 15) & ~15; }
+        if (lane < 8) { dgb[(hs % 3) * PIV + 2 * lane] = pfd[0]; dgb[(hs % 3) * PIV + 2 * lane + 1] = pfd[1]; }
+        if (lane >= 2 && lane < 6) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int jidx = 4 * (lane - 2) + c, hv = pfs0[c];
+            psb[(hs % 3) * PIV + jidx] = hv;
+            jm[(hs & 1) * FR + hv] = jidx;
+            atomicOr(&pm[(hs & 1) * 8 + (hv >> 5)], 1u << (hv & 31));
+          }
+        }
+      }
+    }
+#ifdef QTOS_PF_LATE
+    if (wv != 0 && wv != 12 && !is_upd) prefetch_records();
+#endif
+    KS2(2);
+    // every wave but the factor wave ends the phase with its share of the assembly of stage k+2's records
+    // (the waves without a Schur tile come first and take the low item indices)
+    const int apos = is_upd ? (15 - NU) + uw : uw - NU;   // (wave 12, the header wave, is the last of the free ones)
+    if (wv >= 1 && k + 2 < NS) {
+#ifdef QTOS_ASM_PARTS
+      assemble_eq(A, sbuf, dbuf, apos * 64 + lane, 15 * 64);
+      // the waves without Schur tiles take APW parts each as one run, the oldest update waves one of the rest
+      constexpr int NFREE = 15 - NU, NF4 = NFREE * APW < NPART ? NFREE * APW : NPART;
+      if (apos < NFREE) assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, min(apos * APW, NF4), min(apos * APW + APW, NF4));
+      else assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, min(NF4 + apos - NFREE, NPART), min(NF4 + apos - NFREE + 1, NPART));
+#else
+      // one thread per target, low item indices to the waves that get here first
+      assemble_stage(A, F, sbuf, dbuf, apos * 64 + lane, 15 * 64);
+#endif
+    }
+    if constexpr (CONT) {
+      if (k + 2 < NS) assemble_continuations(wv >= 1 ? apos * 64 + lane : -1, 15 * 64);
+    }
+    KS2(3);
+    lds_barrier();
+    KS2(4);
+    if (k + 2 < NS) prow_next = psb[((k + 2) % 3) * PIV + li];
+    ct_cur = ct_nxt;
+    rc_cur = rc_nxt;
+  }
+  // ---- backward substitution: x_piv = w - V^T x, one barrier per stage.  NH waves share the 16 rows of a
+  //      row tile (wave R + NT h takes rows lk + 4 (NH i + h)); partial sums meet in LDS, every wave forms
+  //      the 16 new entries redundantly (bitwise identical). --------------------------------------------
+  __syncthreads();  // drains the factor-panel stores: they are read back below
+  KS2(7);
+  {
+    const int j = li, q = lk;
+    constexpr int DEPTH = 4, NI = 4 / NH, NBW = NT * NH;
+    const bool owner = wv < NBW;
+    const int R = owner ? wv % NT : 0, h = owner ? wv / NT : 0;
+    double bv[DEPTH][NI], bw[DEPTH];
+    int bps[DEPTH], bun[DEPTH];
+    unsigned bam[DEPTH];
+    auto amask16 = [&](int k) __attribute__((always_inline)) {
+      return (P.amask[max(k, 0) * 8 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu;
+    };
+    unsigned am_next = amask16(NS - 1);
+    auto bload = [&](int k, double (&v)[NI], double &wj, int &psj, int &unkj, unsigned &am) __attribute__((always_inline)) {
+      const int kk = max(k, 0);
+      const double *pk = panel + (size_t)kk * pstride;
+      am = am_next;
+      am_next = amask16(k - 1);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = q + 4 * (NH * i + h);
+        v[i] = pk[(owner && ((am >> row) & 1u)) ? PIV + (16 * R + row) * PIV + 4 * (j & 3) + (j >> 2) : j];
+      }
+      wj = pk[j];
+      psj = P.piv_slot[kk * PIV + j];
+      unkj = P.piv_unknown[kk * PIV + j];
+    };
+    auto bstep = [&](int k, const double (&v)[NI], double wj, int psj, int unkj, unsigned am) __attribute__((always_inline)) {
+      const bool valid = k >= 0;
+      const int kk = max(k, 0);
+      const int nw = valid ? hiall[kk] >> 4 : 0;
+      double p = 0.0;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = q + 4 * (NH * i + h);
+        p = fma(v[i], ((am >> row) & 1u) ? xs[16 * R + row] : 0.0, p);
+      }
+      p += __shfl_xor(p, 16);
+      p += __shfl_xor(p, 32);
+      if (lane < PIV) red[(kk & 1) * 256 + wv * PIV + j] = (valid && owner && R < nw) ? p : 0.0;
+      lds_barrier();
+      double r16[16];
+#pragma unroll
+      for (int w2 = 0; w2 < 16; ++w2) r16[w2] = red[(kk & 1) * 256 + w2 * PIV + j];
+      double s = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < 16; ++w2) s += r16[w2];
+      const double x = wj - s;
+      if (lane < PIV && valid) {
+        xs[psj] = x;
+        if (wv == 0 && unkj >= 0 && unkj < n) dx[unkj] = x;
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) bload(NS - 1 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
+    for (int k0 = NS - 1; k0 >= 0; k0 -= DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        bstep(k0 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
+        bload(k0 - d - DEPTH, bv[d], bw[d], bps[d], bun[d], bam[d]);
+      }
+    }
+  }
+#ifdef QTOS_STAMPS
+  KS2(6);
+  __syncthreads();
+  if (tid < 192 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 16) * 4 + tid] = (double)st2[tid / 12][tid % 12];
+#endif
+}
+
+}  // namespace qtos

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "kkt2.hpp"
 
 using namespace qtos;
 
@@ -39,7 +40,8 @@ struct QtosPlanner {
   std::vector<hipEvent_t> ev;  // 3 per iteration (kkt begin / end, count read back) + 2 (total)
   int last_launches = 0, last_iters = 0;
   size_t kkt_lds = 0, eval_lds = 0;
-  void (*kkt_fn)(DevPlan, DevWork, int) = nullptr;   // k_kkt instantiated for this front size
+  void (*kkt_fn)(DevPlan, DevWork, int) = nullptr;   // k_kkt / k_kkt2 instantiated for this front size
+  int kkt_threads = KT;
   std::string err;
 
   template <class T>
@@ -71,6 +73,18 @@ static void (*kkt_kernel(int F, bool cont))(DevPlan, DevWork, int) {
     QTOS_KKT(16) QTOS_KKT(32) QTOS_KKT(48) QTOS_KKT(64) QTOS_KKT(80) QTOS_KKT(96) QTOS_KKT(112) QTOS_KKT(128)
   }
 #undef QTOS_KKT
+  return nullptr;
+}
+// k_kkt2 (16 waves per problem): fronts up to 208 slots
+static void (*kkt2_kernel(int F, bool cont))(DevPlan, DevWork, int) {
+#define QTOS_KKT2(f) case f: return cont ? k_kkt2<f, true> : k_kkt2<f, false>;
+  switch (F) {
+    QTOS_KKT2(16) QTOS_KKT2(32) QTOS_KKT2(48) QTOS_KKT2(64) QTOS_KKT2(80) QTOS_KKT2(96) QTOS_KKT2(112) QTOS_KKT2(128)
+#ifndef QTOS_DEV_SMALL
+    QTOS_KKT2(144) QTOS_KKT2(160) QTOS_KKT2(176) QTOS_KKT2(192) QTOS_KKT2(208)
+#endif
+  }
+#undef QTOS_KKT2
   return nullptr;
 }
 
@@ -113,6 +127,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   p->device = device;
   p->max_batch = max_batch;
   if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
+  const char *kv = getenv("QTOS_KKT");
+  const bool kkt2 = !(kv && kv[0] == '1');   // QTOS_KKT=1: the 8-wave kernel of round 1 (fronts <= 128), kept for A/B timing
+  p->S.cell_mode = kkt2 ? 2 : 1;
   if (p->S.build(p->M)) { fprintf(stderr, "qtos: %s\n", p->S.err.c_str()); delete p; return -1; }
   const HostModel &M = p->M;
   const Symbolic &S = p->S;
@@ -141,7 +158,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.dyn_chunk = M.dyn_chunk;
   TRY(p->upload(S.amask, &D.amask));
   TRY(p->upload(S.ctab, &D.ctab));
+  TRY(p->upload(S.rtab, &D.rtab));
   D.n_cells = S.n_cells;
+  D.max_part_con = (S.max_part_con + 1) & ~1;
   D.n_cont = 0;
   for (int k = 0; k < S.n_stages; ++k) D.n_cont += S.srec[S.srec_off[k] + 6];
   D.table = nullptr; D.tab_dx = D.tab_dy = nullptr; D.tab_ndx = D.tab_ndy = 0;
@@ -207,10 +226,13 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.panel_stride = (long long)S.n_stages * (S.front + 1) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  p->kkt_lds = kkt_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
-  if (S.max_drec > 2 * 2 * KT || S.max_srec > 3 * 4 * KT || F > 128 || (S.pack_src.size() & 1)) {
+  p->kkt_lds = kkt2 ? kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells, (S.max_part_con + 1) & ~1)
+                    : kkt_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
+  p->kkt_threads = kkt2 ? KT2 : KT;
+  const int max_front = kkt2 ? 208 : 128;
+  if (S.max_drec > 2 * 2 * KT || S.max_srec > 3 * 4 * KT || F > max_front || (S.pack_src.size() & 1)) {
     p->err = "stage record exceeds the prefetch registers";
-    fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints) or front %d > 128\n", S.max_drec, S.max_srec, F);
+    fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints) or front %d > %d\n", S.max_drec, S.max_srec, F, max_front);
     qtos_planner_destroy(p);
     return -4;
   }
@@ -221,7 +243,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     return -4;
   }
   {
-    p->kkt_fn = kkt_kernel(F, D.n_cont > 0);
+    p->kkt_fn = kkt2 ? kkt2_kernel(F, D.n_cont > 0) : kkt_kernel(F, D.n_cont > 0);
     if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
@@ -364,7 +386,7 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
   int iters = D.max_iter;   // real (non-empty) iterations
   for (int it = 0; it < D.max_iter; ++it) {
     HIPCHK(p, hipEventRecord(p->ev[2 + 3 * it], st));
-    hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(KT), p->kkt_lds, st, D, W, B);
+    hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(p->kkt_threads), p->kkt_lds, st, D, W, B);
     HIPCHK(p, hipEventRecord(p->ev[3 + 3 * it], st));
     hipLaunchKernelGGL(k_step, dim3(B), dim3(ET), p->eval_lds, st, D, W, B, it);
     HIPCHK(p, hipMemcpyAsync(p->h_active + it, W.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -583,7 +605,7 @@ int qtos_debug_newton(QtosPlanner *p, int B, const double *start, const double *
   HIPCHK(p, hipMemcpy(W.sig, sig, (size_t)B * m * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(p, hipMemcpy(W.w, w, (size_t)B * m * sizeof(double), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_debug_pack, dim3(B), dim3(256), 0, 0, p->dp, W, B);
-  hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(KT), p->kkt_lds, 0, p->dp, W, B);
+  hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(p->kkt_threads), p->kkt_lds, 0, p->dp, W, B);
   HIPCHK(p, hipDeviceSynchronize());
   HIPCHK(p, hipMemcpy(dx_out, W.dx, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
@@ -607,7 +629,7 @@ int qtos_debug_factor(QtosPlanner *p, int b, double *panel_out, int *piv_slot_ou
     const int F = p->S.front, NS = p->S.n_stages;
     for (int k = 0; k < NS; ++k)
       for (int r = 0; r < F; ++r)
-        if (!((p->S.amask[(size_t)k * 4 + (r >> 5)] >> (r & 31)) & 1u))
+        if (!((p->S.amask[(size_t)k * 8 + (r >> 5)] >> (r & 31)) & 1u))
           std::memset(panel_out + ((size_t)k * (F + 1) + 1 + r) * PIV, 0, PIV * sizeof(double));
   }
   if (piv_slot_out) std::memcpy(piv_slot_out, p->S.piv_slot.data(), p->S.piv_slot.size() * sizeof(int));

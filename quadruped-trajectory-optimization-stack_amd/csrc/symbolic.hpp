@@ -77,7 +77,12 @@ struct Symbolic {
   // entries of K for the stages between their assembly and the gathering of their pivot column.
   std::vector<unsigned short> ctab;   // n_stages x (front/16) x 64 lanes x 4: cell of panel entry (row 16R + lk + 4g, pivot column li), 0 = none
   int n_cells = 0;                    // length of the cell array (zero cell + rhs + entries)
-  std::vector<unsigned> amask;   // per stage 128 bits: front slots whose row of the factor panel V is stored (live, not a pivot of the stage)
+  // cell_mode 2 (k_kkt2: records are assembled during the AB phase, next to the gathering of the previous
+  // stage's columns): right-hand-side entries get cells of their own too (a slot changes hands at a stage
+  // boundary, a cell does not), listed per pivot in rtab, and a cell is recycled one stage later
+  int cell_mode = 1;
+  std::vector<int> rtab;              // n_stages x 16: cell of the assembled right-hand side of every pivot (0 = none)
+  std::vector<unsigned> amask;   // per stage 256 bits (8 words): front slots whose row of the factor panel V is stored (live, not a pivot of the stage)
   // The linearisation kernels write straight into the stream: eq_pos maps the (virtual) G offset of
   // an equality-block entry to its stream position; inequality blocks are contiguous in the stream
   // (Block::goff = stream offset); rhs/sig/w positions per constraint row; constants (static
@@ -158,7 +163,8 @@ struct Symbolic {
 
   // record limits: a stage record travels through the prefetch registers of k_kkt (2 x 16 B of doubles
   // and 3 x 16 B of ints per thread, 512 threads) and its gather codes address 4096 doubles
-  static constexpr int REC_MAX_DOUBLES = 2048, REC_MAX_INTS = 6144, SHDR_INTS = 8;
+  static constexpr int REC_MAX_DOUBLES = 2048, REC_MAX_INTS = 6144, SHDR_INTS = 8, NPART = 16;
+  int max_part_con = 0;    // most contributions in one part of a record (scratch doubles per wave in k_kkt2)
   std::vector<int> cont;   // continuation records: {srec offset, ints, stream offset, doubles} each
   // dynamic part (per block G, sig, w) and gather table of the blocks `blks` of stage k, appended to the
   // record that starts at srec[s0] / pack_src[d0]; patches the record's header ints [4], [5]
@@ -179,7 +185,7 @@ struct Symbolic {
         t2.insert(front * (front + 1) / 2 + sa);
       }
       const bool fits = rest.empty() && dyn < 4096 && dyn + d <= REC_MAX_DOUBLES - 2 && contrib + c < 4096 &&
-                        fixed + (int)t2.size() + 1 + contrib + c <= REC_MAX_INTS - 8;
+                        fixed + (int)t2.size() + 1 + contrib + c <= REC_MAX_INTS - 8 - 2 * (NPART + 1);
       if (fits) { mine.push_back(q); dyn += d; contrib += c; targets.swap(t2); }
       else rest.push_back(q);
     }
@@ -208,6 +214,26 @@ struct Symbolic {
         for (int c = 0; c <= a; ++c) tmap[trs(sa, iq_slots[Q.slot_off + c])].push_back(((int)bi << 16) | (a << 8) | c);
         tmap[front * (front + 1) / 2 + sa].push_back(((int)bi << 16) | (a << 8) | 255);
       }
+    }
+    // k_kkt2 assembles a record in NPART parts, one wave each: a part is a run of consecutive targets with
+    // all their contributions (first every contribution by its own lane into a scratch array, then every
+    // target sums its run in a fixed order); the parts are cut where the cumulative number of contributions
+    // crosses a multiple of total / NPART.  part_t[NPART + 1] (targets), part_c[NPART + 1] (contributions)
+    // sit in front of the target list.
+    {
+      int total = 0, nt = (int)tmap.size();
+      for (auto &kv : tmap) total += (int)kv.second.size();
+      std::vector<int> pt(NPART + 1, nt), pc(NPART + 1, total);
+      pt[0] = 0; pc[0] = 0;
+      int cum = 0, t = 0, p = 1;
+      for (auto &kv : tmap) {
+        while (p < NPART && (long long)cum * NPART >= (long long)total * p) { pt[p] = t; pc[p] = cum; ++p; }
+        cum += (int)kv.second.size();
+        ++t;
+      }
+      for (int q = 0; q < NPART; ++q) max_part_con = std::max(max_part_con, pc[q + 1] - pc[q]);
+      srec.insert(srec.end(), pt.begin(), pt.end());
+      srec.insert(srec.end(), pc.begin(), pc.end());
     }
     srec[s0 + 4] = (int)srec.size() - s0;
     srec[s0 + 5] = (int)tmap.size();
@@ -248,9 +274,22 @@ struct Symbolic {
     std::map<std::pair<int, int>, int> cell;
     std::vector<std::vector<int>> retire(n_stages);
     std::vector<int> free_cells;
-    n_cells = 1 + F;
+    n_cells = cell_mode == 2 ? 1 : 1 + F;
+    const int RHS = 1 << 30;
     auto target = [&](int k, int t) -> int {
-      if (t >= ntri_rhs) return 1 + (t - ntri_rhs);
+      if (t >= ntri_rhs && cell_mode != 2) return 1 + (t - ntri_rhs);
+      if (t >= ntri_rhs) {
+        const int u = occ[(size_t)k * F + (t - ntri_rhs)];
+        if (u < 0) { err = "assembled right-hand side on a free slot"; return -1; }
+        auto it = cell.find({u, RHS});
+        if (it != cell.end()) return it->second;
+        int id;
+        if (!free_cells.empty()) { id = free_cells.back(); free_cells.pop_back(); }
+        else id = n_cells++;
+        cell[{u, RHS}] = id;
+        retire[u / PIV].push_back(id);
+        return id;
+      }
       int r = 0;
       while ((r + 1) * (r + 2) / 2 <= t) ++r;
       const int c = t - r * (r + 1) / 2;
@@ -271,7 +310,7 @@ struct Symbolic {
       const int n_ent = srec[s0], n_rhs = srec[s0 + 1];
       int *e = &srec[s0 + SHDR_INTS + PIV];
       for (int i = 0; i < n_ent; ++i) if ((e[i] = target(k, e[i])) < 0) return -1;
-      for (int i = 0; i < n_rhs; ++i) e[n_ent + i] = 1 + e[n_ent + i];
+      for (int i = 0; i < n_rhs; ++i) if ((e[n_ent + i] = target(k, ntri_rhs + e[n_ent + i])) < 0) return -1;
       if (srec[s0 + 2] == 0) return 0;
       int *tg = &srec[s0 + srec[s0 + 4]];
       for (int t = 0; t < srec[s0 + 5]; ++t) {
@@ -283,7 +322,8 @@ struct Symbolic {
     };
     ctab.assign((size_t)n_stages * F * PIV, 0);
     for (int k = 0; k < n_stages; ++k) {
-      if (k >= 1) { for (int id : retire[k - 1]) free_cells.push_back(id); }
+      const int lag = cell_mode == 2 ? 2 : 1;
+      if (k >= lag) { for (int id : retire[k - lag]) free_cells.push_back(id); }
       std::sort(free_cells.begin(), free_cells.end(), std::greater<int>());   // lowest cell first
       if (rewrite(k, srec_off[k])) return -1;
       const int n_cont = srec[srec_off[k] + 6], c_first = srec[srec_off[k] + 7];
@@ -292,7 +332,9 @@ struct Symbolic {
     }
     if (n_cells >= 65536) { err = "too many live entries for the 16-bit cell table"; return -1; }
     const int NT = F / 16;
+    rtab.assign((size_t)n_stages * PIV, 0);
     for (auto &kv : cell) {
+      if (kv.first.second == RHS) { rtab[kv.first.first] = kv.second; continue; }
       const int u = kv.first.first, v = kv.first.second, k = u / PIV, col = u - k * PIV, r = slot_of[v];
       const int R = r >> 4, rr = r & 15, lk = rr & 3, g = rr >> 2;
       ctab[((((size_t)k * NT + R) * 64) + lk * 16 + col) * 4 + g] = (unsigned short)kv.second;
@@ -372,7 +414,7 @@ struct Symbolic {
     std::vector<char> in_use;
     std::vector<int> slot_stage;   // pivot stage of the unknown occupying a slot, -1 if free
     stage_hi.assign(n_stages, 0);
-    amask.assign((size_t)n_stages * 4, 0u);
+    amask.assign((size_t)n_stages * 8, 0u);
     int n_slots = 0;
     max_active = 0;
     envelope = 0;
@@ -461,11 +503,11 @@ struct Symbolic {
         }
       }
       // rows of the stage's factor panel that can be non-zero: the slots in use, without its own pivots
-      for (int t = 0; t < (int)in_use.size() && t < 128; ++t)
-        if (in_use[t]) amask[(size_t)k * 4 + (t >> 5)] |= 1u << (t & 31);
+      for (int t = 0; t < (int)in_use.size() && t < 256; ++t)
+        if (in_use[t]) amask[(size_t)k * 8 + (t >> 5)] |= 1u << (t & 31);
       for (int i = 0; i < PIV; ++i) {
         const int t = piv_slot[(size_t)k * PIV + i];
-        if (t < 128) amask[(size_t)k * 4 + (t >> 5)] &= ~(1u << (t & 31));
+        if (t < 256) amask[(size_t)k * 8 + (t >> 5)] &= ~(1u << (t & 31));
       }
       // release pivots and dummies
       for (int i = lo; i < lo + PIV; ++i) {

@@ -1,0 +1,22 @@
+import sys, ctypes as C; sys.path.insert(0, '.')
+import numpy as np
+from qtos_amd import capi, workloads
+import os
+capi.LIB_PATH = capi.LIB_PATH.replace("libqtos_planner.so", os.environ.get("QTOS_LIB", "libqtos_planner_stamps.so"))
+from qtos_amd.config import PlannerConfig
+cfg = PlannerConfig.knots100(max_iter=80)
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+P = capi.Planner(cfg, max_batch=NB)
+start, goal = workloads.flat_goals(NB, 0)
+P.plan(start, goal)
+NS = P.dims.n_stages
+acc = np.zeros((16, 12))
+for b in (0, 5, NB - 1):
+    t = np.zeros((cfg.max_iter + 1, 4))
+    P.lib.qtos_debug_trace(P.h, b, t.ctypes.data_as(C.POINTER(C.c_double)))
+    acc += t[16:64].reshape(16, 12)
+acc /= 3 * NS
+print("cycles per stage by wave: 0 AB work | 1 AB wait | 2 C role work (after prefetch issue; update waves: extraction only) | 3 assembly | 4 C wait | 5 update MFMA loop | 6 backward/NS | 7 top | 8 prefetch issue")
+for w in range(16):
+    print("wave %2d: " % w + " ".join("%6.0f" % v for v in acc[w][:9]))
+print("stage total (wave 0):", acc[0][[0, 1, 2, 3, 4, 7, 8]].sum(), "timing", P.timing())
