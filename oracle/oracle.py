@@ -100,6 +100,8 @@ def lib():
         _lib.qo_solve.argtypes = [C.POINTER(QoParams), C.POINTER(QoProblem),
                                   C.POINTER(QoOptions), dp, C.POINTER(QoInfo)]
         _lib.qo_ldlt_solve_dense.argtypes = [C.c_int, dp, dp]
+        _lib.qo_solve_batch.argtypes = [C.POINTER(QoParams), C.c_int, C.POINTER(QoProblem), C.POINTER(QoOptions),
+                                        dp, C.POINTER(QoInfo), C.c_int]
     return _lib
 
 
@@ -208,3 +210,16 @@ class Oracle:
         info = QoInfo()
         lib().qo_solve(C.byref(self.p), C.byref(q), C.byref(o), _dp(x), C.byref(info))
         return x, info
+
+    def solve_batch(self, problems, n_threads=0, opts=None):
+        """Independent cold solves of a list of problems, OpenMP over the problems (qo_solve_batch)."""
+        o = opts or self.default_options()
+        n = len(problems)
+        qs = (QoProblem * n)(*problems)
+        infos = (QoInfo * n)()
+        x = np.empty((n, self.n))
+        rc = lib().qo_solve_batch(C.byref(self.p), n, qs, C.byref(o), _dp(x), infos, int(n_threads))
+        if rc != 0:
+            raise RuntimeError("qo_solve_batch failed")
+        return x, list(infos)
+

@@ -11,6 +11,9 @@
 #include "qtos_oracle.h"
 
 #include <complex.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1266,3 +1269,20 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
   free(rhs); free(dx); free(M); free(xbest);
   return status;
 }
+
+/* Batch of independent solves, OpenMP over the problems (bench.py cpu_baseline: the multi-core figure).
+ * x_io: n_problems x n_vars; every solve is exactly qo_solve. */
+int qo_solve_batch(const qo_params *p, int n_problems, const qo_problem *q, const qo_options *o,
+                   double *x_io, qo_info *info, int n_threads) {
+  qo_layout L;
+  if (qo_get_layout(p, &L)) return -1;
+  int bad = 0;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : bad)
+#endif
+  for (int i = 0; i < n_problems; ++i)
+    if (qo_solve(p, q + i, o, x_io + (size_t)i * L.n_vars, info + i) < 0) bad++;
+  return bad ? -1 : 0;
+}
+

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libqtos_planner.so")
+# (QTOS_LIB names another build of the library in csrc/: A/B timing of kernel variants, scratch/ab.py)
+LIB_PATH = os.path.join(_HERE, "csrc", os.environ.get("QTOS_LIB", "libqtos_planner.so"))
 NEE, MAX_PHASES, START_DOUBLES, CSV_COLS = 4, 32, 24, 37
 
 
@@ -66,6 +67,20 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OSError("HIP planner library not built: %s (run __graft_entry__.build()); "
                       "this package has no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  If this library
+    # pulled in the system copies first, a later `import torch` would map a second runtime and see no GPU
+    # (torch.cuda.is_available() False, RCCL unusable).  Binding to torch's copy -- when torch is installed --
+    # makes the import order irrelevant; without torch the system runtime is used.
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        for loc in (spec.submodule_search_locations or []) if spec else []:
+            hip = os.path.join(loc, "lib", "libamdhip64.so")
+            if os.path.exists(hip):
+                C.CDLL(hip, mode=C.RTLD_GLOBAL)
+                break
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
     lib.qtos_planner_create.argtypes = [C.POINTER(QtosParams), C.c_int, C.c_int, C.POINTER(vp)]

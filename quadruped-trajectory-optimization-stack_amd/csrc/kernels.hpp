@@ -34,6 +34,8 @@ struct DevPlan {
   const LinTerm3 *dyn_t3;
   const int *dyn_t1_off, *dyn_t3_off;   // first entry of every knot chunk (+ end)
   int n_rom_t1;
+  int rom_chunk;               // range-of-motion instances evaluated per pass (LDS scratch bound)
+  const int *rom_t1_off;       // first entry of every range-of-motion chunk (+ end)
   int dyn_chunk;               // dynamics knots evaluated per pass of eval_all (LDS scratch bound)
   // optional table of nominal plans (rest start at the origin, goals on a dx x dy grid) for the initial
   // guess: table[(j * tab_ndx + i) * n_vars + v]; null = towr's straight-line guess
@@ -471,7 +473,7 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
 #define ESTAMP() do {} while (0)
 #endif
   double *x = lds, *loc = lds + eval_loc_offset(P.n_vars);
-  double *vin = loc + max(DYN_LOC * P.dyn_chunk, ROM_LOC * P.n_rom);
+  double *vin = loc + max(DYN_LOC * P.dyn_chunk, ROM_LOC * P.rom_chunk);
   for (int v = tid; v < P.n_vars; v += nt) x[v] = xg[v];
   __syncthreads();
   // the dynamics knots go through the LDS scratch in chunks of P.dyn_chunk (one chunk up to 128 knots)
@@ -507,16 +509,19 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
       ESTAMP();
     }
   }
-  __syncthreads();   // the dynamics knots are done with vin
-  vec_prepass(P.rom, (int)sizeof(RomInst), P.n_rom, 3, x, vin);
-  __syncthreads();
-  for (int i = tid; i < P.n_rom; i += nt) eval_rom<JAC>(P, P.rom[i], vin + (size_t)i * ROM_VIN, g, JAC ? loc + (size_t)i * ROM_LOC : nullptr);
-  if (!JAC) ESTAMP();
-  if (JAC) {
+  for (int c0 = 0, ch = 0; c0 < P.n_rom; c0 += P.rom_chunk, ++ch) {
+    const int cnt = min(P.rom_chunk, P.n_rom - c0);
+    __syncthreads();   // the dynamics knots / the previous chunk are done with vin and loc
+    vec_prepass(P.rom + c0, (int)sizeof(RomInst), cnt, 3, x, vin);
     __syncthreads();
-    ESTAMP();
-    write_terms1(P.rom_t1, 0, P.n_rom_t1, loc, G);
-    ESTAMP();
+    for (int i = tid; i < cnt; i += nt) eval_rom<JAC>(P, P.rom[c0 + i], vin + (size_t)i * ROM_VIN, g, JAC ? loc + (size_t)i * ROM_LOC : nullptr);
+    if (!JAC) ESTAMP();
+    if (JAC) {
+      __syncthreads();
+      ESTAMP();
+      write_terms1(P.rom_t1, P.rom_t1_off[ch], P.rom_t1_off[ch + 1], loc, G);
+      ESTAMP();
+    }
   }
   for (int i = tid; i < P.n_force; i += nt) eval_force<JAC>(P, P.force[i], map, x, g, G);
   for (int i = tid; i < P.n_terr; i += nt) eval_terr<JAC>(P, P.terr[i], map, x, g, G, hold, P.terr_dpos + 2 * i);

@@ -45,7 +45,14 @@ struct Kkt2Cfg {
     return NTILE < 8 ? (NTILE < 1 ? 1 : NTILE) : best;
   }
   static constexpr int NU = pick_nu();
-  static constexpr int MAXT = (NTILE + NU - 1) / NU;
+#ifdef QTOS_AGE_SPLIT
+  // 128-slot front: the four update waves of a SIMD take 4 / 3 / 3 / 2 tiles, oldest first -- the matrix pipe
+  // serves them by age, so the youngest starts its extraction last and should have the least of it
+  static constexpr bool AGE = F == 128;
+#else
+  static constexpr bool AGE = false;
+#endif
+  static constexpr int MAXT = AGE ? 4 : (NTILE + NU - 1) / NU;
   static constexpr int NSV = 16 - NT;            // service waves of the AB phase
   static constexpr int NH = NT <= 8 ? 2 : 1;     // backward pass: waves per row tile
   static constexpr int FR = (F + 63) & ~63;      // by-slot arrays padded to whole waves
@@ -68,16 +75,20 @@ struct Kkt2Layout {
   static constexpr int PM = JM + CF::FR;                 // 2 x 8 ints     pivot-slot bit masks
   static constexpr int MIV = PM + 8;                     // 16 x PLD       (L D L^T)^-1 of the current pivot block
   static constexpr int PB = MIV + PIV * PLD;             // 3 panels of (F+1) x PLD
-  static constexpr int VAR = (PB + 3 * PSZ + 1) & ~1;    // dbuf, then (ints) sbuf, soff, doff, hiall, then the cells A
+  static constexpr int VAR = (PB + 3 * PSZ + 1) & ~1;    // dbuf, then (ints) sbuf, hiall, then the cells A
 };
 inline size_t kkt2_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells, int max_part_con) {
   const int FR = (F + 63) & ~63, PSZ = (F + 1) * PLD;
   const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 2 * (size_t)FR + 2 * 16 * PIV + 64 + 3 * PIV / 2 + 2 + FR + 8 + PIV * PLD;
   size_t o = (fixed + 3 * (size_t)PSZ + 1) & ~(size_t)1;
   o += ((size_t)max_drec + 1) & ~(size_t)1;
-  size_t oi = 2 * o + (((size_t)max_srec + 3) & ~(size_t)3) + 3 * ((((size_t)NS + 1) + 3) & ~(size_t)3);
+  size_t oi = 2 * o + (((size_t)max_srec + 3) & ~(size_t)3) + ((((size_t)NS + 1) + 3) & ~(size_t)3);
   oi += 2 * (((size_t)n_cells + 1) & ~(size_t)1);
+#ifdef QTOS_ASM_PARTS
   oi += 2 * 16 * (size_t)max_part_con;
+#else
+  (void)max_part_con;
+#endif
   return oi * sizeof(int);
 }
 
@@ -173,9 +184,11 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   unsigned *pm = (unsigned *)(lds + LY::PM);
   double *Minv = lds + LY::MIV;
   int *sbuf = (int *)(dbuf + ((P.max_drec + 1) & ~1));
-  int *soff = sbuf + ((P.max_srec + 3) & ~3), *doff = soff + ((NS + 4) & ~3), *hiall = doff + ((NS + 4) & ~3);
+  int *hiall = sbuf + ((P.max_srec + 3) & ~3);
   double *A = (double *)(hiall + ((NS + 4) & ~3));   // cells of the assembled entries
+#ifdef QTOS_ASM_PARTS
   double *scr0 = A + ((P.n_cells + 1) & ~1);   // assembly scratch: max_part_con doubles per part
+#endif
   const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
   double *dx = W.dx + (size_t)b * n;
@@ -189,10 +202,16 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
 #pragma unroll
   for (int i = 0; i < MAXT2; ++i) {
     U[i] = d4_t{0.0, 0.0, 0.0, 0.0};
-    const int t = uw + NU * i;
+    int t = uw + NU * i;
+    bool tv = t < CF::NTILE;
+    if constexpr (CF::AGE) {
+      const int age = uw / 3, col = uw - 3 * age, base = age == 0 ? 0 : (age == 1 ? 4 : (age == 2 ? 7 : 10)), cnt = age == 0 ? 4 : (age == 3 ? 2 : 3);
+      t = col + 3 * (base + i);
+      tv = i < cnt;
+    }
     int R = 0;
-    while (is_upd && ((R + 1) * (R + 2)) >> 1 <= t) ++R;
-    const bool valid = is_upd && t < CF::NTILE;
+    while (is_upd && tv && ((R + 1) * (R + 2)) >> 1 <= t) ++R;
+    const bool valid = is_upd && tv;
     tRC[i] = valid ? (R << 8) | (t - ((R * (R + 1)) >> 1)) : -1;
   }
 
@@ -200,7 +219,6 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   for (int i = tid; i < 3 * PSZ; i += KT2) PB[i] = 0.0;
   for (int i = tid; i < FR; i += KT2) { UF[i] = 0.0; xs[i] = 0.0; }
   for (int v = tid; v < n; v += KT2) dx[v] = 0.0;
-  for (int i = tid; i <= NS; i += KT2) { soff[i] = P.srec_off[i]; doff[i] = P.drec_off[i]; }
   __syncthreads();
 
   auto header_from_lds = [&](int s) __attribute__((always_inline)) {
@@ -215,8 +233,9 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     if (tid == 0) { hib[s % 3] = sbuf[3]; hiall[s] = (sbuf[3] + 15) & ~15; }
   };
   auto load_records = [&](int s) __attribute__((always_inline)) {
-    for (int i = tid; i < soff[s + 1] - soff[s]; i += KT2) sbuf[i] = P.srec[soff[s] + i];
-    for (int i = tid; i < doff[s + 1] - doff[s]; i += KT2) dbuf[i] = stream[doff[s] + i];
+    const int s0 = P.srec_off[s], s1 = P.srec_off[s + 1], d0 = P.drec_off[s], d1 = P.drec_off[s + 1];
+    for (int i = tid; i < s1 - s0; i += KT2) sbuf[i] = P.srec[s0 + i];
+    for (int i = tid; i < d1 - d0; i += KT2) dbuf[i] = stream[d0 + i];
   };
   // wave 0: LDL^T + L^-1 + (L D L^T)^-1 of the pivot block of the panel Pn, then the pivot rows leave the panel
   auto factor_block = [&](double *Pn, const int myps, double *Lin, double *dvn) __attribute__((always_inline)) {
@@ -261,9 +280,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
       for (int i = threadIdx.x; i < dl; i += KT2) dbuf[i] = stream[dof + i];
       for (int i = threadIdx.x; i < sl; i += KT2) sbuf[i] = P.srec[so + i];
       lds_barrier();
-      if (t0 >= 0) {
-        for (int p = t0 >> 6; p < NPART; p += nth >> 6) assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, p, p + 1);
-      }
+      if (t0 >= 0) assemble_stage(A, F, sbuf, dbuf, t0, nth);
     }
   };
 
@@ -273,8 +290,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   __syncthreads();
   header_from_lds(0);
   __syncthreads();
-  assemble_eq(A, sbuf, dbuf, tid, KT2);
-  assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, wv, wv + 1);
+  assemble_stage(A, F, sbuf, dbuf, tid, KT2);
   assemble_continuations(tid, KT2);
   __syncthreads();
   {
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     __syncthreads();
     header_from_lds(s);
     __syncthreads();
-    if (s == 1) { assemble_eq(A, sbuf, dbuf, tid, KT2); assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, wv, wv + 1); assemble_continuations(tid, KT2); }
+    if (s == 1) { assemble_stage(A, F, sbuf, dbuf, tid, KT2); assemble_continuations(tid, KT2); }
     __syncthreads();
   }
 
@@ -337,9 +353,11 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     const bool has_next = k + 1 < NS;
     KS2(7);
     // ---- install the records of stage k+2 (prefetched during phase C of the previous stage; the records of
-    //      stage 2 are in LDS since the prologue).  Thread t holds element (t + 256) mod 1024: the record's
-    //      header sits in the registers of wave 12, which publishes it. ------------------------------------
-    const int pidx = (tid + 256) & (KT2 - 1);
+    //      stage 2 are in LDS since the prologue).  Wave w holds elements 64 rank(w) ..: the record's header sits
+    //      in the registers of wave 12 (rank 0), which publishes it. ------------------------------------
+    // (rank of a wave = how early it can spare the time: header wave, the waves without Schur tiles, update
+    //  waves oldest first, factor wave last; high ranks lie behind the end of most records and skip the loads)
+    const int pidx = (int)((0xEDC0BA928761543Full >> (4 * wv)) & 15u) * 64 + lane;
     if (k >= 1 && k + 2 < NS) {
       const int wbase = __builtin_amdgcn_readfirstlane(pidx);
       if (wbase < pf_nd2) ((d2_t *)dbuf)[min(pidx, pf_nd2)] = pfd;
@@ -582,7 +600,30 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
           }
         }
       }
-    } else if (wv == 12) {
+    }
+#ifdef QTOS_PF_LATE
+    if (wv != 0 && wv != 12 && !is_upd) prefetch_records();
+#endif
+    KS2(2);
+    // every wave but the factor wave ends the phase with its share of the assembly of stage k+2's records
+    // (the waves without a Schur tile come first and take the low item indices)
+    const int apos = is_upd ? (15 - NU) + uw : uw - NU;   // (wave 12, the header wave, is the last of the free ones)
+    if (wv >= 1 && k + 2 < NS) {
+#ifdef QTOS_ASM_PARTS
+      assemble_eq(A, sbuf, dbuf, apos * 64 + lane, 15 * 64);
+      // the waves without Schur tiles take APW parts each as one run, the oldest update waves one of the rest
+      constexpr int NFREE = 15 - NU, NF4 = NFREE * APW < NPART ? NFREE * APW : NPART;
+      if (apos < NFREE) assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, min(apos * APW, NF4), min(apos * APW + APW, NF4));
+      else assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, min(NF4 + apos - NFREE, NPART), min(NF4 + apos - NFREE + 1, NPART));
+#else
+      // one thread per target, low item indices to the waves that get here first
+      assemble_stage(A, F, sbuf, dbuf, apos * 64 + lane, 15 * 64);
+#endif
+    }
+    if constexpr (CONT) {
+      if (k + 2 < NS) assemble_continuations(wv >= 1 ? apos * 64 + lane : -1, 15 * 64);
+    }
+    if (wv == 12) {
 #ifdef QTOS_PF_LATE
       prefetch_records();
 #endif
@@ -606,28 +647,6 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
           }
         }
       }
-    }
-#ifdef QTOS_PF_LATE
-    if (wv != 0 && wv != 12 && !is_upd) prefetch_records();
-#endif
-    KS2(2);
-    // every wave but the factor wave ends the phase with its share of the assembly of stage k+2's records
-    // (the waves without a Schur tile come first and take the low item indices)
-    const int apos = is_upd ? (15 - NU) + uw : uw - NU;   // (wave 12, the header wave, is the last of the free ones)
-    if (wv >= 1 && k + 2 < NS) {
-#ifdef QTOS_ASM_PARTS
-      assemble_eq(A, sbuf, dbuf, apos * 64 + lane, 15 * 64);
-      // the waves without Schur tiles take APW parts each as one run, the oldest update waves one of the rest
-      constexpr int NFREE = 15 - NU, NF4 = NFREE * APW < NPART ? NFREE * APW : NPART;
-      if (apos < NFREE) assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, min(apos * APW, NF4), min(apos * APW + APW, NF4));
-      else assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, min(NF4 + apos - NFREE, NPART), min(NF4 + apos - NFREE + 1, NPART));
-#else
-      // one thread per target, low item indices to the waves that get here first
-      assemble_stage(A, F, sbuf, dbuf, apos * 64 + lane, 15 * 64);
-#endif
-    }
-    if constexpr (CONT) {
-      if (k + 2 < NS) assemble_continuations(wv >= 1 ? apos * 64 + lane : -1, 15 * 64);
     }
     KS2(3);
     lds_barrier();

@@ -156,6 +156,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(S.dyn_t1_off, &D.dyn_t1_off)); TRY(p->upload(S.dyn_t3_off, &D.dyn_t3_off));
   D.n_rom_t1 = (int)S.rom_t1.size();
   D.dyn_chunk = M.dyn_chunk;
+  D.rom_chunk = S.rom_chunk;
+  TRY(p->upload(S.rom_t1_off, &D.rom_t1_off));
   TRY(p->upload(S.amask, &D.amask));
   TRY(p->upload(S.ctab, &D.ctab));
   TRY(p->upload(S.rtab, &D.rtab));
@@ -236,6 +238,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     qtos_planner_destroy(p);
     return -4;
   }
+  if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: front %d, k_kkt LDS %zu B\n", F, p->kkt_lds);
   if (p->kkt_lds > 160 * 1024 - 256) {
     p->err = "front too large for LDS";
     fprintf(stderr, "qtos: front %d needs %zu B of LDS\n", F, p->kkt_lds);
@@ -248,9 +251,14 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
   }
-  p->eval_lds = sizeof(double) * (((size_t)M.n_vars + 1) / 2 * 2 + std::max((size_t)DYN_LOC * D.dyn_chunk, (size_t)ROM_LOC * M.rom.size()) +
-                                  std::max((size_t)DYN_VIN * D.dyn_chunk, (size_t)ROM_VIN * M.rom.size()));
-  if (p->eval_lds > 150 * 1024) { p->err = "too many dynamics knots for the LDS scratch"; qtos_planner_destroy(p); return -4; }
+  p->eval_lds = sizeof(double) * (((size_t)M.n_vars + 1) / 2 * 2 + std::max((size_t)DYN_LOC * D.dyn_chunk, (size_t)ROM_LOC * D.rom_chunk) +
+                                  std::max((size_t)DYN_VIN * D.dyn_chunk, (size_t)ROM_VIN * D.rom_chunk));
+  if (p->eval_lds > 150 * 1024) {
+    p->err = "too many dynamics knots for the LDS scratch";
+    fprintf(stderr, "qtos: evaluation kernels need %zu B of LDS\n", p->eval_lds);
+    qtos_planner_destroy(p);
+    return -4;
+  }
   for (const void *fn : {(const void *)k_start, (const void *)k_step, (const void *)k_debug_eval})
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->eval_lds) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   // sampling tables

@@ -80,7 +80,7 @@ struct Symbolic {
   // cell_mode 2 (k_kkt2: records are assembled during the AB phase, next to the gathering of the previous
   // stage's columns): right-hand-side entries get cells of their own too (a slot changes hands at a stage
   // boundary, a cell does not), listed per pivot in rtab, and a cell is recycled one stage later
-  int cell_mode = 1;
+  int cell_mode = 2;
   std::vector<int> rtab;              // n_stages x 16: cell of the assembled right-hand side of every pivot (0 = none)
   std::vector<unsigned> amask;   // per stage 256 bits (8 words): front slots whose row of the factor panel V is stored (live, not a pivot of the stage)
   // The linearisation kernels write straight into the stream: eq_pos maps the (virtual) G offset of
@@ -105,6 +105,8 @@ struct Symbolic {
   std::vector<LinTerm1> dyn_t1, rom_t1;
   std::vector<LinTerm3> dyn_t3;
   std::vector<int> dyn_t1_off, dyn_t3_off;   // first entry of every knot chunk (+ end)
+  std::vector<int> rom_t1_off;               // same for the chunks of range-of-motion instances
+  int rom_chunk = 1;
   void build_linear_terms(HostModel &M) {
     const int n_dyn = (int)M.dyn.size(), n_ch = std::max(1, (n_dyn + 127) / 128);
     M.dyn_chunk = std::max(1, (n_dyn + n_ch - 1) / n_ch);
@@ -149,21 +151,35 @@ struct Symbolic {
       dyn_t1_off.push_back((int)dyn_t1.size());
       dyn_t3_off.push_back((int)dyn_t3.size());
     }
-    rom_t1.clear();
+    // range-of-motion instances go through the LDS scratch in chunks of at most 512 (one chunk up to a 10 s
+    // horizon; `-duration 20` has 1008 of them)
+    const int n_rom = (int)M.rom.size(), n_chr = std::max(1, (n_rom + 511) / 512);
+    rom_chunk = std::max(1, (n_rom + n_chr - 1) / n_chr);
+    std::vector<std::vector<LinTerm1>> r1(n_chr);
     for (const ColDesc &c : M.rom_cols) {
-      const int base = c.inst * ROM_LOC, d = c.dim;
+      const int ch = c.inst / rom_chunk, base = (c.inst - ch * rom_chunk) * ROM_LOC, d = c.dim;
       for (int i = 0; i < 3; ++i) {
         const int pos = c.gbase + i * c.ncol;   // inequality block: contiguous in the stream
-        if (c.kind == 1) rom_t1.push_back({pos, base + 9 + 3 * i + d, c.w0});
-        else rom_t1.push_back({pos, base + 3 * d + i, (c.kind == 2 ? 1.0 : -1.0) * c.w0});
+        if (c.kind == 1) r1[ch].push_back({pos, base + 9 + 3 * i + d, c.w0});
+        else r1[ch].push_back({pos, base + 3 * d + i, (c.kind == 2 ? 1.0 : -1.0) * c.w0});
       }
     }
-    std::sort(rom_t1.begin(), rom_t1.end(), [](const LinTerm1 &a, const LinTerm1 &b) { return a.pos < b.pos; });
+    rom_t1.clear();
+    rom_t1_off.assign(1, 0);
+    for (int ch = 0; ch < n_chr; ++ch) {
+      std::sort(r1[ch].begin(), r1[ch].end(), [](const LinTerm1 &a, const LinTerm1 &b) { return a.pos < b.pos; });
+      rom_t1.insert(rom_t1.end(), r1[ch].begin(), r1[ch].end());
+      rom_t1_off.push_back((int)rom_t1.size());
+    }
   }
 
   // record limits: a stage record travels through the prefetch registers of k_kkt (2 x 16 B of doubles
   // and 3 x 16 B of ints per thread, 512 threads) and its gather codes address 4096 doubles
-  static constexpr int REC_MAX_DOUBLES = 2048, REC_MAX_INTS = 6144, SHDR_INTS = 8, NPART = 16;
+  static constexpr int SHDR_INTS = 8, NPART = 16;
+  // (set in build once the front is known: a front of up to 128 slots leaves LDS for 6144 ints / 2048 doubles
+  //  per record; larger fronts -- three panels of up to 85 KB -- get 4096 / 1280 and spill the rest of a heavy
+  //  stage into continuation records)
+  int REC_MAX_DOUBLES = 2048, REC_MAX_INTS = 6144;
   int max_part_con = 0;    // most contributions in one part of a record (scratch doubles per wave in k_kkt2)
   std::vector<int> cont;   // continuation records: {srec offset, ints, stream offset, doubles} each
   // dynamic part (per block G, sig, w) and gather table of the blocks `blks` of stage k, appended to the
@@ -519,6 +535,7 @@ struct Symbolic {
       active -= (hi - lo);
     }
     front = ((n_slots + PIV - 1) / PIV) * PIV;
+    if (front > 128 && cell_mode == 2) { REC_MAX_INTS = 4096; REC_MAX_DOUBLES = 1280; }
     for (int j = 0; j < n_unknowns; ++j) {
       if (order[j] < n) var_slot[order[j]] = slot_of[j];
       else row_slot[order[j] - n] = slot_of[j];

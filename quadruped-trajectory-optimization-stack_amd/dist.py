@@ -2,9 +2,9 @@
 
 Planning problems are independent (the reference already runs 32 at once as separate processes,
 QTOS/generateHeightField.py:344-352), so the only exchange is re-assembling the plan batch:
-``all_gather`` of the solution nodes (n_vars doubles per plan) and the status words.  With
-``torch.distributed`` backend "nccl" this is one RCCL all-gather over xGMI; "gloo" is used by the
-CPU tests.  The 1 kHz CSV rows (1.48 MB per plan) are sampled after the gather, never shipped.
+ONE ``all_gather`` of the solution nodes (n_vars doubles per plan) with the status word packed as an
+extra column.  With ``torch.distributed`` backend "nccl" this is one RCCL all-gather over xGMI; "gloo"
+is used by the CPU tests.  The 1 kHz CSV rows (1.48 MB per plan) are sampled after the gather, never shipped.
 """
 import numpy as np
 
@@ -18,27 +18,28 @@ def shard_bounds(n_items, world_size, rank):
 
 def gather_plans(nodes_local, status_local, n_total, group=None):
     """All-gather the per-rank shards (torch tensors, same device) into full (n_total, n_vars) /
-    (n_total,) tensors on every rank.  Shards are padded to equal length so ONE collective moves
-    the nodes and one the status words."""
+    (n_total,) tensors on every rank with ONE collective: the status word of a plan travels as an
+    extra column of its node row (small integers are exact in float64), shards are padded to equal
+    length (pad rows carry status -1)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     per = -(-n_total // world)
     n_vars = nodes_local.shape[1]
-    pad_nodes = torch.zeros((per, n_vars), dtype=nodes_local.dtype, device=nodes_local.device)
-    pad_status = torch.full((per,), -1, dtype=status_local.dtype, device=status_local.device)
-    pad_nodes[:nodes_local.shape[0]] = nodes_local
-    pad_status[:status_local.shape[0]] = status_local
-    all_nodes = torch.empty((world * per, n_vars), dtype=nodes_local.dtype, device=nodes_local.device)
-    all_status = torch.empty((world * per,), dtype=status_local.dtype, device=status_local.device)
-    dist.all_gather_into_tensor(all_nodes, pad_nodes, group=group)
-    dist.all_gather_into_tensor(all_status, pad_status, group=group)
-    keep = []
-    for r in range(world):
-        b, e = shard_bounds(n_total, world, r)
-        keep.append(torch.arange(r * per, r * per + (e - b), device=nodes_local.device))
-    keep = torch.cat(keep)
-    return all_nodes[keep], all_status[keep]
+    n_loc = nodes_local.shape[0]
+    packed = torch.zeros((per, n_vars + 1), dtype=nodes_local.dtype, device=nodes_local.device)
+    packed[:, n_vars] = -1.0
+    packed[:n_loc, :n_vars] = nodes_local
+    packed[:n_loc, n_vars] = status_local.to(nodes_local.dtype)
+    gathered = torch.empty((world * per, n_vars + 1), dtype=nodes_local.dtype, device=nodes_local.device)
+    dist.all_gather_into_tensor(gathered, packed, group=group)
+    if world * per != n_total:   # ragged batch: drop the pad rows
+        keep = []
+        for r in range(world):
+            b, e = shard_bounds(n_total, world, r)
+            keep.append(torch.arange(r * per, r * per + (e - b), device=nodes_local.device))
+        gathered = gathered[torch.cat(keep)]
+    return gathered[:, :n_vars], gathered[:, n_vars].round().to(status_local.dtype)
 
 
 def plan_sharded(solve_fn, start, goal, group=None, device="cpu"):

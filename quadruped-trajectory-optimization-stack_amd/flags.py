@@ -4,6 +4,18 @@ Mirror of QTOS/utils.py:26 (``_flags``) and QTOS/utils.py:644-670 (``cmd_args``)
 flattens its ``args`` dict, in insertion order, into ``key value value value `` groups for every
 key in ``_flags`` with a truthy value, lists printed with ``str()`` and ``[ ] ,`` stripped.
 ``parse_flags`` is the inverse the replacement needs on its side of the boundary.
+
+``-r``.  The reference passes ``-r 5.0`` with every feasibility probe (QTOS/generateHeightField.py:373) and
+``-r 30 * tiles`` / ``120 * tiles`` next to ``-duration 1.0 * tiles`` / ``4.0 * tiles`` in its default-TOWR mode
+(scripts/main.py:119-120, 203-206).  The solver source that reads it is absent from the reference tree and
+no committed artefact shows its effect (the logged solves do not carry it), so its meaning is unpinned.
+Working hypothesis (the only one consistent with all three call sites): a run-time budget for the solver in
+seconds -- short for a probe that only needs an exit status, 30 s of budget per planned second for the long
+single solves.  This planner answers in milliseconds, so no such budget can bind: ``-r`` is parsed, range
+checked (must be a positive finite number, else ValueError: a malformed flag is rejected loudly) and
+reported back in ``LocalPlanner.last["r"]``; it does not enter the NLP.  tests/test_boundary.py holds the
+strings; tests/test_gpu_parity.py::test_r_flag_does_not_change_the_plans checks statuses and plans with
+and without it.
 """
 
 FLAGS = ['-g', '-s', '-s_ang', '-s_vel', '-e1', '-e2', '-e3', '-e4', '-t', '-r', '-resolution',
@@ -53,4 +65,9 @@ def problem_arrays(args):
     t0 = args.get('-t') or 0.0
     if hasattr(t0, "__len__"):
         t0 = t0[0]
+    r = args.get('-r')
+    if r is not None and r != "" and not (hasattr(r, "__len__") and len(r) == 0):
+        rv = float(r[0] if hasattr(r, "__len__") else r)
+        if not (rv > 0.0 and rv < float("inf")):
+            raise ValueError("-r must be a positive finite number (see flags.py), got %r" % (r,))
     return start, goal, float(t0)

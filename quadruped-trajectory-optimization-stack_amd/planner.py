@@ -54,7 +54,10 @@ class LocalPlanner:
         if key not in self._planners:
             cfg = self.cfg
             if abs(duration - cfg.duration) > 1e-12:
-                kw = {k: getattr(cfg, k) for k in cfg.__dataclass_fields__ if k != "phase_durations"}
+                # the schedule of the configured plan stretched to the new horizon (a custom phase table,
+                # e.g. knots200's two-cycle one, keeps its shape)
+                kw = {k: getattr(cfg, k) for k in cfg.__dataclass_fields__}
+                kw["phase_durations"] = [[d * duration / cfg.duration for d in foot] for foot in cfg.phase_durations]
                 kw["duration"] = duration
                 cfg = PlannerConfig(**kw)
             p = capi.Planner(cfg, self.max_batch, self.device)
@@ -64,35 +67,46 @@ class LocalPlanner:
 
     # ---- the boundary ----
     def solve_batch(self, args_list, map_id=None, warm=None, sample=True):
-        """List of reference-style args dicts -> list of exit statuses.  Results in ``self.last``."""
+        """List of reference-style args dicts -> list of exit statuses.  Results in ``self.last``.
+
+        Every ``./main`` call of the reference carries its own ``-duration``: the batch is grouped by
+        horizon and every group is solved on the planner built for it (rows / nodes of ``self.last`` are
+        lists when the horizons differ, arrays otherwise).  ``-r`` (scripts/main.py:119,203;
+        QTOS/generateHeightField.py:373) is accepted and recorded in ``self.last["r"]``: see flags.py."""
         if not args_list:
             return []
-        dur = args_list[0].get('-duration') or None
-        P = self.planner(dur)
-        starts, goals, t0s = [], [], []
-        for a in args_list:
-            s, g, t0 = flags.problem_arrays(a)
-            starts.append(s)
-            goals.append(g)
-            t0s.append(t0)
-        statuses, nodes_all, iters_all, viol_all = [], [], [], []
-        for i in range(0, len(args_list), self.max_batch):
-            sl = slice(i, i + self.max_batch)
-            nodes, status, iters, viol = P.plan(
-                np.array(starts[sl]), np.array(goals[sl]),
-                None if map_id is None else np.asarray(map_id)[sl],
-                None if warm is None else np.asarray(warm)[sl])
-            statuses += [int(s) for s in status]
-            nodes_all.append(nodes)
-            iters_all.append(iters)
-            viol_all.append(viol)
-        nodes = np.concatenate(nodes_all)
-        rows = None
-        if sample:
-            rows = np.concatenate([P.sample(nodes[i:i + self.max_batch], np.array(t0s[i:i + self.max_batch]), self.cfg.hz)
-                                   for i in range(0, len(args_list), self.max_batch)])
-        self.last = dict(nodes=nodes, rows=rows, status=np.array(statuses), iters=np.concatenate(iters_all),
-                         viol=np.concatenate(viol_all), t0=np.array(t0s))
+        n = len(args_list)
+        durs = [float(a.get('-duration') or self.cfg.duration) for a in args_list]
+        order = {}
+        for i, dv in enumerate(durs):
+            order.setdefault(round(dv, 9), []).append(i)
+        statuses = [None] * n
+        nodes_o, rows_o, iters_o, viol_o, t0_o = [None] * n, [None] * n, [None] * n, [None] * n, [None] * n
+        for key, idx in order.items():
+            P = self.planner(key)
+            starts, goals, t0s = [], [], []
+            for i in idx:
+                s, g, t0 = flags.problem_arrays(args_list[i])
+                starts.append(s)
+                goals.append(g)
+                t0s.append(t0)
+            for c in range(0, len(idx), self.max_batch):
+                sl = slice(c, c + self.max_batch)
+                ii = idx[sl]
+                nodes, status, iters, viol = P.plan(
+                    np.array(starts[sl]), np.array(goals[sl]),
+                    None if map_id is None else np.asarray(map_id)[ii],
+                    None if warm is None else np.asarray(warm)[ii])
+                rows = P.sample(nodes, np.array(t0s[sl]), self.cfg.hz) if sample else None
+                for j, i in enumerate(ii):
+                    statuses[i] = int(status[j])
+                    nodes_o[i], iters_o[i], viol_o[i], t0_o[i] = nodes[j], iters[j], viol[j], t0s[c + j]
+                    rows_o[i] = None if rows is None else rows[j]
+        same = len(order) == 1
+        self.last = dict(nodes=np.stack(nodes_o) if same else nodes_o,
+                         rows=(np.stack(rows_o) if same else rows_o) if sample else None,
+                         status=np.array(statuses), iters=np.array(iters_o), viol=np.array(viol_o), t0=np.array(t0_o),
+                         r=[a.get('-r') for a in args_list])
         return statuses
 
     def solve(self, args, out_csv=TRAJ_OUT):

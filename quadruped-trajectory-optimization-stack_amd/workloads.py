@@ -6,7 +6,9 @@ import numpy as np
 from . import heightfield
 
 NOMINAL_FEET = np.array([[0.21, 0.19, 0.0], [0.21, -0.19, 0.0], [-0.21, 0.19, 0.0], [-0.21, -0.19, 0.0]])
-TILE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "heightfields")
+# the 20 x 20 terrain tiles of the reference experiments the workloads are built from (inputs: data/heightfields/*.txt
+# of the reference, SURVEY.md section 2 "Heightfields"); tests/golden/heightfields holds the same files as fixtures
+TILE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "heightfields")
 
 
 def rest_start(x0, y0=0.0, z=0.24, feet_z=None):

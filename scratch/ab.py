@@ -4,7 +4,6 @@ import sys; sys.path.insert(0, '.')
 import numpy as np
 from qtos_amd import capi, workloads
 import os
-capi.LIB_PATH = capi.LIB_PATH.replace("libqtos_planner.so", os.environ["QTOS_LIB"])
 from qtos_amd.config import PlannerConfig
 P = capi.Planner(PlannerConfig.knots100(), max_batch=256)
 s, g = workloads.flat_goals(256, 0)

@@ -157,6 +157,48 @@ def test_p3_cold_start_converges(oracle, name, gv1, gv2, record_property):
     assert com < 0.15 and ee < 0.3
 
 
+GV3_INPUTS = dict(s=[0, 0, 0.24], s_ang=[0, 0, 0], ee=[[0.21, 0.19, 0.0], [0.21, -0.19, 0.0], [-0.21, 0.19, 0.0], [-0.21, -0.19, 0.0]],
+                  g=[0.520000318742596, 3.541584398612406e-07, 0.24], s_vel=[0, 0, 0], s_ang_vel=[0, 0, 0], t0=0.0)
+
+
+def test_gv3_partial_plan_is_consistent_with_the_model(oracle, cfg):
+    """GV3 = data/traj/towr.csv rows 0..1253 of the reference: t = 2.502 .. 3.755 of its logged solve #1
+    (logs/towr_log.out:8-29: rest start, -g 0.520000318742596 3.54e-07 0.24), every 10th row kept.  A third,
+    independent window of reference output: the rows obey the restated model (time stamps, gait schedule,
+    stance feet on the ground, momentum balance at the collocation times), and the oracle's cold solve of the
+    logged inputs is a plan of the same family (same schedule, decimetre-scale distance: the NLP has no cost)."""
+    d = np.load(os.path.join(GOLDEN, "gv3_partial.npz"))
+    rows, idx = d["rows"], d["row_idx"]
+    t = rows[:, 0]
+    assert np.abs(t - (2.502 + 1e-3 * idx)).max() < 5e-7              # 1 kHz rows of a plan that started at t0 = 0
+    # gait schedule: a foot carries force exactly in its stance phases (1 ms switch resolution, so rows
+    # within 2 ms of a switch are not judged); stance feet stand on the flat ground
+    for e in range(4):
+        sw = np.cumsum(cfg.phase_durations[e])
+        phase = np.searchsorted(sw, t, side="right")
+        near = np.min(np.abs(t[:, None] - sw[None, :]), axis=1) < 2e-3
+        stance = phase % 2 == 0
+        f = rows[:, 25 + 3 * e:28 + 3 * e]
+        assert (np.abs(f[~stance & ~near]).max(initial=0.0) == 0.0) and (f[stance & ~near][:, 2] > 0).all()
+        assert np.abs(rows[stance & ~near][:, 7 + 3 * e + 2]).max() < 1e-6
+    # linear momentum balance m a = sum f - m g (a by central differences of the velocity columns over the
+    # +- 10 ms neighbours): the kept rows sit 2 ms behind the 0.1 s collocation times or further away; the
+    # residual is small next to a collocation time and several times larger between them -- the 0.1 s grid
+    k = np.arange(1, len(t) - 1)
+    acc = (rows[k + 1, 19:22] - rows[k - 1, 19:22]) / (t[k + 1] - t[k - 1])[:, None]
+    fsum = rows[k, 25:28] + rows[k, 28:31] + rows[k, 31:34] + rows[k, 34:37]
+    res = np.abs(cfg.mass * acc - fsum + np.array([0, 0, cfg.mass * cfg.gravity])).max(axis=1)
+    ph = (t[k] * 10) % 1.0
+    at_knot, between = res[ph < 0.05], res[(ph > 0.2) & (ph < 0.8)]
+    assert len(at_knot) >= 10 and at_knot.max() < 0.3 and between.max() > 3 * at_knot.max()      # [N]
+    # P3 on the logged inputs: converges from the logged 19.4; its sampled rows in the window are a plan of the same family
+    x, info = oracle.solve(oracle_problem(oracle, GV3_INPUTS))
+    assert info.status == 0 and info.iters <= 15 and abs(info.inf_pr0 - 19.4) < 0.05
+    mine = oracle.sample(x, 0.0)[2502 + idx]
+    assert np.abs(mine[:, 0] - t).max() < 5e-7
+    assert np.abs(mine[:, 1:4] - rows[:, 1:4]).max() < 0.15 and np.abs(mine[:, 7:19] - rows[:, 7:19]).max() < 0.3
+
+
 def test_skyline_ldlt_against_numpy():
     import ctypes as C
     from oracle.oracle import lib
