@@ -66,8 +66,9 @@ def parse_args():
     ap.add_argument("--init", default="straight_line", choices=["straight_line", "table"],
                     help="starting point of the solves: towr's straight-line guess (the reference's behaviour, default) or "
                          "the interpolation of a table of nominal plans solved before the timed region (reported separately)")
-    ap.add_argument("--episode", type=int, default=0,
-                    help="mpc_random: replans per window before it is replaced by a fresh patch (0 = never)")
+    ap.add_argument("--advance", type=float, default=2.5,
+                    help="mpc_random: seconds into its newest plan at which a window's next plan starts (the reference's "
+                         "f_steps = 2500 rows, scripts/main.py:177; moved on until all feet are in contact)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per k_kkt launch from a separate rocprofv3 --pmc pass "
                          "(default: the newest profiles/*_pmc_hbm.json, collected with this same command)")
@@ -155,10 +156,8 @@ def main():
         kw["max_iter"] = args.max_iter
     if args.gait == "trot":
         kw["gait"] = "trot"
-    if mpc:
-        kw["honor_start_velocity"] = True    # a replan continues the motion it starts in
-    if mpc and args.inflight > 1:
-        raise SystemExit("--inflight > 1 is not defined for mpc_random (every replan starts from the previous plan)")
+    if mpc and args.inflight > 1 and args.batch % args.inflight:
+        raise SystemExit("--inflight must divide --batch for mpc_random (the windows are split into that many sets)")
     cfg = {"knots100": PlannerConfig.knots100, "knots200": PlannerConfig.knots200,
            "reference_compat": PlannerConfig.reference_compat}[args.transcription](**kw)
     B = args.batch
@@ -205,46 +204,54 @@ def main():
     iters = torch.empty((B,), dtype=torch.int32, device=dev)
     viol = torch.empty((B,), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream(dev)
-    # receding window (mpc_random): ping-pong node buffers (solution k is the warm start of k+1), the two
-    # CSV rows the next start state is read from
-    nodes_prev = torch.empty_like(nodes) if mpc else None
-    rows2 = torch.empty((B, 2, 37), dtype=torch.float64, device=dev) if mpc else None
-    t0_dev = torch.zeros((B,), dtype=torch.float64, device=dev) if mpc else None
-    state = {"have_warm": False, "k": 0, "cold": 0, "i": 0}
+    # receding windows (mpc_random): qtos_amd.replan.ShiftedWindows -- hand-over row, moving goal, shifted warm start
+    windows = None
+    if mpc:
+        # the B windows of a GPU in `inflight` sets, each on its own planner handle + stream + host thread: a set waits
+        # for its slowest window, the CUs it leaves idle meanwhile serve the other sets
+        from concurrent.futures import ThreadPoolExecutor
+        from qtos_amd.replan import ShiftedWindows
+        gstep = goal_np - start_np[:, 0:3]
+        nset, per = args.inflight, B // args.inflight
+        windows = []
+        for j in range(nset):
+            Pj = P if j == 0 else Planner(cfg, max_batch=per, device=local_rank)
+            if j:
+                Pj.set_heightfields(terrain[0], terrain[1])
+            sl = slice(j * per, (j + 1) * per)
+            windows.append(ShiftedWindows(Pj, start_np[sl], gstep[sl], map_id_np[sl], advance=args.advance, x_range=(0.0, 2.2),   # walk up and down the ledges
+                                          stream=torch.cuda.current_stream(dev) if nset == 1 else torch.cuda.Stream(dev)))
+        mpc_pool = ThreadPoolExecutor(nset) if nset > 1 else None
+    state = {"i": 0}
     solved_dev = torch.zeros((), dtype=torch.int64, device=dev)     # converged plans, accumulated on the device
     iters_dev = torch.zeros((), dtype=torch.int64, device=dev)
-    start = start_all[0].clone()
-    start0 = start.clone() if mpc else None
 
     def step():
-        nonlocal nodes, nodes_prev
-        i = state["i"] % n_sets
-        state["i"] += 1
-        warm_ptr = None
-        if mpc and args.episode > 0 and state["k"] % args.episode == 0:   # new episode: fresh patches, cold start
-            start.copy_(start0)
-            state["have_warm"] = False
-            state["cold"] += 1
-        if mpc and state["have_warm"]:
-            nodes, nodes_prev = nodes_prev, nodes
-            warm_ptr = nodes_prev.data_ptr()
-        st_ptr = start.data_ptr() if mpc else start_all[i].data_ptr()
-        rc = P.lib.qtos_plan_batch_device(P.h, B, st_ptr, goal_all[i].data_ptr(),
-                                          None if map_all is None else map_all[i].data_ptr(), warm_ptr,
-                                          nodes.data_ptr(), status.data_ptr(), iters.data_ptr(),
-                                          viol.data_ptr(), C.c_void_p(stream.cuda_stream))
-        if rc != 0:
-            raise RuntimeError("qtos_plan_batch_device failed: %d %s" % (rc, P.lib.qtos_last_error(P.h)))
-        solved_dev.add_((status == 0).sum())
-        iters_dev.add_(iters.sum())
-        if mpc:   # the window moves on by 20 ms: CSV row 1 at 50 Hz, columns 1..24 = the next start vector
-            rc = P.lib.qtos_sample_csv_device(P.h, B, nodes.data_ptr(), t0_dev.data_ptr(), C.c_double(50.0), 2,
-                                              rows2.data_ptr(), C.c_void_p(stream.cuda_stream))
+        nonlocal nodes, status, iters
+        if mpc:
+            if mpc_pool is None:
+                windows[0].replan()
+            else:
+                def one(Wj):
+                    Wj.replan()
+                    Wj.stream.synchronize()
+                list(mpc_pool.map(one, windows))
+            nodes = torch.cat([Wj.nodes for Wj in windows])
+            status = torch.cat([Wj.status for Wj in windows])
+            iters = torch.cat([Wj.iters for Wj in windows])
+            solved_dev.add_((status == 0).sum())
+            iters_dev.add_(iters.sum())
+        else:
+            i = state["i"] % n_sets
+            state["i"] += 1
+            rc = P.lib.qtos_plan_batch_device(P.h, B, start_all[i].data_ptr(), goal_all[i].data_ptr(),
+                                              None if map_all is None else map_all[i].data_ptr(), None,
+                                              nodes.data_ptr(), status.data_ptr(), iters.data_ptr(),
+                                              viol.data_ptr(), C.c_void_p(stream.cuda_stream))
             if rc != 0:
-                raise RuntimeError("qtos_sample_csv_device failed: %d" % rc)
-            start.copy_(rows2[:, 1, 1:25])
-            state["have_warm"] = True
-            state["k"] += 1
+                raise RuntimeError("qtos_plan_batch_device failed: %d %s" % (rc, P.lib.qtos_last_error(P.h)))
+            solved_dev.add_((status == 0).sum())
+            iters_dev.add_(iters.sum())
         if use_dist:
             return gather_plans(nodes, status, B * world)
         return nodes, status
@@ -256,7 +263,7 @@ def main():
 
     # optional: several batches in flight (separate planner handles / streams / outputs)
     lanes = []
-    if args.inflight > 1:
+    if args.inflight > 1 and not mpc:
         from concurrent.futures import ThreadPoolExecutor
         for _ in range(args.inflight):
             Pl = Planner(cfg, max_batch=B, device=local_rank)
@@ -283,7 +290,6 @@ def main():
     sync()
     solved_dev.zero_()
     iters_dev.zero_()
-    state["cold"] = 0
     kkt_s, kkt_n, tot_s = 0.0, 0, 0.0
     solved_inflight = None
     if lanes:
@@ -334,7 +340,7 @@ def main():
                         "constraint rows), %s" %
                         (B, {"exp1_flat": "exp_1 flat-ground", "exp5_step": "exp_5 step-climb",
                              "mixed": "mixed exp_1/exp_3/exp_5",
-                             "mpc_random": "receding-window replans (20 ms shift, warm-started) on randomized exp_5 heightfields: ledge"}[args.workload],
+                             "mpc_random": "receding-window replans (hand-over row %.1f s into the newest plan as the reference's stitcher picks it, cold start) on randomized exp_5 heightfields: ledge" % args.advance}[args.workload],
                          args.transcription, d.n_base_nodes - 1, d.n_vars, d.n_cons,
                          "walk gait of the reference's golden plans" if args.gait == "walk" else "diagonal-pair trot (config.TROT_UNNORMALISED, unpinned)"),
             "global_batch": total_plans, "plans_timed": total_plans * args.steps, "converged": n_solved,
@@ -350,9 +356,10 @@ def main():
     }
     if mpc:
         out["config"]["replan_hz_per_window"] = round(args.steps / elapsed, 2)
-        out["config"]["window_shift_s"] = 0.02
-        out["config"]["replans_per_episode"] = args.episode
-        out["config"]["cold_steps"] = state["cold"]
+        out["config"]["windows_per_gpu"] = B
+        out["config"]["hand_over_s_into_newest_plan"] = args.advance
+        out["config"]["episode_resets"] = 0
+        out["config"]["converged_fraction"] = round(n_solved / max(total_plans * args.steps, 1), 4)
     headline = args.transcription == "knots100" and args.workload == "exp1_flat" and B == 256 and args.gait == "walk"
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
     import glob

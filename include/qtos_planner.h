@@ -40,7 +40,10 @@ typedef struct QtosParams {
   int terrain_mode;         /* 0 bilinear heightfield (exact slope), 1 nearest cell (flat ledges) */
   int max_iter;
   double tol, mu_init, mu_min, delta_x, eps_dual;
-  double slack_push; /* cold-start slack push, fraction of the bound range (0.2); warm starts use 0.01 */
+  double slack_push; /* cold-start slack push, fraction of the bound range (0.2) */
+  double warm_slack_push; /* the same for a solve that is given `warm` nodes (or a table guess): Ipopt's 0.01 keeps a
+                             feasible warm start where it is; a time-shifted previous plan is only a guess and
+                             does better with a larger push; 0 = 0.01 */
   int stall_iters;   /* stop a problem (status 1, best iterate returned) after this many iterations
                         without a new lowest violation; 0 = only the iteration limit stops it */
   int hold_from;     /* two-phase solve: once an iterate (number >= hold_from) has brought the constraint
@@ -122,6 +125,18 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
 int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
                            const int *d_map_id, const double *d_warm, double *d_nodes_out,
                            int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream);
+
+/* Time-shifted warm start for a receding-horizon replan (the reference re-plans from the
+ * row `lookahead` steps ahead in the plan being executed, QTOS/combiner.py:245-296, and restarts the gait
+ * schedule with every plan): warm_out[b] = the previous plan nodes_prev[b] read at offset[b] + (node time) for
+ * every variable of the new plan whose shifted time still lies inside the previous horizon, towr's
+ * straight-line guess of the new problem (start[b] -> goal[b]) beyond it, and the new start / goal in the fixed
+ * variables.  Pass warm_out as `warm` of qtos_plan_batch*.  offset in seconds (>= 0). */
+int qtos_shift_warm(QtosPlanner *p, int B, const double *nodes_prev, const double *offset,
+                    const double *start, const double *goal, const int *map_id, double *warm_out);
+int qtos_shift_warm_device(QtosPlanner *p, int B, const double *d_nodes_prev, const double *d_offset,
+                           const double *d_start, const double *d_goal, const int *d_map_id,
+                           double *d_warm_out, void *stream);
 
 /* 1 kHz sampling of solution nodes into the reference's CSV row layout (37 columns,
  * QTOS/utils.py:107-148; producer build/traj.csv).  rows_out is B x n_rows x 37, row k is at

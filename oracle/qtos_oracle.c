@@ -913,6 +913,7 @@ void qo_default_options(qo_options *o) {
   o->delta_x = 1e-2;
   o->eps_dual = 1e-8;
   o->slack_push = 0.2;
+  o->warm_slack_push = 0.01;
   o->stall_iters = 5;
   o->hold_from = 2;
   o->hold_weight = 1e6;
@@ -1111,7 +1112,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
      * bound_frac).  A cold start uses a LARGE push (o->slack_push, 0.2): the first Newton steps are
      * then not cut by the fraction-to-the-boundary rule (4 iterations instead of 4-6 on the
      * benchmark goals); a warm start keeps Ipopt's 0.01 so that a feasible point stays put. */
-    const double kp = o->warm_start ? 0.01 : o->slack_push;
+    const double kp = o->warm_start ? (o->warm_slack_push > 0 ? o->warm_slack_push : 0.01) : o->slack_push;
     double pl = hl ? kp * fmax(1.0, fabs(l)) : 0, pu = hu ? kp * fmax(1.0, fabs(u)) : 0;
     if (hl && hu) { pl = fmin(pl, kp * (u - l)); pu = fmin(pu, kp * (u - l)); }
     double si = g[r];

@@ -96,6 +96,7 @@ typedef struct {
   double delta_x;      /* proximal weight (W = delta I)                        */
   double eps_dual;     /* quasi-definite regularisation on the equality block  */
   double slack_push;   /* cold-start slack push as a fraction of the bound range */
+  double warm_slack_push; /* the same when warm_start is set (Ipopt's 0.01) */
   int warm_start;      /* 1: x_io holds the starting point                     */
   int verbose;
   int stall_iters;     /* stop (status 1, best iterate returned) after this many iterations

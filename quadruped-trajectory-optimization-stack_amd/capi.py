@@ -27,7 +27,7 @@ class QtosParams(C.Structure):
         ("honor_start_velocity", C.c_int), ("terrain_mode", C.c_int),
         ("max_iter", C.c_int),
         ("tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
-        ("delta_x", C.c_double), ("eps_dual", C.c_double), ("slack_push", C.c_double),
+        ("delta_x", C.c_double), ("eps_dual", C.c_double), ("slack_push", C.c_double), ("warm_slack_push", C.c_double),
         ("stall_iters", C.c_int), ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double),
     ]
 
@@ -53,7 +53,7 @@ EXPORTS = [
     "qtos_set_heightfields", "qtos_plan_batch", "qtos_plan_batch_device", "qtos_sample_csv",
     "qtos_sample_csv_device", "qtos_last_timing", "qtos_debug_eval", "qtos_debug_newton",
     "qtos_debug_structure", "qtos_debug_trace", "qtos_debug_factor", "qtos_analyze",
-    "qtos_set_init_table", "qtos_debug_initial_guess",
+    "qtos_set_init_table", "qtos_debug_initial_guess", "qtos_shift_warm", "qtos_shift_warm_device",
 ]
 
 _lib = None
@@ -103,6 +103,8 @@ def load():
     lib.qtos_analyze.argtypes = [C.POINTER(QtosParams), C.POINTER(QtosDims), ip, C.c_int]
     lib.qtos_set_init_table.argtypes = [vp, C.c_int, dp, C.c_int, dp, dp]
     lib.qtos_debug_initial_guess.argtypes = [vp, C.c_int, dp, dp, ip, dp]
+    lib.qtos_shift_warm.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, dp]
+    lib.qtos_shift_warm_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -139,6 +141,7 @@ def params_from_config(cfg):
     p.max_iter, p.tol = cfg.max_iter, cfg.tol
     p.mu_init, p.mu_min, p.delta_x, p.eps_dual = cfg.mu_init, cfg.mu_min, cfg.delta_x, cfg.eps_dual
     p.slack_push = cfg.slack_push
+    p.warm_slack_push = cfg.warm_slack_push
     p.stall_iters = cfg.stall_iters
     p.hold_from, p.hold_weight, p.hold_tol = cfg.foothold_hold_from, cfg.foothold_hold_weight, cfg.foothold_hold_tol
     return p
@@ -223,6 +226,18 @@ class Planner:
         rows = np.empty((B, n_rows, CSV_COLS))
         self._chk(self.lib.qtos_sample_csv(self.h, B, _dp(nodes), _dp(t0), hz, n_rows, _dp(rows)), "sample_csv")
         return rows
+
+    def shift_warm(self, nodes_prev, offset, start, goal, map_id=None):
+        """Time-shifted warm start of a replan (qtos_shift_warm): previous plan read `offset` seconds later."""
+        nodes_prev = np.ascontiguousarray(nodes_prev, np.float64).reshape(-1, self.n)
+        B = nodes_prev.shape[0]
+        off = np.ascontiguousarray(np.broadcast_to(np.asarray(offset, np.float64), (B,)))
+        start = np.ascontiguousarray(start, np.float64).reshape(B, START_DOUBLES)
+        goal = np.ascontiguousarray(goal, np.float64).reshape(B, 3)
+        mid = None if map_id is None else np.ascontiguousarray(map_id, np.int32)
+        out = np.empty((B, self.n))
+        self._chk(self.lib.qtos_shift_warm(self.h, B, _dp(nodes_prev), _dp(off), _dp(start), _dp(goal), _ip(mid), _dp(out)), "shift_warm")
+        return out
 
     # ---- optional: nominal-plan table for the starting point of cold solves ----
     def set_init_table(self, dx=None, dy=None, nodes=None):

@@ -82,6 +82,7 @@ class PlannerConfig:
     delta_x: float = 1e-2
     eps_dual: float = 1e-8
     slack_push: float = 0.2            # cold-start slack push (fraction of the bound range)
+    warm_slack_push: float = 0.01      # slack push of a solve started from given nodes (Ipopt's bound_push)
     stall_iters: int = 5               # stop after this many iterations without a new lowest violation (0 = off)
     # Two-phase solve: the first Newton iterations place the feet; once an iterate (number >=
     # `foothold_hold_from`) has a constraint violation <= `foothold_hold_tol`, the stance footholds are

@@ -76,9 +76,10 @@ struct DevPlan {
   const double *con_lo, *con_hi;
   const int *row_kind;
   const InitDesc *init;
+  const double *var_time;      // node time of every variable (k_shift_warm)
   double mass, gravity, Ib[9], mu_fric, f_max, T;
   double nominal[NEE][3];
-  double tol, mu_init, mu_min, delta_x, eps_dual, slack_push;
+  double tol, mu_init, mu_min, delta_x, eps_dual, slack_push, warm_slack_push;
   int max_iter, stall_iters;
   const double *height;
   int n_maps, hnx, hny, terrain_mode;
@@ -654,6 +655,7 @@ __device__ inline double table_value(const DevPlan &P, const TableCell &c, int v
   const double d = P.table[((size_t)c.j1 * P.tab_ndx + c.i0) * n + v], e = P.table[((size_t)c.j1 * P.tab_ndx + c.i1) * n + v];
   return (1.0 - c.wy) * ((1.0 - c.wx) * a + c.wx * b) + c.wy * ((1.0 - c.wx) * d + c.wx * e);
 }
+__device__ inline double straight_line_value(const DevPlan &P, const InitDesc &I, const double *st, const double *gl, int map);
 __device__ inline double initial_value(const DevPlan &P, const DevWork &W, int b, int v, const double *st, const double *gl,
                                        int map, const TableCell &tc) {
   const InitDesc I = P.init[v];
@@ -668,7 +670,10 @@ __device__ inline double initial_value(const DevPlan &P, const DevWork &W, int b
     }
     return val;
   }
-  // towr's straight-line guess (nlp_formulation.cc Make*Variables)
+  return straight_line_value(P, I, st, gl, map);
+}
+// towr's straight-line guess (nlp_formulation.cc Make*Variables)
+__device__ inline double straight_line_value(const DevPlan &P, const InitDesc &I, const double *st, const double *gl, int map) {
   const double fin[3] = {gl[0], gl[1], terrain_at(P, map, gl[0], gl[1]).h - P.nominal[0][2]};
   double a, e;
   if (I.set == 0) { a = st[I.dim]; e = fin[I.dim]; }
@@ -709,7 +714,7 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     if (P.row_kind[r] != 2) { s[r] = 0; zl[r] = 0; zu[r] = 0; continue; }
     const double l = P.con_lo[r], u = P.con_hi[r];
     const bool hl = l > -1e19, hu = u < 1e19;
-    const double kp = (W.warm || P.table) ? 0.01 : P.slack_push;   // large push on cold starts, Ipopt's 0.01 on warm starts (a table guess is one)
+    const double kp = (W.warm || P.table) ? P.warm_slack_push : P.slack_push;   // large push on cold starts, Ipopt's 0.01 on warm starts (a table guess is one)
     double pl = hl ? kp * fmax(1.0, fabs(l)) : 0.0, pu = hu ? kp * fmax(1.0, fabs(u)) : 0.0;
     if (hl && hu) { pl = fmin(pl, kp * (u - l)); pu = fmin(pu, kp * (u - l)); }
     double si = g[r];

@@ -210,6 +210,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(S.iq_blocks, &D.iq_blocks)); TRY(p->upload(S.iq_slots, &D.iq_slots));
   TRY(p->upload(M.con_lo, &D.con_lo)); TRY(p->upload(M.con_hi, &D.con_hi));
   TRY(p->upload(M.row_kind, &D.row_kind)); TRY(p->upload(M.init, &D.init));
+  TRY(p->upload(M.var_time, &D.var_time));
   D.max_stage_g = S.max_stage_g;
   TRY(p->upload(S.srec, &D.srec)); TRY(p->upload(S.srec_off, &D.srec_off));
   TRY(p->upload(S.pack_src, &D.pack_src)); TRY(p->upload(S.drec_off, &D.drec_off));
@@ -223,6 +224,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.tol = M.P.tol; D.mu_init = M.P.mu_init; D.mu_min = M.P.mu_min; D.delta_x = M.P.delta_x;
   D.eps_dual = M.P.eps_dual; D.max_iter = M.P.max_iter; D.stall_iters = M.P.stall_iters;
   D.slack_push = M.P.slack_push > 0 ? M.P.slack_push : 0.01;
+  D.warm_slack_push = M.P.warm_slack_push > 0 ? M.P.warm_slack_push : 0.01;
   D.terrain_mode = M.P.terrain_mode;
   D.g_doubles = S.g_doubles;
   D.panel_stride = (long long)S.n_stages * (S.front + 1) * PIV;
@@ -483,6 +485,69 @@ int qtos_sample_csv(QtosPlanner *p, int B, const double *nodes, const double *t0
     if (e != hipSuccess) rc = -2;
   }
   (void)hipFree(d_nodes); (void)hipFree(d_t0); (void)hipFree(d_rows);
+  return rc;
+}
+
+// ---- time-shifted warm start (receding-horizon replans) ---------------------------------------------
+// Every variable of the new plan sits at a node time t; where the previous plan still covers offset + t its
+// spline is evaluated there (positions / velocities / forces in the common world frame), beyond its horizon
+// the straight-line guess of the new problem takes over; fixed variables carry the new start / goal.
+__global__ __launch_bounds__(256) void k_shift_warm(DevPlan P, SamplePlan S, const double *prev, const double *offset,
+                                                    const double *start, const double *goal, const int *map_id, double *out, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const double *x = prev + (size_t)b * P.n_vars, *st = start + (size_t)b * QTOS_START_DOUBLES, *gl = goal + (size_t)b * 3;
+  const int map = map_id ? map_id[b] : 0;
+  const double off = offset[b];
+  for (int v = threadIdx.x; v < P.n_vars; v += blockDim.x) {
+    const InitDesc I = P.init[v];
+    double val;
+    if (I.fix_src >= 0) val = I.fix_src < 24 ? st[I.fix_src] : (I.fix_src < 26 ? gl[I.fix_src - 24] : 0.0);
+    else {
+      const double t = off + P.var_time[v];
+      if (t <= S.T + 1e-9) {
+        const SampleSpline &sp = I.set == 0 ? S.lin : (I.set == 1 ? S.ang : (I.set < 6 ? S.eem[I.set - 2] : S.eef[I.set - 6]));
+        double o3[3];
+        sample_spline(sp, x, fmin(t, S.T), I.is_vel, o3);
+        val = o3[I.dim];
+      } else val = straight_line_value(P, I, st, gl, map);
+    }
+    out[(size_t)b * P.n_vars + v] = val;
+  }
+}
+
+int qtos_shift_warm_device(QtosPlanner *p, int B, const double *d_nodes_prev, const double *d_offset, const double *d_start,
+                           const double *d_goal, const int *d_map_id, double *d_warm_out, void *stream_) {
+  if (!p || B < 1 || !d_nodes_prev || !d_offset || !d_start || !d_goal || !d_warm_out) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  hipLaunchKernelGGL(k_shift_warm, dim3(B), dim3(256), 0, (hipStream_t)stream_, p->dp, p->sp, d_nodes_prev, d_offset, d_start, d_goal,
+                     d_map_id, d_warm_out, B);
+  HIPCHK(p, hipGetLastError());
+  return 0;
+}
+
+int qtos_shift_warm(QtosPlanner *p, int B, const double *nodes_prev, const double *offset, const double *start, const double *goal,
+                    const int *map_id, double *warm_out) {
+  if (!p || B < 1 || B > p->max_batch || !nodes_prev || !offset || !start || !goal || !warm_out) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  const size_t n = p->M.n_vars;
+  hipStream_t st = p->own_stream;
+  double *d_off = nullptr;
+  HIPCHK(p, hipMalloc((void **)&d_off, B * sizeof(double)));
+  hipError_t e = hipSuccess;
+  auto cp = [&](void *dst, const void *src, size_t bytes, hipMemcpyKind k) { if (e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, k, st); };
+  cp(p->d_nodes, nodes_prev, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice);
+  cp(d_off, offset, B * sizeof(double), hipMemcpyHostToDevice);
+  cp(p->d_start, start, (size_t)B * QTOS_START_DOUBLES * sizeof(double), hipMemcpyHostToDevice);
+  cp(p->d_goal, goal, (size_t)B * 3 * sizeof(double), hipMemcpyHostToDevice);
+  if (map_id) cp(p->d_map, map_id, B * sizeof(int), hipMemcpyHostToDevice);
+  int rc = e == hipSuccess ? qtos_shift_warm_device(p, B, p->d_nodes, d_off, p->d_start, p->d_goal, map_id ? p->d_map : nullptr, p->d_warm, (void *)st) : -2;
+  if (!rc) {
+    cp(warm_out, p->d_warm, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = -2;
+  }
+  (void)hipFree(d_off);
   return rc;
 }
 

@@ -464,6 +464,75 @@ def test_replan_loop_stitches_two_plans(gv1):
     lp.close()
 
 
+def test_replan_loop_state_machine_follows_the_reference_update_thread():
+    """scripts/main.py:_run/_update as qtos_amd.replan.ReplanLoop on exp_1 (flat, goal x = 2.5): plan, wait for f_steps
+    rows, stitch, plan ... with Global_Planner.pop() feeding the goals; the stitched plan is one seamless 1 kHz
+    trajectory.  The time-shifted warm start (qtos_shift_warm) is an option of the loop: same statuses, and its
+    iteration count is recorded next to the cold start's (replan.py: it does not pay on this NLP)."""
+    from qtos_amd.global_planner import GlobalPlanner
+    from qtos_amd.planner import LocalPlanner
+    from qtos_amd.replan import ReplanLoop
+    gp = GlobalPlanner(np.zeros((20, 40)), [0, 0, 0.24], [2.5, 0, 0.24], step_size=1.0, resolution=0.1, lookahead=3750)
+    lp = LocalPlanner(max_batch=2)
+    loop = ReplanLoop(lp, gp, {"-resolution": 0.1}, lookahead=3750, f_steps=2500)
+    plan = loop.run(max_plans=4)
+    kinds = [e[0] for e in loop.events]
+    assert kinds[:7] == ["plan", "plan", "stitch", "plan", "stitch", "plan", "stitch"][:len(kinds[:7])] and kinds.count("plan") == 4
+    assert all(s == 0 for s in loop.statuses)
+    # goals come from the global planner (the logged -g of the reference's first two solves: logs/towr_log.out:8,140)
+    assert abs(loop.events[0][1]) < 1e-12
+    t = plan[:, 0]
+    assert np.all(np.diff(t) > 0) and abs(np.diff(t).max() - 0.001) < 1e-9            # seamless time base
+    assert np.abs(np.diff(plan[:, 1:19], axis=0)).max() < 5e-3                           # positions continuous over the splices
+    # second plan started lookahead rows ahead of the clock it was asked at, on an all-feet-down row
+    assert loop.st.legs_in_contact({k: v for k, v in zip(("FL_FOOT", "FR_FOOT", "HL_FOOT", "HR_FOOT"), np.round(loop.new[0, 7:19], 6).reshape(4, 3).tolist())})
+    cold_iters = int(lp.last["iters"][0])
+    # the same loop with the time-shifted previous plan as starting point
+    gp2 = GlobalPlanner(np.zeros((20, 40)), [0, 0, 0.24], [2.5, 0, 0.24], step_size=1.0, resolution=0.1, lookahead=3750)
+    loop2 = ReplanLoop(lp, gp2, {"-resolution": 0.1}, lookahead=3750, f_steps=2500, shifted_warm_start=True)
+    loop2.run(max_plans=4)
+    assert [e[0] for e in loop2.events] == kinds and all(s == 0 for s in loop2.statuses)
+    print("last replan: %d iterations cold, %d from the shifted plan" % (cold_iters, int(lp.last["iters"][0])))
+    lp.close()
+
+
+def test_shifted_windows_match_oracle_over_five_replans():
+    """BASELINE configs[4] loop (qtos_amd.replan.ShiftedWindows, bench.py --workload mpc_random): five consecutive
+    replans of four windows on randomized heightfields; every replan starts from an all-feet-down hand-over row of
+    the previous plan -- cold for the first three replans (the loop's default), from the time-shifted previous plan
+    (qtos_shift_warm) for the last two.  The oracle solves the same problems from the same starting points: same
+    statuses, iteration counts and nodes."""
+    import torch
+    from oracle.oracle import Oracle
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    from qtos_amd.replan import ShiftedWindows
+    cfg = PlannerConfig.knots200()
+    maps, cell = workloads.random_terrains()
+    P = Planner(cfg, max_batch=4)
+    P.set_heightfields(maps, cell)
+    start, goal, map_id = workloads.mpc_goals(4, seed=5, terrains=(maps, cell))
+    W = ShiftedWindows(P, start, goal - start[:, 0:3], map_id, advance=2.5)
+    oracles = [Oracle(cfg.oracle_dict(), height=maps[m], hcell=cell) for m in map_id]
+    for k in range(6):
+        W.warm_mode = "shifted" if k >= 4 else "none"
+        nodes, status = W.replan()
+        torch.cuda.synchronize()
+        st, gl = W.start.cpu().numpy(), W.goal.cpu().numpy()
+        warm = W.warm.cpu().numpy() if k >= 4 else [None] * 4
+        it = W.iters.cpu().numpy()
+        if k > 0:   # hand-over rows: all four feet carry force, a few hundred rows after `advance`
+            assert (W.offset.cpu().numpy() >= 2.5).all() and (W.offset.cpu().numpy() <= 2.9).all()
+        for b in range(4):
+            O = oracles[b]
+            q = O.problem(st[b, 0:3], st[b, 3:6], st[b, 6:18].reshape(4, 3), gl[b])
+            xo, info = O.solve(q, x0=warm[b])
+            assert info.status == int(status[b]) == 0 and info.iters == int(it[b])
+            assert np.abs(nodes[b].cpu().numpy() - xo).max() < 1e-6
+    P.close()
+
+
 def test_mixed_terrain_batch_with_map_ids(cfg):
     """BASELINE configs[3] (single-GPU shard of it): exp_1 / exp_3 / exp_5 patches in one batch, a
     heightfield index per problem; every converged plan is feasible on ITS OWN terrain."""
