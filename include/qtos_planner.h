@@ -120,8 +120,12 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
                     const int *map_id, const double *warm, double *nodes_out, int *status_out,
                     int *iters_out, double *viol_out);
 
-/* Same, all pointers in device memory of the planner's device, asynchronous on `stream`
- * (a hipStream_t passed as void*, NULL = default stream).  This is the form bench.py times. */
+/* Same, all pointers in device memory of the planner's device, work queued on `stream` (a hipStream_t passed
+ * as void*, NULL = default stream).  The call returns when the last Newton iteration has been queued: the host
+ * reads the number of unfinished problems back before it queues an iteration (it spins on an event meanwhile),
+ * so it is busy for about the duration of the solve; the copies into the output buffers are still in flight on
+ * `stream` at return.  One planner handle serves one call at a time; different handles / streams are independent.
+ * This is the form bench.py times. */
 int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
                            const int *d_map_id, const double *d_warm, double *d_nodes_out,
                            int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream);

@@ -103,8 +103,9 @@ def load():
     lib.qtos_analyze.argtypes = [C.POINTER(QtosParams), C.POINTER(QtosDims), ip, C.c_int]
     lib.qtos_set_init_table.argtypes = [vp, C.c_int, dp, C.c_int, dp, dp]
     lib.qtos_debug_initial_guess.argtypes = [vp, C.c_int, dp, dp, ip, dp]
-    lib.qtos_shift_warm.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, dp]
-    lib.qtos_shift_warm_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    if hasattr(lib, "qtos_shift_warm"):   # (absent from older builds loaded through QTOS_LIB for A/B timing)
+        lib.qtos_shift_warm.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, dp]
+        lib.qtos_shift_warm_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
 

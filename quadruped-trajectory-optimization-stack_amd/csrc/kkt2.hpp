@@ -77,12 +77,21 @@ struct Kkt2Layout {
   static constexpr int PB = MIV + PIV * PLD;             // 3 panels of (F+1) x PLD
   static constexpr int VAR = (PB + 3 * PSZ + 1) & ~1;    // dbuf, then (ints) sbuf, hiall, then the cells A
 };
+// record buffers: a front of up to 128 slots has two of them, filled by LDS-DMA (1 KB per wave instruction: sizes
+// in 1 KB granules); larger fronts have one, filled through prefetch registers
+__host__ __device__ inline size_t kkt2_dbuf_doubles(int F, int max_drec) {
+  return F <= 128 ? (((size_t)max_drec * 8 + 1023) & ~(size_t)1023) / 8 : (((size_t)max_drec + 1) & ~(size_t)1);
+}
+__host__ __device__ inline size_t kkt2_sbuf_ints(int F, int max_srec) {
+  return F <= 128 ? (((size_t)max_srec * 4 + 1023) & ~(size_t)1023) / 4 : (((size_t)max_srec + 3) & ~(size_t)3);
+}
 inline size_t kkt2_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells, int max_part_con) {
   const int FR = (F + 63) & ~63, PSZ = (F + 1) * PLD;
   const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 2 * (size_t)FR + 2 * 16 * PIV + 64 + 3 * PIV / 2 + 2 + FR + 8 + PIV * PLD;
   size_t o = (fixed + 3 * (size_t)PSZ + 1) & ~(size_t)1;
-  o += ((size_t)max_drec + 1) & ~(size_t)1;
-  size_t oi = 2 * o + (((size_t)max_srec + 3) & ~(size_t)3) + ((((size_t)NS + 1) + 3) & ~(size_t)3);
+  const size_t nbuf = F <= 128 ? 2 : 1;
+  o += nbuf * kkt2_dbuf_doubles(F, max_drec);
+  size_t oi = 2 * o + nbuf * kkt2_sbuf_ints(F, max_srec) + ((((size_t)NS + 1) + 3) & ~(size_t)3);
   oi += 2 * (((size_t)n_cells + 1) & ~(size_t)1);
 #ifdef QTOS_ASM_PARTS
   oi += 2 * 16 * (size_t)max_part_con;
@@ -183,8 +192,14 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   int *psb = (int *)(lds + LY::PSB), *hib = (int *)(lds + LY::HIB), *jm = (int *)(lds + LY::JM);
   unsigned *pm = (unsigned *)(lds + LY::PM);
   double *Minv = lds + LY::MIV;
-  int *sbuf = (int *)(dbuf + ((P.max_drec + 1) & ~1));
-  int *hiall = sbuf + ((P.max_srec + 3) & ~3);
+  // record buffers: [dbuf 0][dbuf 1][sbuf 0][sbuf 1] with DMA (record s lives in buffer s & 1), one of each without
+  constexpr bool DMA = F <= 128;
+  constexpr int NBUF = DMA ? 2 : 1;
+  const int dstride = (int)kkt2_dbuf_doubles(F, P.max_drec), sstride = (int)kkt2_sbuf_ints(F, P.max_srec);
+  double *const dbuf0 = dbuf;
+  int *const sbuf0 = (int *)(dbuf + NBUF * dstride);
+  int *sbuf = sbuf0;
+  int *hiall = sbuf0 + NBUF * sstride;
   double *A = (double *)(hiall + ((NS + 4) & ~3));   // cells of the assembled entries
 #ifdef QTOS_ASM_PARTS
   double *scr0 = A + ((P.n_cells + 1) & ~1);   // assembly scratch: max_part_con doubles per part
@@ -286,6 +301,10 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
 
   // ---- prologue: assemble stages 0 and 1, gather and factor the pivot block of stage 0, leave the
   //      records of stage 2 in LDS ----------------------------------------------------------------
+  auto point_buffers = [&](int s) __attribute__((always_inline)) {   // the buffer that holds the records of stage s
+    if constexpr (DMA) { dbuf = dbuf0 + (s & 1) * dstride; sbuf = sbuf0 + (s & 1) * sstride; }
+  };
+  point_buffers(0);
   load_records(0);
   __syncthreads();
   header_from_lds(0);
@@ -312,6 +331,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     if (wv == 0) factor_block(P0, ps0[li], Lib, dvb);
   }
   for (int s = 1; s < 3 && s < NS; ++s) {
+    point_buffers(s);
     load_records(s);
     __syncthreads();
     header_from_lds(s);
@@ -358,7 +378,8 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     // (rank of a wave = how early it can spare the time: header wave, the waves without Schur tiles, update
     //  waves oldest first, factor wave last; high ranks lie behind the end of most records and skip the loads)
     const int pidx = (int)((0xEDC0BA928761543Full >> (4 * wv)) & 15u) * 64 + lane;
-    if (k >= 1 && k + 2 < NS) {
+    point_buffers(k + 2);      // (with LDS-DMA the records of stage k+2 landed during the previous stage: nothing to install)
+    if (!DMA && k >= 1 && k + 2 < NS) {
       const int wbase = __builtin_amdgcn_readfirstlane(pidx);
       if (wbase < pf_nd2) ((d2_t *)dbuf)[min(pidx, pf_nd2)] = pfd;
       if (wbase < pf_ns4) ((i4_t *)sbuf)[min(pidx, pf_ns4)] = pfs0;
@@ -496,7 +517,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     // its urgent work of the phase is done (48 KB-wide loads at once keep the CU's memory pipe busy for ~800 cycles);
     // a wave skips the loads that lie wholly behind the record's end
     auto prefetch_records = [&]() __attribute__((always_inline)) {
-      if (k + 3 < NS) {
+      if (!DMA && k + 3 < NS) {
         const int s = k + 3;
         int d0, d1, s0, s1;
         sload2(P.drec_off + s, d0, d1);
@@ -623,6 +644,26 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     if constexpr (CONT) {
       if (k + 2 < NS) assemble_continuations(wv >= 1 ? apos * 64 + lane : -1, 15 * 64);
     }
+    // LDS-DMA of the records of stage k+3 into the other buffer, by the three waves without Schur tiles once
+    // their assembly is done (1 KB per instruction, chunk c of a record by wave c mod 3; wave 12 takes the
+    // chunks with the header it publishes below); the loads are waited for before the phase's barrier
+    if constexpr (DMA) {
+      if (!(wv & 3) && wv != 0 && k + 3 < NS) {
+        const int s = k + 3, wi = wv == 12 ? 0 : wv >> 2;
+        int d0, d1, s0, s1;
+        sload2(P.drec_off + s, d0, d1);
+        sload2(P.srec_off + s, s0, s1);
+        const int nbd = (d1 - d0) * 8, nbs = (s1 - s0) * 4;
+        const char *gd = (const char *)(stream + d0), *gs = (const char *)(P.srec + s0);
+        typedef __attribute__((address_space(3))) char lds_char;
+        lds_char *ld = (lds_char *)(dbuf0 + (s & 1) * dstride), *ls = (lds_char *)(sbuf0 + (s & 1) * sstride);
+        for (int c = wi; c * 1024 < nbd; c += 3)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gd + min(c * 1024 + lane * 16, nbd - 16)), (__attribute__((address_space(3))) void *)(ld + c * 1024), 16, 0, 0);
+        for (int c = wi; c * 1024 < nbs; c += 3)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gs + min(c * 1024 + lane * 16, nbs - 16)), (__attribute__((address_space(3))) void *)(ls + c * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
     if (wv == 12) {
 #ifdef QTOS_PF_LATE
       prefetch_records();
@@ -635,6 +676,18 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
       if (hs < NS) {
         if (lane < 8) pm[(hs & 1) * 8 + lane] = 0u;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (DMA) {   // the header sits in the first chunks, which this wave has just waited for
+          const int *hb = sbuf0 + (hs & 1) * sstride;
+          const double *hdb = dbuf0 + (hs & 1) * dstride;
+          if (lane == 0) { const int hv = hb[3]; hib[hs % 3] = hv; hiall[hs] = (hv + 15) & ~15; }
+          if (lane < PIV) {
+            const int hv = hb[SHDR + lane];
+            dgb[(hs % 3) * PIV + lane] = hdb[lane];
+            psb[(hs % 3) * PIV + lane] = hv;
+            jm[(hs & 1) * FR + hv] = lane;
+            atomicOr(&pm[(hs & 1) * 8 + (hv >> 5)], 1u << (hv & 31));
+          }
+        } else {
         if (lane == 0) { hib[hs % 3] = pfs0[3]; hiall[hs] = (pfs0[3] + 15) & ~15; }
         if (lane < 8) { dgb[(hs % 3) * PIV + 2 * lane] = pfd[0]; dgb[(hs % 3) * PIV + 2 * lane + 1] = pfd[1]; }
         if (lane >= 2 && lane < 6) {
@@ -645,6 +698,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
             jm[(hs & 1) * FR + hv] = jidx;
             atomicOr(&pm[(hs & 1) * 8 + (hv >> 5)], 1u << (hv & 31));
           }
+        }
         }
       }
     }
