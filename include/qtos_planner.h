@@ -51,6 +51,10 @@ typedef struct QtosParams {
                         get the proximal weight hold_weight instead of delta_x): the first iterations
                         place the feet, the rest of the solve is a fixed-foothold problem; 0 = never */
   double hold_weight, hold_tol;
+  double chord_tol;  /* an iterate with violation <= chord_tol that was reached by a full step (alpha = 1) of a
+                        freshly factored KKT system is followed by ONE chord step: the stored factorisation is
+                        reused with the right-hand side of the new iterate (k_chord: forward + backward sweep over
+                        the factor panels, about a fifth of a factorisation); 0 = every iteration factors */
 } QtosParams;
 
 typedef struct QtosDims {
@@ -155,6 +159,8 @@ int qtos_sample_csv_device(QtosPlanner *p, int B, const double *d_nodes, const d
  * KKT launches.  Used by bench.py for the roofline figure. */
 int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, double *total_seconds,
                      int *iterations);
+/* The same for the chord-step launches (k_chord, QtosParams.chord_tol) of the last call. */
+int qtos_last_timing_chord(QtosPlanner *p, double *chord_seconds, int *chord_launches);
 
 /* ---- introspection for the parity tests (host pointers) ------------------------------------ */
 /* constraint values (B x n_cons) and, if J_out != NULL, the dense Jacobian (B x n_cons x n_vars,
@@ -167,6 +173,9 @@ int qtos_debug_eval(QtosPlanner *p, int B, const double *start, const double *go
 int qtos_debug_newton(QtosPlanner *p, int B, const double *start, const double *goal,
                       const int *map_id, const double *nodes, const double *sig, const double *w,
                       double *dx_out);
+/* the same system once more through the chord-step kernel: the factorisation the preceding qtos_debug_newton
+ * call left on the device + the right-hand side in elimination order (parity of k_chord with k_kkt2) */
+int qtos_debug_chord(QtosPlanner *p, int B, double *dx_out);
 /* working-set description: row_kind[n_cons] (0 dropped, 1 equality, 2 inequality),
  * var_free[n_vars] (0/1), unknown order[n_unknowns] (var index, or n_vars + row for multipliers) */
 int qtos_debug_structure(const QtosPlanner *p, int *row_kind, int *var_free, int *order);

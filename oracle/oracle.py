@@ -57,7 +57,7 @@ class QoOptions(C.Structure):
         ("max_iter", C.c_int), ("tol", C.c_double), ("mu_init", C.c_double),
         ("mu_min", C.c_double), ("delta_x", C.c_double), ("eps_dual", C.c_double), ("slack_push", C.c_double), ("warm_slack_push", C.c_double),
         ("warm_start", C.c_int), ("verbose", C.c_int), ("stall_iters", C.c_int),
-        ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double),
+        ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double), ("chord_tol", C.c_double),
     ]
 
 

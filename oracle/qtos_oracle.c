@@ -914,6 +914,7 @@ void qo_default_options(qo_options *o) {
   o->eps_dual = 1e-8;
   o->slack_push = 0.2;
   o->warm_slack_push = 0.01;
+  o->chord_tol = 1e-3;
   o->stall_iters = 5;
   o->hold_from = 2;
   o->hold_weight = 1e6;
@@ -1136,6 +1137,8 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
   double best_viol = INFINITY;
   int best_it = 0;
   double *xbest = (double *)malloc(sizeof(double) * n);
+  int chord_ok = 0;      /* the last step was a full step (alpha = 1) of a freshly factored system */
+  int n_chord = 0;
   for (it = 0; it < o->max_iter; ++it) {
     double theta = 0;
     viol = 0;
@@ -1158,13 +1161,17 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     eval_all(p, M, x, NULL, J);
     t_eval += now_s() - t0;
     t0 = now_s();
-    memset(K.a, 0, sizeof(double) * K.start[N]);
+    const int chord = o->chord_tol > 0 && chord_ok && viol <= o->chord_tol;
+    chord_ok = 0;
+    n_chord += chord;
+    if (!chord) memset(K.a, 0, sizeof(double) * K.start[N]);
     memset(rhs, 0, sizeof(double) * N);
+    if (!chord)
     for (int i = 0; i < n; ++i)
       if (vpos[i] >= 0) *sky_at(&K, vpos[i], vpos[i]) = o->delta_x;
     /* two-phase solve: once the first iterations have placed the feet, the stance footholds stay */
     if (o->hold_from > 0 && it >= o->hold_from && viol <= o->hold_tol) held = 1;
-    if (held)
+    if (held && !chord)
       for (int e = 0; e < QO_NEE; ++e)
         for (int sn = 0; sn < M->n_stance[e]; ++sn)
           for (int d = 0; d < 2; ++d) {
@@ -1186,7 +1193,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
         int ca = ci[a], pa = vpos[ca];
         double ja = Jr[ca];
         rhs[pa] -= ja * w;
-        for (int b = rp[r]; b < rp[r + 1]; ++b) {
+        if (!chord) for (int b = rp[r]; b < rp[r + 1]; ++b) {
           int pb = vpos[ci[b]];
           if (pb <= pa) *sky_at(&K, pa, pb) += sg * ja * Jr[ci[b]];
         }
@@ -1195,15 +1202,16 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     for (int e = 0; e < nE; ++e) {
       int r = Er[e], pe = epos[e];
       const double *Jr = J + (size_t)r * n;
-      *sky_at(&K, pe, pe) = -o->eps_dual;
       rhs[pe] = -g[r];
+      if (chord) continue;
+      *sky_at(&K, pe, pe) = -o->eps_dual;
       for (int a = rp[r]; a < rp[r + 1]; ++a) {
         int pv = vpos[ci[a]];
         if (pv < pe) *sky_at(&K, pe, pv) += Jr[ci[a]];
         else *sky_at(&K, pv, pe) += Jr[ci[a]];
       }
     }
-    if (sky_factor(&K)) { status = 2; break; }
+    if (!chord && sky_factor(&K)) { status = 2; break; }
     sky_solve(&K, rhs);
     t_fac += now_s() - t0;
     for (int i = 0; i < n; ++i) dx[i] = vpos[i] >= 0 ? rhs[vpos[i]] : 0.0;
@@ -1241,7 +1249,16 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
       if (th <= (1 - 1e-4 * al) * th0 || th < 1e-9) break;
       if (ls < 5) al *= 0.5;
     }
-    if (o->verbose) fprintf(stderr, "oracle:    amax %.3f alpha %.4f az %.3f ls %d th %.3e -> %.3e\n", amax, al, az, ls, th0, th);
+    if (o->verbose) fprintf(stderr, "oracle:    amax %.3f alpha %.4f az %.3f ls %d th %.3e -> %.3e%s\n", amax, al, az, ls, th0, th, chord ? (al == 1.0 ? " (chord)" : " (chord, rejected)") : "");
+    /* a chord step is taken whole or not at all: cut by the fraction-to-the-boundary rule or by the line search
+     * it is discarded (the iterate stays, the next iteration factors) -- a damped chord step can park a slack
+     * right on its bound, and the KKT matrix of that point is too badly scaled for the block elimination */
+    if (chord && al != 1.0) {
+      al = 0.0;
+      az = 0.0;
+      memcpy(xt, x, sizeof(double) * n);
+      memcpy(gt, g, sizeof(double) * m);
+    }
     memcpy(x, xt, sizeof(double) * n);
     memcpy(g, gt, sizeof(double) * m);
     for (int i = 0; i < nI; ++i) {
@@ -1256,6 +1273,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
       if (hu) zu[i] = fmin(fmax(zu[i], mu / (kap * (u - s[i]))), kap * mu / (u - s[i]));
     }
     if (al > 0.3) mu = fmax(o->mu_min, 0.2 * mu);
+    chord_ok = !chord && al == 1.0;
   }
   info->status = status;
   info->iters = it;

@@ -105,6 +105,9 @@ typedef struct {
                           footholds (x, y) carry the proximal weight hold_weight instead of
                           delta_x for the rest of the solve; 0 = never              */
   double hold_weight, hold_tol;
+  double chord_tol;    /* an iterate with violation <= chord_tol that was reached by a full step of a freshly
+                          factored system is followed by ONE chord step: the same factorisation, the right-hand
+                          side of the new iterate; 0 = every iteration factors */
 } qo_options;
 
 typedef struct {

@@ -29,6 +29,7 @@ class QtosParams(C.Structure):
         ("tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
         ("delta_x", C.c_double), ("eps_dual", C.c_double), ("slack_push", C.c_double), ("warm_slack_push", C.c_double),
         ("stall_iters", C.c_int), ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double),
+        ("chord_tol", C.c_double),
     ]
 
 
@@ -54,6 +55,7 @@ EXPORTS = [
     "qtos_sample_csv_device", "qtos_last_timing", "qtos_debug_eval", "qtos_debug_newton",
     "qtos_debug_structure", "qtos_debug_trace", "qtos_debug_factor", "qtos_analyze",
     "qtos_set_init_table", "qtos_debug_initial_guess", "qtos_shift_warm", "qtos_shift_warm_device",
+    "qtos_last_timing_chord", "qtos_debug_chord",
 ]
 
 _lib = None
@@ -103,6 +105,9 @@ def load():
     lib.qtos_analyze.argtypes = [C.POINTER(QtosParams), C.POINTER(QtosDims), ip, C.c_int]
     lib.qtos_set_init_table.argtypes = [vp, C.c_int, dp, C.c_int, dp, dp]
     lib.qtos_debug_initial_guess.argtypes = [vp, C.c_int, dp, dp, ip, dp]
+    if hasattr(lib, "qtos_last_timing_chord"):
+        lib.qtos_last_timing_chord.argtypes = [vp, dp, ip]
+        lib.qtos_debug_chord.argtypes = [vp, C.c_int, dp]
     if hasattr(lib, "qtos_shift_warm"):   # (absent from older builds loaded through QTOS_LIB for A/B timing)
         lib.qtos_shift_warm.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, dp]
         lib.qtos_shift_warm_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
@@ -145,6 +150,7 @@ def params_from_config(cfg):
     p.warm_slack_push = cfg.warm_slack_push
     p.stall_iters = cfg.stall_iters
     p.hold_from, p.hold_weight, p.hold_tol = cfg.foothold_hold_from, cfg.foothold_hold_weight, cfg.foothold_hold_tol
+    p.chord_tol = cfg.chord_tol
     return p
 
 
@@ -288,7 +294,12 @@ class Planner:
         k, t = C.c_double(), C.c_double()
         nl, it = C.c_int(), C.c_int()
         self._chk(self.lib.qtos_last_timing(self.h, C.byref(k), C.byref(nl), C.byref(t), C.byref(it)), "last_timing")
-        return dict(kkt_seconds=k.value, kkt_launches=nl.value, total_seconds=t.value, iterations=it.value)
+        out = dict(kkt_seconds=k.value, kkt_launches=nl.value, total_seconds=t.value, iterations=it.value)
+        if hasattr(self.lib, "qtos_last_timing_chord"):
+            c, nc = C.c_double(), C.c_int()
+            self._chk(self.lib.qtos_last_timing_chord(self.h, C.byref(c), C.byref(nc)), "last_timing_chord")
+            out.update(chord_seconds=c.value, chord_launches=nc.value)
+        return out
 
     # ---- introspection (parity tests) ----
     def debug_eval(self, start, goal, nodes, map_id=None, jac=True):
@@ -312,6 +323,12 @@ class Planner:
         dx = np.empty((B, self.n))
         mid = None if map_id is None else np.ascontiguousarray(map_id, np.int32)
         self._chk(self.lib.qtos_debug_newton(self.h, B, _dp(start), _dp(goal), _ip(mid), _dp(nodes), _dp(sig), _dp(w), _dp(dx)), "debug_newton")
+        return dx
+
+    def debug_chord(self, B):
+        """dx of the system of the preceding debug_newton call, solved again by k_chord with the stored factorisation."""
+        dx = np.empty((B, self.n))
+        self._chk(self.lib.qtos_debug_chord(self.h, B, _dp(dx)), "debug_chord")
         return dx
 
     def structure(self):

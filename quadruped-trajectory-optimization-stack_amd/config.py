@@ -94,6 +94,10 @@ class PlannerConfig:
     foothold_hold_from: int = 2
     foothold_hold_weight: float = 1e6
     foothold_hold_tol: float = 0.25
+    # Chord step: an iterate with violation <= chord_tol reached by a full step of a freshly factored KKT system is
+    # followed by one step that reuses that factorisation with the new right-hand side (k_chord).  The flat batch goes
+    # 27 -> 6.5 -> 0.11 -> 5.7e-4 -> (chord) 3.9e-5: three factorisations instead of four.  0 = off.
+    chord_tol: float = 1e-3
     phase_durations: List[List[float]] = field(default=None)
 
     def __post_init__(self):
@@ -135,3 +139,13 @@ class PlannerConfig:
                     gravity=self.gravity, inertia_b=self.inertia_b, max_dev=self.max_deviation,
                     mu=self.friction, f_max=self.force_limit, t_swing_avg=self.t_swing_avg,
                     terrain_mode=self.terrain_mode)
+
+    def oracle_options(self, O):
+        """qo_options of the oracle with this configuration's solver settings (tests only)."""
+        o = O.default_options()
+        o.max_iter, o.tol, o.mu_init, o.mu_min = self.max_iter, self.tol, self.mu_init, self.mu_min
+        o.delta_x, o.eps_dual, o.slack_push, o.warm_slack_push = self.delta_x, self.eps_dual, self.slack_push, self.warm_slack_push
+        o.stall_iters, o.hold_from, o.hold_weight, o.hold_tol = (self.stall_iters, self.foothold_hold_from,
+                                                                 self.foothold_hold_weight, self.foothold_hold_tol)
+        o.chord_tol = self.chord_tol
+        return o

@@ -51,6 +51,12 @@ struct DevPlan {
   const unsigned short *ctab;  // n_stages x (front/16) x 64 x 4: cell of every entry of a stage's pivot columns (Symbolic::ctab)
   int n_cells;                 // cells of the assembled entries: [0] zero, [1 + slot] right-hand side, then the entries
   int max_part_con;            // most contributions in one assembly part (k_kkt2 scratch, Symbolic::max_part_con)
+  // chord step (QtosParams.chord_tol): right-hand side of the KKT system in elimination order, formed by k_step:
+  // unknown p is a multiplier (rhs_ptr[p+1] - rhs_ptr[p] == 1, rhs_gpos < 0: rhs = -g[rhs_row]) or a variable
+  // (rhs = -sum G[rhs_gpos] * w[rhs_row] over the inequality rows that contain it)
+  double chord_tol;
+  int n_unknowns;
+  const int *rhs_ptr, *rhs_gpos, *rhs_row;
   const int *rtab;             // n_stages x 16: cell of the assembled right-hand side of every pivot (k_kkt2, Symbolic::rtab)
   const Block *blocks;
   const int *block_cols;
@@ -95,7 +101,10 @@ struct DevWork {
   double *best_viol, *xbest;   // stall detection: lowest violation seen and the iterate that had it
   int *held;                   // two-phase solve: 1 once the problem's footholds are held
   int *best_it;
-  int *status, *iters, *done, *n_active;
+  int *status, *iters, *done, *n_active;   // n_active[0]: unfinished problems, n_active[1]: of those, flagged for a chord step
+  int *chord;                  // per problem: the next KKT solve reuses the stored factorisation (k_chord)
+  double *rhs;                 // per problem n_unknowns: right-hand side for that solve
+  double *minv;                // per problem n_stages x 256: inverse of every pivot block (written by k_kkt2)
 };
 
 // ---- tiny forward-mode dual (one tangent) for the rotation-dependent Jacobians ---------------
@@ -743,6 +752,7 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     W.best_viol[b] = viol;
     W.best_it[b] = 0;
     W.held[b] = 0;
+    W.chord[b] = 0;
     if (!conv && !bad) atomicAdd(W.n_active, 1);
     record_trace(P, W, b, 0, viol, theta, 0.0, mu);
   }
@@ -1545,6 +1555,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   double mu = W.mu[b];
   const double best_viol = W.best_viol[b];   // read before anybody writes them (tid 0, end of the kernel)
   const int best_it = W.best_it[b];
+  const int was_chord = W.chord[b];          // this iteration's dx came from a chord step
 #ifdef QTOS_STAMPS
   unsigned long long ks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kt0 = 0;
 #define KSTAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ks[i] += t_ - kt0; kt0 = t_; } } while (0)
@@ -1606,9 +1617,16 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     if (ls < 5) al *= 0.5;
   }
   KSTAMP(2);
-  for (int v = tid; v < n; v += blockDim.x) x[v] = xt[v];
+  // a chord step is taken whole or not at all: cut by the fraction-to-the-boundary rule or by the line search it
+  // is discarded (the iterate stays, the next iteration factors): a damped chord step can park a slack right on
+  // its bound, and the KKT matrix of that point is too badly scaled for the block elimination
+  const bool reject = was_chord && al != 1.0;
+  if (reject) { al = 0.0; az = 0.0; th = 0.0; }
+  else {
+    for (int v = tid; v < n; v += blockDim.x) x[v] = xt[v];
 #pragma unroll 4
-  for (int r = tid; r < m; r += blockDim.x) g[r] = gt[r];
+    for (int r = tid; r < m; r += blockDim.x) g[r] = gt[r];
+  }
 #pragma unroll 4
   for (int i = tid; i < P.n_iq; i += blockDim.x) {
     const int r = P.iq_idx[i];
@@ -1650,10 +1668,13 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     if (conv || bad || stalled) {
       W.status[b] = conv ? 0 : (bad ? 2 : 1);
       W.done[b] = 1;
+      W.chord[b] = 0;
       atomicAdd(W.n_active, -1);
     }
   }
   if (conv || bad || stalled) return;
+  // chord step next?  (an iterate this close, reached by a full step of a freshly factored system)
+  const bool next_chord = P.chord_tol > 0 && !was_chord && al == 1.0 && viol <= P.chord_tol;
   // two-phase solve: latch the hold once this iterate is close enough
   const int held = (W.held[b] || (P.hold_from > 0 && it + 1 >= P.hold_from && viol <= P.hold_tol)) ? 1 : 0;
   __syncthreads();
@@ -1664,6 +1685,24 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   KSTAMP(4);
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
   KSTAMP(5);
+  if (tid == 0) {
+    W.chord[b] = next_chord ? 1 : 0;
+    if (next_chord) atomicAdd(W.n_active + 1, 1);
+  }
+  if (next_chord) {
+    // right-hand side of the KKT system at the new iterate, in elimination order, for k_chord
+    __syncthreads();   // the stream and w of this launch are complete
+    const double *__restrict__ Gs = W.stream + (size_t)b * P.stream_len, *__restrict__ wr = W.w + (size_t)b * m;
+    double *__restrict__ rhs = W.rhs + (size_t)b * P.n_unknowns;
+    for (int p = tid; p < P.n_unknowns; p += blockDim.x) {
+      const int t0 = P.rhs_ptr[p], t1 = P.rhs_ptr[p + 1];
+      double acc = 0.0;
+      if (t1 - t0 == 1 && P.rhs_gpos[t0] < 0) acc = -g[P.rhs_row[t0]];
+      else
+        for (int t = t0; t < t1; ++t) acc = fma(-Gs[P.rhs_gpos[t]], wr[P.rhs_row[t]], acc);
+      rhs[p] = acc;
+    }
+  }
 #ifdef QTOS_STAMPS
   if (tid == 0 && W.trace && it == 1) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 34) * 4 + i] = (double)ks[i];
 #endif

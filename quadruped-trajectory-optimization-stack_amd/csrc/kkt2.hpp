@@ -180,7 +180,7 @@ __device__ __forceinline__ void assemble_part(double *A, const int *sbuf, const 
 template <int F, bool CONT>
 __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
-  if (b >= B || W.done[b]) return;
+  if (b >= B || W.done[b] || W.chord[b]) return;   // (a problem flagged for a chord step is k_chord's)
   extern __shared__ double lds[];
   using CF = Kkt2Cfg<F>;
   using LY = Kkt2Layout<F>;
@@ -253,7 +253,8 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     for (int i = tid; i < d1 - d0; i += KT2) dbuf[i] = stream[d0 + i];
   };
   // wave 0: LDL^T + L^-1 + (L D L^T)^-1 of the pivot block of the panel Pn, then the pivot rows leave the panel
-  auto factor_block = [&](double *Pn, const int myps, double *Lin, double *dvn) __attribute__((always_inline)) {
+  double *minv_g = W.minv + (size_t)b * NS * (PIV * PIV);   // inverse of every pivot block, kept for chord steps
+  auto factor_block = [&](double *Pn, const int myps, double *Lin, double *dvn, int ks) __attribute__((always_inline)) {
     double a[PIV], v[PIV], myinv;
 #pragma unroll
     for (int j = 0; j < PIV; ++j) {
@@ -280,7 +281,10 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) mi = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[s4], lt[s4] * ld[s4], mi, 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) Minv[(lk + 4 * g) * PLD + li] = mi[g];
+      for (int g = 0; g < 4; ++g) {
+        Minv[(lk + 4 * g) * PLD + li] = mi[g];
+        minv_g[(size_t)ks * (PIV * PIV) + (lk + 4 * g) * PIV + li] = mi[g];
+      }
     }
   };
   auto assemble_continuations = [&](int t0, int nth) __attribute__((always_inline)) {
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
       A[cell0(r, j)] = 0.0;
     }
     __syncthreads();
-    if (wv == 0) factor_block(P0, ps0[li], Lib, dvb);
+    if (wv == 0) factor_block(P0, ps0[li], Lib, dvb, 0);
   }
   for (int s = 1; s < 3 && s < NS; ++s) {
     point_buffers(s);
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
 #endif
     if (wv == 0) {
       __builtin_amdgcn_s_setprio(3);
-      if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV);
+      if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV, k + 1);
       __builtin_amdgcn_s_setprio(0);
 #ifdef QTOS_PF_LATE
       prefetch_records();
@@ -781,6 +785,158 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   __syncthreads();
   if (tid < 192 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 16) * 4 + tid] = (double)st2[tid / 12][tid % 12];
 #endif
+}
+
+
+// =================================================================================================
+// k_chord: one KKT solve with the factorisation k_kkt2 left behind and a new right-hand side (QtosParams.chord_tol).
+// Per stage the factor panel holds V_k = P_k B_k^-1 (rows of the live slots) and k_kkt2 also keeps B_k^-1:
+//   forward   p_F = rhs_k + u[piv_k];   w_k = B_k^-1 p_F  (to the panel);   u -= V_k p_F
+//   backward  x_k = w_k - V_k^T x       (as in k_kkt2)
+// with the right-hand side in elimination order from k_step.  Two barriers per forward stage, one per
+// backward stage; no records, no Schur tiles: the launch streams the panels twice.
+constexpr int KTC = 1024;
+template <int F>
+__global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
+  const int b = blockIdx.x;
+  if (b >= B || W.done[b] || !W.chord[b]) return;
+  using CF = Kkt2Cfg<F>;
+  constexpr int NT = CF::NT, NH = CF::NH, FR = CF::FR, NI = 4 / NH, NBW = NT * NH;
+  __shared__ double UF[FR], xs[FR], pf[PIV], red[2 * 16 * PIV];
+  __shared__ int hiall_dummy;
+  (void)hiall_dummy;
+  const int tid = threadIdx.x, NS = P.n_stages, n = P.n_vars;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int j = li, q = lk;
+  double *panel = W.panel + (size_t)b * P.panel_stride;
+  const double *minv = W.minv + (size_t)b * NS * (PIV * PIV);
+  const double *rhs = W.rhs + (size_t)b * P.n_unknowns;
+  double *dx = W.dx + (size_t)b * n;
+  const int pstride = (F + 1) * PIV;
+  const bool owner = wv < NBW;
+  const int R = owner ? wv % NT : 0, h = owner ? wv / NT : 0;
+  const int vcol = 4 * (j & 3) + (j >> 2);   // where column j of a V row sits
+  if (tid == 0) atomicAdd(W.n_active + 1, -1);   // flag consumed
+  for (int i = tid; i < FR; i += KTC) { UF[i] = 0.0; xs[i] = 0.0; }
+  for (int v = tid; v < n; v += KTC) dx[v] = 0.0;
+  __syncthreads();
+  auto amask16 = [&](int k) __attribute__((always_inline)) {
+    return (P.amask[min(max(k, 0), NS - 1) * 8 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu;
+  };
+  constexpr int DEPTH = 4;
+  // ---- forward -------------------------------------------------------------------------------------
+  {
+    double fv[DEPTH][NI];
+    unsigned fam[DEPTH];
+    double mrow[DEPTH][4], frhs[DEPTH];
+    int fps[DEPTH];
+    auto fload = [&](int k, double (&v)[NI], unsigned &am, double (&mr)[4], double &rk, int &psj) __attribute__((always_inline)) {
+      const int kk = min(k, NS - 1);
+      const double *pk = panel + (size_t)kk * pstride;
+      am = amask16(kk);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = q + 4 * (NH * i + h);
+        v[i] = pk[(owner && ((am >> row) & 1u)) ? PIV + (16 * R + row) * PIV + vcol : PIV];
+      }
+      if (wv == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mr[t] = minv[(size_t)kk * (PIV * PIV) + j * PIV + q + 4 * t];
+        rk = rhs[min(kk * PIV + j, P.n_unknowns - 1)];
+        psj = P.piv_slot[kk * PIV + j];
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fload(d, fv[d], fam[d], mrow[d], frhs[d], fps[d]);
+    for (int k0 = 0; k0 < NS; k0 += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int k = k0 + d;
+        const bool valid = k < NS;
+        if (wv == 0 && valid) {
+          // p_F = rhs_k + u[piv]; the slots are retired; w = B^-1 p_F
+          const bool real = k * PIV + j < P.n_unknowns;     // (dummy pivots of a short last stage)
+          const double p = (real ? frhs[d] : 0.0) + UF[fps[d]];
+          if (lane < PIV) { pf[j] = p; UF[fps[d]] = 0.0; }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          double acc = 0.0;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc = fma(mrow[d][t], pf[q + 4 * t], acc);
+          acc += __shfl_xor(acc, 16);
+          acc += __shfl_xor(acc, 32);
+          if (lane < PIV) panel[(size_t)k * pstride + j] = acc;
+        }
+        lds_barrier();
+        if (valid && owner) {
+          // u[row] -= V[row, :] p_F : lane (column j, row group q) -> sum over the 16 lanes of a DPP row
+          const double pj = pf[j];
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int row = q + 4 * (NH * i + h);
+            double t = ((fam[d] >> row) & 1u) ? fv[d][i] * pj : 0.0;
+            t += __shfl_xor(t, 8);
+            t += __shfl_xor(t, 4);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 1);
+            if (li == 0 && ((fam[d] >> row) & 1u)) UF[16 * R + row] -= t;
+          }
+        }
+        fload(k + DEPTH, fv[d], fam[d], mrow[d], frhs[d], fps[d]);
+        lds_barrier();
+      }
+    }
+  }
+  __syncthreads();   // the w entries written above are read back below (same workgroup: visible after the barrier)
+  // ---- backward (k_kkt2's) ---------------------------------------------------------------------------
+  {
+    double bv[DEPTH][NI], bw[DEPTH];
+    int bps[DEPTH], bun[DEPTH];
+    unsigned bam[DEPTH];
+    auto bload = [&](int k, double (&v)[NI], double &wj, int &psj, int &unkj, unsigned &am) __attribute__((always_inline)) {
+      const int kk = max(k, 0);
+      const double *pk = panel + (size_t)kk * pstride;
+      am = amask16(kk);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = q + 4 * (NH * i + h);
+        v[i] = pk[(owner && ((am >> row) & 1u)) ? PIV + (16 * R + row) * PIV + vcol : j];
+      }
+      wj = pk[j];
+      psj = P.piv_slot[kk * PIV + j];
+      unkj = P.piv_unknown[kk * PIV + j];
+    };
+    auto bstep = [&](int k, const double (&v)[NI], double wj, int psj, int unkj, unsigned am) __attribute__((always_inline)) {
+      const bool valid = k >= 0;
+      const int kk = max(k, 0);
+      double p = 0.0;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = q + 4 * (NH * i + h);
+        p = fma(v[i], ((am >> row) & 1u) ? xs[16 * R + row] : 0.0, p);
+      }
+      p += __shfl_xor(p, 16);
+      p += __shfl_xor(p, 32);
+      if (lane < PIV) red[(kk & 1) * 256 + wv * PIV + j] = (valid && owner) ? p : 0.0;
+      lds_barrier();
+      double s = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < 16; ++w2) s += red[(kk & 1) * 256 + w2 * PIV + j];
+      const double x = wj - s;
+      if (lane < PIV && valid) {
+        xs[psj] = x;
+        if (wv == 0 && unkj >= 0 && unkj < n) dx[unkj] = x;
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) bload(NS - 1 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
+    for (int k0 = NS - 1; k0 >= 0; k0 -= DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        bstep(k0 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
+        bload(k0 - d - DEPTH, bv[d], bw[d], bps[d], bun[d], bam[d]);
+      }
+    }
+  }
 }
 
 }  // namespace qtos

@@ -40,6 +40,8 @@ struct QtosPlanner {
   std::vector<hipEvent_t> ev;  // 3 per iteration (kkt begin / end, count read back) + 2 (total)
   int last_launches = 0, last_iters = 0;
   size_t kkt_lds = 0, eval_lds = 0;
+  void (*chord_fn)(DevPlan, DevWork, int) = nullptr; // k_chord instantiated for this front size (null: chord steps off)
+  std::vector<char> was_kkt, was_chord;              // per iteration of the last call: which solve kernels were launched
   void (*kkt_fn)(DevPlan, DevWork, int) = nullptr;   // k_kkt / k_kkt2 instantiated for this front size
   int kkt_threads = KT;
   std::string err;
@@ -85,6 +87,17 @@ static void (*kkt2_kernel(int F, bool cont))(DevPlan, DevWork, int) {
 #endif
   }
 #undef QTOS_KKT2
+  return nullptr;
+}
+static void (*chord_kernel(int F))(DevPlan, DevWork, int) {
+#define QTOS_CHORD(f) case f: return k_chord<f>;
+  switch (F) {
+    QTOS_CHORD(16) QTOS_CHORD(32) QTOS_CHORD(48) QTOS_CHORD(64) QTOS_CHORD(80) QTOS_CHORD(96) QTOS_CHORD(112) QTOS_CHORD(128)
+#ifndef QTOS_DEV_SMALL
+    QTOS_CHORD(144) QTOS_CHORD(160) QTOS_CHORD(176) QTOS_CHORD(192) QTOS_CHORD(208)
+#endif
+  }
+#undef QTOS_CHORD
   return nullptr;
 }
 
@@ -161,6 +174,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(S.amask, &D.amask));
   TRY(p->upload(S.ctab, &D.ctab));
   TRY(p->upload(S.rtab, &D.rtab));
+  TRY(p->upload(S.rhs_ptr, &D.rhs_ptr)); TRY(p->upload(S.rhs_gpos, &D.rhs_gpos)); TRY(p->upload(S.rhs_row, &D.rhs_row));
+  D.n_unknowns = S.n_unknowns;
+  D.chord_tol = kkt2 ? M.P.chord_tol : 0.0;   // (the 8-wave kernel does not keep the pivot-block inverses)
   D.n_cells = S.n_cells;
   D.max_part_con = (S.max_part_con + 1) & ~1;
   D.n_cont = 0;
@@ -249,6 +265,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   }
   {
     p->kkt_fn = kkt2 ? kkt2_kernel(F, D.n_cont > 0) : kkt_kernel(F, D.n_cont > 0);
+    p->chord_fn = kkt2 ? chord_kernel(F) : nullptr;
     if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
@@ -291,12 +308,17 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.held, Bm));
   TRY(p->alloc(&W.trace, Bm * (size_t)(M.P.max_iter + 1) * 4));
   TRY(p->alloc(&W.status, Bm)); TRY(p->alloc(&W.iters, Bm)); TRY(p->alloc(&W.done, Bm));
-  TRY(p->alloc(&W.n_active, 1));
+  TRY(p->alloc(&W.n_active, 2));
+  TRY(p->alloc(&W.chord, Bm));
+  TRY(p->alloc(&W.rhs, Bm * (size_t)S.n_unknowns));
+  TRY(p->alloc(&W.minv, kkt2 ? Bm * (size_t)S.n_stages * PIV * PIV : 1));
   TRY(p->alloc(&p->d_start, Bm * QTOS_START_DOUBLES)); TRY(p->alloc(&p->d_goal, Bm * 3));
   TRY(p->alloc(&p->d_nodes, Bm * n)); TRY(p->alloc(&p->d_warm, Bm * n)); TRY(p->alloc(&p->d_map, Bm));
-  if (hipHostMalloc((void **)&p->h_active, sizeof(int) * ((size_t)M.P.max_iter + 1)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
+  if (hipHostMalloc((void **)&p->h_active, 2 * sizeof(int) * ((size_t)M.P.max_iter + 1)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
+  p->was_kkt.assign(M.P.max_iter + 1, 0);
+  p->was_chord.assign(M.P.max_iter + 1, 0);
   if (hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
-  p->ev.resize(3 * (size_t)M.P.max_iter + 3);
+  p->ev.resize(5 * (size_t)M.P.max_iter + 3);
   for (auto &e : p->ev)
     if (hipEventCreate(&e) != hipSuccess) { qtos_planner_destroy(p); return -2; }
 #undef TRY
@@ -383,34 +405,49 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
   // spin on the event instead of a blocking wait: the wake-up latency would be paid once per iteration), so
   // every k_kkt / k_step launch does work -- no empty launches in the timing or in a profiler's averages --
   // and no state is kept between calls.  The device idles ~10 us per iteration while the word travels.
-  const int ev_start = 2 + 3 * D.max_iter;   // event behind the read-back of k_start's count
-  auto count_after = [&](int it, int *n) -> int {   // it = -1: after k_start
+  // (events per iteration: k_kkt begin / end, k_chord begin / end, read-back)
+  const int ev_start = 2 + 5 * D.max_iter;   // event behind the read-back of k_start's counts
+  auto count_after = [&](int it, int *n, int *nc) -> int {   // it = -1: after k_start
     hipError_t q;
-    while ((q = hipEventQuery(p->ev[it < 0 ? ev_start : 4 + 3 * it])) == hipErrorNotReady) {}
+    while ((q = hipEventQuery(p->ev[it < 0 ? ev_start : 6 + 5 * it])) == hipErrorNotReady) {}
     if (q != hipSuccess) { p->err = std::string("hipEventQuery: ") + hipGetErrorString(q); return -2; }
-    *n = p->h_active[it < 0 ? D.max_iter : it];
+    const int *h = p->h_active + 2 * (it < 0 ? D.max_iter : it);
+    *n = h[0];
+    *nc = h[1];
     return 0;
   };
-  HIPCHK(p, hipMemcpyAsync(p->h_active + D.max_iter, W.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(p, hipMemsetAsync(W.n_active + 1, 0, sizeof(int), st));   // (the unfinished count was cleared above, before k_start)
+  HIPCHK(p, hipMemcpyAsync(p->h_active + 2 * D.max_iter, W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(p, hipEventRecord(p->ev[ev_start], st));
   int iters = D.max_iter;
   for (int it = 0; it < D.max_iter; ++it) {
-    int n = 0;
-    if (int rc = count_after(it - 1, &n)) return rc;
+    int n = 0, nc = 0;
+    if (int rc = count_after(it - 1, &n, &nc)) return rc;
     if (n <= 0) { iters = it; break; }
-    HIPCHK(p, hipEventRecord(p->ev[2 + 3 * it], st));
-    hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(p->kkt_threads), p->kkt_lds, st, D, W, B);
-    HIPCHK(p, hipEventRecord(p->ev[3 + 3 * it], st));
+    // problems flagged by k_step reuse the stored factorisation (k_chord), the others factor (k_kkt2)
+    p->was_kkt[it] = n - nc > 0;
+    p->was_chord[it] = nc > 0 && p->chord_fn;
+    if (getenv("QTOS_DEBUG_LOOP")) fprintf(stderr, "qtos: it %d unfinished %d chord %d\n", it, n, nc);
+    if (p->was_kkt[it]) {
+      HIPCHK(p, hipEventRecord(p->ev[2 + 5 * it], st));
+      hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(p->kkt_threads), p->kkt_lds, st, D, W, B);
+      HIPCHK(p, hipEventRecord(p->ev[3 + 5 * it], st));
+    }
+    if (p->was_chord[it]) {
+      HIPCHK(p, hipEventRecord(p->ev[4 + 5 * it], st));
+      hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), 0, st, D, W, B);
+      HIPCHK(p, hipEventRecord(p->ev[5 + 5 * it], st));
+    }
     hipLaunchKernelGGL(k_step, dim3(B), dim3(ET), p->eval_lds, st, D, W, B, it);
-    HIPCHK(p, hipMemcpyAsync(p->h_active + it, W.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(p, hipEventRecord(p->ev[4 + 3 * it], st));
+    HIPCHK(p, hipMemcpyAsync(p->h_active + 2 * it, W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(p, hipEventRecord(p->ev[6 + 5 * it], st));
   }
   HIPCHK(p, hipMemcpyAsync(d_nodes_out, W.x, (size_t)B * D.n_vars * sizeof(double), hipMemcpyDeviceToDevice, st));
   if (d_status_out) HIPCHK(p, hipMemcpyAsync(d_status_out, W.status, B * sizeof(int), hipMemcpyDeviceToDevice, st));
   if (d_iters_out) HIPCHK(p, hipMemcpyAsync(d_iters_out, W.iters, B * sizeof(int), hipMemcpyDeviceToDevice, st));
   if (d_viol_out) HIPCHK(p, hipMemcpyAsync(d_viol_out, W.viol, B * sizeof(double), hipMemcpyDeviceToDevice, st));
   HIPCHK(p, hipEventRecord(p->ev[1], st));
-  p->last_launches = iters;   // real (non-empty) k_kkt launches: the ones qtos_last_timing sums
+  p->last_launches = iters;   // iterations whose solve kernels qtos_last_timing sums
   p->last_iters = iters;
   HIPCHK(p, hipGetLastError());
   return 0;
@@ -445,17 +482,38 @@ int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, dou
   HIPCHK(p, hipSetDevice(p->device));
   HIPCHK(p, hipEventSynchronize(p->ev[1]));
   double kkt = 0;
+  int n_kkt = 0;
   for (int i = 0; i < p->last_launches; ++i) {
+    if (!p->was_kkt[i]) continue;
     float ms = 0;
-    HIPCHK(p, hipEventElapsedTime(&ms, p->ev[2 + 3 * i], p->ev[3 + 3 * i]));
+    HIPCHK(p, hipEventElapsedTime(&ms, p->ev[2 + 5 * i], p->ev[3 + 5 * i]));
     kkt += ms * 1e-3;
+    ++n_kkt;
   }
   float tot = 0;
   HIPCHK(p, hipEventElapsedTime(&tot, p->ev[0], p->ev[1]));
   if (kkt_seconds) *kkt_seconds = kkt;
-  if (kkt_launches) *kkt_launches = p->last_launches;
+  if (kkt_launches) *kkt_launches = n_kkt;
   if (total_seconds) *total_seconds = tot * 1e-3;
   if (iterations) *iterations = p->last_iters;
+  return 0;
+}
+
+int qtos_last_timing_chord(QtosPlanner *p, double *chord_seconds, int *chord_launches) {
+  if (!p) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  HIPCHK(p, hipEventSynchronize(p->ev[1]));
+  double t = 0;
+  int nl = 0;
+  for (int i = 0; i < p->last_launches; ++i) {
+    if (!p->was_chord[i]) continue;
+    float ms = 0;
+    HIPCHK(p, hipEventElapsedTime(&ms, p->ev[4 + 5 * i], p->ev[5 + 5 * i]));
+    t += ms * 1e-3;
+    ++nl;
+  }
+  if (chord_seconds) *chord_seconds = t;
+  if (chord_launches) *chord_launches = nl;
   return 0;
 }
 
@@ -681,6 +739,43 @@ int qtos_debug_newton(QtosPlanner *p, int B, const double *start, const double *
   hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(p->kkt_threads), p->kkt_lds, 0, p->dp, W, B);
   HIPCHK(p, hipDeviceSynchronize());
   HIPCHK(p, hipMemcpy(dx_out, W.dx, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// right-hand side of the KKT system from the state debug_upload / k_debug_pack left behind (k_step's formula)
+__global__ __launch_bounds__(256) void k_debug_rhs(DevPlan P, DevWork W, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const size_t m = P.n_cons;
+  const double *g = W.g + b * m, *wr = W.w + b * m, *Gs = W.stream + (size_t)b * P.stream_len;
+  double *rhs = W.rhs + (size_t)b * P.n_unknowns;
+  for (int p = threadIdx.x; p < P.n_unknowns; p += blockDim.x) {
+    const int t0 = P.rhs_ptr[p], t1 = P.rhs_ptr[p + 1];
+    double acc = 0.0;
+    if (t1 - t0 == 1 && P.rhs_gpos[t0] < 0) acc = -g[P.rhs_row[t0]];
+    else
+      for (int t = t0; t < t1; ++t) acc = fma(-Gs[P.rhs_gpos[t]], wr[P.rhs_row[t]], acc);
+    rhs[p] = acc;
+  }
+  if (threadIdx.x == 0) { W.chord[b] = 1; atomicAdd(W.n_active + 1, 1); }
+}
+__global__ void k_debug_unchord(DevWork W, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) W.chord[b] = 0;
+  if (b == 0) W.n_active[1] = 0;
+}
+
+/* the same solve as qtos_debug_newton once more, this time by k_chord: the factorisation the preceding
+ * qtos_debug_newton call left behind + the right-hand side in elimination order.  dx_out: B x n_vars */
+int qtos_debug_chord(QtosPlanner *p, int B, double *dx_out) {
+  if (!p || B < 1 || B > p->max_batch || !dx_out || !p->chord_fn) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  DevWork W = p->wk;
+  hipLaunchKernelGGL(k_debug_rhs, dim3(B), dim3(256), 0, 0, p->dp, W, B);
+  hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), 0, 0, p->dp, W, B);
+  hipLaunchKernelGGL(k_debug_unchord, dim3((B + 63) / 64), dim3(64), 0, 0, W, B);
+  HIPCHK(p, hipDeviceSynchronize());
+  HIPCHK(p, hipMemcpy(dx_out, W.dx, (size_t)B * p->M.n_vars * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 

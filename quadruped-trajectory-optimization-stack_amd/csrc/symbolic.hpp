@@ -80,6 +80,7 @@ struct Symbolic {
   // cell_mode 2 (k_kkt2: records are assembled during the AB phase, next to the gathering of the previous
   // stage's columns): right-hand-side entries get cells of their own too (a slot changes hands at a stage
   // boundary, a cell does not), listed per pivot in rtab, and a cell is recycled one stage later
+  std::vector<int> rhs_ptr, rhs_gpos, rhs_row;   // right-hand side of K by unknown position (DevPlan::rhs_ptr ...)
   int cell_mode = 2;
   std::vector<int> rtab;              // n_stages x 16: cell of the assembled right-hand side of every pivot (0 = none)
   std::vector<unsigned> amask;   // per stage 256 bits (8 words): front slots whose row of the factor panel V is stored (live, not a pivot of the stage)
@@ -719,6 +720,25 @@ struct Symbolic {
       if (b.kind == 1) b.goff = iq_first[b.goff];
     M.finalize_goff();
     build_linear_terms(M);
+    {   // right-hand side lists for the chord step: multipliers -g[row]; variables -sum_r G[r][a] w_r over their blocks
+      std::vector<std::vector<std::pair<int, int>>> terms(n_unknowns);
+      for (const Block &b : M.blocks) {
+        if (b.kind != 1) continue;
+        for (int a = 0; a < b.n; ++a) {
+          const int p = var_pos[M.block_cols[b.col_off + a]];
+          if (p < 0) continue;
+          for (int r = 0; r < b.m; ++r) terms[p].push_back({b.goff + r * b.n + a, b.row0 + r});
+        }
+      }
+      rhs_ptr.assign(1, 0);
+      rhs_gpos.clear(); rhs_row.clear();
+      for (int p = 0; p < n_unknowns; ++p) {
+        if (order[p] >= n) { rhs_gpos.push_back(-1); rhs_row.push_back(order[p] - n); }
+        else
+          for (auto &t : terms[p]) { rhs_gpos.push_back(t.first); rhs_row.push_back(t.second); }
+        rhs_ptr.push_back((int)rhs_gpos.size());
+      }
+    }
     // bytes = w * [ sum_k (p + c_k) * p  +  2 M ]   (matrix once, rhs in, solution out)
     algorithmic_bytes = 0;
     flops = 0;

@@ -152,6 +152,40 @@ def test_kkt_solve_matches_dense_reference(planner, oracle, gv1, cfg):
         assert np.all(dx[b, fx] == 0)
 
 
+def test_chord_step_kernel_matches_the_factorising_kernel(planner, oracle, gv1, cfg):
+    """k_chord (QtosParams.chord_tol: reuse of the stored factorisation with a new right-hand side) solves the system
+    of the preceding factorisation to the accuracy of that factorisation; and a solve with chord steps uses one
+    factorisation less than one without, for the same plan to 1e-5 (the oracle applies the same rule)."""
+    import dataclasses
+    from qtos_amd.capi import Planner
+    rng = np.random.default_rng(3)
+    inp = gv1["inputs"]
+    B = 4
+    x = gv1["x"][None] + 0.01 * rng.standard_normal((B, planner.n))
+    start = np.repeat(start_vector(inp)[None], B, 0)
+    goal = np.repeat(np.array(inp["g"])[None], B, 0)
+    rk, _, _ = planner.structure()
+    I = rk == 2
+    sig = np.zeros((B, planner.m))
+    w = np.zeros((B, planner.m))
+    sig[:, I] = 10.0 ** rng.uniform(-3, 3, (B, I.sum()))
+    w[:, I] = rng.standard_normal((B, I.sum()))
+    dx = planner.debug_newton(start, goal, x, sig, w)
+    dc = planner.debug_chord(B)
+    assert np.abs(dc - dx).max() <= 1e-7 * np.abs(dx).max()
+    # full solves: 3 factorisations + 1 chord step instead of 4 factorisations on the benchmark goals
+    s, g = _random_problems(12, seed=11)
+    n1, st1, it1, _ = planner.plan(s, g)
+    t1 = planner.timing()
+    P0 = Planner(dataclasses.replace(cfg, chord_tol=0.0), max_batch=12)
+    n0, st0, it0, _ = P0.plan(s, g)
+    t0 = P0.timing()
+    P0.close()
+    assert (st1 == 0).all() and (st0 == 0).all() and np.array_equal(it1, it0)
+    assert t1["chord_launches"] == 1 and t1["kkt_launches"] == t0["kkt_launches"] - 1 and t0["chord_launches"] == 0
+    assert np.abs(n1 - n0).max() < 1e-5
+
+
 def test_full_solve_matches_oracle_on_seeded_batch(planner, oracle):
     start, goal = _random_problems(12, seed=11)
     nodes, status, iters, viol = planner.plan(start, goal)
@@ -617,14 +651,15 @@ def test_stall_detection_returns_best_iterate(cfg):
     piecewise-constant exp_5 terrain) stops `stall_iters` iterations after its best iterate with
     status 1 and returns that iterate; converged problems are untouched; with the rule switched
     off the same problems run to the iteration limit.  The oracle applies the same rule.
-    (Footholds left free for the whole solve, `foothold_hold_from` = 0.)"""
+    (Footholds left free for the whole solve, `foothold_hold_from` = 0; chord steps off: the rule under test is
+    about the cycling iterates of the plain Newton sequence.)"""
     import dataclasses
     from oracle.oracle import Oracle
     from qtos_amd import workloads
     from qtos_amd.capi import Planner
     hxy, cell = workloads.exp5_terrain()
     start, goal = workloads.step_goals(256, seed=1, terrain=(hxy, cell))
-    cfg = dataclasses.replace(cfg, foothold_hold_from=0)
+    cfg = dataclasses.replace(cfg, foothold_hold_from=0, chord_tol=0.0)
     P = Planner(cfg, max_batch=256)
     P.set_heightfields(hxy, cell)
     nodes, status, iters, viol = P.plan(start, goal)
@@ -643,6 +678,7 @@ def test_stall_detection_returns_best_iterate(cfg):
     s, g = start[b], goal[b]
     oo = O.default_options()
     oo.hold_from = 0
+    oo.chord_tol = 0.0
     xo, info = O.solve(O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g, (0, 0, 0), (0, 0, 0), 0.0), opts=oo)
     assert info.status == 1 and info.iters < cfg.max_iter
     P0 = Planner(dataclasses.replace(cfg, stall_iters=0), max_batch=256)

@@ -221,7 +221,8 @@ def test_oracle_stall_rule_stops_cycling_problems():
     the tolerance.  With stall_iters = 5 (default) the solve stops five iterations after its best
     iterate and returns it; with the rule off it runs to the iteration limit and ends no better.
     (Footholds left free for the whole solve, hold_from = 0: with the default two-phase solve the
-    foot is held after the second iteration and the same problem converges.)"""
+    foot is held after the second iteration and the same problem converges.  Chord steps off: the rule
+    under test is about the cycling iterates of the plain Newton sequence.)"""
     from oracle.oracle import Oracle
     from qtos_amd import workloads
     from qtos_amd.config import PlannerConfig
@@ -236,9 +237,11 @@ def test_oracle_stall_rule_stops_cycling_problems():
     assert (o.stall_iters, o.hold_from, o.hold_weight, o.hold_tol) == (5, 2, 1e6, 0.25)
     assert ih.status == 0 and ih.iters <= 6 and O.max_violation(xh) <= 1e-4 + 1e-9
     o.hold_from = 0
+    o.chord_tol = 0.0
     x5, i5 = O.solve(q, opts=o)
     o = O.default_options()
     o.hold_from = 0
+    o.chord_tol = 0.0
     o.stall_iters = 0
     x0, i0 = O.solve(q, opts=o)
     assert i5.status == 1 and i0.status == 1 and i5.iters < i0.iters == o.max_iter
