@@ -291,6 +291,7 @@ def main():
     solved_dev.zero_()
     iters_dev.zero_()
     kkt_s, kkt_n, tot_s = 0.0, 0, 0.0
+    chord_s, chord_n = 0.0, 0
     solved_inflight = None
     if lanes:
         for j, L in enumerate(lanes):
@@ -315,6 +316,8 @@ def main():
         kkt_s += tm["kkt_seconds"]
         kkt_n += tm["kkt_launches"]
         tot_s += tm["total_seconds"]
+        chord_s += tm.get("chord_seconds", 0.0)
+        chord_n += tm.get("chord_launches", 0)
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -387,6 +390,11 @@ def main():
             "bytes_per_launch": alg_bytes, "avg_launch_ms": round(1e3 * avg, 4), "launches": kkt_n,
             "fp64_tflops": round(B * d.kkt_flops / avg / 1e12, 3), "fp64_peak_tflops": 78.6,
             "kkt_share_of_device_time": round(kkt_s / max(tot_s, 1e-12), 3),
+            "launches_per_step": round(kkt_n / max(args.steps, 1), 2),
+            # k_chord: a solve that re-uses the factor panels of the preceding k_kkt2 launch (no assembly,
+            # no factorisation); it reads the panels once more: same algorithmic read bytes, no write
+            "chord_launches_per_step": round(chord_n / max(args.steps, 1), 2),
+            "chord_avg_launch_ms": round(1e3 * chord_s / chord_n, 4) if chord_n else None,
         }
         f = newest("r*_pmc_sq.json") if headline else None
         if f:
