@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     }
   }
 #ifdef QTOS_STAMPS
-  if (tid == 0 && W.trace && it == 1) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 34) * 4 + i] = (double)ks[i];
+  if (tid == 0 && W.trace && it == 1) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 70) * 4 + i] = (double)ks[i];
 #endif
 }
 

@@ -4,8 +4,10 @@
 // stage, Schur updates in MFMA accumulator registers, assembled entries in LDS cells, factor panels to
 // HBM for the backward pass), re-cut so that no wave carries two jobs in a row:
 //
-//   AB(k)  waves 0 .. NT-1   one 16-row tile of the panel each (V = P (L D L^T)^-1, next pivot columns,
-//                             Y = P L^-T), as before
+//   AB(k)  waves 0 .. NT-1   one 16-row tile of the panel each: V = P (L D L^T)^-1, next pivot columns, and the two
+//                             operands of the Schur update into LDS: -V and P with the rows of the next pivots
+//                             blanked (U -= V P^T = Y D^-1 Y^T without forming Y; fronts above 128 slots have no
+//                             room for the second panel and form Y = P L^-T as k_kkt does)
 //          service waves      (the other 16 - NT): assembly of stage k+2's records into the cells -- it used
 //                             to close phase C on every wave --, and, on the first of them, the whole
 //                             right-hand-side row: w = (L D L^T)^-1 p_F (to HBM), rhs -= P w, the right-hand
@@ -74,8 +76,10 @@ struct Kkt2Layout {
   static constexpr int JM = HIB + 2;                     // 2 x FR ints    slot -> pivot index
   static constexpr int PM = JM + CF::FR;                 // 2 x 8 ints     pivot-slot bit masks
   static constexpr int MIV = PM + 8;                     // 16 x PLD       (L D L^T)^-1 of the current pivot block
-  static constexpr int PB = MIV + PIV * PLD;             // 3 panels of (F+1) x PLD
-  static constexpr int VAR = (PB + 3 * PSZ + 1) & ~1;    // dbuf, then (ints) sbuf, hiall, then the cells A
+  static constexpr int PB = MIV + PIV * PLD;             // 3 panels of (F+1) x PLD: P_k / P_k+1 alternate in 0 and 2, 1 = operand A of the update
+  static constexpr bool VP = F <= 128;                   // update as  U -= V P^T  (operand B in a fourth panel: no room for it on larger fronts)
+  static constexpr int PMB = PB + 3 * PSZ;               // F x PLD: rows of P_k with those of the next pivots blanked
+  static constexpr int VAR = (PMB + (VP ? F * PLD : 0) + 1) & ~1;   // dbuf, then (ints) sbuf, hiall, then the cells A
 };
 // record buffers: a front of up to 128 slots has two of them, filled by LDS-DMA (1 KB per wave instruction: sizes
 // in 1 KB granules); larger fronts have one, filled through prefetch registers
@@ -88,7 +92,7 @@ __host__ __device__ inline size_t kkt2_sbuf_ints(int F, int max_srec) {
 inline size_t kkt2_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells, int max_part_con) {
   const int FR = (F + 63) & ~63, PSZ = (F + 1) * PLD;
   const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 2 * (size_t)FR + 2 * 16 * PIV + 64 + 3 * PIV / 2 + 2 + FR + 8 + PIV * PLD;
-  size_t o = (fixed + 3 * (size_t)PSZ + 1) & ~(size_t)1;
+  size_t o = (fixed + 3 * (size_t)PSZ + (F <= 128 ? (size_t)F * PLD : 0) + 1) & ~(size_t)1;
   const size_t nbuf = F <= 128 ? 2 : 1;
   o += nbuf * kkt2_dbuf_doubles(F, max_drec);
   size_t oi = 2 * o + nbuf * kkt2_sbuf_ints(F, max_srec) + ((((size_t)NS + 1) + 3) & ~(size_t)3);
@@ -434,6 +438,16 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
       for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[s4], npp[s4], acc, 0, 0, 0);   // acc -= V P[piv]^T
 #pragma unroll
       for (int g = 0; g < 4; ++g) A[aidx[g]] = 0.0;   // retired (the zero cell stays zero)
+      if constexpr (LY::VP) {
+        // operands of the Schur update: -V (accumulator layout -> row-major) and the raw rows, next pivots' rows blanked
+        const bool myrowpiv = has_next && ((grp16(m1, R) >> li) & 1u);
+        double *Pm = lds + LY::PMB;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          Yk[(16 * R + li) * PLD + lk + 4 * g] = myrowpiv ? 0.0 : -vt[g];
+          Pm[(16 * R + li) * PLD + lk + 4 * g] = myrowpiv ? 0.0 : pr[g];
+        }
+      } else
       // Y = P L^-T of this tile: here for the tiles without a partner wave, else on service wave R (below)
       if (R == 0 || R >= NSV) {
         double la[4];
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
           }
         }
       }
-      else if (sv < NT) {
+      else if (!LY::VP && sv < NT) {
         // Y = P L^-T of row tile R = sv for its tile wave
         const int R = sv;
         double la[4], pr[4];
@@ -553,15 +567,18 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
       const int *jm2 = jm + (k & 1) * FR;
       double *Xnn = Pk;   // the panel of stage k is dead: it receives the columns of stage k+2
       double dv4[4];
+      if constexpr (!LY::VP) {
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) dv4[s4] = -dik[lk + 4 * s4];
+        for (int s4 = 0; s4 < 4; ++s4) dv4[s4] = -dik[lk + 4 * s4];
+      }
+      const double *Bop = LY::VP ? lds + LY::PMB : Yk;
       int rcs[MAXT2];
 #pragma unroll
       for (int t = 0; t < MAXT2; ++t) { rcs[t] = tRC[t]; asm volatile("" : "+s"(rcs[t])); }
       double wa[2][4], pbv[2][4];
       auto tile_loads = [&](int rc, double (&w)[4], double (&pq)[4]) __attribute__((always_inline)) {
         const int R = rc < 0 ? 0 : rc >> 8, C = rc < 0 ? 0 : rc & 255;
-        const double *wrow = Yk + (16 * R + li) * PLD + lk, *prow2 = Yk + (16 * C + li) * PLD + lk;
+        const double *wrow = Yk + (16 * R + li) * PLD + lk, *prow2 = Bop + (16 * C + li) * PLD + lk;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) { w[s4] = wrow[4 * s4]; pq[s4] = prow2[4 * s4]; }
       };
@@ -571,7 +588,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
         if (t + 1 < MAXT2) tile_loads(rcs[t + 1], wa[(t + 1) & 1], pbv[(t + 1) & 1]);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
-          U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[t & 1][s4] * dv4[s4], pbv[t & 1][s4], U[t], 0, 0, 0);
+          U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(LY::VP ? wa[t & 1][s4] : wa[t & 1][s4] * dv4[s4], pbv[t & 1][s4], U[t], 0, 0, 0);
       }
       KS2(5);
 #ifdef QTOS_PF_LATE
@@ -641,7 +658,8 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
       if (apos < NFREE) assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, min(apos * APW, NF4), min(apos * APW + APW, NF4));
       else assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, min(NF4 + apos - NFREE, NPART), min(NF4 + apos - NFREE + 1, NPART));
 #else
-      // one thread per target, low item indices to the waves that get here first
+      // one thread per target, low item indices to the waves that get here first (equal shares: handing the waves
+      // without Schur tiles more of it was tried -- they share the factor wave's SIMD and are the slowest at it)
       assemble_stage(A, F, sbuf, dbuf, apos * 64 + lane, 15 * 64);
 #endif
     }

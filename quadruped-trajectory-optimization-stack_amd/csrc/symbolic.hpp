@@ -473,7 +473,12 @@ struct Symbolic {
               else nfree++;
             }
             if (!nfree) continue;
-            const int score = same > 0 ? 2000 + same : (used == 0 ? 1000 : nfree);
+            static const int place = getenv("QTOS_PLACE") ? atoi(getenv("QTOS_PLACE")) : 0;
+            int score = same > 0 ? 2000 + same : (used == 0 ? 1000 : nfree);
+            if (place == 1) score = 1000 - grp;                                   // lowest free slot
+            if (place == 2) score = same > 0 ? 2000 + same : 1000 - grp;           // siblings, else lowest group
+            if (place == 3) score = same > 0 ? 2000 + same : (used > 0 ? 1000 + nfree : 500 - grp);   // siblings, else the used group with most room, else lowest empty group
+            if (place == 4) score = same > 0 ? 2000 + same : (used > 0 ? 1000 + 16 * (16 - grp) + nfree : 500 - grp);
             if (score > best_score) { best_score = score; best_grp = grp; }
           }
           for (int t = best_grp * 16; t < best_grp * 16 + 16; ++t)
@@ -690,6 +695,35 @@ struct Symbolic {
       for (int k = 0; k < n_stages; ++k) fprintf(stderr, " %d", active_count[k]);
       fprintf(stderr, "\nhi per stage:");
       for (int k = 0; k < n_stages; ++k) fprintf(stderr, " %d", stage_hi[k]);
+      {
+        double tiles = 0, pgs = 0, xt = 0;
+        for (int k = 0; k < n_stages; ++k) {
+          int g = 0, pg = 0;
+          unsigned pgm = 0, gm = 0;
+          for (int grp = 0; grp < 16; ++grp) {
+            const unsigned w = (amask[(size_t)k * 8 + (grp >> 1)] >> ((grp & 1) * 16)) & 0xffffu;
+            if (w) { g++; gm |= 1u << grp; }
+          }
+          for (int i = 0; i < PIV; ++i) pgm |= 1u << (piv_slot[(size_t)k * PIV + i] >> 4);
+          pg = __builtin_popcount(pgm);
+          tiles += g * (g + 1) / 2.0;
+          pgs += pg;
+          // tiles touched by the extraction of this stage's columns (two stages earlier: use this stage's occupancy)
+          int t = 0;
+          for (int R = 0; R < 16; ++R) for (int Cc = 0; Cc <= R; ++Cc)
+            if (((gm | pgm) >> R & 1) && ((gm | pgm) >> Cc & 1) && ((pgm >> R & 1) || (pgm >> Cc & 1))) t++;
+          xt += t;
+        }
+        fprintf(stderr, "\nmean update tiles %.2f, pivot groups %.2f, extraction tiles %.2f", tiles / n_stages, pgs / n_stages, xt / n_stages);
+      }
+      {
+        std::map<std::pair<int,int>, int> bh;
+        long long con = 0, conw = 0;
+        for (const Block &b : M.blocks) if (b.kind == 1) { bh[{b.m, b.n}]++; con += (long long)b.n * (b.n + 1) / 2 + b.n; conw += ((long long)b.n * (b.n + 1) / 2 + b.n) * b.m; }
+        fprintf(stderr, "\ninequality blocks (rows x cols: count):");
+        for (auto &kv : bh) fprintf(stderr, " %dx%d:%d", kv.first.first, kv.first.second, kv.second);
+        fprintf(stderr, "\ncontributions %lld, row-weighted %lld", con, conw);
+      }
       fprintf(stderr, "\nenter per stage:");
       for (int k = 0; k < n_stages; ++k) fprintf(stderr, " %d", (int)enter[k].size());
       fprintf(stderr, "\n");

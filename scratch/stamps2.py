@@ -20,3 +20,9 @@ print("cycles per stage by wave: 0 AB work | 1 AB wait | 2 C role work (after pr
 for w in range(16):
     print("wave %2d: " % w + " ".join("%6.0f" % v for v in acc[w][:9]))
 print("stage total (wave 0):", acc[0][[0, 1, 2, 3, 4, 7, 8]].sum(), "timing", P.timing())
+ks = np.zeros(8)
+for b in (0, 5, NB - 1):
+    t = np.zeros((cfg.max_iter + 1, 4))
+    P.lib.qtos_debug_trace(P.h, b, t.ctypes.data_as(C.POINTER(C.c_double)))
+    ks += t[70:72].reshape(8)
+print("k_step cycles (iteration 1): ds=Ji dx | ratio tests + th0 | line search evals | updates + infeasibility | eval with Jacobian | barrier terms:", (ks / 3).round(0))
