@@ -48,6 +48,8 @@ struct DevPlan {
   int hold_from;               // two-phase solve: stance footholds are held once an iterate >= hold_from has violation <= hold_tol (0: never)
   double hold_weight, hold_tol;
   const unsigned *amask;       // n_stages x 8: rows of the factor panel that are stored / read back (Symbolic::amask)
+  const unsigned *amask2;      // the same without the slots of the next stage's pivots (Symbolic::amask2)
+  const int *nxt_pack;         // n_stages x 4: slots of the next stage's pivots in this stage's panel, 255 = none (Symbolic::nxt_pack)
   const unsigned short *ctab;  // n_stages x (front/16) x 64 x 4: cell of every entry of a stage's pivot columns (Symbolic::ctab)
   int n_cells;                 // cells of the assembled entries: [0] zero, [1 + slot] right-hand side, then the entries
   int max_part_con;            // most contributions in one assembly part (k_kkt2 scratch, Symbolic::max_part_con)

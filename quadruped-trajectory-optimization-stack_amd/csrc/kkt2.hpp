@@ -102,7 +102,9 @@ inline size_t kkt2_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_ce
 #else
   (void)max_part_con;
 #endif
-  return oi * sizeof(int);
+  // (the backward pass keeps NS x 12 ints of sweep tables where the panels were)
+  const size_t sweep = fixed * sizeof(double) + (size_t)NS * 12 * sizeof(int);
+  return oi * sizeof(int) > sweep ? oi * sizeof(int) : sweep;
 }
 
 // pivot-slot mask of up to 256 bits: lane l holds word l & 7
@@ -180,6 +182,140 @@ __device__ __forceinline__ void assemble_part(double *A, const int *sbuf, const 
     A[tv >> 12] = a_old + acc;
   }
 }
+
+// ---- substitution sweeps with a one-stage look-ahead ------------------------------------------------------------
+// A triangular solve with the chain of fronts is a chain of NS dependent steps: x_k needs x_{k+1} (backward), p_k needs
+// p_{k-1} (forward).  Per stage only a 16 x 16 block carries that dependence -- the rows of V_k that belong to the
+// pivots of stage k+1 (Symbolic::nxt_pack) --; every other row of V_k meets values that are one stage older.  Wave 0
+// carries the chain (the block product, in registers), waves 1..NT apply the other rows one stage behind it
+// (Symbolic::amask2) and hand their partial sums over through LDS: one barrier per stage, and between two barriers
+// the chain costs one reduction of 16 partials and 16 row-broadcast multiply-adds.
+
+// elementwise sum over the four 16-lane rows of the wave, the same bits on every lane: (r0 + r2) + (r1 + r3)
+__device__ __forceinline__ double rowsum4(double p) {
+  int lo = __double2loint(p), hi = __double2hiint(p);
+  auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double s = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+  lo = __double2loint(s);
+  hi = __double2hiint(s);
+  auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(h2[0], l2[0]) + __hiloint2double(h2[1], l2[1]);
+}
+// sum over the four lanes of a quad, on every lane of it
+__device__ __forceinline__ double quadsum(double t) {
+  double o = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(t), 0xB1, 0xf, 0xf, false),
+                              __builtin_amdgcn_update_dpp(0, __double2loint(t), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  t += o;
+  o = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(t), 0x4E, 0xf, 0xf, false),
+                       __builtin_amdgcn_update_dpp(0, __double2loint(t), 0x4E, 0xf, 0xf, false));          // quad_perm [2,3,0,1]
+  return t + o;
+}
+// acc += (lane K of the 16-lane row of x) * b on the rows of the wave selected by RM
+template <int K, int RM>
+__device__ __forceinline__ void fma_bc_rows(double &acc, double x, double b) {
+  asm volatile("v_fmac_f64 %0, %1, %2 row_newbcast:%3 row_mask:%4 bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(b), "n"(K), "n"(RM));
+}
+// on the lanes of row q:  sum_m x[q + 4 m] c[m]   (x[i] lives on lane i of every row; four independent chains)
+__device__ __forceinline__ double dot4_by_row(double x, const double (&c)[4]) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  asm volatile("s_nop 1" : "+v"(x), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));   // DPP read of a VALU result: two wait states
+  fma_bc_rows<0, 1>(a0, x, c[0]); fma_bc_rows<1, 2>(a0, x, c[0]); fma_bc_rows<2, 4>(a0, x, c[0]); fma_bc_rows<3, 8>(a0, x, c[0]);
+  fma_bc_rows<4, 1>(a1, x, c[1]); fma_bc_rows<5, 2>(a1, x, c[1]); fma_bc_rows<6, 4>(a1, x, c[1]); fma_bc_rows<7, 8>(a1, x, c[1]);
+  fma_bc_rows<8, 1>(a2, x, c[2]); fma_bc_rows<9, 2>(a2, x, c[2]); fma_bc_rows<10, 4>(a2, x, c[2]); fma_bc_rows<11, 8>(a2, x, c[2]);
+  fma_bc_rows<12, 1>(a3, x, c[3]); fma_bc_rows<13, 2>(a3, x, c[3]); fma_bc_rows<14, 4>(a3, x, c[3]); fma_bc_rows<15, 8>(a3, x, c[3]);
+  return (a0 + a1) + (a2 + a3);
+}
+#ifndef QTOS_SWD
+#define QTOS_SWD 4
+#endif
+constexpr int SWD = QTOS_SWD;   // stages of factor panel in flight per wave (prefetch ring of the sweeps)
+
+// backward substitution  x_k = w_k - V_k^T x  over the whole chain.  xs (solution by slot) zeroed, red = 2 x 16 x 16
+// doubles, nxp = LDS copy of Symbolic::nxt_pack (NS x 4 ints) followed by Symbolic::amask2 (NS x 8): they are addresses of
+// the panel loads, a copy in global memory would put a second memory round trip in front of every one of them.  The
+// caller has synchronised the workgroup.
+template <int F>
+__device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *__restrict__ panel, double *__restrict__ dx,
+                                               double *xs, double *red, const int *nxp, int wv, int lane) {
+  constexpr int NT = Kkt2Cfg<F>::NT, pstride = (F + 1) * PIV;
+  const int NS = P.n_stages, n = P.n_vars;
+  const int j = lane & 15, q = lane >> 4;
+  const int vcol = 4 * (j & 3) + (j >> 2);   // where column j of a V row sits
+  const bool owner = wv >= 1 && wv <= NT;
+  const int R = owner ? wv - 1 : 0;
+  // ring slot of a stage: four doubles -- the chain block on wave 0, the rows of the wave's tile on waves 1..NT --, and on
+  // wave 0 the stage's w, pivot slots and unknowns
+  double bv[SWD][4], bw[SWD];
+  int bps[SWD], bun[SWD];
+  unsigned bam[SWD];
+  auto load = [&](int s, double (&v)[4], unsigned &am, double &wj, int &psj, int &unkj) __attribute__((always_inline)) {
+    const int kk = max(s, 0);
+    const double *pk = panel + (size_t)kk * pstride;
+    // (the masks and slots below are addresses of the loads: from LDS)
+    am = owner ? ((unsigned)nxp[NS * 4 + kk * 8 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu : 0u;
+    const unsigned np = (unsigned)nxp[kk * 4 + q];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = q + 4 * i;
+      const unsigned nr = (np >> (8 * i)) & 255u;
+      const int off = wv == 0 ? (nr != 255u ? PIV + (int)nr * PIV + vcol : j) : (((am >> row) & 1u) ? PIV + (16 * R + row) * PIV + vcol : j);
+      v[i] = pk[off];
+    }
+    if (wv == 0) {
+      wj = pk[j];
+      psj = P.piv_slot[kk * PIV + j];
+      unkj = P.piv_unknown[kk * PIV + j];
+    }
+  };
+  if (lane < PIV) { red[wv * PIV + lane] = 0.0; red[256 + wv * PIV + lane] = 0.0; }   // (the last stage has no rows besides its pivots)
+#pragma unroll
+  for (int d = 0; d < SWD; ++d) load(NS - 1 - d, bv[d], bam[d], bw[d], bps[d], bun[d]);
+  double corr = 0.0;
+  lds_barrier();
+  for (int k0 = NS - 1; k0 >= 0; k0 -= SWD) {
+#pragma unroll
+    for (int d = 0; d < SWD; ++d) {
+      const int t = k0 - d, dn = (d + 1) % SWD;   // stage of the chain; ring slot of stage t - 1
+      if (wv == 0) {
+        double r16[16];
+#pragma unroll
+        for (int w2 = 0; w2 < 16; ++w2) r16[w2] = red[(t & 1) * 256 + w2 * PIV + j];
+        double sm = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < 16; ++w2) sm += r16[w2];
+        const double x = t >= 0 ? bw[d] - sm - corr : 0.0;
+        if (lane < PIV && t >= 0) {
+          xs[bps[d]] = x;
+          if (bun[d] >= 0 && bun[d] < n) dx[bun[d]] = x;
+        }
+        // the block of stage t - 1 against the entries just found
+        const unsigned np = (unsigned)nxp[max(t - 1, 0) * 4 + q];
+        double c[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) c[m] = ((np >> (8 * m)) & 255u) != 255u && t >= 1 ? bv[dn][m] : 0.0;
+        corr = rowsum4(dot4_by_row(x, c));
+      }
+      // the other rows of stage t - 1 (they meet entries that are at least one barrier old)
+      {
+        double pp = 0.0;
+        const unsigned am = bam[dn];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = q + 4 * i;
+          const double xv = xs[16 * R + row];
+          pp = ((am >> row) & 1u) ? fma(bv[dn][i], xv, pp) : pp;
+        }
+        pp = rowsum4(pp);
+        if (lane < PIV && wv >= 1) red[((t - 1) & 1) * 256 + wv * PIV + j] = (owner && t >= 1) ? pp : 0.0;
+      }
+      lds_barrier();
+      load(t - SWD, bv[d], bam[d], bw[d], bps[d], bun[d]);
+    }
+  }
+}
+
 
 template <int F, bool CONT>
 __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
@@ -482,8 +618,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
         double part = 0.0;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) part = fma(Minv[li * PLD + lk + 4 * s4], Pk[F * PLD + lk + 4 * s4], part);
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);            // w[li] on every lane
+        part = rowsum4(part);                    // w[li] on every lane
         if (lane < PIV) panel[(size_t)k * pstride + lane] = part;
         if (has_next) {
           asm volatile("s_nop 4" : "+v"(part));    // DPP hazard distance for the broadcast reads below
@@ -731,72 +866,15 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     ct_cur = ct_nxt;
     rc_cur = rc_nxt;
   }
-  // ---- backward substitution: x_piv = w - V^T x, one barrier per stage.  NH waves share the 16 rows of a
-  //      row tile (wave R + NT h takes rows lk + 4 (NH i + h)); partial sums meet in LDS, every wave forms
-  //      the 16 new entries redundantly (bitwise identical). --------------------------------------------
+  // ---- backward substitution (sweep_backward below: one barrier per stage, one-stage look-ahead) ---------------
   __syncthreads();  // drains the factor-panel stores: they are read back below
   KS2(7);
   {
-    const int j = li, q = lk;
-    constexpr int DEPTH = 4, NI = 4 / NH, NBW = NT * NH;
-    const bool owner = wv < NBW;
-    const int R = owner ? wv % NT : 0, h = owner ? wv / NT : 0;
-    double bv[DEPTH][NI], bw[DEPTH];
-    int bps[DEPTH], bun[DEPTH];
-    unsigned bam[DEPTH];
-    auto amask16 = [&](int k) __attribute__((always_inline)) {
-      return (P.amask[max(k, 0) * 8 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu;
-    };
-    unsigned am_next = amask16(NS - 1);
-    auto bload = [&](int k, double (&v)[NI], double &wj, int &psj, int &unkj, unsigned &am) __attribute__((always_inline)) {
-      const int kk = max(k, 0);
-      const double *pk = panel + (size_t)kk * pstride;
-      am = am_next;
-      am_next = amask16(k - 1);
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int row = q + 4 * (NH * i + h);
-        v[i] = pk[(owner && ((am >> row) & 1u)) ? PIV + (16 * R + row) * PIV + 4 * (j & 3) + (j >> 2) : j];
-      }
-      wj = pk[j];
-      psj = P.piv_slot[kk * PIV + j];
-      unkj = P.piv_unknown[kk * PIV + j];
-    };
-    auto bstep = [&](int k, const double (&v)[NI], double wj, int psj, int unkj, unsigned am) __attribute__((always_inline)) {
-      const bool valid = k >= 0;
-      const int kk = max(k, 0);
-      const int nw = valid ? hiall[kk] >> 4 : 0;
-      double p = 0.0;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int row = q + 4 * (NH * i + h);
-        p = fma(v[i], ((am >> row) & 1u) ? xs[16 * R + row] : 0.0, p);
-      }
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
-      if (lane < PIV) red[(kk & 1) * 256 + wv * PIV + j] = (valid && owner && R < nw) ? p : 0.0;
-      lds_barrier();
-      double r16[16];
-#pragma unroll
-      for (int w2 = 0; w2 < 16; ++w2) r16[w2] = red[(kk & 1) * 256 + w2 * PIV + j];
-      double s = 0.0;
-#pragma unroll
-      for (int w2 = 0; w2 < 16; ++w2) s += r16[w2];
-      const double x = wj - s;
-      if (lane < PIV && valid) {
-        xs[psj] = x;
-        if (wv == 0 && unkj >= 0 && unkj < n) dx[unkj] = x;
-      }
-    };
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) bload(NS - 1 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
-    for (int k0 = NS - 1; k0 >= 0; k0 -= DEPTH) {
-#pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {
-        bstep(k0 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
-        bload(k0 - d - DEPTH, bv[d], bw[d], bps[d], bun[d], bam[d]);
-      }
-    }
+    int *nxp = (int *)PB;   // (the panels are dead)
+    for (int i = tid; i < NS * 4; i += KT2) nxp[i] = P.nxt_pack[i];
+    for (int i = tid; i < NS * 8; i += KT2) nxp[NS * 4 + i] = (int)P.amask2[i];
+    __syncthreads();
+    sweep_backward<F>(P, panel, dx, xs, red, nxp, wv, lane);
   }
 #ifdef QTOS_STAMPS
   KS2(6);
@@ -806,155 +884,113 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
 }
 
 
+
 // =================================================================================================
 // k_chord: one KKT solve with the factorisation k_kkt2 left behind and a new right-hand side (QtosParams.chord_tol).
 // Per stage the factor panel holds V_k = P_k B_k^-1 (rows of the live slots) and k_kkt2 also keeps B_k^-1:
-//   forward   p_F = rhs_k + u[piv_k];   w_k = B_k^-1 p_F  (to the panel);   u -= V_k p_F
-//   backward  x_k = w_k - V_k^T x       (as in k_kkt2)
-// with the right-hand side in elimination order from k_step.  Two barriers per forward stage, one per
-// backward stage; no records, no Schur tiles: the launch streams the panels twice.
+//   forward   p_k = rhs_k + u[piv_k];   w_k = B_k^-1 p_k  (to the panel);   u -= V_k p_k
+//   backward  x_k = w_k - V_k^T x       (sweep_backward)
+// with the right-hand side in elimination order from k_step.  Both sweeps run with the one-stage look-ahead described
+// above: one barrier per stage; the launch streams the panels twice and is bound by that.
+//   wave 0          the chain: p_k, and the block of V_k that feeds p_{k+1}
+//   waves 1 .. NT   u -= V_{k-1} p_{k-1} on the other rows of row tile wv - 1, one stage behind
+//   wave NT + 1     w_{k-1} = B_{k-1}^-1 p_{k-1}
 constexpr int KTC = 1024;
+inline size_t chord_lds_bytes(int NS) { return sizeof(int) * (size_t)NS * 12; }
 template <int F>
 __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
   if (b >= B || W.done[b] || !W.chord[b]) return;
   using CF = Kkt2Cfg<F>;
-  constexpr int NT = CF::NT, NH = CF::NH, FR = CF::FR, NI = 4 / NH, NBW = NT * NH;
-  __shared__ double UF[FR], xs[FR], pf[PIV], red[2 * 16 * PIV];
-  __shared__ int hiall_dummy;
-  (void)hiall_dummy;
+  constexpr int NT = CF::NT, FR = CF::FR;
+  static_assert(NT + 1 < 16, "k_chord: waves 1..NT own the row tiles, wave NT + 1 solves with the pivot blocks");
+  __shared__ double UF[FR], xs[FR], pf[2 * PIV], red[2 * 16 * PIV];
+  extern __shared__ int nxp[];   // Symbolic::nxt_pack, then Symbolic::amask2
   const int tid = threadIdx.x, NS = P.n_stages, n = P.n_vars;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int j = li, q = lk;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int j = lane & 15, q = lane >> 4;
   double *panel = W.panel + (size_t)b * P.panel_stride;
   const double *minv = W.minv + (size_t)b * NS * (PIV * PIV);
   const double *rhs = W.rhs + (size_t)b * P.n_unknowns;
   double *dx = W.dx + (size_t)b * n;
-  const int pstride = (F + 1) * PIV;
-  const bool owner = wv < NBW;
-  const int R = owner ? wv % NT : 0, h = owner ? wv / NT : 0;
-  const int vcol = 4 * (j & 3) + (j >> 2);   // where column j of a V row sits
+  constexpr int pstride = (F + 1) * PIV;
   if (tid == 0) atomicAdd(W.n_active + 1, -1);   // flag consumed
   for (int i = tid; i < FR; i += KTC) { UF[i] = 0.0; xs[i] = 0.0; }
+  for (int i = tid; i < NS * 4; i += KTC) nxp[i] = P.nxt_pack[i];
+  for (int i = tid; i < NS * 8; i += KTC) nxp[NS * 4 + i] = (int)P.amask2[i];
   for (int v = tid; v < n; v += KTC) dx[v] = 0.0;
   __syncthreads();
-  auto amask16 = [&](int k) __attribute__((always_inline)) {
-    return (P.amask[min(max(k, 0), NS - 1) * 8 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu;
-  };
-  constexpr int DEPTH = 4;
   // ---- forward -------------------------------------------------------------------------------------
   {
-    double fv[DEPTH][NI];
-    unsigned fam[DEPTH];
-    double mrow[DEPTH][4], frhs[DEPTH];
-    int fps[DEPTH];
-    auto fload = [&](int k, double (&v)[NI], unsigned &am, double (&mr)[4], double &rk, int &psj) __attribute__((always_inline)) {
-      const int kk = min(k, NS - 1);
+    const bool owner = wv >= 1 && wv <= NT, solver = wv == NT + 1;
+    const int R = owner ? wv - 1 : 0;
+    const int rowl = lane >> 2, jq = lane & 3;   // bulk rows: lane = (row of the tile, four columns jq + 4 m: one 32-byte piece of the V row)
+    // ring slot of a stage: one 32-byte piece -- of the chain block on wave 0 (V_k[slot of pivot j of stage k+1][q + 4 m]), of
+    // the wave's rows on waves 1..NT, of B_k^-1 on wave NT + 1 --, and on wave 0 the stage's right-hand side and pivot slots
+    d4_t fv[SWD];
+    double frhs[SWD];
+    int fps[SWD];
+    unsigned fam[SWD];
+    auto load = [&](int s, d4_t &v, unsigned &am, double &rk, int &psj) __attribute__((always_inline)) {
+      const int kk = min(s, NS - 1);
       const double *pk = panel + (size_t)kk * pstride;
-      am = amask16(kk);
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int row = q + 4 * (NH * i + h);
-        v[i] = pk[(owner && ((am >> row) & 1u)) ? PIV + (16 * R + row) * PIV + vcol : PIV];
-      }
+      am = owner ? ((unsigned)nxp[NS * 4 + kk * 8 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu : 0u;
+      const unsigned nr = ((unsigned)nxp[kk * 4 + (j & 3)] >> (8 * (j >> 2))) & 255u;   // slot of pivot j of stage kk + 1
+      const double *src = wv == 0 ? pk + (nr != 255u ? PIV + (int)nr * PIV + 4 * q : 0)
+                        : solver  ? minv + (size_t)kk * (PIV * PIV) + j * PIV + 4 * q
+                                  : pk + (((am >> rowl) & 1u) ? PIV + (16 * R + rowl) * PIV + 4 * jq : 0);
+      v = *(const d4_t *)src;
       if (wv == 0) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) mr[t] = minv[(size_t)kk * (PIV * PIV) + j * PIV + q + 4 * t];
         rk = rhs[min(kk * PIV + j, P.n_unknowns - 1)];
         psj = P.piv_slot[kk * PIV + j];
       }
     };
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) fload(d, fv[d], fam[d], mrow[d], frhs[d], fps[d]);
-    for (int k0 = 0; k0 < NS; k0 += DEPTH) {
+    for (int d = 0; d < SWD; ++d) load(d, fv[d], fam[d], frhs[d], fps[d]);
+    double corr = 0.0;
+    for (int k0 = 0; k0 <= NS; k0 += SWD) {
 #pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {
-        const int k = k0 + d;
-        const bool valid = k < NS;
-        if (wv == 0 && valid) {
-          // p_F = rhs_k + u[piv]; the slots are retired; w = B^-1 p_F
+      for (int d = 0; d < SWD; ++d) {
+        const int k = k0 + d, dp = (d + SWD - 1) % SWD;   // stage of the chain; ring slot of stage k - 1
+        if (wv == 0 && k < NS) {
           const bool real = k * PIV + j < P.n_unknowns;     // (dummy pivots of a short last stage)
-          const double p = (real ? frhs[d] : 0.0) + UF[fps[d]];
-          if (lane < PIV) { pf[j] = p; UF[fps[d]] = 0.0; }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          double acc = 0.0;
+          const double p = (real ? frhs[d] : 0.0) + UF[fps[d]] - corr;
+          if (lane < PIV) { pf[(k & 1) * PIV + j] = p; UF[fps[d]] = 0.0; }   // (the slots are retired)
+          const unsigned nr = ((unsigned)nxp[k * 4 + (j & 3)] >> (8 * (j >> 2))) & 255u;
+          double c[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc = fma(mrow[d][t], pf[q + 4 * t], acc);
-          acc += __shfl_xor(acc, 16);
-          acc += __shfl_xor(acc, 32);
-          if (lane < PIV) panel[(size_t)k * pstride + j] = acc;
+          for (int m = 0; m < 4; ++m) c[m] = nr != 255u ? fv[d][m] : 0.0;
+          corr = rowsum4(dot4_by_row(p, c));   // what stage k adds to the rows of the pivots of stage k + 1
+        }
+        if (owner && k >= 1 && k <= NS) {
+          // u[row] -= V_{k-1}[row, :] p_{k-1} on the rows that are not pivots of stage k
+          const double *pp = pf + ((k - 1) & 1) * PIV + jq;
+          const bool on = (fam[dp] >> rowl) & 1u;
+          double t = fv[dp][0] * pp[0];
+          t = fma(fv[dp][1], pp[4], t);
+          t = fma(fv[dp][2], pp[8], t);
+          t = fma(fv[dp][3], pp[12], t);
+          t = quadsum(on ? t : 0.0);
+          if (on && jq == 0) UF[16 * R + rowl] -= t;
+        }
+        if (solver && k >= 1 && k <= NS) {
+          // (lane (j, q) holds B^-1[j][4 q .. 4 q + 3])
+          const double *pp = pf + ((k - 1) & 1) * PIV + 4 * q;
+          double acc = fv[dp][0] * pp[0];
+          acc = fma(fv[dp][1], pp[1], acc);
+          acc = fma(fv[dp][2], pp[2], acc);
+          acc = fma(fv[dp][3], pp[3], acc);
+          acc = rowsum4(acc);
+          if (lane < PIV) panel[(size_t)(k - 1) * pstride + j] = acc;
         }
         lds_barrier();
-        if (valid && owner) {
-          // u[row] -= V[row, :] p_F : lane (column j, row group q) -> sum over the 16 lanes of a DPP row
-          const double pj = pf[j];
-#pragma unroll
-          for (int i = 0; i < NI; ++i) {
-            const int row = q + 4 * (NH * i + h);
-            double t = ((fam[d] >> row) & 1u) ? fv[d][i] * pj : 0.0;
-            t += __shfl_xor(t, 8);
-            t += __shfl_xor(t, 4);
-            t += __shfl_xor(t, 2);
-            t += __shfl_xor(t, 1);
-            if (li == 0 && ((fam[d] >> row) & 1u)) UF[16 * R + row] -= t;
-          }
-        }
-        fload(k + DEPTH, fv[d], fam[d], mrow[d], frhs[d], fps[d]);
-        lds_barrier();
+        // ring slot dp (stage k - 1) is free now
+        if (k >= 1) load(k - 1 + SWD, fv[dp], fam[dp], frhs[dp], fps[dp]);
       }
     }
   }
   __syncthreads();   // the w entries written above are read back below (same workgroup: visible after the barrier)
-  // ---- backward (k_kkt2's) ---------------------------------------------------------------------------
-  {
-    double bv[DEPTH][NI], bw[DEPTH];
-    int bps[DEPTH], bun[DEPTH];
-    unsigned bam[DEPTH];
-    auto bload = [&](int k, double (&v)[NI], double &wj, int &psj, int &unkj, unsigned &am) __attribute__((always_inline)) {
-      const int kk = max(k, 0);
-      const double *pk = panel + (size_t)kk * pstride;
-      am = amask16(kk);
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int row = q + 4 * (NH * i + h);
-        v[i] = pk[(owner && ((am >> row) & 1u)) ? PIV + (16 * R + row) * PIV + vcol : j];
-      }
-      wj = pk[j];
-      psj = P.piv_slot[kk * PIV + j];
-      unkj = P.piv_unknown[kk * PIV + j];
-    };
-    auto bstep = [&](int k, const double (&v)[NI], double wj, int psj, int unkj, unsigned am) __attribute__((always_inline)) {
-      const bool valid = k >= 0;
-      const int kk = max(k, 0);
-      double p = 0.0;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int row = q + 4 * (NH * i + h);
-        p = fma(v[i], ((am >> row) & 1u) ? xs[16 * R + row] : 0.0, p);
-      }
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
-      if (lane < PIV) red[(kk & 1) * 256 + wv * PIV + j] = (valid && owner) ? p : 0.0;
-      lds_barrier();
-      double s = 0.0;
-#pragma unroll
-      for (int w2 = 0; w2 < 16; ++w2) s += red[(kk & 1) * 256 + w2 * PIV + j];
-      const double x = wj - s;
-      if (lane < PIV && valid) {
-        xs[psj] = x;
-        if (wv == 0 && unkj >= 0 && unkj < n) dx[unkj] = x;
-      }
-    };
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) bload(NS - 1 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
-    for (int k0 = NS - 1; k0 >= 0; k0 -= DEPTH) {
-#pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {
-        bstep(k0 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
-        bload(k0 - d - DEPTH, bv[d], bw[d], bps[d], bun[d], bam[d]);
-      }
-    }
-  }
+  sweep_backward<F>(P, panel, dx, xs, red, nxp, wv, lane);
 }
 
 }  // namespace qtos

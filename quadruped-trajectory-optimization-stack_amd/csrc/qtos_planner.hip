@@ -172,6 +172,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.rom_chunk = S.rom_chunk;
   TRY(p->upload(S.rom_t1_off, &D.rom_t1_off));
   TRY(p->upload(S.amask, &D.amask));
+  TRY(p->upload(S.amask2, &D.amask2));
+  TRY(p->upload(S.nxt_pack, &D.nxt_pack));
   TRY(p->upload(S.ctab, &D.ctab));
   TRY(p->upload(S.rtab, &D.rtab));
   TRY(p->upload(S.rhs_ptr, &D.rhs_ptr)); TRY(p->upload(S.rhs_gpos, &D.rhs_gpos)); TRY(p->upload(S.rhs_row, &D.rhs_row));
@@ -435,7 +437,7 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
     }
     if (p->was_chord[it]) {
       HIPCHK(p, hipEventRecord(p->ev[4 + 5 * it], st));
-      hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), 0, st, D, W, B);
+      hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), chord_lds_bytes(p->S.n_stages), st, D, W, B);
       HIPCHK(p, hipEventRecord(p->ev[5 + 5 * it], st));
     }
     hipLaunchKernelGGL(k_step, dim3(B), dim3(ET), p->eval_lds, st, D, W, B, it);
@@ -772,7 +774,7 @@ int qtos_debug_chord(QtosPlanner *p, int B, double *dx_out) {
   HIPCHK(p, hipSetDevice(p->device));
   DevWork W = p->wk;
   hipLaunchKernelGGL(k_debug_rhs, dim3(B), dim3(256), 0, 0, p->dp, W, B);
-  hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), 0, 0, p->dp, W, B);
+  hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), chord_lds_bytes(p->S.n_stages), 0, p->dp, W, B);
   hipLaunchKernelGGL(k_debug_unchord, dim3((B + 63) / 64), dim3(64), 0, 0, W, B);
   HIPCHK(p, hipDeviceSynchronize());
   HIPCHK(p, hipMemcpy(dx_out, W.dx, (size_t)B * p->M.n_vars * sizeof(double), hipMemcpyDeviceToHost));

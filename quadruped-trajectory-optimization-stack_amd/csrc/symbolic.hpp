@@ -84,6 +84,10 @@ struct Symbolic {
   int cell_mode = 2;
   std::vector<int> rtab;              // n_stages x 16: cell of the assembled right-hand side of every pivot (0 = none)
   std::vector<unsigned> amask;   // per stage 256 bits (8 words): front slots whose row of the factor panel V is stored (live, not a pivot of the stage)
+  // substitution sweeps with a one-stage look-ahead (k_chord, backward pass of k_kkt2): the rows of V_k that belong to
+  // the pivots of stage k+1 are applied by the wave that carries the chain, the other rows by everybody else
+  std::vector<unsigned> amask2;  // amask without the slots of the next stage's pivots
+  std::vector<int> nxt_pack;     // n_stages x 4: bytes m = 0..3 of word q: slot of pivot q + 4m of stage k+1 if its row of V_k is live, else 255
   // The linearisation kernels write straight into the stream: eq_pos maps the (virtual) G offset of
   // an equality-block entry to its stream position; inequality blocks are contiguous in the stream
   // (Block::goff = stream offset); rhs/sig/w positions per constraint row; constants (static
@@ -540,6 +544,18 @@ struct Symbolic {
       std::sort(free_slots.begin(), free_slots.end(), std::greater<int>());
       active -= (hi - lo);
     }
+    amask2 = amask;
+    nxt_pack.assign((size_t)n_stages * 4, -1);
+    for (int k = 0; k + 1 < n_stages; ++k)
+      for (int i = 0; i < PIV; ++i) {
+        const int t = piv_slot[(size_t)(k + 1) * PIV + i];
+        const bool live = t < 256 && ((amask[(size_t)k * 8 + (t >> 5)] >> (t & 31)) & 1u);
+        if (live) {
+          amask2[(size_t)k * 8 + (t >> 5)] &= ~(1u << (t & 31));
+          unsigned &w = (unsigned &)nxt_pack[(size_t)k * 4 + (i & 3)];
+          w = (w & ~(0xffu << (8 * (i >> 2)))) | ((unsigned)t << (8 * (i >> 2)));
+        }
+      }
     front = ((n_slots + PIV - 1) / PIV) * PIV;
     if (front > 128 && cell_mode == 2) { REC_MAX_INTS = 4096; REC_MAX_DOUBLES = 1280; }
     for (int j = 0; j < n_unknowns; ++j) {
