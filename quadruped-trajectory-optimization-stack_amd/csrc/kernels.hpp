@@ -1612,7 +1612,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   for (int ls = 0; ls < 6; ++ls) {
     for (int v = tid; v < n; v += blockDim.x) xt[v] = x[v] + al * dx[v];
     __syncthreads();
-    eval_all<false>(P, map, xt, gt, nullptr, evl, (W.trace && it == 1 && ls == 0) ? W.trace + ((size_t)b * (P.max_iter + 1) + 40) * 4 : nullptr);
+    eval_all<false>(P, map, xt, gt, nullptr, evl, (W.trace && it == 1 && ls == 0) ? W.trace + ((size_t)b * (P.max_iter + 1) + 76) * 4 : nullptr);
     __syncthreads();
     th = l1_infeasibility(P, gt, s, ds, al, scratch);
     if (th <= (1.0 - 1e-4 * al) * th0 || th < 1e-9) break;
@@ -1681,7 +1681,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   const int held = (W.held[b] || (P.hold_from > 0 && it + 1 >= P.hold_from && viol <= P.hold_tol)) ? 1 : 0;
   __syncthreads();
   if (tid == 0) W.held[b] = held;
-  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, (W.trace && it == 1) ? W.trace + ((size_t)b * (P.max_iter + 1) + 36) * 4 : nullptr,
+  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, (W.trace && it == 1) ? W.trace + ((size_t)b * (P.max_iter + 1) + 72) * 4 : nullptr,
                  held);
   __syncthreads();
   KSTAMP(4);

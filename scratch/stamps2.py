@@ -26,3 +26,10 @@ for b in (0, 5, NB - 1):
     P.lib.qtos_debug_trace(P.h, b, t.ctypes.data_as(C.POINTER(C.c_double)))
     ks += t[70:72].reshape(8)
 print("k_step cycles (iteration 1): ds=Ji dx | ratio tests + th0 | line search evals | updates + infeasibility | eval with Jacobian | barrier terms:", (ks / 3).round(0))
+es = np.zeros(16); el = np.zeros(16)
+for b in (0, 5, NB - 1):
+    t = np.zeros((cfg.max_iter + 1, 4))
+    P.lib.qtos_debug_trace(P.h, b, t.ctypes.data_as(C.POINTER(C.c_double)))
+    es += t[72:76].reshape(16); el += t[76:80].reshape(16)
+print("eval_all<true> stamps:", (es / 3).round(0))
+print("eval_all<false> stamps:", (el / 3).round(0))
