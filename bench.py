@@ -59,9 +59,13 @@ def parse_args():
     ap.add_argument("--no-parity", action="store_true", help="skip the golden-plan parity block")
     ap.add_argument("--tol", type=float, default=None,
                     help="constraint-violation tolerance (default: the planner's 1e-4; the reference's Ipopt runs at ~1e-3)")
-    ap.add_argument("--inflight", type=int, default=1,
+    ap.add_argument("--inflight", type=int, default=None,
                     help="batches in flight per GPU (each on its own planner handle + HIP stream + host thread). "
-                         "Default 1 = the configuration BASELINE.json names")
+                         "Default 1 = the configuration BASELINE.json names; mpc_random: the windows of a GPU run as this "
+                         "many independent sets (default 4), every set at the pace of its own slowest window")
+    ap.add_argument("--chord-tol", type=float, default=None,
+                    help="violation below which an iterate reached by a full step is followed by a solve that re-uses "
+                         "the factorisation (default: the planner's 1e-3; 0 = every iteration factors)")
     ap.add_argument("--max-iter", type=int, default=None, help="Newton iteration limit per solve (default: the planner's 24)")
     ap.add_argument("--init", default="straight_line", choices=["straight_line", "table"],
                     help="starting point of the solves: towr's straight-line guess (the reference's behaviour, default) or "
@@ -154,6 +158,14 @@ def main():
     mpc = args.workload == "mpc_random"
     if args.max_iter is not None:
         kw["max_iter"] = args.max_iter
+    if args.inflight is None:
+        args.inflight = 4 if mpc else 1
+    if args.chord_tol is not None:
+        kw["chord_tol"] = args.chord_tol
+    elif mpc:
+        # replanned windows are at different points of their solves in every iteration: a chord step saves no launch
+        # there (the batch still factors for the others) and a discarded one costs an iteration
+        kw["chord_tol"] = 0.0
     if args.gait == "trot":
         kw["gait"] = "trot"
     if mpc and args.inflight > 1 and args.batch % args.inflight:
@@ -308,9 +320,27 @@ def main():
                 futs.append(pool.submit(lane_step, lanes[nxt % len(lanes)], args.warmup + nxt))
                 nxt += 1
         all_nodes, all_status = lanes[0]["nodes"], lanes[0]["status"]
+    elif mpc and mpc_pool is not None:
+        # the sets of windows are independent robots: every set runs its K replans on its own (no rendezvous between
+        # sets after every replan: a set waits for ITS slowest window only); a step = one replan of every window
+        def run_set(Wj):
+            cnt = torch.zeros((), dtype=torch.int64, device=dev)
+            with torch.cuda.stream(Wj.stream):
+                for _ in range(args.steps):
+                    Wj.replan()
+                    cnt.add_((Wj.status == 0).sum())
+            Wj.stream.synchronize()
+            return int(cnt.item())
+        t0 = time.perf_counter()
+        solved_inflight = sum(mpc_pool.map(run_set, windows))
+        all_nodes = torch.cat([Wj.nodes for Wj in windows])
+        all_status = torch.cat([Wj.status for Wj in windows])
+        if use_dist:
+            all_nodes, all_status = gather_plans(all_nodes, all_status, B * world)
+        iters = torch.cat([Wj.iters for Wj in windows])
     else:
         t0 = time.perf_counter()
-    for _ in range(0 if lanes else args.steps):
+    for _ in range(0 if (lanes or (mpc and mpc_pool is not None)) else args.steps):
         all_nodes, all_status = step()
         tm = P.timing()   # HIP events recorded on the launch stream around every k_kkt launch
         kkt_s += tm["kkt_seconds"]
@@ -352,7 +382,7 @@ def main():
             "iterations_mean": round(float(iters_dev.item()) / max(B * args.steps, 1), 3) if solved_inflight is None else None,
             "parallelism": "batch-shard x%d + 1 %s" % (world, "RCCL all-gather" if use_dist else "all-gather (not launched under torch.distributed: single process)"),
             "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front,
-            "batches_in_flight": args.inflight, "max_iter": cfg.max_iter,
+            "batches_in_flight": args.inflight, "max_iter": cfg.max_iter, "chord_tol": cfg.chord_tol,
             "initial_guess": "towr straight line" if args.init == "straight_line" else
                              "interpolated table of %d nominal plans (solved before the timed region)" % (P.init_table[2].shape[0] * P.init_table[2].shape[1]),
         },

@@ -1138,6 +1138,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
   int best_it = 0;
   double *xbest = (double *)malloc(sizeof(double) * n);
   int chord_ok = 0;      /* the last step was a full step (alpha = 1) of a freshly factored system */
+  int chord_banned = 0;  /* a chord step of this solve was discarded: every later iteration factors */
   int n_chord = 0;
   for (it = 0; it < o->max_iter; ++it) {
     double theta = 0;
@@ -1161,7 +1162,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     eval_all(p, M, x, NULL, J);
     t_eval += now_s() - t0;
     t0 = now_s();
-    const int chord = o->chord_tol > 0 && chord_ok && viol <= o->chord_tol;
+    const int chord = o->chord_tol > 0 && chord_ok && !chord_banned && viol <= o->chord_tol;
     chord_ok = 0;
     n_chord += chord;
     if (!chord) memset(K.a, 0, sizeof(double) * K.start[N]);
@@ -1254,6 +1255,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
      * it is discarded (the iterate stays, the next iteration factors) -- a damped chord step can park a slack
      * right on its bound, and the KKT matrix of that point is too badly scaled for the block elimination */
     if (chord && al != 1.0) {
+      chord_banned = 1;   /* one discarded chord step and the solve factors every iteration from then on */
       al = 0.0;
       az = 0.0;
       memcpy(xt, x, sizeof(double) * n);

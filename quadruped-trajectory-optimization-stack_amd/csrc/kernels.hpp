@@ -1557,7 +1557,8 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   double mu = W.mu[b];
   const double best_viol = W.best_viol[b];   // read before anybody writes them (tid 0, end of the kernel)
   const int best_it = W.best_it[b];
-  const int was_chord = W.chord[b];          // this iteration's dx came from a chord step
+  const int chord_state = W.chord[b];        // 1: this iteration's dx came from a chord step; 2: chord steps are off for this solve
+  const bool was_chord = chord_state == 1;
 #ifdef QTOS_STAMPS
   unsigned long long ks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kt0 = 0;
 #define KSTAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ks[i] += t_ - kt0; kt0 = t_; } } while (0)
@@ -1676,7 +1677,10 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   }
   if (conv || bad || stalled) return;
   // chord step next?  (an iterate this close, reached by a full step of a freshly factored system)
-  const bool next_chord = P.chord_tol > 0 && !was_chord && al == 1.0 && viol <= P.chord_tol;
+  // (one discarded chord step and the solve factors every iteration from then on: near a terrain edge the attempt
+  //  fails again and again, and every failure is an iteration the whole batch waits for)
+  const bool chord_off = chord_state == 2 || reject;
+  const bool next_chord = P.chord_tol > 0 && !was_chord && !chord_off && al == 1.0 && viol <= P.chord_tol;
   // two-phase solve: latch the hold once this iterate is close enough
   const int held = (W.held[b] || (P.hold_from > 0 && it + 1 >= P.hold_from && viol <= P.hold_tol)) ? 1 : 0;
   __syncthreads();
@@ -1688,7 +1692,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
   KSTAMP(5);
   if (tid == 0) {
-    W.chord[b] = next_chord ? 1 : 0;
+    W.chord[b] = next_chord ? 1 : (chord_off ? 2 : 0);
     if (next_chord) atomicAdd(W.n_active + 1, 1);
   }
   if (next_chord) {

@@ -320,7 +320,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
 template <int F, bool CONT>
 __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
-  if (b >= B || W.done[b] || W.chord[b]) return;   // (a problem flagged for a chord step is k_chord's)
+  if (b >= B || W.done[b] || W.chord[b] == 1) return;   // (a problem flagged for a chord step is k_chord's)
   extern __shared__ double lds[];
   using CF = Kkt2Cfg<F>;
   using LY = Kkt2Layout<F>;
@@ -900,7 +900,7 @@ inline size_t chord_lds_bytes(int NS) { return sizeof(int) * (size_t)NS * 12; }
 template <int F>
 __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
-  if (b >= B || W.done[b] || !W.chord[b]) return;
+  if (b >= B || W.done[b] || W.chord[b] != 1) return;
   using CF = Kkt2Cfg<F>;
   constexpr int NT = CF::NT, FR = CF::FR;
   static_assert(NT + 1 < 16, "k_chord: waves 1..NT own the row tiles, wave NT + 1 solves with the pivot blocks");

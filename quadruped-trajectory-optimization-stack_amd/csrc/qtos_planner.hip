@@ -35,6 +35,8 @@ struct QtosPlanner {
   int *d_map = nullptr;
   double *d_height = nullptr;
   hipStream_t own_stream = nullptr;   // stream of the host-pointer entry points (non-blocking: other handles / streams are not synchronised)
+  hipStream_t side_stream = nullptr;  // k_chord of an iteration in which other problems of the batch factor: the two kernels run side by side
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *d_table = nullptr, *d_tab_dx = nullptr, *d_tab_dy = nullptr;   // nominal-plan table (qtos_set_init_table)
   int *h_active = nullptr;  // pinned, one word per Newton iteration: unfinished problems after it
   std::vector<hipEvent_t> ev;  // 3 per iteration (kkt begin / end, count read back) + 2 (total)
@@ -130,6 +132,9 @@ void qtos_planner_destroy(QtosPlanner *p) {
     if (q) (void)hipFree(q);
   if (p->h_active) (void)hipHostFree(p->h_active);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+  if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   delete p;
 }
 
@@ -320,6 +325,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   p->was_kkt.assign(M.P.max_iter + 1, 0);
   p->was_chord.assign(M.P.max_iter + 1, 0);
   if (hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+  if (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+  if (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   p->ev.resize(5 * (size_t)M.P.max_iter + 3);
   for (auto &e : p->ev)
     if (hipEventCreate(&e) != hipSuccess) { qtos_planner_destroy(p); return -2; }
@@ -430,15 +437,28 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
     p->was_kkt[it] = n - nc > 0;
     p->was_chord[it] = nc > 0 && p->chord_fn;
     if (getenv("QTOS_DEBUG_LOOP")) fprintf(stderr, "qtos: it %d unfinished %d chord %d\n", it, n, nc);
+    // Next to a factorisation of other problems the chord solve runs on the side stream: the workgroups of k_kkt2
+    // that belong to its problems leave at once and k_chord gets their CUs, so a batch whose problems are at
+    // different points of their solves pays max(k_kkt2, k_chord) per iteration, not the sum.
+    const bool fork = p->was_kkt[it] && p->was_chord[it];
+    hipStream_t cs = fork ? p->side_stream : st;
+    if (fork) {
+      HIPCHK(p, hipEventRecord(p->ev_fork, st));            // everything up to the previous k_step
+      HIPCHK(p, hipStreamWaitEvent(cs, p->ev_fork, 0));
+    }
     if (p->was_kkt[it]) {
       HIPCHK(p, hipEventRecord(p->ev[2 + 5 * it], st));
       hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(p->kkt_threads), p->kkt_lds, st, D, W, B);
       HIPCHK(p, hipEventRecord(p->ev[3 + 5 * it], st));
     }
     if (p->was_chord[it]) {
-      HIPCHK(p, hipEventRecord(p->ev[4 + 5 * it], st));
-      hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), chord_lds_bytes(p->S.n_stages), st, D, W, B);
-      HIPCHK(p, hipEventRecord(p->ev[5 + 5 * it], st));
+      HIPCHK(p, hipEventRecord(p->ev[4 + 5 * it], cs));
+      hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), chord_lds_bytes(p->S.n_stages), cs, D, W, B);
+      HIPCHK(p, hipEventRecord(p->ev[5 + 5 * it], cs));
+    }
+    if (fork) {
+      HIPCHK(p, hipEventRecord(p->ev_join, cs));
+      HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
     }
     hipLaunchKernelGGL(k_step, dim3(B), dim3(ET), p->eval_lds, st, D, W, B, it);
     HIPCHK(p, hipMemcpyAsync(p->h_active + 2 * it, W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));

@@ -19,7 +19,10 @@ b batch512 --cpu-sample 0 --no-parity --batch 512
 b batch1024 --cpu-sample 0 --no-parity --batch 1024
 b knots200 --cpu-sample 0 --no-parity --transcription knots200
 b mpc --cpu-sample 0 --no-parity --transcription knots200 --workload mpc_random --steps 200
+b mpc_1set --cpu-sample 0 --no-parity --transcription knots200 --workload mpc_random --steps 200 --inflight 1
 b table --cpu-sample 0 --no-parity --init table
+b inflight2 --cpu-sample 0 --no-parity --inflight 2
+b nochord --cpu-sample 0 --no-parity --chord-tol 0
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --cpu-sample 0 --no-parity > $O/bench_${T}_torchrun1.json 2>/dev/null; cut -c1-160 $O/bench_${T}_torchrun1.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*\(MFMA\|BUSY\|WAVE_CYCLES\|LDS_BANK\|LDS_IDX\|WAIT_INST\|WAIT_ANY\)[A-Z_0-9]*" | sort -u | tr '\n' ' ' > $O/counters_$T.txt; cat $O/counters_$T.txt; echo

@@ -310,7 +310,7 @@ def test_gather_plans_on_device_world_1():
     from conftest import ROOT
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500), RANK="0",
                WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", _GATHER_SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=180)
+    r = subprocess.run([sys.executable, "-c", _GATHER_SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "GATHER_OK" in r.stdout, r.stderr[-2000:]
 
 
