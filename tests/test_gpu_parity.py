@@ -4,8 +4,8 @@ with the committed golden plans, or through size-independent properties at the f
 
 Floating-point tolerances (all double precision):
   constraint values / Jacobian entries  1e-10 abs   (same formulas, different summation order)
-  one KKT solve                          <= 20x the spread between LAPACK and the oracle's LDL^T
-                                         (indefinite system, cond ~1e11), never above 2e-5 rel
+  one KKT solve                          5e-6 of the largest entry (achieved 6e-8 .. 1.6e-6 at cond ~5e6, recorded by
+                                         the test; LAPACK vs the oracle's LDL^T: 1e-9 .. 1e-8)
   full NLP solve, nodes                  1e-6 abs    (north_star allows 1e-3 m; we hold 1e-6)
 """
 import json
@@ -127,6 +127,7 @@ def test_kkt_solve_matches_dense_reference(planner, oracle, gv1, cfg):
     dx = planner.debug_newton(start, goal, x, sig, w)
     free, E, Ii = np.nonzero(~fx)[0], np.nonzero(rk == 1)[0], np.nonzero(I)[0]
     nf, nE = len(free), len(E)
+    achieved = []
     for b in range(B):
         Jo, go = oracle.jacobian(x[b]), oracle.constraints(x[b])
         JE, JI = Jo[np.ix_(E, free)], Jo[np.ix_(Ii, free)]
@@ -142,14 +143,23 @@ def test_kkt_solve_matches_dense_reference(planner, oracle, gv1, cfg):
         Kc = np.ascontiguousarray(K)
         assert olib().qo_ldlt_solve_dense(nf + nE, Kc.ctypes.data_as(C.POINTER(C.c_double)),
                                           sol.ctypes.data_as(C.POINTER(C.c_double))) == 0
-        # K is indefinite (cond ~5e6 here).  LAPACK and the oracle's LDL^T agree to ~1e-8; the
-        # GPU's 16-pivot block elimination currently uses an explicit inverse of each pivot block
-        # and loses about two digits against that (tracked in DESIGN.md); gate at 2e-5 relative.
+        # K is indefinite (cond 4e6 .. 6e6 here, barrier weights over six decades).  LAPACK and the oracle's LDL^T agree
+        # to 1e-9 .. 1e-8 of the largest entry; the GPU's 16-pivot block elimination multiplies with the explicit inverse
+        # of every pivot block and achieves 6e-8 .. 1.6e-6 (profiles/r02_kkt_accuracy.json): gate at
+        # 5e-6 relative (2e-5 in round 1).
         cpu_spread = np.abs(sol[:nf] - ref).max()
-        tol = 2e-5 * scale if cpu_spread < 1e-6 * scale else 20 * cpu_spread
-        assert np.abs(dx[b, free] - ref).max() <= tol
-        assert np.abs(dx[b, free] - sol[:nf]).max() <= tol
+        tol = 5e-6 * scale if cpu_spread < 2.5e-7 * scale else 20 * cpu_spread
+        err_lapack, err_oracle = np.abs(dx[b, free] - ref).max(), np.abs(dx[b, free] - sol[:nf]).max()
+        achieved.append(dict(problem=b, cond=float(np.linalg.cond(K)), scale=float(scale), lapack_vs_oracle=float(cpu_spread / scale),
+                             gpu_vs_lapack=float(err_lapack / scale), gpu_vs_oracle=float(err_oracle / scale)))
+        assert err_lapack <= tol
+        assert err_oracle <= tol
         assert np.all(dx[b, fx] == 0)
+    # the achieved errors (relative to the largest entry of the solution), for DESIGN.md: printed and, on the GPU box, kept
+    print("KKT solve, achieved relative errors:", json.dumps(achieved))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(achieved, open(os.path.join(out, "kkt_accuracy.json"), "w"), indent=1)
 
 
 def test_chord_step_kernel_matches_the_factorising_kernel(planner, oracle, gv1, cfg):
