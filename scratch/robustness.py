@@ -1,5 +1,5 @@
 """Convergence statistics over many seeded batches (evidence for DESIGN.md section 6)."""
-import sys; sys.path.insert(0, '.')
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from qtos_amd import capi, workloads
 from qtos_amd.config import PlannerConfig
