@@ -52,7 +52,6 @@ struct DevPlan {
   const int *nxt_pack;         // n_stages x 4: slots of the next stage's pivots in this stage's panel, 255 = none (Symbolic::nxt_pack)
   const unsigned short *ctab;  // n_stages x (front/16) x 64 x 4: cell of every entry of a stage's pivot columns (Symbolic::ctab)
   int n_cells;                 // cells of the assembled entries: [0] zero, [1 + slot] right-hand side, then the entries
-  int max_part_con;            // most contributions in one assembly part (k_kkt2 scratch, Symbolic::max_part_con)
   // chord step (QtosParams.chord_tol): right-hand side of the KKT system in elimination order, formed by k_step:
   // unknown p is a multiplier (rhs_ptr[p+1] - rhs_ptr[p] == 1, rhs_gpos < 0: rhs = -g[rhs_row]) or a variable
   // (rhs = -sum G[rhs_gpos] * w[rhs_row] over the inequality rows that contain it)
@@ -895,19 +894,36 @@ __device__ __forceinline__ double gather_term(const double *dbuf, int code) {
   const double *sg = Gb + qm * qn, *wq = sg + qm;
   const bool rhs = c == 63;
   const int cc = rhs ? a : c;
-  double ga[5], gc[5], sw[5];
+  // rows 0..2 always (most blocks have three rows: the range-of-motion boxes), rows 3 and 4 only when a lane of the
+  // wave has a block that deep (friction pyramids)
+  double ga[3], gc[3], sw[3];
 #pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int rr = min(r, qm - 1);
-    ga[r] = Gb[rr * qn + a];
-    gc[r] = Gb[rr * qn + cc];
-    sw[r] = rhs ? wq[rr] : sg[rr];
+  for (int r = 0; r < 3; ++r) {
+    // (rows beyond a shallow block's last read whatever follows it in the record -- still LDS -- and are discarded below)
+    ga[r] = Gb[r * qn + a];
+    gc[r] = Gb[r * qn + cc];
+    sw[r] = rhs ? wq[r] : sg[r];
   }
   double acc = 0.0;
 #pragma unroll
-  for (int r = 0; r < 5; ++r) {
+  for (int r = 0; r < 3; ++r) {
     const double term = rhs ? -(ga[r] * sw[r]) : sw[r] * ga[r] * gc[r];
     acc += r < qm ? term : 0.0;
+  }
+  if (__builtin_amdgcn_ballot_w64(qm > 3) != 0ull) {
+    double gb[2], gd[2], sv[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int rr = min(r + 3, qm - 1);
+      gb[r] = Gb[rr * qn + a];
+      gd[r] = Gb[rr * qn + cc];
+      sv[r] = rhs ? wq[rr] : sg[rr];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double term = rhs ? -(gb[r] * sv[r]) : sv[r] * gb[r] * gd[r];
+      acc += r + 3 < qm ? term : 0.0;
+    }
   }
   return acc;
 }

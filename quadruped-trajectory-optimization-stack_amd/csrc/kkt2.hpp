@@ -89,7 +89,7 @@ __host__ __device__ inline size_t kkt2_dbuf_doubles(int F, int max_drec) {
 __host__ __device__ inline size_t kkt2_sbuf_ints(int F, int max_srec) {
   return F <= 128 ? (((size_t)max_srec * 4 + 1023) & ~(size_t)1023) / 4 : (((size_t)max_srec + 3) & ~(size_t)3);
 }
-inline size_t kkt2_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells, int max_part_con) {
+inline size_t kkt2_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells) {
   const int FR = (F + 63) & ~63, PSZ = (F + 1) * PLD;
   const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 2 * (size_t)FR + 2 * 16 * PIV + 64 + 3 * PIV / 2 + 2 + FR + 8 + PIV * PLD;
   size_t o = (fixed + 3 * (size_t)PSZ + (F <= 128 ? (size_t)F * PLD : 0) + 1) & ~(size_t)1;
@@ -97,11 +97,6 @@ inline size_t kkt2_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_ce
   o += nbuf * kkt2_dbuf_doubles(F, max_drec);
   size_t oi = 2 * o + nbuf * kkt2_sbuf_ints(F, max_srec) + ((((size_t)NS + 1) + 3) & ~(size_t)3);
   oi += 2 * (((size_t)n_cells + 1) & ~(size_t)1);
-#ifdef QTOS_ASM_PARTS
-  oi += 2 * 16 * (size_t)max_part_con;
-#else
-  (void)max_part_con;
-#endif
   // (the backward pass keeps NS x 12 ints of sweep tables where the panels were)
   const size_t sweep = fixed * sizeof(double) + (size_t)NS * 12 * sizeof(int);
   return oi * sizeof(int) > sweep ? oi * sizeof(int) : sweep;
@@ -140,47 +135,6 @@ __device__ __forceinline__ void sload2(const int *p, int &a, int &b) {
   asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
   a = r[0];
   b = r[1];
-}
-
-// Assembly of one stage's records (in LDS) into the cells.  Equality entries and multiplier right-hand sides
-// are distinct targets: one item per thread.  The inequality blocks come in NPART parts (Symbolic::emit_blocks),
-// one wave each and no barrier: first every contribution  sum_r sig_r G[r][a] G[r][c]  (or  -sum_r G[r][a] w_r)
-// is formed by its own lane and parked in the wave's scratch array, then every target of the part sums its
-// run of contributions in list order (fixed order => bitwise reproducible) and adds it to its cell.
-constexpr int NPART = Symbolic::NPART;
-constexpr int APW = 4;   // parts a wave without Schur tiles takes in phase C (merged into one run)
-__device__ __forceinline__ void assemble_eq(double *A, const int *sbuf, const double *dbuf, int t0, int nth) {
-  const int n_ent = sbuf[0], n_rhs = sbuf[1];
-  const int *eidx = sbuf + SHDR + PIV;
-  const double *eval = dbuf + PIV;
-  for (int i = t0; i < n_ent + n_rhs; i += nth) A[eidx[i]] += eval[i];   // (rhs targets and values follow the entries)
-}
-// parts [p0, p1) as one run (consecutive parts are consecutive targets / contributions); scr0 = scratch of part 0
-__device__ __forceinline__ void assemble_part(double *A, const int *sbuf, const double *dbuf, double *scr0, int mpc, int lane, int p0, int p1) {
-  if (sbuf[2] == 0 || p0 >= p1) return;
-  double *scr = scr0 + p0 * mpc;
-  const int *tg = sbuf + sbuf[4];
-  const int *pt = tg - 2 * (NPART + 1), *pc = pt + (NPART + 1);
-  const int *cl = tg + sbuf[5] + 1;
-  const int t0 = pt[p0], t1 = pt[p1], c0 = pc[p0], c1 = pc[p1];
-#ifdef QTOS_EXP_NOASM
-  return;
-#endif
-  for (int j = c0 + lane; j < c1; j += 64) scr[j - c0] = gather_term(dbuf, cl[j]);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the LDS operations of one wave complete in order)
-  for (int t = t0 + lane; t < t1; t += 64) {
-    const int tv = tg[t], b = (tv & 4095) - c0, e = (tg[t + 1] & 4095) - c0;
-    const double a_old = A[tv >> 12];
-    double acc = 0.0;
-    for (int j = b; j < e; j += 4) {
-      double v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = scr[min(j + u, e - 1)];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc += j + u < e ? v[u] : 0.0;
-    }
-    A[tv >> 12] = a_old + acc;
-  }
 }
 
 // ---- substitution sweeps with a one-stage look-ahead ------------------------------------------------------------
@@ -341,9 +295,6 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   int *sbuf = sbuf0;
   int *hiall = sbuf0 + NBUF * sstride;
   double *A = (double *)(hiall + ((NS + 4) & ~3));   // cells of the assembled entries
-#ifdef QTOS_ASM_PARTS
-  double *scr0 = A + ((P.n_cells + 1) & ~1);   // assembly scratch: max_part_con doubles per part
-#endif
   const double *stream = W.stream + (size_t)b * P.stream_len;
   double *panel = W.panel + (size_t)b * P.panel_stride;
   double *dx = W.dx + (size_t)b * n;
@@ -786,17 +737,9 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     // (the waves without a Schur tile come first and take the low item indices)
     const int apos = is_upd ? (15 - NU) + uw : uw - NU;   // (wave 12, the header wave, is the last of the free ones)
     if (wv >= 1 && k + 2 < NS) {
-#ifdef QTOS_ASM_PARTS
-      assemble_eq(A, sbuf, dbuf, apos * 64 + lane, 15 * 64);
-      // the waves without Schur tiles take APW parts each as one run, the oldest update waves one of the rest
-      constexpr int NFREE = 15 - NU, NF4 = NFREE * APW < NPART ? NFREE * APW : NPART;
-      if (apos < NFREE) assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, min(apos * APW, NF4), min(apos * APW + APW, NF4));
-      else assemble_part(A, sbuf, dbuf, scr0, P.max_part_con, lane, min(NF4 + apos - NFREE, NPART), min(NF4 + apos - NFREE + 1, NPART));
-#else
       // one thread per target, low item indices to the waves that get here first (equal shares: handing the waves
       // without Schur tiles more of it was tried -- they share the factor wave's SIMD and are the slowest at it)
       assemble_stage(A, F, sbuf, dbuf, apos * 64 + lane, 15 * 64);
-#endif
     }
     if constexpr (CONT) {
       if (k + 2 < NS) assemble_continuations(wv >= 1 ? apos * 64 + lane : -1, 15 * 64);

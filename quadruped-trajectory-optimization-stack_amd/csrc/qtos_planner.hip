@@ -185,7 +185,6 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.n_unknowns = S.n_unknowns;
   D.chord_tol = kkt2 ? M.P.chord_tol : 0.0;   // (the 8-wave kernel does not keep the pivot-block inverses)
   D.n_cells = S.n_cells;
-  D.max_part_con = (S.max_part_con + 1) & ~1;
   D.n_cont = 0;
   for (int k = 0; k < S.n_stages; ++k) D.n_cont += S.srec[S.srec_off[k] + 6];
   D.table = nullptr; D.tab_dx = D.tab_dy = nullptr; D.tab_ndx = D.tab_ndy = 0;
@@ -253,7 +252,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.panel_stride = (long long)S.n_stages * (S.front + 1) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  p->kkt_lds = kkt2 ? kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells, (S.max_part_con + 1) & ~1)
+  p->kkt_lds = kkt2 ? kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells)
                     : kkt_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
   p->kkt_threads = kkt2 ? KT2 : KT;
   const int max_front = kkt2 ? 208 : 128;
