@@ -321,6 +321,9 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     tRC[i] = valid ? (R << 8) | (t - ((R * (R + 1)) >> 1)) : -1;
   }
 
+  unsigned ge4_keep = 0u, gt4_keep = 0u;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { ge4_keep |= (lk + 4 * g >= li ? 1u : 0u) << (4 * g); gt4_keep |= (lk + 4 * g > li ? 1u : 0u) << (4 * g); }
   for (int i = tid; i < P.n_cells; i += KT2) A[i] = 0.0;
   for (int i = tid; i < 3 * PSZ; i += KT2) PB[i] = 0.0;
   for (int i = tid; i < FR; i += KT2) { UF[i] = 0.0; xs[i] = 0.0; }
@@ -699,10 +702,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
           asm volatile("" : "+v"(jcs[t]), "+v"(jrs[t][0]), "+v"(jrs[t][1]), "+v"(jrs[t][2]), "+v"(jrs[t][3]));
         double *dummy = red + 2 * 16 * PIV + lane;
         // bit 4g of ge4 / gt4: row lk + 4g of a diagonal tile lies on or below / strictly below column li
-        // (recomputed every stage: two registers less across the loop)
-        unsigned ge4 = 0u, gt4 = 0u;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { ge4 |= (lk + 4 * g >= li ? 1u : 0u) << (4 * g); gt4 |= (lk + 4 * g > li ? 1u : 0u) << (4 * g); }
+        const unsigned ge4 = ge4_keep, gt4 = gt4_keep;
 #pragma unroll
         for (int t = 0; t < MAXT2; ++t) {
           const int rc = rcs[t];
