@@ -1720,8 +1720,21 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
       const int t0 = P.rhs_ptr[p], t1 = P.rhs_ptr[p + 1];
       double acc = 0.0;
       if (t1 - t0 == 1 && P.rhs_gpos[t0] < 0) acc = -g[P.rhs_row[t0]];
-      else
-        for (int t = t0; t < t1; ++t) acc = fma(-Gs[P.rhs_gpos[t]], wr[P.rhs_row[t]], acc);
+      else {
+        // eight entries per round: their index pairs, then their values, in flight together (a base node has a
+        // hundred entries and every one is two dependent memory round trips); summed in list order
+        constexpr int RU = 8;
+        for (int t = t0; t < t1; t += RU) {
+          int gp[RU], rw[RU];
+#pragma unroll
+          for (int u = 0; u < RU; ++u) { const int tt = min(t + u, t1 - 1); gp[u] = P.rhs_gpos[tt]; rw[u] = P.rhs_row[tt]; }
+          double gv[RU], wv[RU];
+#pragma unroll
+          for (int u = 0; u < RU; ++u) { gv[u] = Gs[gp[u]]; wv[u] = wr[rw[u]]; }
+#pragma unroll
+          for (int u = 0; u < RU; ++u) acc = t + u < t1 ? fma(-gv[u], wv[u], acc) : acc;
+        }
+      }
       rhs[p] = acc;
     }
   }
