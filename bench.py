@@ -262,8 +262,7 @@ def main():
                                               viol.data_ptr(), C.c_void_p(stream.cuda_stream))
             if rc != 0:
                 raise RuntimeError("qtos_plan_batch_device failed: %d %s" % (rc, P.lib.qtos_last_error(P.h)))
-            solved_dev.add_((status == 0).sum())
-            iters_dev.add_(iters.sum())
+            # (converged plans and iterations are tallied on the device by the planner itself: qtos_plan_totals)
         if use_dist:
             return gather_plans(nodes, status, B * world)
         return nodes, status
@@ -302,6 +301,7 @@ def main():
     sync()
     solved_dev.zero_()
     iters_dev.zero_()
+    P.totals(reset=True)
     kkt_s, kkt_n, tot_s = 0.0, 0, 0.0
     chord_s, chord_n = 0.0, 0
     solved_inflight = None
@@ -350,6 +350,10 @@ def main():
         chord_n += tm.get("chord_launches", 0)
     sync()
     elapsed = time.perf_counter() - t0
+    if not mpc and not lanes:
+        tc, ti = P.totals()
+        solved_dev.fill_(tc)
+        iters_dev.fill_(ti)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     n_local = solved_dev.to(torch.float64).reshape(1) if solved_inflight is None else torch.tensor([float(solved_inflight)], dtype=torch.float64, device=dev)
     if use_dist:

@@ -161,6 +161,10 @@ int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, dou
                      int *iterations);
 /* The same for the chord-step launches (k_chord, QtosParams.chord_tol) of the last call. */
 int qtos_last_timing_chord(QtosPlanner *p, double *chord_seconds, int *chord_launches);
+/* Running totals over all qtos_plan_batch* calls of the handle since the last reset: problems returned with
+ * status 0 and Newton iterations spent, tallied on the device at the end of every call (no read-back, no extra
+ * work for the caller between batches).  Synchronises the stream of the last call.  reset != 0 clears them. */
+int qtos_plan_totals(QtosPlanner *p, long long *converged, long long *iterations, int reset);
 
 /* ---- introspection for the parity tests (host pointers) ------------------------------------ */
 /* constraint values (B x n_cons) and, if J_out != NULL, the dense Jacobian (B x n_cons x n_vars,

@@ -55,7 +55,7 @@ EXPORTS = [
     "qtos_sample_csv_device", "qtos_last_timing", "qtos_debug_eval", "qtos_debug_newton",
     "qtos_debug_structure", "qtos_debug_trace", "qtos_debug_factor", "qtos_analyze",
     "qtos_set_init_table", "qtos_debug_initial_guess", "qtos_shift_warm", "qtos_shift_warm_device",
-    "qtos_last_timing_chord", "qtos_debug_chord",
+    "qtos_last_timing_chord", "qtos_debug_chord", "qtos_plan_totals",
 ]
 
 _lib = None
@@ -107,6 +107,8 @@ def load():
     lib.qtos_debug_initial_guess.argtypes = [vp, C.c_int, dp, dp, ip, dp]
     if hasattr(lib, "qtos_last_timing_chord"):
         lib.qtos_last_timing_chord.argtypes = [vp, dp, ip]
+    if hasattr(lib, "qtos_plan_totals"):
+        lib.qtos_plan_totals.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]
         lib.qtos_debug_chord.argtypes = [vp, C.c_int, dp]
     if hasattr(lib, "qtos_shift_warm"):   # (absent from older builds loaded through QTOS_LIB for A/B timing)
         lib.qtos_shift_warm.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, dp]
@@ -300,6 +302,12 @@ class Planner:
             self._chk(self.lib.qtos_last_timing_chord(self.h, C.byref(c), C.byref(nc)), "last_timing_chord")
             out.update(chord_seconds=c.value, chord_launches=nc.value)
         return out
+
+    def totals(self, reset=False):
+        """(problems returned with status 0, Newton iterations) over all plan calls of this handle since the last reset."""
+        c, n = C.c_longlong(), C.c_longlong()
+        self._chk(self.lib.qtos_plan_totals(self.h, C.byref(c), C.byref(n), int(bool(reset))), "plan_totals")
+        return c.value, n.value
 
     # ---- introspection (parity tests) ----
     def debug_eval(self, start, goal, nodes, map_id=None, jac=True):

@@ -35,6 +35,8 @@ struct QtosPlanner {
   int *d_map = nullptr;
   double *d_height = nullptr;
   hipStream_t own_stream = nullptr;   // stream of the host-pointer entry points (non-blocking: other handles / streams are not synchronised)
+  long long *d_totals = nullptr;      // converged problems, iterations: tallied at the end of every plan call (qtos_plan_totals)
+  hipStream_t last_stream = nullptr;
   hipStream_t side_stream = nullptr;  // k_chord of an iteration in which other problems of the batch factor: the two kernels run side by side
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *d_table = nullptr, *d_tab_dx = nullptr, *d_tab_dy = nullptr;   // nominal-plan table (qtos_set_init_table)
@@ -133,6 +135,7 @@ void qtos_planner_destroy(QtosPlanner *p) {
   if (p->h_active) (void)hipHostFree(p->h_active);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
   if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
+  if (p->d_totals) (void)hipFree(p->d_totals);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   delete p;
@@ -325,6 +328,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   p->was_chord.assign(M.P.max_iter + 1, 0);
   if (hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   if (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+  if (hipMalloc(&p->d_totals, 2 * sizeof(long long)) != hipSuccess || hipMemset(p->d_totals, 0, 2 * sizeof(long long)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
+  p->last_stream = p->own_stream;
   if (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   p->ev.resize(5 * (size_t)M.P.max_iter + 3);
   for (auto &e : p->ev)
@@ -397,6 +402,28 @@ int qtos_set_heightfields(QtosPlanner *p, int n_maps, const double *height, int 
   return 0;
 }
 
+// results of a batch to the caller's buffers (one launch instead of four copies) and the running totals of
+// qtos_plan_totals
+__global__ void k_export(const double *x, const int *status, const int *iters, const double *viol, int n, double *nodes_out,
+                         int *status_out, int *iters_out, double *viol_out, long long *tot) {
+  const int b = blockIdx.x;
+  const d2_t *src = (const d2_t *)(x + (size_t)b * n);
+  d2_t *dst = (d2_t *)(nodes_out + (size_t)b * n);
+  if ((n & 1) == 0 && ((((size_t)nodes_out) & 15) == 0)) {
+    for (int i = threadIdx.x; i < n / 2; i += blockDim.x) dst[i] = src[i];
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) nodes_out[(size_t)b * n + i] = x[(size_t)b * n + i];
+  }
+  if (threadIdx.x == 0) {
+    const int st = status[b], it = iters[b];
+    if (status_out) status_out[b] = st;
+    if (iters_out) iters_out[b] = it;
+    if (viol_out) viol_out[b] = viol[b];
+    if (st == 0) atomicAdd((unsigned long long *)tot, 1ull);
+    atomicAdd((unsigned long long *)(tot + 1), (unsigned long long)it);
+  }
+}
+
 int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
                            const int *d_map_id, const double *d_warm, double *d_nodes_out,
                            int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream_) {
@@ -463,14 +490,25 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
     HIPCHK(p, hipMemcpyAsync(p->h_active + 2 * it, W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(p, hipEventRecord(p->ev[6 + 5 * it], st));
   }
-  HIPCHK(p, hipMemcpyAsync(d_nodes_out, W.x, (size_t)B * D.n_vars * sizeof(double), hipMemcpyDeviceToDevice, st));
-  if (d_status_out) HIPCHK(p, hipMemcpyAsync(d_status_out, W.status, B * sizeof(int), hipMemcpyDeviceToDevice, st));
-  if (d_iters_out) HIPCHK(p, hipMemcpyAsync(d_iters_out, W.iters, B * sizeof(int), hipMemcpyDeviceToDevice, st));
-  if (d_viol_out) HIPCHK(p, hipMemcpyAsync(d_viol_out, W.viol, B * sizeof(double), hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_export, dim3(B), dim3(256), 0, st, W.x, W.status, W.iters, W.viol, D.n_vars, d_nodes_out, d_status_out, d_iters_out,
+                     d_viol_out, p->d_totals);
+  p->last_stream = st;
   HIPCHK(p, hipEventRecord(p->ev[1], st));
   p->last_launches = iters;   // iterations whose solve kernels qtos_last_timing sums
   p->last_iters = iters;
   HIPCHK(p, hipGetLastError());
+  return 0;
+}
+
+int qtos_plan_totals(QtosPlanner *p, long long *converged, long long *iterations, int reset) {
+  if (!p) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  long long h[2] = {0, 0};
+  HIPCHK(p, hipMemcpyAsync(h, p->d_totals, sizeof(h), hipMemcpyDeviceToHost, p->last_stream));
+  if (reset) HIPCHK(p, hipMemsetAsync(p->d_totals, 0, sizeof(h), p->last_stream));
+  HIPCHK(p, hipStreamSynchronize(p->last_stream));
+  if (converged) *converged = h[0];
+  if (iterations) *iterations = h[1];
   return 0;
 }
 
