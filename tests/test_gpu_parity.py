@@ -337,9 +337,13 @@ def test_full_batch_properties_and_determinism(planner, cfg):
     """BASELINE configs[1]-sized batch on the reference transcription: size-independent properties."""
     from qtos_amd import workloads
     start, goal = workloads.flat_goals(256, seed=0)
+    planner.totals(reset=True)
     n1, s1, i1, v1 = planner.plan(start, goal)
     n2, s2, i2, v2 = planner.plan(start, goal)
     assert np.array_equal(n1, n2) and np.array_equal(s1, s2)      # bitwise reproducible
+    # the planner's own running totals (qtos_plan_totals, bench.py's count of converged plans)
+    assert planner.totals() == (int((s1 == 0).sum() + (s2 == 0).sum()), int(i1.sum() + i2.sum()))
+    assert planner.totals(reset=True)[0] == 512 and planner.totals() == (0, 0)
     assert (s1 == 0).all() and v1.max() <= cfg.tol and i1.max() <= 15
     rk, vf, _ = planner.structure()
     fixed = np.nonzero(vf == 0)[0]
