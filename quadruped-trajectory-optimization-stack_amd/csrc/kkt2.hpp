@@ -744,11 +744,14 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     // every wave but the factor wave ends the phase with its share of the assembly of stage k+2's records
     // (the waves without a Schur tile come first and take the low item indices)
     const int apos = is_upd ? (15 - NU) + uw : uw - NU;   // (wave 12, the header wave, is the last of the free ones)
-    if (wv >= 1 && k + 2 < NS) {
-      // one thread per target, low item indices to the waves that get here first (equal shares: handing the waves
-      // without Schur tiles more of it was tried -- they share the factor wave's SIMD and are the slowest at it)
-      assemble_stage(A, F, sbuf, dbuf, apos * 64 + lane, 15 * 64);
-    }
+#ifndef QTOS_ASM_SKIP
+#define QTOS_ASM_SKIP 3
+#endif
+    // one thread per target, low item indices to the waves that get here first (handing the waves without Schur tiles
+    // more of it was tried -- they share the factor wave's SIMD and are the slowest at it).  The youngest update wave of
+    // every SIMD gets its matrix instructions last and ends the phase: it takes no part in the assembly.
+    constexpr int NASM = 15 - (NU >= 12 ? QTOS_ASM_SKIP : 0);
+    if (wv >= 1 && k + 2 < NS && apos < NASM) assemble_stage(A, F, sbuf, dbuf, apos * 64 + lane, NASM * 64);
     if constexpr (CONT) {
       if (k + 2 < NS) assemble_continuations(wv >= 1 ? apos * 64 + lane : -1, 15 * 64);
     }
