@@ -224,6 +224,16 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
     }
   };
   if (lane < PIV) { red[wv * PIV + lane] = 0.0; red[256 + wv * PIV + lane] = 0.0; }   // (the last stage has no rows besides its pivots)
+  // waves NT+1 .. 15 have no rows: they only meet the barriers (a SIMD has one vector ALU: what they would execute on
+  // dummies is time the working waves of their SIMD do not get)
+  const bool active = wv <= NT;
+  if (!active) {
+    lds_barrier();
+    for (int k0 = NS - 1; k0 >= 0; k0 -= SWD)
+#pragma unroll
+      for (int d = 0; d < SWD; ++d) lds_barrier();
+    return;
+  }
 #pragma unroll
   for (int d = 0; d < SWD; ++d) load(NS - 1 - d, bv[d], bam[d], bw[d], bps[d], bun[d]);
   double corr = 0.0;
@@ -252,7 +262,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
         corr = rowsum4(dot4_by_row(x, c));
       }
       // the other rows of stage t - 1 (they meet entries that are at least one barrier old)
-      {
+      if (wv >= 1) {
         double pp = 0.0;
         const unsigned am = bam[dn];
 #pragma unroll
@@ -262,7 +272,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
           pp = ((am >> row) & 1u) ? fma(bv[dn][i], xv, pp) : pp;
         }
         pp = rowsum4(pp);
-        if (lane < PIV && wv >= 1) red[((t - 1) & 1) * 256 + wv * PIV + j] = (owner && t >= 1) ? pp : 0.0;
+        if (lane < PIV) red[((t - 1) & 1) * 256 + wv * PIV + j] = t >= 1 ? pp : 0.0;
       }
       lds_barrier();
       load(t - SWD, bv[d], bam[d], bw[d], bps[d], bun[d]);
