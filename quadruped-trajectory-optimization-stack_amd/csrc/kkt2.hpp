@@ -243,12 +243,12 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
     for (int d = 0; d < SWD; ++d) {
       const int t = k0 - d, dn = (d + 1) % SWD;   // stage of the chain; ring slot of stage t - 1
       if (wv == 0) {
-        double r16[16];
+        double r16[NT];                           // (the partial sums of waves 1 .. NT)
 #pragma unroll
-        for (int w2 = 0; w2 < 16; ++w2) r16[w2] = red[(t & 1) * 256 + w2 * PIV + j];
+        for (int w2 = 0; w2 < NT; ++w2) r16[w2] = red[(t & 1) * 256 + (w2 + 1) * PIV + j];
         double sm = 0.0;
 #pragma unroll
-        for (int w2 = 0; w2 < 16; ++w2) sm += r16[w2];
+        for (int w2 = 0; w2 < NT; ++w2) sm += r16[w2];
         const double x = t >= 0 ? bw[d] - sm - corr : 0.0;
         if (lane < PIV && t >= 0) {
           xs[bps[d]] = x;
