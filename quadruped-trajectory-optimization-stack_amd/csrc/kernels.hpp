@@ -951,611 +951,6 @@ __device__ __forceinline__ void assemble_stage(double *A, int F, const int *sbuf
   }
 }
 
-// 128-bit pivot-slot mask: lane l of the wave holds word l & 3; the 16 bits of slot group `grp` are
-// fetched with a scalar-indexed v_readlane (a select chain over scalars would be turned into a
-// stack table by the compiler)
-struct Mask128 {
-  int v;
-};
-__device__ __forceinline__ Mask128 load_mask(const unsigned *pm4, int lane) {
-  Mask128 m;
-  m.v = (int)pm4[lane & 3];
-  return m;
-}
-__device__ __forceinline__ unsigned grp16(const Mask128 &m, int grp) {
-  return ((unsigned)__builtin_amdgcn_readlane(m.v, grp >> 1) >> ((grp & 1) * 16)) & 0xffffu;
-}
-// LDS layout of k_kkt.  Everything whose size depends only on the front F sits at compile-time
-// offsets (small, hot arrays first so that they are reachable through the 16-bit offset field of the
-// ds instructions); the per-transcription arrays follow.  Offsets in doubles.
-template <int F>
-struct KktLayout {
-  static constexpr int PSZ = (F + 1) * PLD;
-  static constexpr int NTRI = (F + 1) * (F + 2) / 2;
-  static constexpr int LIB = 0;                          // 2 x 16 x PLD   L^-1 (current / next)
-  static constexpr int DVB = LIB + 2 * PIV * PLD;        // 2 x 16         1 / d
-  static constexpr int DGB = DVB + 2 * PIV;              // 3 x 16         pivot diagonals (ring)
-  static constexpr int UF = DGB + 3 * PIV;               // 128            accumulated rhs updates
-  static constexpr int XS = UF + 128;                    // 128            solution by slot (backward)
-  static constexpr int RED = XS + 128;                   // 256 + 64       partials / Y[piv] rows / dummy slots
-  static constexpr int PSB = RED + 2 * 8 * PIV + 64;     // 3 x 16 ints    pivot slots (ring)
-  static constexpr int HIB = PSB + 3 * PIV / 2;          // 4 ints
-  static constexpr int JM = HIB + 2;                     // 2 x 128 ints   slot -> pivot index
-  static constexpr int PM = JM + 128;                    // 8 ints         pivot-slot bit masks
-  static constexpr int MIV = PM + 4;                     // 16 x PLD        (L D L^T)^-1 of the current pivot block
-  static constexpr int PB = MIV + PIV * PLD;             // 3 panels of (F+1) x PLD
-  static constexpr int VAR = (PB + 3 * PSZ + 1) & ~1;    // dbuf, then (ints) sbuf, soff, doff, hiall, then the cells A
-};
-__host__ __device__ inline size_t kkt_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells) {
-  const int PSZ = (F + 1) * PLD;
-  const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 128 + 128 + 2 * 8 * PIV + 64 + 3 * PIV / 2 + 2 + 128 + 4 + PIV * PLD;
-  size_t o = (fixed + 3 * (size_t)PSZ + 1) & ~(size_t)1;
-  o += ((size_t)max_drec + 1) & ~(size_t)1;
-  size_t oi = 2 * o + (((size_t)max_srec + 3) & ~(size_t)3) + 3 * ((((size_t)NS + 1) + 3) & ~(size_t)3);
-  oi += 2 * (((size_t)n_cells + 1) & ~(size_t)1);
-  return oi * sizeof(int);
-}
-
-// CONT: the plan has continuation records (compiled out of the standard transcriptions' kernel)
-template <int F, bool CONT>
-__global__ __launch_bounds__(KT) void k_kkt(DevPlan P, DevWork W, int B) {
-
-  const int b = blockIdx.x;
-  if (b >= B || W.done[b]) return;
-  extern __shared__ double lds[];
-  constexpr int NT = F >> 4;
-  const int tid = threadIdx.x, NS = P.n_stages, n = P.n_vars;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  using LY = KktLayout<F>;
-  constexpr int PSZ = LY::PSZ;
-  double *Lib = lds + LY::LIB, *dvb = lds + LY::DVB, *dgb = lds + LY::DGB, *UF = lds + LY::UF, *xs = lds + LY::XS;
-  double *red = lds + LY::RED, *PB = lds + LY::PB, *dbuf = lds + LY::VAR;
-  int *psb = (int *)(lds + LY::PSB), *hib = (int *)(lds + LY::HIB), *jm = (int *)(lds + LY::JM);
-  unsigned *pm = (unsigned *)(lds + LY::PM);
-  double *Minv = lds + LY::MIV;
-  int *sbuf = (int *)(dbuf + ((P.max_drec + 1) & ~1));
-  int *soff = sbuf + ((P.max_srec + 3) & ~3), *doff = soff + ((NS + 4) & ~3), *hiall = doff + ((NS + 4) & ~3);
-  double *A = (double *)(hiall + ((NS + 4) & ~3));   // cells of the assembled entries (Symbolic::compact_cells)
-  const double *stream = W.stream + (size_t)b * P.stream_len;
-  double *panel = W.panel + (size_t)b * P.panel_stride;
-  double *dx = W.dx + (size_t)b * n;
-  const int pstride = (F + 1) * PIV;   // per stage: w (16), V (F x 16)
-
-  // ---- U tiles of this wave (waves 1..6): tile t = (wv-1) + 6 i of the lower triangle ------------
-  d4_t U[MAXT];
-  int tRC[MAXT];   // (R << 8) | C, or -1
-  const int ntile_all = (NT * (NT + 1)) >> 1;
-#pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    U[i] = d4_t{0.0, 0.0, 0.0, 0.0};
-    const int t = (wv - 1) + 6 * i;
-    int R = 0;
-    while (((R + 1) * (R + 2)) >> 1 <= t) ++R;
-    const bool valid = wv >= 1 && wv <= 6 && t < ntile_all;
-    tRC[i] = valid ? (R << 8) | (t - ((R * (R + 1)) >> 1)) : -1;
-  }
-  // bit g of ge4 / gt4: row lk + 4g of a diagonal tile lies on or below / strictly below column li
-  unsigned ge4 = 0u, gt4 = 0u;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) { ge4 |= (lk + 4 * g >= li ? 1u : 0u) << (4 * g); gt4 |= (lk + 4 * g > li ? 1u : 0u) << (4 * g); }   // (bit 4g: the layout of (mask >> lk) & 0x1111)
-
-  for (int i = tid; i < P.n_cells; i += KT) A[i] = 0.0;
-  for (int i = tid; i < 3 * PSZ; i += KT) PB[i] = 0.0;
-  for (int i = tid; i < 128; i += KT) { UF[i] = 0.0; xs[i] = 0.0; }
-  for (int v = tid; v < n; v += KT) dx[v] = 0.0;
-  for (int i = tid; i <= NS; i += KT) { soff[i] = P.srec_off[i]; doff[i] = P.drec_off[i]; }
-  __syncthreads();
-
-  // header of the stage whose records sit in sbuf / dbuf: pivot slots, diagonals, hi, slot -> pivot
-  // index map and pivot bit mask (ring buffers by stage)
-  auto header_from_lds = [&](int s) __attribute__((always_inline)) {
-    if (tid < 4) pm[(s & 1) * 4 + tid] = 0u;
-    if (tid < PIV) {
-      const int slot = sbuf[SHDR + tid];
-      psb[(s % 3) * PIV + tid] = slot;
-      jm[(s & 1) * 128 + slot] = tid;
-      dgb[(s % 3) * PIV + tid] = dbuf[tid];
-      atomicOr(&pm[(s & 1) * 4 + (slot >> 5)], 1u << (slot & 31));
-    }
-    if (tid == 0) { hib[s % 3] = sbuf[3]; hiall[s] = (sbuf[3] + 15) & ~15; }
-  };
-  auto load_records = [&](int s) __attribute__((always_inline)) {
-    for (int i = tid; i < soff[s + 1] - soff[s]; i += KT) sbuf[i] = P.srec[soff[s] + i];
-    for (int i = tid; i < doff[s + 1] - doff[s]; i += KT) dbuf[i] = stream[doff[s] + i];
-  };
-  // wave 0: LDL^T + L^-1 of the pivot block of the panel Pn (rows = pivot slots psn), then the pivot
-  // rows leave the panel
-  auto factor_block = [&](double *Pn, const int myps, double *Lin, double *dvn) __attribute__((always_inline)) {
-    double a[PIV], v[PIV], myinv;
-#pragma unroll
-    for (int j = 0; j < PIV; ++j) {
-      const int pj = __builtin_amdgcn_readlane(myps, j);
-      a[j] = Pn[li >= j ? myps * PLD + j : pj * PLD + li];   // lower triangle (by pivot index), mirrored
-    }
-    ldlt16(a, v, myinv, li);
-    if (lane >= PIV && lane < 2 * PIV) {
-#pragma unroll
-      for (int j = 0; j < PIV; ++j) Lin[li * PLD + j] = j == li ? 1.0 : v[j];
-    }
-    if (lane < PIV) {
-      dvn[li] = myinv;
-#pragma unroll
-      for (int j = 0; j < PIV; ++j) Pn[myps * PLD + j] = 0.0;
-    }
-    // inverse of the whole pivot block, (L D L^T)^-1 = L^-T D^-1 L^-1, on the matrix core: with it the
-    // panel product V = P (L D L^T)^-1 of the next AB phase does not have to wait for Y = P L^-T
-    {
-      d4_t mi = {0.0, 0.0, 0.0, 0.0};
-      double lt[4], ld[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) { lt[s4] = Lin[(lk + 4 * s4) * PLD + li]; ld[s4] = dvn[lk + 4 * s4]; }
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) mi = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[s4], lt[s4] * ld[s4], mi, 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) Minv[(lk + 4 * g) * PLD + li] = mi[g];
-    }
-  };
-
-  // ---- prologue: assemble stages 0 and 1, gather and factor the pivot block of stage 0, leave the
-  //      records of stage 2 in LDS ----------------------------------------------------------------
-  //      (stage 1 may reuse the slots of stage 0's pivots: it is assembled after they were gathered)
-  // continuation records of the stage whose record sits in sbuf / dbuf (a stage that owns more
-  // inequality blocks than one record holds -- long stance phases): fetched and assembled one by one
-  auto assemble_continuations = [&]() __attribute__((always_inline)) {
-    if constexpr (!CONT) return;
-    const int n_cont = __builtin_amdgcn_readfirstlane(sbuf[6]), c_first = __builtin_amdgcn_readfirstlane(sbuf[7]);
-    for (int c = 0; c < n_cont; ++c) {
-      lds_barrier();   // everybody is done with the current contents of sbuf / dbuf
-      const int *co = P.cont + 4 * (c_first + c);
-      const int so = co[0], sl = co[1], dof = co[2], dl = co[3];
-      for (int i = threadIdx.x; i < dl; i += KT) dbuf[i] = stream[dof + i];
-      for (int i = threadIdx.x; i < sl; i += KT) sbuf[i] = P.srec[so + i];
-      lds_barrier();
-      assemble_stage(A, F, sbuf, dbuf, threadIdx.x, KT);
-    }
-  };
-  load_records(0);
-  __syncthreads();
-  header_from_lds(0);
-  __syncthreads();
-  assemble_stage(A, F, sbuf, dbuf, tid, KT);
-  assemble_continuations();
-  __syncthreads();
-  {
-    double *P0 = PB;   // stage 0 lives in panel 0
-    const int *ps0 = psb;
-    // cell of panel entry (row r, pivot column j) of stage 0: P.ctab, laid out for the AB phase's lanes
-    auto cell0 = [&](int r, int j, int c) __attribute__((always_inline)) {
-      return r < F ? (int)P.ctab[(((r >> 4) * 64) + (r & 3) * 16 + j) * 4 + ((r & 15) >> 2)] : 1 + c;
-    };
-    for (int i = tid; i < (F + 1) * PIV; i += KT) {
-      const int r = i >> 4, j = i & 15, c = ps0[j];
-      P0[r * PLD + j] = A[cell0(r, j, c)] + (r == c ? dgb[j] : 0.0);
-    }
-    __syncthreads();
-    for (int i = tid; i < (F + 1) * PIV; i += KT) {
-      const int r = i >> 4, j = i & 15, c = ps0[j];
-      A[cell0(r, j, c)] = 0.0;
-    }
-    __syncthreads();
-    if (wv == 0) factor_block(P0, ps0[li], Lib, dvb);
-  }
-  for (int s = 1; s < 3 && s < NS; ++s) {
-    load_records(s);
-    __syncthreads();
-    header_from_lds(s);
-    __syncthreads();
-    if (s == 1) { assemble_stage(A, F, sbuf, dbuf, tid, KT); assemble_continuations(); }
-    __syncthreads();
-  }
-
-#ifdef QTOS_STAMPS
-  __shared__ unsigned long long stamp_lds[8 * 4 + 3 + 16];
-  unsigned long long *st0 = stamp_lds, *st1 = stamp_lds + 8, *st7 = stamp_lds + 12, *tl_st0 = stamp_lds + 16, *tl_st1 = stamp_lds + 17,
-                     *tl_st7 = stamp_lds + 18;
-  unsigned long long &wasum = stamp_lds[19 + wv];        // per wave: cycles from the top of a stage to its arrival at the AB barrier
-  unsigned long long &wcsum = stamp_lds[19 + 8 + wv];    // per wave: cycles from the start of phase C to its own arrival at the barrier
-  if (tid < 8 * 4 + 3 + 16) stamp_lds[tid] = 0;
-  __syncthreads();
-  if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tl_st0[0] = t_; }
-#endif
-  // per-thread prefetch registers: 128-bit loads of a stage's records.  Only the first wave of every SIMD
-  // (waves 0..3) moves records: in the AB phase it reaches the barrier ~1 k cycles before its partner anyway
-  constexpr int XW = 4, XT = 64 * XW, PFD2 = 2 * KT / XT, PFS4 = 3 * KT / XT;
-  d2_t pfd[PFD2];
-  i4_t pfs[PFS4];
-  int pf_nd2 = 0, pf_ns4 = 0;
-  int prow_next = NS > 1 ? psb[PIV + li] : 0;   // pivot slot li of stage k+1
-  // cells that feed this lane's four entries of the next stage's pivot columns (row tile = wave): one 8-byte
-  // load per lane and stage from the static table, fetched a stage ahead
-  typedef unsigned short us4_t __attribute__((ext_vector_type(4)));
-  const us4_t *ctab4 = (const us4_t *)P.ctab;
-  us4_t ct_cur = ctab4[((size_t)min(1, NS - 1) * NT + min(wv, NT - 1)) * 64 + lane];
-  const int tid_outer = tid, lane_outer = lane;
-  for (int k = 0; k < NS; ++k) {
-    // per-iteration opaque copies of the thread / lane index: everything derived from them is
-    // recomputed each stage instead of being hoisted out of the loop into (spilled) registers
-    int tid = tid_outer, lane = lane_outer;
-    asm volatile("" : "+v"(tid), "+v"(lane));
-    const int li = lane & 15, lk = lane >> 4;
-    const int pb = (k & 1) ? 2 : 0;
-    double *Pk = PB + pb * PSZ, *Yk = PB + PSZ, *Xn = PB + (2 - pb) * PSZ;
-    const double *Lik = Lib + (k & 1) * PIV * PLD, *dik = dvb + (k & 1) * PIV;
-    const int *psn = psb + ((k + 1) % 3) * PIV;
-    const bool has_next = k + 1 < NS;
-#ifdef QTOS_STAMPS
-    unsigned long long wa0 = 0;
-    if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wa0) :: "memory");
-#endif
-    // ---- install the records of stage k+2 (prefetched during stage k-1), prefetch stage k+3 --------
-    if (wv < XW && k >= 1 && k + 2 < NS) {
-#pragma unroll
-      // (no lane-dependent branches: threads beyond the record write the spare element behind it,
-      //  and below re-read its last element)
-      for (int jj = 0; jj < PFD2; ++jj) ((d2_t *)dbuf)[min(tid + jj * XT, pf_nd2)] = pfd[jj];
-#pragma unroll
-      for (int jj = 0; jj < PFS4; ++jj) ((i4_t *)sbuf)[min(tid + jj * XT, pf_ns4)] = pfs[jj];
-      // (the header of these records -- pivot slots, diagonals, slot map, masks -- was published one
-      //  stage ago by wave 7, off the critical path)
-    }
-    if (wv < XW && k + 3 < NS) {
-      const int s = k + 3;
-      pf_nd2 = (doff[s + 1] - doff[s]) >> 1;
-      pf_ns4 = (soff[s + 1] - soff[s]) >> 2;
-      const d2_t *dsrc = (const d2_t *)(stream + doff[s]);
-      const i4_t *ssrc = (const i4_t *)(P.srec + soff[s]);
-#pragma unroll
-      for (int jj = 0; jj < PFD2; ++jj) pfd[jj] = dsrc[min(tid + jj * XT, pf_nd2 - 1)];
-#pragma unroll
-      for (int jj = 0; jj < PFS4; ++jj) pfs[jj] = ssrc[min(tid + jj * XT, pf_ns4 - 1)];
-    }
-    const us4_t ct_nxt = ctab4[((size_t)min(k + 2, NS - 1) * NT + min(wv, NT - 1)) * 64 + lane];
-    STAMPW(0, st0, 5);
-    // ---- AB(k): one 16-row panel tile per wave.  All LDS reads are issued up front (no lane-dependent
-    //      branches around loads), then the 12 MFMAs, then the stores. --------------------------------
-    const int hi16 = (hib[k % 3] + 15) & ~15;
-    const Mask128 m1 = load_mask(pm + ((k + 1) & 1) * 4, lane);   // pivot slots of stage k+1
-    if (wv < NT) {
-      const int R = wv;
-      const unsigned am_word = P.amask[k * 8 + (R >> 1)];   // row mask of this stage's panel: fetched now, used at the end of the phase
-      const int prow = has_next ? prow_next : 0;
-      double la[4], pr[4], pp[4], lm[4], xv[4], av[4];
-      int aidx[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int r = 16 * R + lk + 4 * s4;
-        la[s4] = Lik[li * PLD + lk + 4 * s4];
-        pr[s4] = Pk[(16 * R + li) * PLD + lk + 4 * s4];
-        pp[s4] = Pk[prow * PLD + lk + 4 * s4];
-        lm[s4] = Minv[li * PLD + lk + 4 * s4];
-        xv[s4] = Xn[r * PLD + li];
-        aidx[s4] = ct_cur[s4];   // 0 (the zero cell) where K has no entry or the entry belongs to the mirrored position
-        av[s4] = A[aidx[s4]];
-      }
-      const double dgn = dgb[((k + 1) % 3) * PIV + li];
-      // V = P (L D L^T)^-1 in accumulator layout: vt[g] = V[16R+li][lk+4g] -- which is V itself as the A
-      // operand of the next product.  It heads the chain; Y = P L^-T (kept for the Schur updates of phase C)
-      // follows on the side.
-      d4_t vt = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) vt = __builtin_amdgcn_mfma_f64_16x16x4f64(lm[s4], pr[s4], vt, 0, 0, 0);
-      STAMPW(0, st0, 6);
-      // next pivot columns: assembled entries (read here, retired below), extracted Schur updates,
-      // pivot diagonal; an entry between two pivots of stage k+1 is delivered once, to the row with the
-      // larger pivot index (the cell table says so)
-      d4_t acc;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = 16 * R + lk + 4 * g;
-        acc[g] = xv[g] + av[g] + (r == prow ? dgn : 0.0);
-      }
-      double npp[4];   // (the sign of the last product sits on its B operand, off the MFMA chain)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) npp[g] = -pp[g];
-      // Y D^-1 Y[piv]^T = V P[piv]^T: the raw rows of the next pivots serve as B operand (no Y[piv] to
-      // compute or to share)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[s4], npp[s4], acc, 0, 0, 0);   // acc -= V P[piv]^T
-      d4_t yt = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-        yt = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s4], pr[s4], yt, 0, 0, 0);   // yt[g] = Y[16R+li][lk+4g]
-      STAMPW(0, st0, 7);
-      // Y rows of the next pivots are stored as zeros: their rows/columns of U were extracted (and
-      // zeroed) one stage ago and must not be touched by this stage's update any more
-      const bool myrowpiv = has_next && ((grp16(m1, R) >> li) & 1u);
-      if (wv == 0 && has_next) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) red[(lk + 4 * g) * PIV + li] = pp[g];   // PT[q][j] = P[piv_j][q] for wave 7
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        Yk[(16 * R + li) * PLD + lk + 4 * g] = myrowpiv ? 0.0 : yt[g];
-        A[aidx[g]] = 0.0;   // retired (the zero cell stays zero)
-      }
-      if (has_next) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) Xn[(16 * R + lk + 4 * g) * PLD + li] = acc[g];
-      }
-      // only the rows of live, non-pivot slots are kept (the others are zero and never read back)
-      const unsigned am16 = (am_word >> ((R & 1) * 16)) & 0xffffu;
-      if ((am16 >> li) & 1u) {
-        double *pv = panel + (size_t)k * pstride + PIV;
-        *(d4_t *)(pv + (16 * R + li) * PIV + 4 * lk) = vt;   // column c of a row sits at 4 (c & 3) + (c >> 2): 32 contiguous bytes per lane
-      }
-    }
-    if (wv == 7 && lane < PIV && has_next) {   // assembled right-hand side of the next pivots (read and retired)
-      const int idx = 1 + prow_next;
-      Xn[F * PLD + lane] = A[idx];
-      A[idx] = 0.0;
-    }
-#ifdef QTOS_STAMPS
-    if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); wasum += t_ - wa0; }
-#endif
-    lds_barrier();
-    STAMPW(0, st0, 0);
-#ifdef QTOS_STAMPS
-    unsigned long long wc0 = 0;
-    if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wc0) :: "memory");
-#endif
-    // ---- C(k) ---------------------------------------------------------------------------------------
-    if (wv == 0) {
-      if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV);
-      STAMPW(0, st0, 1);
-    } else if (wv <= 6) {
-#ifdef QTOS_STAMPS
-      if (tid == 64) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tl_st1[0] = t_; }
-#endif
-      const Mask128 m2 = load_mask(pm + (k & 1) * 4, lane);   // pivot slots of stage k+2
-      const bool extract = k + 2 < NS;
-      const int *jm2 = jm + (k & 1) * 128;
-      double *Xnn = Pk;   // the panel of stage k is dead: it receives the columns of stage k+2
-      double dv4[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) dv4[s4] = -dik[lk + 4 * s4];
-      // --- update: U(R,C) -= Y_R D^-1 Y_C^T for the six tiles of this wave; the operand reads of the next
-      //     tile are issued before the MFMAs of the current one (rows beyond the stage's range are zero
-      //     in Y, unused tile slots alias tile (0,0) and are never extracted: no tests in this loop)
-      int rcs[MAXT];
-#pragma unroll
-      for (int t = 0; t < MAXT; ++t) { rcs[t] = tRC[t]; asm volatile("" : "+s"(rcs[t])); }
-      double wa[2][4], pbv[2][4];
-      auto tile_loads = [&](int rc, double (&w)[4], double (&pq)[4]) __attribute__((always_inline)) {
-        const int R = rc < 0 ? 0 : rc >> 8, C = rc < 0 ? 0 : rc & 255;
-        const double *wrow = Yk + (16 * R + li) * PLD + lk, *prow2 = Yk + (16 * C + li) * PLD + lk;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { w[s4] = wrow[4 * s4]; pq[s4] = prow2[4 * s4]; }
-      };
-      tile_loads(rcs[0], wa[0], pbv[0]);
-#pragma unroll
-      for (int t = 0; t < MAXT; ++t) {
-        if (t + 1 < MAXT) tile_loads(rcs[t + 1], wa[(t + 1) & 1], pbv[(t + 1) & 1]);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-          U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[t & 1][s4] * dv4[s4], pbv[t & 1][s4], U[t], 0, 0, 0);
-      }
-      STAMPW(1, st1, 2);
-      // --- extraction: columns / rows of the pivots of stage k+2 leave U for the panel under construction
-      //     (and are zeroed: later updates skip them).  Loops over the pivot slots of each tile's column
-      //     / row group are wave-uniform; a pivot column lives on the four lanes li == b, a pivot row on
-      //     the 16 lanes lk == b & 3 in register b >> 2.
-      if (extract) {
-        // slot -> pivot index of every row / column this lane may send out, read in one batch
-        int jcs[MAXT], jrs[MAXT][4];
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-          const int rc = rcs[t] < 0 ? 0 : rcs[t];
-          jcs[t] = jm2[16 * (rc & 255) + li];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) jrs[t][g] = jm2[16 * (rc >> 8) + lk + 4 * g];
-        }
-        // (pinned here: left alone the compiler sinks each read into its tile's branch, where its latency is exposed)
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-          asm volatile("" : "+v"(jcs[t]), "+v"(jrs[t][0]), "+v"(jrs[t][1]), "+v"(jrs[t][2]), "+v"(jrs[t][3]));
-        double *dummy = red + 2 * 8 * PIV + lane;   // per-lane scratch slot: unselected stores land here
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-          const int rc = rcs[t];
-          if (rc < 0) continue;
-          const int R = rc >> 8, C = rc & 255;
-          const unsigned cw2 = grp16(m2, C), rw2 = grp16(m2, R);   // wave-uniform
-          if ((cw2 | rw2) == 0u) continue;
-          // bit 4g of cm / rmk: entry g of this lane leaves with its column / with its row
-          const unsigned cm = ((cw2 >> li) & 1u) ? (R > C ? 0x1111u : ge4) : 0u;
-          const unsigned rmk = (rw2 >> lk) & (R > C ? 0x1111u : gt4);
-          double *xr = Xnn + (16 * R + lk) * PLD + jcs[t], *xc = Xnn + (16 * C + li) * PLD;
-          // (one wave-uniform branch per direction, not one per entry)
-          if (cw2) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) *(((cm >> (4 * g)) & 1u) ? xr + g * 4 * PLD : dummy) = U[t][g];
-          }
-          if (rw2) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) *(((rmk >> (4 * g)) & 1u) ? xc + jrs[t][g] : dummy) = U[t][g];
-          }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {   // sign-extended bit -> all-ones mask -> and-not on both halves
-            const int z = ~__builtin_amdgcn_sbfe((int)(cm | rmk), 4 * g, 1);
-            U[t][g] = __hiloint2double(__double2hiint(U[t][g]) & z, __double2loint(U[t][g]) & z);
-          }
-        }
-      }
-      STAMPW(1, st1, 0);
-    } else {
-      // wave 7: right-hand-side row.  y_F = p_F L^-T, w = L^-T D^-1 y_F (to HBM), the update of the
-      // accumulated right-hand side, and the right-hand side of the next pivots
-#ifdef QTOS_STAMPS
-      if (tid == 448) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tl_st7[0] = t_; }
-#endif
-      // header of stage k+3 (static ints 0..23: counts, hi, pivot slots; dynamic doubles 0..15: pivot
-      // diagonals): read from global memory now, published to the LDS rings at the end of this phase.
-      // The ring slots it overwrites (stage k's pivot slots / diagonals, stage k+1's slot map and mask)
-      // have no reader left in this phase or later.
-      const int hs = k + 3;
-      int hv = 0;
-      double hd = 0.0;
-      if (hs < NS) {
-        if (lane < SHDR + PIV) hv = P.srec[soff[hs] + lane];
-        if (lane < PIV) hd = stream[doff[hs] + lane];
-      }
-      double part = 0.0, lq[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        part += Lik[li * PLD + lk + 4 * s4] * Pk[F * PLD + lk + 4 * s4];
-        lq[s4] = Lik[(lk + 4 * s4) * PLD + li];
-      }
-      const double uf0 = UF[lane], uf1 = UF[lane + 64];
-      part += __shfl_xor(part, 16);
-      part += __shfl_xor(part, 32);
-      const double yd = part * dik[li];            // (y_F D^-1)[li] on every lane with that li
-      double ydq[PIV];
-#pragma unroll
-      for (int q = 0; q < PIV; ++q) ydq[q] = __shfl(yd, q);
-      double wsum = 0.0;
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) wsum += __shfl(yd, lk + 4 * s4) * lq[s4];
-      wsum += __shfl_xor(wsum, 16);
-      wsum += __shfl_xor(wsum, 32);
-      if (lane < PIV) panel[(size_t)k * pstride + lane] = wsum;
-      if (has_next) {
-        // right-hand-side update for the columns c = lane and lane + 64
-        double a0 = 0.0, a1 = 0.0;
-        {
-          double yr[PIV];
-#pragma unroll
-          for (int q = 0; q < PIV; ++q) yr[q] = Yk[lane * PLD + q];
-#pragma unroll
-          for (int q = 0; q < PIV; ++q) a0 = fma(ydq[q], yr[q], a0);
-#pragma unroll
-          for (int q = 0; q < PIV; ++q) yr[q] = Yk[min(lane + 64, F - 1) * PLD + q];
-#pragma unroll
-          for (int q = 0; q < PIV; ++q) a1 = fma(ydq[q], yr[q], a1);
-        }
-        UF[lane] = uf0 - a0;          // rows beyond the stage's range have Y = 0
-        UF[lane + 64] = lane + 64 < F ? uf1 - a1 : 0.0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // this stage's update of the next pivots' right-hand side (their Y rows are zero in LDS):
-        // (y_F D^-1) Y[piv_j] = (y_F D^-1 L^-1) P[piv_j] = w . P[piv_j]
-        double corr = 0.0;
-#pragma unroll
-        for (int c = 0; c < PIV; ++c) corr = fma(__shfl(wsum, c), red[c * PIV + li], corr);
-        if (lane < PIV) {
-          const int c = prow_next;
-          Xn[F * PLD + lane] += UF[c] - corr;
-          UF[c] = 0.0;
-        }
-      }
-      if (hs < NS) {
-        if (lane < 4) pm[(hs & 1) * 4 + lane] = 0u;
-        if (lane == 3) { hib[hs % 3] = hv; hiall[hs] = (hv + 15) & ~15; }
-        if (lane < PIV) dgb[(hs % 3) * PIV + lane] = hd;
-        if (lane >= SHDR && lane < SHDR + PIV) {
-          const int jidx = lane - SHDR;
-          psb[(hs % 3) * PIV + jidx] = hv;
-          jm[(hs & 1) * 128 + hv] = jidx;
-          atomicOr(&pm[(hs & 1) * 4 + (hv >> 5)], 1u << (hv & 31));
-        }
-      }
-      STAMPW(7, st7, 0);
-    }
-    // every wave ends the phase with its share of the assembly of stage k+2 (nobody else touches A here)
-    // (most stages have fewer items than threads, so the order of the waves matters: the low item
-    // indices go to the waves with the most slack in this phase -- measured order 3, 0, 2, 7, 1, 4, 6, 5:
-    // the two update waves that come second on a shared matrix pipe are last)
-    if (k + 2 < NS) {
-      const int aslot = (0x36750241 >> (4 * wv)) & 7;   // wave -> position in the assembly order
-      assemble_stage(A, F, sbuf, dbuf, aslot * 64 + lane, KT);
-      assemble_continuations();
-    }
-    STAMPW(1, st1, 1);
-#ifdef QTOS_STAMPS
-    if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); wcsum += t_ - wc0; }
-#endif
-    lds_barrier();
-    if (k + 2 < NS) prow_next = psb[((k + 2) % 3) * PIV + li];   // pivot slot li of the stage after next
-    ct_cur = ct_nxt;
-    STAMPW(0, st0, 2);
-  }
-  // ---- backward substitution: x_piv = w - V^T x, one barrier per stage.  Wave w owns rows 16w..16w+15
-  //      of every panel (prefetched four stages ahead into registers), partial sums meet in LDS and
-  //      every wave forms the 16 new entries redundantly (bitwise identical), so a wave only ever
-  //      reads solution entries it has written itself. --------------------------------------------
-  __syncthreads();  // drains the factor-panel stores: they are read back below
-  STAMPW(0, st0, 3);
-  {
-    const int j = li, q = lk;
-    constexpr int DEPTH = 4;
-    double bv[DEPTH][4], bw[DEPTH];
-    int bps[DEPTH], bun[DEPTH];
-    unsigned bam[DEPTH];
-    // the rows this wave reads of a stage: 16 bits of the stage's row mask, fetched one stage ahead of
-    // the panel loads that depend on it
-    auto amask16 = [&](int k) __attribute__((always_inline)) {
-      return (P.amask[max(k, 0) * 8 + (wv >> 1)] >> ((wv & 1) * 16)) & 0xffffu;
-    };
-    unsigned am_next = amask16(NS - 1);
-    // loads are unconditional (clamped indices) so that the compiler can wait with partial vmcnt
-    // counts instead of draining the whole prefetch ring at every stage
-    auto bload = [&](int k, double (&v)[4], double &wj, int &psj, int &unkj, unsigned &am) __attribute__((always_inline)) {
-      const int kk = max(k, 0);
-      const double *pk = panel + (size_t)kk * pstride;
-      am = am_next;
-      am_next = amask16(k - 1);
-      // rows that were not stored are not fetched either: their lanes re-read w (finite, multiplied by 0 below)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        v[i] = pk[((am >> (q + 4 * i)) & 1u) ? PIV + (16 * wv + q + 4 * i) * PIV + 4 * (j & 3) + (j >> 2) : j];
-      wj = pk[j];
-      psj = P.piv_slot[kk * PIV + j];
-      unkj = P.piv_unknown[kk * PIV + j];
-    };
-    auto bstep = [&](int k, const double (&v)[4], double wj, int psj, int unkj, unsigned am) __attribute__((always_inline)) {
-      const bool valid = k >= 0;          // the stage count is padded to a multiple of DEPTH with no-op steps
-      const int kk = max(k, 0);
-      const int nw = valid ? hiall[kk] >> 4 : 0;
-      double p = 0.0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) p = fma(v[i], ((am >> (q + 4 * i)) & 1u) ? xs[16 * wv + q + 4 * i] : 0.0, p);
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
-      if (lane < PIV) red[(kk & 1) * 128 + wv * PIV + j] = (valid && wv < nw) ? p : 0.0;   // rows beyond the stage's range: no contribution
-      lds_barrier();
-      double r8[8];
-#pragma unroll
-      for (int w2 = 0; w2 < 8; ++w2) r8[w2] = red[(kk & 1) * 128 + w2 * PIV + j];
-      double s = 0.0;
-#pragma unroll
-      for (int w2 = 0; w2 < 8; ++w2) s += r8[w2];
-      const double x = wj - s;
-      if (lane < PIV && valid) {
-        xs[psj] = x;
-        if (wv == 0 && unkj >= 0 && unkj < n) dx[unkj] = x;
-      }
-    };
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) bload(NS - 1 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
-    // straight-line body (four steps, no stage-dependent branches) so that the compiler waits for each
-    // prefetched group with a partial vmcnt instead of draining the whole ring
-    for (int k0 = NS - 1; k0 >= 0; k0 -= DEPTH) {
-#pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {
-        bstep(k0 - d, bv[d], bw[d], bps[d], bun[d], bam[d]);
-        bload(k0 - d - DEPTH, bv[d], bw[d], bps[d], bun[d], bam[d]);
-      }
-    }
-  }
-#ifdef QTOS_STAMPS
-  STAMPW(0, st0, 4);
-  if (tid == 0 && W.trace) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 30) * 4 + i] = (double)st0[i];
-  if (tid == 64 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 32) * 4 + i] = (double)st1[i];
-  if (tid == 448 && W.trace) for (int i = 0; i < 4; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 33) * 4 + i] = (double)st7[i];
-  if (lane == 0 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 38) * 4 + wv] = (double)wcsum;
-  if (lane == 0 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 42) * 4 + wv] = (double)wasum;
-#endif
-}
-
-
 // =================================================================================================
 __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it) {
   const int b = blockIdx.x;

@@ -73,14 +73,6 @@ struct QtosPlanner {
 
 // k_kkt is compiled once per front size (multiples of 16 up to 128): the LDS layout and every tile
 // loop bound are compile-time constants
-static void (*kkt_kernel(int F, bool cont))(DevPlan, DevWork, int) {
-#define QTOS_KKT(f) case f: return cont ? k_kkt<f, true> : k_kkt<f, false>;
-  switch (F) {
-    QTOS_KKT(16) QTOS_KKT(32) QTOS_KKT(48) QTOS_KKT(64) QTOS_KKT(80) QTOS_KKT(96) QTOS_KKT(112) QTOS_KKT(128)
-  }
-#undef QTOS_KKT
-  return nullptr;
-}
 // k_kkt2 (16 waves per problem): fronts up to 208 slots
 static void (*kkt2_kernel(int F, bool cont))(DevPlan, DevWork, int) {
 #define QTOS_KKT2(f) case f: return cont ? k_kkt2<f, true> : k_kkt2<f, false>;
@@ -148,9 +140,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   p->device = device;
   p->max_batch = max_batch;
   if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
-  const char *kv = getenv("QTOS_KKT");
-  const bool kkt2 = !(kv && kv[0] == '1');   // QTOS_KKT=1: the 8-wave kernel of round 1 (fronts <= 128), kept for A/B timing
-  p->S.cell_mode = kkt2 ? 2 : 1;
+  p->S.cell_mode = 2;
   if (p->S.build(p->M)) { fprintf(stderr, "qtos: %s\n", p->S.err.c_str()); delete p; return -1; }
   const HostModel &M = p->M;
   const Symbolic &S = p->S;
@@ -186,7 +176,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(S.rtab, &D.rtab));
   TRY(p->upload(S.rhs_ptr, &D.rhs_ptr)); TRY(p->upload(S.rhs_gpos, &D.rhs_gpos)); TRY(p->upload(S.rhs_row, &D.rhs_row));
   D.n_unknowns = S.n_unknowns;
-  D.chord_tol = kkt2 ? M.P.chord_tol : 0.0;   // (the 8-wave kernel does not keep the pivot-block inverses)
+  D.chord_tol = M.P.chord_tol;
   D.n_cells = S.n_cells;
   D.n_cont = 0;
   for (int k = 0; k < S.n_stages; ++k) D.n_cont += S.srec[S.srec_off[k] + 6];
@@ -255,10 +245,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.panel_stride = (long long)S.n_stages * (S.front + 1) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  p->kkt_lds = kkt2 ? kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells)
-                    : kkt_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
-  p->kkt_threads = kkt2 ? KT2 : KT;
-  const int max_front = kkt2 ? 208 : 128;
+  p->kkt_lds = kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
+  p->kkt_threads = KT2;
+  const int max_front = 208;
   if (S.max_drec > 2 * 2 * KT || S.max_srec > 3 * 4 * KT || F > max_front || (S.pack_src.size() & 1)) {
     p->err = "stage record exceeds the prefetch registers";
     fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints) or front %d > %d\n", S.max_drec, S.max_srec, F, max_front);
@@ -273,8 +262,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     return -4;
   }
   {
-    p->kkt_fn = kkt2 ? kkt2_kernel(F, D.n_cont > 0) : kkt_kernel(F, D.n_cont > 0);
-    p->chord_fn = kkt2 ? chord_kernel(F) : nullptr;
+    p->kkt_fn = kkt2_kernel(F, D.n_cont > 0);
+    p->chord_fn = chord_kernel(F);
     if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
@@ -320,7 +309,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.n_active, 2));
   TRY(p->alloc(&W.chord, Bm));
   TRY(p->alloc(&W.rhs, Bm * (size_t)S.n_unknowns));
-  TRY(p->alloc(&W.minv, kkt2 ? Bm * (size_t)S.n_stages * PIV * PIV : 1));
+  TRY(p->alloc(&W.minv, Bm * (size_t)S.n_stages * PIV * PIV));
   TRY(p->alloc(&p->d_start, Bm * QTOS_START_DOUBLES)); TRY(p->alloc(&p->d_goal, Bm * 3));
   TRY(p->alloc(&p->d_nodes, Bm * n)); TRY(p->alloc(&p->d_warm, Bm * n)); TRY(p->alloc(&p->d_map, Bm));
   if (hipHostMalloc((void **)&p->h_active, 2 * sizeof(int) * ((size_t)M.P.max_iter + 1)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
