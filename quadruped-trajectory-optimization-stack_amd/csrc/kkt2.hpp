@@ -47,14 +47,7 @@ struct Kkt2Cfg {
     return NTILE < 8 ? (NTILE < 1 ? 1 : NTILE) : best;
   }
   static constexpr int NU = pick_nu();
-#ifdef QTOS_AGE_SPLIT
-  // 128-slot front: the four update waves of a SIMD take 4 / 3 / 3 / 2 tiles, oldest first -- the matrix pipe
-  // serves them by age, so the youngest starts its extraction last and should have the least of it
-  static constexpr bool AGE = F == 128;
-#else
-  static constexpr bool AGE = false;
-#endif
-  static constexpr int MAXT = AGE ? 4 : (NTILE + NU - 1) / NU;
+  static constexpr int MAXT = (NTILE + NU - 1) / NU;
   static constexpr int NSV = 16 - NT;            // service waves of the AB phase
   static constexpr int NH = NT <= 8 ? 2 : 1;     // backward pass: waves per row tile
   static constexpr int FR = (F + 63) & ~63;      // by-slot arrays padded to whole waves
@@ -323,11 +316,6 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     U[i] = d4_t{0.0, 0.0, 0.0, 0.0};
     int t = uw + NU * i;
     bool tv = t < CF::NTILE;
-    if constexpr (CF::AGE) {
-      const int age = uw / 3, col = uw - 3 * age, base = age == 0 ? 0 : (age == 1 ? 4 : (age == 2 ? 7 : 10)), cnt = age == 0 ? 4 : (age == 3 ? 2 : 3);
-      t = col + 3 * (base + i);
-      tv = i < cnt;
-    }
     int R = 0;
     while (is_upd && tv && ((R + 1) * (R + 2)) >> 1 <= t) ++R;
     const bool valid = is_upd && tv;
@@ -652,17 +640,12 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
         if (wbase + KT2 < pf_ns4) pfs1 = ssrc[min(pidx + KT2, pf_ns4 - 1)];
       }
     };
-#ifndef QTOS_PF_LATE
     prefetch_records();
     KS2(8);
-#endif
     if (wv == 0) {
       __builtin_amdgcn_s_setprio(3);
       if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV, k + 1);
       __builtin_amdgcn_s_setprio(0);
-#ifdef QTOS_PF_LATE
-      prefetch_records();
-#endif
     } else if (is_upd) {
       const Mask256 m2 = load_mask8(pm + (k & 1) * 8, lane);   // pivot slots of stage k+2
       const bool extract = k + 2 < NS;
@@ -702,10 +685,6 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
           U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(LY::VP ? wa[t & 1][s4] : wa[t & 1][s4] * dv4[s4], pbv[t & 1][s4], U[t], 0, 0, 0);
       }
       KS2(5);
-#ifdef QTOS_PF_LATE
-      prefetch_records();
-      KS2(8);
-#endif
 #ifdef QTOS_EXP_NOEXTRACT
       if (false) {
 #else
@@ -747,9 +726,6 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
         }
       }
     }
-#ifdef QTOS_PF_LATE
-    if (wv != 0 && wv != 12 && !is_upd) prefetch_records();
-#endif
     KS2(2);
     // every wave but the factor wave ends the phase with its share of the assembly of stage k+2's records
     // (the waves without a Schur tile come first and take the low item indices)
@@ -786,9 +762,6 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
       }
     }
     if (wv == 12) {
-#ifdef QTOS_PF_LATE
-      prefetch_records();
-#endif
       // header of stage k+3, published to the LDS rings (their slots have no reader left in this phase:
       // stage k's pivot slots / diagonals, stage k+1's slot map and mask) from this wave's share of the
       // prefetched record: lane l holds ints 4l .. 4l+3 (static header 0..7, pivot slots 8..23) and doubles

@@ -451,7 +451,6 @@ int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const d
     // problems flagged by k_step reuse the stored factorisation (k_chord), the others factor (k_kkt2)
     p->was_kkt[it] = n - nc > 0;
     p->was_chord[it] = nc > 0 && p->chord_fn;
-    if (getenv("QTOS_DEBUG_LOOP")) fprintf(stderr, "qtos: it %d unfinished %d chord %d\n", it, n, nc);
     // Next to a factorisation of other problems the chord solve runs on the side stream: the workgroups of k_kkt2
     // that belong to its problems leave at once and k_chord gets their CUs, so a batch whose problems are at
     // different points of their solves pays max(k_kkt2, k_chord) per iteration, not the sum.
