@@ -1,28 +1,26 @@
-// kkt2.hpp -- k_kkt2: the KKT factor + solve kernel with 16 waves per problem (1024 threads).
+// kkt2.hpp -- the KKT kernels: k_kkt2 (factor + solve, 16 waves = 1024 threads per problem) and k_chord (solve with the
+// factorisation of the preceding k_kkt2 launch and a new right-hand side).
 //
-// Same mathematics and the same data structures as k_kkt (kernels.hpp: chain of fronts, 16 pivots per
-// stage, Schur updates in MFMA accumulator registers, assembled entries in LDS cells, factor panels to
-// HBM for the backward pass), re-cut so that no wave carries two jobs in a row:
+// Chain of fronts, 16 pivots per stage: the assembled original entries in LDS cells (Symbolic::compact_cells), the
+// Schur updates in f64 MFMA accumulator registers, the factor panels V_k = P_k B_k^-1 and w_k to HBM for the sweeps.
+// Per stage two phases and two LDS-only barriers, no wave with two jobs in a row:
 //
 //   AB(k)  waves 0 .. NT-1   one 16-row tile of the panel each: V = P (L D L^T)^-1, next pivot columns, and the two
 //                             operands of the Schur update into LDS: -V and P with the rows of the next pivots
 //                             blanked (U -= V P^T = Y D^-1 Y^T without forming Y; fronts above 128 slots have no
-//                             room for the second panel and form Y = P L^-T as k_kkt does)
-//          service waves      (the other 16 - NT): assembly of stage k+2's records into the cells -- it used
-//                             to close phase C on every wave --, and, on the first of them, the whole
-//                             right-hand-side row: w = (L D L^T)^-1 p_F (to HBM), rhs -= P w, the right-hand
-//                             side of the next pivots.  (y_F D^-1 Y[r]^T = P[r] w, so the row needs nothing
-//                             this phase produces.)
-//   C(k)   wave 0             LDL^T + inverses of the next pivot block (nothing else)
-//          update waves       (those not on the factor wave's SIMD: the f64 matrix and vector pipes are one)
-//                             U -= Y D^-1 Y^T on MAXT tiles each,
-//                             extraction of stage k+2's columns
-//          wave 12            header of stage k+3 (pivot slots, slot map, masks, diagonals)
-//          all                install the records of stage k+3 (prefetched into 12 registers per thread
-//                             at the top of the stage)
+//                             room for the second panel and form Y = P L^-T on service waves)
+//          wave NT            the whole right-hand-side row: w = (L D L^T)^-1 p_F (to HBM), rhs -= P w, the right-hand
+//                             side of the next pivots.  (y_F D^-1 Y[r]^T = P[r] w: the row needs nothing this phase makes.)
+//   C(k)   wave 0             LDL^T + L^-1 of the next pivot block in registers, B^-1 = L^-T D^-1 L^-1 on the matrix core
+//          update waves       (those not on the factor wave's SIMD: a SIMD has one vector ALU, and it stands still while
+//                             an f64 matrix instruction runs) U -= V P^T on MAXT tiles each, extraction of stage k+2's
+//                             columns, their share of the assembly of stage k+2's records
+//          waves 4, 8, 12     assembly, then LDS-DMA of the records of stage k+3; wave 12: header of stage k+3 (pivot
+//                             slots, slot map, masks, diagonals)
+//   backward substitution and both sweeps of k_chord: one-stage look-ahead, one barrier per stage (sweep_backward)
 //
-// Fronts up to 208 slots: 13 row tiles, 91 Schur tiles = 7 per update wave (56 registers); the LDS
-// budget holds because the assembled entries live in cells (Symbolic::compact_cells, cell_mode 2).
+// Fronts up to 208 slots: 13 row tiles, 91 Schur tiles = 7 per update wave (56 registers); the LDS budget holds
+// because the assembled entries live in cells; records through prefetch registers instead of LDS-DMA there.
 #pragma once
 #include "kernels.hpp"
 
