@@ -234,6 +234,10 @@ def main():
             windows.append(ShiftedWindows(Pj, start_np[sl], gstep[sl], map_id_np[sl], advance=args.advance, x_range=(0.0, 2.2),   # walk up and down the ledges
                                           stream=torch.cuda.current_stream(dev) if nset == 1 else torch.cuda.Stream(dev)))
         mpc_pool = ThreadPoolExecutor(nset) if nset > 1 else None
+    gwork = None
+    if use_dist:
+        from qtos_amd.dist import gather_buffers
+        gwork = gather_buffers(B * world, d.n_vars, world, torch.float64, dev)
     state = {"i": 0}
     solved_dev = torch.zeros((), dtype=torch.int64, device=dev)     # converged plans, accumulated on the device
     iters_dev = torch.zeros((), dtype=torch.int64, device=dev)
@@ -264,7 +268,7 @@ def main():
                 raise RuntimeError("qtos_plan_batch_device failed: %d %s" % (rc, P.lib.qtos_last_error(P.h)))
             # (converged plans and iterations are tallied on the device by the planner itself: qtos_plan_totals)
         if use_dist:
-            return gather_plans(nodes, status, B * world)
+            return gather_plans(nodes, status, B * world, work=gwork)
         return nodes, status
 
     def sync():

@@ -16,22 +16,30 @@ def shard_bounds(n_items, world_size, rank):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def gather_plans(nodes_local, status_local, n_total, group=None):
+def gather_buffers(n_total, n_vars, world, dtype, device):
+    """Send / receive buffers of gather_plans, to be reused by a caller that gathers batch after batch (bench.py):
+    no allocation and no fill kernels between the solve and the collective."""
+    import torch
+    per = -(-n_total // world)
+    packed = torch.zeros((per, n_vars + 1), dtype=dtype, device=device)
+    packed[:, n_vars] = -1.0
+    return packed, torch.empty((world * per, n_vars + 1), dtype=dtype, device=device)
+
+
+def gather_plans(nodes_local, status_local, n_total, group=None, work=None):
     """All-gather the per-rank shards (torch tensors, same device) into full (n_total, n_vars) /
     (n_total,) tensors on every rank with ONE collective: the status word of a plan travels as an
     extra column of its node row (small integers are exact in float64), shards are padded to equal
-    length (pad rows carry status -1)."""
+    length (pad rows carry status -1).  work = gather_buffers(...): reused buffers (the result is a view of them)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     per = -(-n_total // world)
     n_vars = nodes_local.shape[1]
     n_loc = nodes_local.shape[0]
-    packed = torch.zeros((per, n_vars + 1), dtype=nodes_local.dtype, device=nodes_local.device)
-    packed[:, n_vars] = -1.0
+    packed, gathered = work if work is not None else gather_buffers(n_total, n_vars, world, nodes_local.dtype, nodes_local.device)
     packed[:n_loc, :n_vars] = nodes_local
     packed[:n_loc, n_vars] = status_local.to(nodes_local.dtype)
-    gathered = torch.empty((world * per, n_vars + 1), dtype=nodes_local.dtype, device=nodes_local.device)
     dist.all_gather_into_tensor(gathered, packed, group=group)
     if world * per != n_total:   # ragged batch: drop the pad rows
         keep = []
