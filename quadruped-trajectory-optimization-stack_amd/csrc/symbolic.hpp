@@ -716,6 +716,25 @@ struct Symbolic {
           xt += t;
         }
         fprintf(stderr, "\nmean update tiles %.2f, pivot groups %.2f, extraction tiles %.2f", tiles / n_stages, pgs / n_stages, xt / n_stages);
+        if (front == 128) {   // tiles per SIMD if the tiles of empty groups were skipped (k_kkt2's static tile -> wave map: 12 update waves)
+          double mx = 0;
+          for (int k = 0; k < n_stages; ++k) {
+            unsigned gm = 0;
+            for (int grp = 0; grp < 8; ++grp)
+              if ((amask[(size_t)k * 8 + (grp >> 1)] >> ((grp & 1) * 16)) & 0xffffu) gm |= 1u << grp;
+            int per[4] = {0, 0, 0, 0};
+            for (int uw = 0; uw < 12; ++uw)
+              for (int i = 0; i < 3; ++i) {
+                const int t = uw + 12 * i;
+                int R = 0;
+                while ((R + 1) * (R + 2) / 2 <= t) ++R;
+                const int Cc = t - R * (R + 1) / 2;
+                if (((gm >> R) & 1) && ((gm >> Cc) & 1)) per[(uw + 1 + uw / 3) & 3]++;
+              }
+            mx += std::max(per[1], std::max(per[2], per[3]));
+          }
+          fprintf(stderr, "\nmean over stages of the busiest SIMD's tiles with empty groups skipped: %.2f of 12", mx / n_stages);
+        }
       }
       {
         std::map<std::pair<int,int>, int> bh;
