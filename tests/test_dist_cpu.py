@@ -25,6 +25,17 @@ def _worker(rank, world, port, tmp):
     nodes, status = qd.plan_sharded(fake_solve, start, goal)
     np.save(os.path.join(tmp, "nodes%d.npy" % rank), nodes)
     np.save(os.path.join(tmp, "status%d.npy" % rank), status)
+    # the same gather batch after batch through reused buffers (bench.py's N > 1 path)
+    import torch
+    b, e = qd.shard_bounds(B, world, rank)
+    work = qd.gather_buffers(B, n, world, torch.float64, "cpu")
+    ok = True
+    for rep in range(3):
+        loc_n, loc_s = fake_solve(start[b:e] + rep, goal[b:e])
+        an, as_ = qd.gather_plans(torch.as_tensor(loc_n), torch.as_tensor(loc_s), B, work=work)
+        wn, ws = fake_solve(start + rep, goal)
+        ok = ok and np.array_equal(an.numpy(), wn) and np.array_equal(as_.numpy(), ws)
+    np.save(os.path.join(tmp, "reuse%d.npy" % rank), np.array([ok]))
     dist.destroy_process_group()
 
 
@@ -50,3 +61,4 @@ def test_world_size_2_gloo_allgather(tmp_path):
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / ("nodes%d.npy" % r)), want_nodes)
         assert np.array_equal(np.load(tmp_path / ("status%d.npy" % r)), want_status)
+        assert np.load(tmp_path / ("reuse%d.npy" % r)).all()
