@@ -320,6 +320,8 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     tRC[i] = valid ? (R << 8) | (t - ((R * (R + 1)) >> 1)) : -1;
   }
 
+  int tile_lane = (li * PLD + lk) * 8;   // (li, lk): row li, column lk of a 16 x 16 tile of a panel, in bytes
+  asm volatile("" : "+v"(tile_lane));
   unsigned ge4_keep = 0u, gt4_keep = 0u;
 #pragma unroll
   for (int g = 0; g < 4; ++g) { ge4_keep |= (lk + 4 * g >= li ? 1u : 0u) << (4 * g); gt4_keep |= (lk + 4 * g > li ? 1u : 0u) << (4 * g); }
@@ -659,11 +661,14 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
 #pragma unroll
       for (int t = 0; t < MAXT2; ++t) { rcs[t] = tRC[t]; asm volatile("" : "+s"(rcs[t])); }
       double wa[2][4], pbv[2][4];
+      // operand addresses: a lane part that never changes (tile_lane, bytes) plus a wave-uniform tile offset formed on the
+      // scalar unit
       auto tile_loads = [&](int rc, double (&w)[4], double (&pq)[4]) __attribute__((always_inline)) {
         const int R = rc < 0 ? 0 : rc >> 8, C = rc < 0 ? 0 : rc & 255;
-        const double *wrow = Yk + (16 * R + li) * PLD + lk, *prow2 = Bop + (16 * C + li) * PLD + lk;
+        const int oR = __builtin_amdgcn_readfirstlane(R * (16 * PLD * 8)), oC = __builtin_amdgcn_readfirstlane(C * (16 * PLD * 8));
+        const char *wrow = (const char *)Yk + (tile_lane + oR), *prow2 = (const char *)Bop + (tile_lane + oC);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { w[s4] = wrow[4 * s4]; pq[s4] = prow2[4 * s4]; }
+        for (int s4 = 0; s4 < 4; ++s4) { w[s4] = *(const double *)(wrow + 32 * s4); pq[s4] = *(const double *)(prow2 + 32 * s4); }
       };
       // pivot indices of the columns (li) and of the four rows (lk + 4g) this lane holds in each tile: fetched ahead of
       // the products (the extraction behind them starts with no LDS round trip of its own: -5.5 % per launch)
