@@ -73,6 +73,13 @@ def parse_args():
     ap.add_argument("--advance", type=float, default=2.5,
                     help="mpc_random: seconds into its newest plan at which a window's next plan starts (the reference's "
                          "f_steps = 2500 rows, scripts/main.py:177; moved on until all feet are in contact)")
+    ap.add_argument("--force-torchrun", action="store_true",
+                    help="launch the ranks through torch.distributed.run even for --gpus 1 (exercises the child-process path "
+                         "and the RCCL all-gather at world size 1)")
+    ap.add_argument("--child-timeout", type=float, default=1800.0, help="seconds after which the launcher ends its torchrun child")
+    ap.add_argument("--no-trot", action="store_true",
+                    help="skip the trot-gait leg that the default headline run times after the walk (BASELINE.json's metric names a trot)")
+    ap.add_argument("--trot-steps", type=int, default=10)
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per k_kkt launch from a separate rocprofv3 --pmc pass "
                          "(default: the newest profiles/*_pmc_hbm.json, collected with this same command)")
@@ -80,16 +87,38 @@ def parse_args():
 
 
 def relaunch_under_torchrun(args):
-    """--gpus N > 1 outside a torch.distributed launch: become the launcher (no GPU call has been made)."""
+    """--gpus N > 1 (or --force-torchrun) outside a torch.distributed launch: become the launcher.  No GPU call has
+    been made by this process (torch.cuda.device_count() does not initialise the runtime) and none is made: the ranks
+    run in a child process whose exit code becomes ours."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print("bench.py: --gpus %d but this node has %d GPU(s)" % (args.gpus, have), file=sys.stderr)
+        sys.exit(2)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    argv = [a for a in sys.argv[1:] if a != "--force-torchrun"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    sys.exit(subprocess.call(cmd, env=env))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        rc = child.wait(timeout=args.child_timeout)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the torchrun child did not finish within %.0f s; ending its process group" % args.child_timeout, file=sys.stderr)
+        try:
+            os.killpg(child.pid, 15)
+            child.wait(timeout=20)
+        except Exception:
+            try:
+                os.killpg(child.pid, 9)
+            except Exception:
+                pass
+        rc = 124
+    sys.exit(rc)
 
 
 def golden_parity(Planner, PlannerConfig, device):
@@ -130,7 +159,7 @@ def golden_parity(Planner, PlannerConfig, device):
 
 def main():
     args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_torchrun) and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args)
 
     import numpy as np
@@ -233,12 +262,17 @@ def main():
             sl = slice(j * per, (j + 1) * per)
             windows.append(ShiftedWindows(Pj, start_np[sl], gstep[sl], map_id_np[sl], advance=args.advance, x_range=(0.0, 2.2),   # walk up and down the ledges
                                           stream=torch.cuda.current_stream(dev) if nset == 1 else torch.cuda.Stream(dev)))
+        # several sets: one host thread per set (every replan queues ~40 small kernels -- sampling, hand-over rows, the
+        # solve --: issued by ONE thread in turn for four sets the launches arrive too slowly, 31 ms per replan of all
+        # windows instead of 16; ShiftedWindows.begin / poll exist for callers that prefer it)
         mpc_pool = ThreadPoolExecutor(nset) if nset > 1 else None
     gwork = None
     if use_dist:
         from qtos_amd.dist import gather_buffers
         gwork = gather_buffers(B * world, d.n_vars, world, torch.float64, dev)
-    state = {"i": 0}
+    state = {"i": 0, "timed": 0}
+    # HIP events around the collective of every timed step (recorded on the stream the solve is queued on)
+    gather_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if use_dist else None
     solved_dev = torch.zeros((), dtype=torch.int64, device=dev)     # converged plans, accumulated on the device
     iters_dev = torch.zeros((), dtype=torch.int64, device=dev)
 
@@ -268,6 +302,14 @@ def main():
                 raise RuntimeError("qtos_plan_batch_device failed: %d %s" % (rc, P.lib.qtos_last_error(P.h)))
             # (converged plans and iterations are tallied on the device by the planner itself: qtos_plan_totals)
         if use_dist:
+            # (the result is a view of the reused gather buffers: the next step overwrites it, nothing here keeps it)
+            if gather_ev is not None and state["timed"] < len(gather_ev):
+                e0, e1 = gather_ev[state["timed"]]
+                state["timed"] += 1
+                e0.record()
+                out_ = gather_plans(nodes, status, B * world, work=gwork)
+                e1.record()
+                return out_
             return gather_plans(nodes, status, B * world, work=gwork)
         return nodes, status
 
@@ -276,33 +318,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # optional: several batches in flight (separate planner handles / streams / outputs)
-    lanes = []
+    # optional: several batches in flight: a pool of planner handles (own workspace + stream each) fed by THIS thread
+    # (qtos_amd.pool.PlannerPool: submit to a free lane, poll the others -- no host threads)
+    lanes = None
     if args.inflight > 1 and not mpc:
-        from concurrent.futures import ThreadPoolExecutor
-        for _ in range(args.inflight):
-            Pl = Planner(cfg, max_batch=B, device=local_rank)
-            Pl.set_heightfields(terrain[0], terrain[1])
+        from qtos_amd.pool import PlannerPool
+        def pool_done(lane):      # (runs on the lane's stream: one pair of counters per lane)
+            lane.solved_acc.add_((lane.status[:lane.n] == 0).sum())
+            lane.iters_acc.add_(lane.iters[:lane.n].sum())
+        lanes = PlannerPool(cfg, n_lanes=args.inflight, max_batch=B, device=local_rank, heightfields=(terrain[0], terrain[1]), on_done=pool_done)
+        for L in lanes.lanes:
+            with torch.cuda.stream(L.stream):
+                L.solved_acc = torch.zeros((), dtype=torch.int64, device=dev)
+                L.iters_acc = torch.zeros((), dtype=torch.int64, device=dev)
             if args.init == "table":
-                Pl.set_init_table(*P.init_table)
-            lanes.append(dict(P=Pl, stream=torch.cuda.Stream(dev), nodes=torch.empty_like(nodes),
-                              status=torch.empty_like(status), iters=torch.empty_like(iters), viol=torch.empty_like(viol)))
-        pool = ThreadPoolExecutor(args.inflight)
+                L.P.set_init_table(*P.init_table)
 
-        def lane_step(L, i):
+        def pool_step(i):
             i %= n_sets
-            rc = L["P"].lib.qtos_plan_batch_device(L["P"].h, B, start_all[i].data_ptr(), goal_all[i].data_ptr(),
-                                                   None if map_all is None else map_all[i].data_ptr(), None,
-                                                   L["nodes"].data_ptr(), L["status"].data_ptr(), L["iters"].data_ptr(),
-                                                   L["viol"].data_ptr(), C.c_void_p(L["stream"].cuda_stream))
-            if rc != 0:
-                raise RuntimeError("qtos_plan_batch_device failed: %d" % rc)
-            L["stream"].synchronize()
-            return int((L["status"] == 0).sum().item())
+            return lanes.submit(start_all[i], goal_all[i], None if map_all is None else map_all[i])
 
     for _ in range(args.warmup):
         step()
     sync()
+    state["timed"] = 0
     solved_dev.zero_()
     iters_dev.zero_()
     P.totals(reset=True)
@@ -310,26 +349,29 @@ def main():
     chord_s, chord_n = 0.0, 0
     solved_inflight = None
     if lanes:
-        for j, L in enumerate(lanes):
-            lane_step(L, j)
+        for j in range(2 * args.inflight):
+            pool_step(j)
+        lanes.drain()
+        sync()
+        for L in lanes.lanes:
+            with torch.cuda.stream(L.stream):
+                L.solved_acc.zero_()
+                L.iters_acc.zero_()
         sync()
         t0 = time.perf_counter()
-        futs = [pool.submit(lane_step, lanes[j % len(lanes)], args.warmup + j) for j in range(len(lanes))]
-        done_steps, solved_inflight, nxt = 0, 0, len(lanes)
-        while done_steps < args.steps:          # keep `inflight` batches running until K are done
-            f = futs.pop(0)
-            solved_inflight += f.result()
-            done_steps += 1
-            if nxt < args.steps:
-                futs.append(pool.submit(lane_step, lanes[nxt % len(lanes)], args.warmup + nxt))
-                nxt += 1
-        all_nodes, all_status = lanes[0]["nodes"], lanes[0]["status"]
+        for j in range(args.steps):
+            last_lane = pool_step(args.warmup + j)
+        lanes.drain()
+        sync()
+        solved_inflight = sum(int(L.solved_acc.item()) for L in lanes.lanes)
+        iters_dev.fill_(sum(int(L.iters_acc.item()) for L in lanes.lanes))
+        all_nodes, all_status = last_lane.nodes, last_lane.status
     elif mpc and mpc_pool is not None:
         # the sets of windows are independent robots: every set runs its K replans on its own (no rendezvous between
         # sets after every replan: a set waits for ITS slowest window only); a step = one replan of every window
         def run_set(Wj):
-            cnt = torch.zeros((), dtype=torch.int64, device=dev)
             with torch.cuda.stream(Wj.stream):
+                cnt = torch.zeros((), dtype=torch.int64, device=dev)   # (created on the stream that adds to it)
                 for _ in range(args.steps):
                     Wj.replan()
                     cnt.add_((Wj.status == 0).sum())
@@ -360,9 +402,16 @@ def main():
         iters_dev.fill_(ti)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     n_local = solved_dev.to(torch.float64).reshape(1) if solved_inflight is None else torch.tensor([float(solved_inflight)], dtype=torch.float64, device=dev)
+    rank_rate = (n_local / elapsed).clone()           # this rank's own plans/s over its own clock
+    rate_min, rate_max = rank_rate.clone(), rank_rate.clone()
+    allgather_ms = None
     if use_dist:
+        if gather_ev is not None and state["timed"] > 0 and not (lanes or (mpc and mpc_pool is not None)):
+            allgather_ms = sum(e0.elapsed_time(e1) for e0, e1 in gather_ev[:state["timed"]]) / state["timed"]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(n_local)
+        dist.all_reduce(rate_min, op=dist.ReduceOp.MIN)
+        dist.all_reduce(rate_max, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     n_solved = int(n_local.item())          # converged plans of all ranks over the K timed steps
     total_plans = B * world
@@ -373,7 +422,7 @@ def main():
         "metric": "NLP solves/sec (%d-knot SOLO12 %s gait, %g s horizon, converged to %s); CoM L-inf vs TOWR in `parity`" %
                   (d.n_dyn_times - 2, args.gait, cfg.duration, ("%.0e" % cfg.tol).replace("e-0", "e-")),
         "value": round(value, 2), "unit": "plans/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "timed_region_s": round(elapsed, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {
@@ -387,7 +436,7 @@ def main():
             "global_batch": total_plans, "plans_timed": total_plans * args.steps, "converged": n_solved,
             "batches": "one seeded batch replayed" if n_sets == 1 else "%d seeded batches, one per step" % n_sets,
             "iterations_max_last_step": int(itn.max()),
-            "iterations_mean": round(float(iters_dev.item()) / max(B * args.steps, 1), 3) if solved_inflight is None else None,
+            "iterations_mean": round(float(iters_dev.item()) / max(B * args.steps, 1), 3) if (solved_inflight is None or lanes) else None,
             "parallelism": "batch-shard x%d + 1 %s" % (world, "RCCL all-gather" if use_dist else "all-gather (not launched under torch.distributed: single process)"),
             "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front,
             "batches_in_flight": args.inflight, "max_iter": cfg.max_iter, "chord_tol": cfg.chord_tol,
@@ -395,6 +444,9 @@ def main():
                              "interpolated table of %d nominal plans (solved before the timed region)" % (P.init_table[2].shape[0] * P.init_table[2].shape[1]),
         },
     }
+    out["per_rank_plans_per_s"] = {"min": round(float(rate_min.item()), 1), "max": round(float(rate_max.item()), 1)}
+    if use_dist:
+        out["allgather_ms"] = None if allgather_ms is None else round(allgather_ms, 4)
     if mpc:
         out["config"]["replan_hz_per_window"] = round(args.steps / elapsed, 2)
         out["config"]["windows_per_gpu"] = B
@@ -440,17 +492,61 @@ def main():
                 out["roofline"]["counters"] = dict(json.load(open(f))["k_kkt"], source=os.path.relpath(f, ROOT))
             except Exception:
                 pass
+    if headline and world == 1 and rank == 0 and not args.no_trot and not lanes and args.trot_steps > 0:
+        # BASELINE.json's metric names a trot; the reference's committed plans (and so the headline above) are the walk.
+        # The same batch size and goals with the diagonal-pair trot schedule, timed right behind the walk.
+        cfg_t = PlannerConfig.knots100(gait="trot", **{k: v for k, v in kw.items() if k != "gait"})
+        Pt = Planner(cfg_t, max_batch=B, device=local_rank)
+        Pt.set_heightfields(terrain[0], terrain[1])
+        dt_ = Pt.dims
+        nodes_t = torch.empty((B, dt_.n_vars), dtype=torch.float64, device=dev)
+        status_t, iters_t, viol_t = torch.empty_like(status), torch.empty_like(iters), torch.empty_like(viol)
+
+        def trot_step(i):
+            i %= n_sets
+            rc = Pt.lib.qtos_plan_batch_device(Pt.h, B, start_all[i].data_ptr(), goal_all[i].data_ptr(), None, None,
+                                               nodes_t.data_ptr(), status_t.data_ptr(), iters_t.data_ptr(), viol_t.data_ptr(),
+                                               C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError("qtos_plan_batch_device (trot) failed: %d" % rc)
+        for i in range(2):
+            trot_step(i)
+        torch.cuda.synchronize(dev)
+        Pt.totals(reset=True)
+        tk_s, tk_n = 0.0, 0
+        tt0 = time.perf_counter()
+        for i in range(args.trot_steps):
+            trot_step(2 + i)
+            tm = Pt.timing()
+            tk_s += tm["kkt_seconds"]
+            tk_n += tm["kkt_launches"]
+        torch.cuda.synchronize(dev)
+        tel = time.perf_counter() - tt0
+        tconv, titer = Pt.totals()
+        tavg = tk_s / max(tk_n, 1)
+        out["trot"] = {
+            "value": round(tconv / tel, 2), "unit": "plans/s", "steps": args.trot_steps, "ms_per_step": round(1e3 * tel / args.trot_steps, 4),
+            "timed_region_s": round(tel, 4), "plans_timed": B * args.trot_steps, "converged": int(tconv),
+            "iterations_mean": round(titer / max(B * args.trot_steps, 1), 3),
+            "kkt_unknowns": dt_.n_unknowns, "kkt_stages": dt_.n_stages, "front": dt_.front, "n_vars": dt_.n_vars,
+            "gait": "diagonal-pair trot (config.TROT_UNNORMALISED; not pinned by any reference artefact)",
+            "roofline": {"kernel": "k_kkt2", "bound": "hbm", "achieved": round(B * dt_.kkt_algorithmic_bytes / tavg / 1e9, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(B * dt_.kkt_algorithmic_bytes / tavg / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                         "bytes_per_launch": float(B) * dt_.kkt_algorithmic_bytes, "avg_launch_ms": round(1e3 * tavg, 4), "launches": tk_n,
+                         "fp64_tflops": round(B * dt_.kkt_flops / tavg / 1e12, 3)},
+        }
+        Pt.close()
     if parity is not None:
         out["parity"] = parity
     if rank == 0 and world == 1 and args.cpu_sample > 0 and args.workload not in ("mixed", "mpc_random"):
-        from oracle.oracle import Oracle
-        O = Oracle(cfg.oracle_dict(), height=None if args.workload == "exp1_flat" else terrain[0],
+        from oracle.oracle import Oracle, oracle_dict
+        O = Oracle(oracle_dict(cfg), height=None if args.workload == "exp1_flat" else terrain[0],
                    hcell=0.1 if args.workload == "exp1_flat" else terrain[1])
         n_s = min(args.cpu_sample, B)
         # the LAST timed batch is still on the device: its first n_s plans are re-solved on the host
-        last = (state["i"] - 1) % n_sets if not lanes else 0
+        last = (state["i"] - 1) % n_sets if not lanes else (args.warmup + args.steps - 1) % n_sets
         s_np, g_np = sets[last][0], sets[last][1]
-        nodes_h = (nodes if not lanes else lanes[0]["nodes"]).cpu().numpy()
+        nodes_h = (nodes if not lanes else last_lane.nodes).cpu().numpy()
         qs = [O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g) for s, g in zip(s_np[:n_s], g_np[:n_s])]
         n1 = max(1, n_s // 4)
         tc = time.perf_counter()

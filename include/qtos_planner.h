@@ -125,11 +125,26 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
                     int *iters_out, double *viol_out);
 
 /* Same, all pointers in device memory of the planner's device, work queued on `stream` (a hipStream_t passed
- * as void*, NULL = default stream).  The call returns when the last Newton iteration has been queued: the host
- * reads the number of unfinished problems back before it queues an iteration (it spins on an event meanwhile),
- * so it is busy for about the duration of the solve; the copies into the output buffers are still in flight on
- * `stream` at return.  One planner handle serves one call at a time; different handles / streams are independent.
- * This is the form bench.py times. */
+ * as void*, NULL = default stream) -- the asynchronous form of the boundary, in three entry points that replace the
+ * reference's pool of `docker exec ./main` workers pulling probes from a queue (QTOS/generateHeightField.py:344-352,
+ * 375-377; scripts/main.py:49-50 for the single call):
+ *
+ *   qtos_plan_submit   queues the initial guess, the first Newton iteration(s) and an export of the results that runs
+ *                      only if they were enough, and returns at once.  With qtos_set_speculation(n > 1) it queues as
+ *                      many iterations as the previous call of this handle needed, up to n, without a host round
+ *                      trip ("blind" iterations: both solve kernels are launched, the workgroups of problems that
+ *                      are finished or belong to the other kernel leave at once).
+ *   qtos_plan_poll     non-blocking: reads the counts of unfinished problems the iterations sent back; a batch that
+ *                      needs more iterations gets them queued one by one (only the kernels with work), then the
+ *                      export; *done = 1 once everything the call needs is on the stream.
+ *   qtos_plan_wait     polls until done.
+ *
+ * qtos_plan_batch_device = submit + wait: it returns when the last kernel of the call has been QUEUED; the results are
+ * in the output buffers once `stream` has been synchronised.  For a batch whose problems all finish within the blind
+ * iterations (qtos_set_speculation; off by default) the host does nothing between the submit and the end.  One planner handle serves one call at a time (a second submit before the first is done returns -5);
+ * handles are independent: several handles on their own streams keep several batches in flight from ONE host thread
+ * (qtos_amd.pool.PlannerPool: submit to a free handle, poll the others) -- a batch that waits for its slowest problem
+ * then shares the GPU with the next ones.  This is the form bench.py times. */
 int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
                            const int *d_map_id, const double *d_warm, double *d_nodes_out,
                            int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream);
@@ -153,6 +168,17 @@ int qtos_sample_csv(QtosPlanner *p, int B, const double *nodes, const double *t0
                     int n_rows, double *rows_out);
 int qtos_sample_csv_device(QtosPlanner *p, int B, const double *d_nodes, const double *d_t0,
                            double hz, int n_rows, double *d_rows_out, void *stream);
+
+int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
+                     const int *d_map_id, const double *d_warm, double *d_nodes_out,
+                     int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream);
+int qtos_plan_poll(QtosPlanner *p, int *done);
+int qtos_plan_wait(QtosPlanner *p);
+/* Upper limit of the iterations qtos_plan_submit queues blind.  Default 1: the host looks at the counts in front of
+ * every iteration but the first and launches only the kernels that have work (measured faster on every workload:
+ * the gaps between dependent kernels of a stream are launch latency either way, and a blind iteration pays for
+ * launches without work).  A larger limit buys a host that is free for the whole solve. */
+int qtos_set_speculation(QtosPlanner *p, int max_blind_iterations);
 
 /* Seconds spent in the KKT kernels / all kernels during the last qtos_plan_batch* call, from HIP
  * events on the launch stream (valid after the stream has been synchronised), and the number of

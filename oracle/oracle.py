@@ -109,6 +109,28 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def oracle_dict(cfg):
+    """A qtos_amd.config.PlannerConfig in the key names Oracle() expects (moved here from the product package:
+    test infrastructure only)."""
+    return dict(phase_durations=cfg.phase_durations, nominal_stance=cfg.nominal_stance,
+                dt_base=cfg.dt_base, dt_dyn=cfg.dt_dynamic, dt_rom=cfg.dt_range_of_motion,
+                force_polys_per_stance=cfg.force_polys_per_stance, mass=cfg.mass,
+                gravity=cfg.gravity, inertia_b=cfg.inertia_b, max_dev=cfg.max_deviation,
+                mu=cfg.friction, f_max=cfg.force_limit, t_swing_avg=cfg.t_swing_avg,
+                terrain_mode=cfg.terrain_mode)
+
+
+def oracle_options(cfg, O):
+    """qo_options of the oracle O with the solver settings of a PlannerConfig."""
+    o = O.default_options()
+    o.max_iter, o.tol, o.mu_init, o.mu_min = cfg.max_iter, cfg.tol, cfg.mu_init, cfg.mu_min
+    o.delta_x, o.eps_dual, o.slack_push, o.warm_slack_push = cfg.delta_x, cfg.eps_dual, cfg.slack_push, cfg.warm_slack_push
+    o.stall_iters, o.hold_from, o.hold_weight, o.hold_tol = (cfg.stall_iters, cfg.foothold_hold_from,
+                                                             cfg.foothold_hold_weight, cfg.foothold_hold_tol)
+    o.chord_tol = cfg.chord_tol
+    return o
+
+
 class Oracle:
     """Thin object wrapper: Oracle(cfg_dict).  cfg keys mirror qo_params."""
 

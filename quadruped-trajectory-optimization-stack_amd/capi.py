@@ -56,6 +56,7 @@ EXPORTS = [
     "qtos_debug_structure", "qtos_debug_trace", "qtos_debug_factor", "qtos_analyze",
     "qtos_set_init_table", "qtos_debug_initial_guess", "qtos_shift_warm", "qtos_shift_warm_device",
     "qtos_last_timing_chord", "qtos_debug_chord", "qtos_plan_totals",
+    "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation",
 ]
 
 _lib = None
@@ -84,6 +85,7 @@ def load():
     except Exception:
         pass
     lib = C.CDLL(LIB_PATH)
+    _warn_if_two_hip_runtimes()
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
     lib.qtos_planner_create.argtypes = [C.POINTER(QtosParams), C.c_int, C.c_int, C.POINTER(vp)]
     lib.qtos_planner_destroy.argtypes = [vp]
@@ -110,11 +112,31 @@ def load():
     if hasattr(lib, "qtos_plan_totals"):
         lib.qtos_plan_totals.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]
         lib.qtos_debug_chord.argtypes = [vp, C.c_int, dp]
+    if hasattr(lib, "qtos_plan_submit"):
+        lib.qtos_plan_submit.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.qtos_plan_poll.argtypes = [vp, ip]
+        lib.qtos_plan_wait.argtypes = [vp]
+        lib.qtos_set_speculation.argtypes = [vp, C.c_int]
     if hasattr(lib, "qtos_shift_warm"):   # (absent from older builds loaded through QTOS_LIB for A/B timing)
         lib.qtos_shift_warm.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, dp]
         lib.qtos_shift_warm_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
+
+
+def _warn_if_two_hip_runtimes():
+    """The pre-load above gives ONE HIP runtime only if torch's libamdhip64 has the SONAME this library was linked against:
+    with a torch wheel built for another ROCm major both copies get mapped and the kernels register with whichever wins
+    symbol lookup.  Said loudly instead of failing obscurely later."""
+    try:
+        paths = {ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln}
+        real = {os.path.realpath(q) for q in paths}
+        if len(real) > 1:
+            import warnings
+            warnings.warn("two HIP runtimes are mapped into this process (%s): the planner library and PyTorch do not share "
+                          "one libamdhip64; GPU work may fail or see no device" % ", ".join(sorted(real)))
+    except OSError:
+        pass
 
 
 def _dp(a):
@@ -225,6 +247,24 @@ class Planner:
         self._chk(self.lib.qtos_plan_batch(self.h, B, _dp(start), _dp(goal), _ip(mid), _dp(wm),
                                            _dp(nodes), _ip(status), _ip(iters), _dp(viol)), "plan_batch")
         return nodes, status, iters, viol
+
+    # ---- asynchronous form (device pointers): submit / poll / wait, see include/qtos_planner.h ----
+    def submit(self, B, d_start, d_goal, d_map_id, d_warm, d_nodes, d_status, d_iters, d_viol, stream):
+        """Queue a whole solve on `stream` (raw device pointers / None, stream = hipStream_t as int) and return at once."""
+        self._chk(self.lib.qtos_plan_submit(self.h, B, d_start, d_goal, d_map_id, d_warm, d_nodes, d_status, d_iters, d_viol,
+                                            C.c_void_p(stream)), "plan_submit")
+
+    def poll(self):
+        """True once everything the submitted call needs has been queued (results: synchronise its stream)."""
+        done = C.c_int(0)
+        self._chk(self.lib.qtos_plan_poll(self.h, C.byref(done)), "plan_poll")
+        return bool(done.value)
+
+    def wait(self):
+        self._chk(self.lib.qtos_plan_wait(self.h), "plan_wait")
+
+    def set_speculation(self, max_blind_iterations):
+        self._chk(self.lib.qtos_set_speculation(self.h, int(max_blind_iterations)), "set_speculation")
 
     def sample(self, nodes, t0, hz=1000.0, n_rows=None):
         nodes = np.ascontiguousarray(nodes, np.float64).reshape(-1, self.n)

@@ -130,22 +130,3 @@ class PlannerConfig:
             table = [list(f[:-1]) + [f[-1] + f[0]] + list(f[1:]) for f in REFERENCE_WALK_UNNORMALISED]
             kw["phase_durations"] = scaled_phases(table, kw["duration"])
         return cls(**kw)
-
-    def oracle_dict(self):
-        """The same numbers in the key names oracle/oracle.py expects (tests only)."""
-        return dict(phase_durations=self.phase_durations, nominal_stance=self.nominal_stance,
-                    dt_base=self.dt_base, dt_dyn=self.dt_dynamic, dt_rom=self.dt_range_of_motion,
-                    force_polys_per_stance=self.force_polys_per_stance, mass=self.mass,
-                    gravity=self.gravity, inertia_b=self.inertia_b, max_dev=self.max_deviation,
-                    mu=self.friction, f_max=self.force_limit, t_swing_avg=self.t_swing_avg,
-                    terrain_mode=self.terrain_mode)
-
-    def oracle_options(self, O):
-        """qo_options of the oracle with this configuration's solver settings (tests only)."""
-        o = O.default_options()
-        o.max_iter, o.tol, o.mu_init, o.mu_min = self.max_iter, self.tol, self.mu_init, self.mu_min
-        o.delta_x, o.eps_dual, o.slack_push, o.warm_slack_push = self.delta_x, self.eps_dual, self.slack_push, self.warm_slack_push
-        o.stall_iters, o.hold_from, o.hold_weight, o.hold_tol = (self.stall_iters, self.foothold_hold_from,
-                                                                 self.foothold_hold_weight, self.foothold_hold_tol)
-        o.chord_tol = self.chord_tol
-        return o

@@ -871,6 +871,110 @@ __device__ __forceinline__ void ldlt16(double (&a)[PIV], double (&v)[PIV], doubl
   ldlt16_steps<0>(a, v, myinv, i);
 }
 
+// ---- LDL^T of a 16 x 16 block in the split layout (round 3) --------------------------------------------------------
+// The block is held ONCE by the wave, not once per 16-lane row: lane (li, lk) = (lane & 15, lane >> 4) keeps
+// a[g] = B[li][4 g + lk], g = 0..3 -- row li, the four columns = lk (mod 4); this is also the accumulator layout of the
+// f64 MFMA for a symmetric matrix.  Step K (column K = 4 gK + qK, held by row group qK): 1 / d_K and the multipliers
+// l_i = B[i][K] / d_K exist in row group qK only and cross to the other three row groups with v_permlane32_swap +
+// v_permlane16_swap; the rank-1 update of the trailing columns is then ONE row-broadcast FMA per register that still holds
+// live columns (row_mask keeps the finished columns of register gK), and W = L^-1 (same layout, starts as I) gets the
+// same row operation on its columns <= K: 5 FMAs per step instead of 15.
+template <int Q>
+__device__ __forceinline__ double bcast_rowgroup(double x) {   // the values of row group Q on all four row groups
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);   // [0] = groups (0, 1, 0, 1), [1] = groups (2, 3, 2, 3)
+  auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  lo = l[Q >> 1];
+  hi = h[Q >> 1];
+  auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // [0] = the even groups of the source, [1] = the odd ones
+  auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(h2[Q & 1], l2[Q & 1]);
+}
+// a += bcast_K(a) * b on the row groups selected by RM (callers keep two instructions between a VALU write of `a` and
+// this cross-lane read of it: here `a` was last written a whole step earlier)
+template <int K, int RM>
+__device__ __forceinline__ void fma_bc_self_rows(double &a, double b) {
+  if constexpr (RM != 0)
+    asm volatile("v_fmac_f64 %0, %0, %1 row_newbcast:%2 row_mask:%3 bank_mask:0xf" : "+v"(a) : "v"(b), "n"(K), "n"(RM));
+}
+// bc16 with the two wait states a DPP read of a fresh VALU result needs (the compiler does not see through the inline
+// assembly that wrote the source)
+template <int K>
+__device__ __forceinline__ double bc16_safe(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v), olo, ohi;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+               : "=&v"(olo), "=&v"(ohi) : "v"(lo), "v"(hi), "n"(K));
+  return __hiloint2double(ohi, olo);
+}
+template <int K>
+__device__ __forceinline__ void ldlt16s_steps(double (&a)[4], double (&w)[4], double &myinv, int li, int lk) {
+  if constexpr (K < PIV) {
+    constexpr int gK = K >> 2, qK = K & 3;
+    const double inv = fast_rcp(bc16_safe<K>(a[gK]));   // 1 / d_K on row group qK (other groups: don't care)
+    if (li == K && lk == qK) myinv = inv;
+    if constexpr (K < PIV - 1) {
+      double nl = li > K ? -(a[gK] * inv) : 0.0;    // -L[i][K] for rows i > K, 0 for finished rows (row group qK)
+      nl = bcast_rowgroup<qK>(nl);
+      // trailing columns: register gK holds columns 4 gK + (0..3): only the row groups behind qK; later registers whole
+      fma_bc_self_rows<K, (0xF << (qK + 1)) & 0xF>(a[gK], nl);
+      if constexpr (gK + 1 < 4) fma_bc_self_rows<K, 0xF>(a[gK + 1 < 4 ? gK + 1 : 3], nl);
+      if constexpr (gK + 2 < 4) fma_bc_self_rows<K, 0xF>(a[gK + 2 < 4 ? gK + 2 : 3], nl);
+      if constexpr (gK + 3 < 4) fma_bc_self_rows<K, 0xF>(a[gK + 3 < 4 ? gK + 3 : 3], nl);
+      // inverse factor: row i -= L[i][K] * (row K of W), columns <= K (W[K][K] = 1 delivers W[i][K] = -L[i][K])
+      if constexpr (gK >= 1) fma_bc_self_rows<K, 0xF>(w[0], nl);
+      if constexpr (gK >= 2) fma_bc_self_rows<K, 0xF>(w[1], nl);
+      if constexpr (gK >= 3) fma_bc_self_rows<K, 0xF>(w[2], nl);
+      fma_bc_self_rows<K, (1 << (qK + 1)) - 1>(w[gK], nl);
+    }
+    ldlt16s_steps<K + 1>(a, w, myinv, li, lk);
+  }
+}
+// On return w[g] = (L^-1)[li][4 g + lk] (unit diagonal included, zeros above it) and, on the lanes with lk == (li & 3),
+// myinv = 1 / d_li.
+__device__ __forceinline__ void ldlt16s(double (&a)[4], double (&w)[4], double &myinv, int li, int lk) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) w[g] = li == 4 * g + lk ? 1.0 : 0.0;
+  myinv = 0.0;
+  asm volatile("s_nop 4" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+  ldlt16s_steps<0>(a, w, myinv, li, lk);
+}
+
+// The same factorisation with the row-group crossing taken off the dependency chain: the next two pivot columns are
+// kept replicated on all four row groups (cK: column K after the steps before K; cN: column K + 1 after the steps
+// before K); a step forms its multipliers from cK with no crossing, brings cN up to date with one more FMA, and fetches
+// column K + 2 from the split matrix for the step after next.
+template <int K>
+__device__ __forceinline__ void ldlt16p_steps(double (&a)[4], double (&w)[4], double &myinv, double cK, double cN, int li, int lk) {
+  if constexpr (K < PIV) {
+    constexpr int gK = K >> 2, qK = K & 3;
+    const double inv = fast_rcp(bc16_safe<K>(cK));
+    if (li == K && lk == qK) myinv = inv;
+    if constexpr (K < PIV - 1) {
+      const double nl = li > K ? -(cK * inv) : 0.0;
+      fma_bc_self_rows<K, 0xF>(cN, nl);             // column K + 1 after step K: the next step's pivot column
+      fma_bc_self_rows<K, (0xF << (qK + 1)) & 0xF>(a[gK], nl);
+      if constexpr (gK + 1 < 4) fma_bc_self_rows<K, 0xF>(a[gK + 1 < 4 ? gK + 1 : 3], nl);
+      if constexpr (gK + 2 < 4) fma_bc_self_rows<K, 0xF>(a[gK + 2 < 4 ? gK + 2 : 3], nl);
+      if constexpr (gK + 3 < 4) fma_bc_self_rows<K, 0xF>(a[gK + 3 < 4 ? gK + 3 : 3], nl);
+      if constexpr (gK >= 1) fma_bc_self_rows<K, 0xF>(w[0], nl);
+      if constexpr (gK >= 2) fma_bc_self_rows<K, 0xF>(w[1], nl);
+      if constexpr (gK >= 3) fma_bc_self_rows<K, 0xF>(w[2], nl);
+      fma_bc_self_rows<K, (1 << (qK + 1)) - 1>(w[gK], nl);
+      double c2 = 0.0;
+      if constexpr (K + 2 < PIV) c2 = bcast_rowgroup<(K + 2) & 3>(a[(K + 2) >> 2]);   // column K + 2 after step K
+      ldlt16p_steps<K + 1>(a, w, myinv, cN, c2, li, lk);
+    }
+  }
+}
+__device__ __forceinline__ void ldlt16p(double (&a)[4], double (&w)[4], double &myinv, int li, int lk) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) w[g] = li == 4 * g + lk ? 1.0 : 0.0;
+  myinv = 0.0;
+  double c0 = bcast_rowgroup<0>(a[0]), c1 = bcast_rowgroup<1>(a[0]);
+  asm volatile("s_nop 4" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(c0), "+v"(c1));
+  ldlt16p_steps<0>(a, w, myinv, c0, c1, li, lk);
+}
+
 #ifdef QTOS_STAMPS
 // (accumulators in LDS, not in registers: the diagnostic build must not spill where the production build does not)
 #define STAMPW(w, arr, i) do { if (tid == 64 * (w)) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); arr[i] += t_ - tl_##arr[0]; tl_##arr[0] = t_; } } while (0)

@@ -349,23 +349,24 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   };
   // wave 0: LDL^T + L^-1 + (L D L^T)^-1 of the pivot block of the panel Pn, then the pivot rows leave the panel
   double *minv_g = W.minv + (size_t)b * NS * (PIV * PIV);   // inverse of every pivot block, kept for chord steps
-  auto factor_block = [&](double *Pn, const int myps, double *Lin, double *dvn, int ks) __attribute__((always_inline)) {
-    double a[PIV], v[PIV], myinv;
+  auto factor_block = [&](double *Pn, const int myps, const int *ps, double *Lin, double *dvn, int ks) __attribute__((always_inline)) {
+    // split layout (ldlt16s): lane (li, lk) holds row li of the block, columns c = 4 g + lk.  The pivot rows of the panel
+    // carry the block's lower triangle (by pivot index): the entries above the diagonal are read from the mirrored
+    // position, so the block that is factored is exactly symmetric (ps = the stage's pivot slots in LDS)
+    double a[4], wi[4], myinv;
+    double *prow_p = Pn + myps * PLD + lk;
+    int pc[4];
 #pragma unroll
-    for (int j = 0; j < PIV; ++j) {
-      const int pj = __builtin_amdgcn_readlane(myps, j);
-      a[j] = Pn[li >= j ? myps * PLD + j : pj * PLD + li];
-    }
-    ldlt16(a, v, myinv, li);
-    if (lane >= PIV && lane < 2 * PIV) {
+    for (int g = 0; g < 4; ++g) pc[g] = ps[4 * g + lk];
 #pragma unroll
-      for (int j = 0; j < PIV; ++j) Lin[li * PLD + j] = j == li ? 1.0 : v[j];
-    }
-    if (lane < PIV) {
-      dvn[li] = myinv;
+    for (int g = 0; g < 4; ++g) a[g] = 4 * g + lk > li ? Pn[pc[g] * PLD + li] : prow_p[4 * g];
+    ldlt16s(a, wi, myinv, li, lk);
 #pragma unroll
-      for (int j = 0; j < PIV; ++j) Pn[myps * PLD + j] = 0.0;
+    for (int g = 0; g < 4; ++g) {
+      Lin[li * PLD + 4 * g + lk] = wi[g];
+      prow_p[4 * g] = 0.0;   // the pivot rows leave the panel
     }
+    if (lk == (li & 3)) dvn[li] = myinv;
     {
       double zero = 0.0;
       asm volatile("" : "+v"(zero));
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
       A[cell0(r, j)] = 0.0;
     }
     __syncthreads();
-    if (wv == 0) factor_block(P0, ps0[li], Lib, dvb, 0);
+    if (wv == 0) factor_block(P0, ps0[li], ps0, Lib, dvb, 0);
   }
   for (int s = 1; s < 3 && s < NS; ++s) {
     point_buffers(s);
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     KS2(8);
     if (wv == 0) {
       __builtin_amdgcn_s_setprio(3);
-      if (has_next) factor_block(Xn, prow_next, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV, k + 1);
+      if (has_next) factor_block(Xn, prow_next, psb + ((k + 1) % 3) * PIV, Lib + ((k + 1) & 1) * PIV * PLD, dvb + ((k + 1) & 1) * PIV, k + 1);
       __builtin_amdgcn_s_setprio(0);
     } else if (is_upd) {
       const Mask256 m2 = load_mask8(pm + (k & 1) * 8, lane);   // pivot slots of stage k+2
@@ -740,7 +741,18 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     // more of it was tried -- they share the factor wave's SIMD and are the slowest at it).  The youngest update wave of
     // every SIMD gets its matrix instructions last and ends the phase: it takes no part in the assembly.
     constexpr int NASM = 15 - (NU >= 12 ? QTOS_ASM_SKIP : 0);
-    if (wv >= 1 && k + 2 < NS && apos < NASM) assemble_stage(A, F, sbuf, dbuf, apos * 64 + lane, NASM * 64);
+#ifndef QTOS_ASM_FREEW
+#define QTOS_ASM_FREEW 1
+#endif
+    // the waves without Schur tiles (they share the factor wave's SIMD, which runs no matrix instructions in this phase)
+    // take FREEW shares each
+    constexpr int FREEW = NU == 12 ? QTOS_ASM_FREEW : 1, NFREE = 15 - NU, NVIRT = NASM + NFREE * (FREEW - 1);
+    if (wv >= 1 && k + 2 < NS && apos < NASM) {
+      if (apos < NFREE) {
+#pragma unroll
+        for (int f = 0; f < FREEW; ++f) assemble_stage(A, F, sbuf, dbuf, (apos * FREEW + f) * 64 + lane, NVIRT * 64);
+      } else assemble_stage(A, F, sbuf, dbuf, (apos + NFREE * (FREEW - 1)) * 64 + lane, NVIRT * 64);
+    }
     if constexpr (CONT) {
       if (k + 2 < NS) assemble_continuations(wv >= 1 ? apos * 64 + lane : -1, 15 * 64);
     }

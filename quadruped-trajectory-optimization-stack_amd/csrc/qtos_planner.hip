@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -40,9 +41,23 @@ struct QtosPlanner {
   hipStream_t side_stream = nullptr;  // k_chord of an iteration in which other problems of the batch factor: the two kernels run side by side
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *d_table = nullptr, *d_tab_dx = nullptr, *d_tab_dy = nullptr;   // nominal-plan table (qtos_set_init_table)
-  int *h_active = nullptr;  // pinned, one word per Newton iteration: unfinished problems after it
+  int *h_active = nullptr;  // pinned + mapped, two words per Newton iteration: unfinished problems after it, of those flagged for a chord step
+  int *h_active_dev = nullptr;   // the same memory as the device sees it (k_post_counts stores there: no copy engine between two kernels)
   std::vector<hipEvent_t> ev;  // 3 per iteration (kkt begin / end, count read back) + 2 (total)
   int last_launches = 0, last_iters = 0;
+  // the call in flight (qtos_plan_submit .. qtos_plan_poll): what was queued without knowing the counts, what has been
+  // looked at.  One call per handle at a time (`busy`).
+  struct Call {
+    bool open = false;
+    int B = 0, spec = 0, enq = 0, chk = 0;   // iterations queued blind / queued in all / whose preceding counts have been read
+    hipStream_t st = nullptr;
+    DevWork W;
+    double *nodes_out = nullptr, *viol_out = nullptr;
+    int *status_out = nullptr, *iters_out = nullptr;
+  } call;
+  int spec_next = 1;                 // blind iterations of the next call: the iterations the last one took
+  int spec_cap = 1;                  // limit of the blind iterations (qtos_set_speculation): 1 = off, the measured optimum
+  std::atomic<int> busy{0};
   size_t kkt_lds = 0, eval_lds = 0;
   void (*chord_fn)(DevPlan, DevWork, int) = nullptr; // k_chord instantiated for this front size (null: chord steps off)
   std::vector<char> was_kkt, was_chord;              // per iteration of the last call: which solve kernels were launched
@@ -304,6 +319,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.mu, Bm)); TRY(p->alloc(&W.viol, Bm));
   TRY(p->alloc(&W.best_viol, Bm)); TRY(p->alloc(&W.best_it, Bm)); TRY(p->alloc(&W.xbest, Bm * n));
   TRY(p->alloc(&W.held, Bm));
+#ifdef QTOS_STAMPS
+  if (M.P.max_iter < 79) { p->err = "diagnostic build (QTOS_STAMPS) parks its stamps in trace rows 16..79: create the planner with max_iter >= 79"; fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -1; }
+#endif
   TRY(p->alloc(&W.trace, Bm * (size_t)(M.P.max_iter + 1) * 4));
   TRY(p->alloc(&W.status, Bm)); TRY(p->alloc(&W.iters, Bm)); TRY(p->alloc(&W.done, Bm));
   TRY(p->alloc(&W.n_active, 2));
@@ -312,13 +330,15 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.minv, Bm * (size_t)S.n_stages * PIV * PIV));
   TRY(p->alloc(&p->d_start, Bm * QTOS_START_DOUBLES)); TRY(p->alloc(&p->d_goal, Bm * 3));
   TRY(p->alloc(&p->d_nodes, Bm * n)); TRY(p->alloc(&p->d_warm, Bm * n)); TRY(p->alloc(&p->d_map, Bm));
-  if (hipHostMalloc((void **)&p->h_active, 2 * sizeof(int) * ((size_t)M.P.max_iter + 1)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
+  if (hipHostMalloc((void **)&p->h_active, 2 * sizeof(int) * ((size_t)M.P.max_iter + 1), hipHostMallocMapped) != hipSuccess) { qtos_planner_destroy(p); return -3; }
+  if (hipHostGetDevicePointer((void **)&p->h_active_dev, p->h_active, 0) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   p->was_kkt.assign(M.P.max_iter + 1, 0);
   p->was_chord.assign(M.P.max_iter + 1, 0);
   if (hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   if (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   if (hipMalloc(&p->d_totals, 2 * sizeof(long long)) != hipSuccess || hipMemset(p->d_totals, 0, 2 * sizeof(long long)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
   p->last_stream = p->own_stream;
+  if (const char *e = getenv("QTOS_SPEC_CAP")) p->spec_cap = std::max(0, atoi(e));   // (diagnostic: limit of the blind iterations)
   if (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   p->ev.resize(5 * (size_t)M.P.max_iter + 3);
   for (auto &e : p->ev)
@@ -394,7 +414,9 @@ int qtos_set_heightfields(QtosPlanner *p, int n_maps, const double *height, int 
 // results of a batch to the caller's buffers (one launch instead of four copies) and the running totals of
 // qtos_plan_totals
 __global__ void k_export(const double *x, const int *status, const int *iters, const double *viol, int n, double *nodes_out,
-                         int *status_out, int *iters_out, double *viol_out, long long *tot) {
+                         int *status_out, int *iters_out, double *viol_out, long long *tot, const int *only_if_zero) {
+  // (queued behind iterations that were launched without knowing whether they would be the last: it runs only if they were)
+  if (only_if_zero && *only_if_zero != 0) return;
   const int b = blockIdx.x;
   const d2_t *src = (const d2_t *)(x + (size_t)b * n);
   d2_t *dst = (d2_t *)(nodes_out + (size_t)b * n);
@@ -413,78 +435,168 @@ __global__ void k_export(const double *x, const int *status, const int *iters, c
   }
 }
 
+// The counts of unfinished problems to the host: a store into mapped pinned memory by a one-wave kernel.  (A copy
+// (hipMemcpyAsync) between two kernels of a stream makes the compute queue wait on the copy engine's signal; with more
+// streams than hardware queues that wait holds up the other streams of the queue too: four sets of receding windows
+// then ran one after the other.)
+__global__ void k_post_counts(const int *n_active, int *host_slot) {
+  if (threadIdx.x < 2) host_slot[threadIdx.x] = n_active[threadIdx.x];
+  __threadfence_system();
+}
+
+// One Newton iteration of the call in flight, queued on its stream.  informed: the counts of unfinished problems (n) and of
+// problems flagged for a chord step (nc) before this iteration are known -- only the kernels with work are launched, and
+// next to a factorisation of other problems the chord solve runs on the side stream (the workgroups of k_kkt2 that belong
+// to its problems leave at once and k_chord gets their CUs: the batch pays max(k_kkt2, k_chord), not the sum).  Blind
+// (queued before the counts of the preceding iteration have come back): both solve kernels are launched, each leaves at
+// once for the problems that are not its own (a launch whose workgroups all leave costs a few microseconds).
+static int queue_iteration(QtosPlanner *p, int it, bool informed, int n, int nc) {
+  QtosPlanner::Call &c = p->call;
+  const DevPlan &D = p->dp;
+  hipStream_t st = c.st;
+  const bool do_kkt = informed ? n - nc > 0 : true;
+  const bool do_chord = p->chord_fn && (informed ? nc > 0 : it >= 1);
+  p->was_kkt[it] = do_kkt;       // (blind iterations: corrected once their counts are known)
+  p->was_chord[it] = do_chord;
+  const bool fork = do_kkt && do_chord;
+  hipStream_t cs = fork ? p->side_stream : st;
+  if (fork) {
+    HIPCHK(p, hipEventRecord(p->ev_fork, st));            // everything up to the previous k_step
+    HIPCHK(p, hipStreamWaitEvent(cs, p->ev_fork, 0));
+  }
+  if (do_kkt) {
+    HIPCHK(p, hipEventRecord(p->ev[2 + 5 * it], st));
+    hipLaunchKernelGGL(p->kkt_fn, dim3(c.B), dim3(p->kkt_threads), p->kkt_lds, st, D, c.W, c.B);
+    HIPCHK(p, hipEventRecord(p->ev[3 + 5 * it], st));
+  }
+  if (do_chord) {
+    HIPCHK(p, hipEventRecord(p->ev[4 + 5 * it], cs));
+    hipLaunchKernelGGL(p->chord_fn, dim3(c.B), dim3(KTC), chord_lds_bytes(p->S.n_stages), cs, D, c.W, c.B);
+    HIPCHK(p, hipEventRecord(p->ev[5 + 5 * it], cs));
+  }
+  if (fork) {
+    HIPCHK(p, hipEventRecord(p->ev_join, cs));
+    HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
+  }
+  hipLaunchKernelGGL(k_step, dim3(c.B), dim3(ET), p->eval_lds, st, D, c.W, c.B, it);
+  hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * it);
+  HIPCHK(p, hipEventRecord(p->ev[6 + 5 * it], st));
+  return 0;
+}
+
+static int queue_export(QtosPlanner *p, bool conditional) {
+  QtosPlanner::Call &c = p->call;
+  hipLaunchKernelGGL(k_export, dim3(c.B), dim3(256), 0, c.st, c.W.x, c.W.status, c.W.iters, c.W.viol, p->dp.n_vars, c.nodes_out,
+                     c.status_out, c.iters_out, c.viol_out, p->d_totals, conditional ? c.W.n_active : nullptr);
+  HIPCHK(p, hipGetLastError());
+  return 0;
+}
+
+int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
+                     const int *d_map_id, const double *d_warm, double *d_nodes_out,
+                     int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream_) {
+  if (!p || B < 1 || B > p->max_batch || !d_start || !d_goal || !d_nodes_out) return -1;
+  int expected = 0;
+  if (!p->busy.compare_exchange_strong(expected, 1)) { p->err = "the planner handle already serves a call (one call per handle at a time)"; return -5; }
+  QtosPlanner::Call &c = p->call;
+  auto fail = [&](int rc) { c.open = false; p->busy.store(0); return rc; };
+  hipStream_t st = (hipStream_t)stream_;
+  if (hipSetDevice(p->device) != hipSuccess) return fail(-2);
+  c = QtosPlanner::Call();
+  c.open = true; c.B = B; c.st = st;
+  c.W = p->wk;
+  c.W.start = d_start; c.W.goal = d_goal; c.W.map_id = d_map_id; c.W.warm = d_warm;
+  c.nodes_out = d_nodes_out; c.status_out = d_status_out; c.iters_out = d_iters_out; c.viol_out = d_viol_out;
+  const DevPlan &D = p->dp;
+#define SUBCHK(call_) do { hipError_t e_ = (call_); if (e_ != hipSuccess) { p->err = std::string(#call_) + ": " + hipGetErrorString(e_); return fail(e_ == hipErrorOutOfMemory ? -3 : -2); } } while (0)
+  SUBCHK(hipMemsetAsync(c.W.n_active, 0, 2 * sizeof(int), st));
+  SUBCHK(hipEventRecord(p->ev[0], st));
+  hipLaunchKernelGGL(k_start, dim3(B), dim3(ET), p->eval_lds, st, D, c.W, B);
+  // counts after k_start (slot max_iter of the pinned array), event ev_start
+  const int ev_start = 2 + 5 * D.max_iter;
+  hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * D.max_iter);
+  SUBCHK(hipEventRecord(p->ev[ev_start], st));
+#undef SUBCHK
+  // Blind iterations: as many as the previous call of this handle needed (its slowest problem), queued without a host
+  // round trip; the results leave through an export that runs only if they were enough.  A batch that needs more is
+  // continued by qtos_plan_poll from the counts the iterations send back.
+  c.spec = std::max(0, std::min(std::min(p->spec_next, p->spec_cap), D.max_iter));
+  for (int it = 0; it < c.spec; ++it)
+    if (int rc = queue_iteration(p, it, false, 0, 0)) return fail(rc);
+  c.enq = c.spec;
+  if (c.spec > 0)
+    if (int rc = queue_export(p, true)) return fail(rc);
+  if (hipEventRecord(p->ev[1], st) != hipSuccess) return fail(-2);
+  p->last_stream = st;
+  return 0;
+}
+
+int qtos_plan_poll(QtosPlanner *p, int *done) {
+  if (!p || !done) return -1;
+  QtosPlanner::Call &c = p->call;
+  *done = 0;
+  if (!c.open) { *done = 1; return 0; }
+  const DevPlan &D = p->dp;
+  bool device_set = false;     // (only in front of launches: hipSetDevice in a spin loop of several host threads is a lock fight)
+  const int ev_start = 2 + 5 * D.max_iter;
+  for (;;) {
+    // counts in front of iteration c.chk (behind k_start / iteration c.chk - 1)
+    const hipError_t q = hipEventQuery(p->ev[c.chk == 0 ? ev_start : 6 + 5 * (c.chk - 1)]);
+    if (q == hipErrorNotReady) return 0;
+    if (q != hipSuccess) { p->err = std::string("hipEventQuery: ") + hipGetErrorString(q); c.open = false; p->busy.store(0); return -2; }
+    const int *h = p->h_active + 2 * (c.chk == 0 ? D.max_iter : c.chk - 1);
+    const int n = h[0], nc = h[1];
+    if (n <= 0 || c.chk >= D.max_iter) {
+      // finished in front of iteration c.chk.  The blind export ran iff the blind iterations were enough.
+      const int iters = c.chk;
+      for (int j = iters; j < c.enq; ++j) { p->was_kkt[j] = 0; p->was_chord[j] = 0; }   // blind launches behind the end: no work
+      const bool blind_export_ran = c.spec > 0 && (iters < c.spec || (iters == c.spec && n <= 0));
+      if (!blind_export_ran) {
+        if (!device_set) { HIPCHK(p, hipSetDevice(p->device)); device_set = true; }
+        if (int rc = queue_export(p, false)) { c.open = false; p->busy.store(0); return rc; }
+        HIPCHK(p, hipEventRecord(p->ev[1], c.st));
+      }
+      p->last_launches = iters;
+      p->last_iters = iters;
+      p->spec_next = std::max(1, iters);
+      c.open = false;
+      p->busy.store(0);
+      *done = 1;
+      return 0;
+    }
+    if (c.chk < c.spec) {
+      // a blind iteration that did run: which of its two solve kernels had work
+      p->was_kkt[c.chk] = n - nc > 0;
+      p->was_chord[c.chk] = nc > 0 && p->chord_fn && c.chk >= 1;
+    }
+    if (c.chk == c.enq) {
+      if (!device_set) { HIPCHK(p, hipSetDevice(p->device)); device_set = true; }
+      if (int rc = queue_iteration(p, c.chk, true, n, nc)) { c.open = false; p->busy.store(0); return rc; }
+      c.enq++;
+      HIPCHK(p, hipEventRecord(p->ev[1], c.st));
+    }
+    c.chk++;
+  }
+}
+
+int qtos_plan_wait(QtosPlanner *p) {
+  if (!p) return -1;
+  int done = 0;
+  while (!done)
+    if (int rc = qtos_plan_poll(p, &done)) return rc;
+  return 0;
+}
+
 int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
                            const int *d_map_id, const double *d_warm, double *d_nodes_out,
                            int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream_) {
-  if (!p || B < 1 || B > p->max_batch || !d_start || !d_goal || !d_nodes_out) return -1;
-  hipStream_t st = (hipStream_t)stream_;
-  HIPCHK(p, hipSetDevice(p->device));
-  DevWork W = p->wk;
-  W.start = d_start; W.goal = d_goal; W.map_id = d_map_id; W.warm = d_warm;
-  const DevPlan &D = p->dp;
-  HIPCHK(p, hipMemsetAsync(W.n_active, 0, sizeof(int), st));
-  HIPCHK(p, hipEventRecord(p->ev[0], st));
-  hipLaunchKernelGGL(k_start, dim3(B), dim3(ET), p->eval_lds, st, D, W, B);
-  // Newton iterations: the count of unfinished problems is read back before every iteration is queued (a
-  // spin on the event instead of a blocking wait: the wake-up latency would be paid once per iteration), so
-  // every k_kkt / k_step launch does work -- no empty launches in the timing or in a profiler's averages --
-  // and no state is kept between calls.  The device idles ~10 us per iteration while the word travels.
-  // (events per iteration: k_kkt begin / end, k_chord begin / end, read-back)
-  const int ev_start = 2 + 5 * D.max_iter;   // event behind the read-back of k_start's counts
-  auto count_after = [&](int it, int *n, int *nc) -> int {   // it = -1: after k_start
-    hipError_t q;
-    while ((q = hipEventQuery(p->ev[it < 0 ? ev_start : 6 + 5 * it])) == hipErrorNotReady) {}
-    if (q != hipSuccess) { p->err = std::string("hipEventQuery: ") + hipGetErrorString(q); return -2; }
-    const int *h = p->h_active + 2 * (it < 0 ? D.max_iter : it);
-    *n = h[0];
-    *nc = h[1];
-    return 0;
-  };
-  HIPCHK(p, hipMemsetAsync(W.n_active + 1, 0, sizeof(int), st));   // (the unfinished count was cleared above, before k_start)
-  HIPCHK(p, hipMemcpyAsync(p->h_active + 2 * D.max_iter, W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK(p, hipEventRecord(p->ev[ev_start], st));
-  int iters = D.max_iter;
-  for (int it = 0; it < D.max_iter; ++it) {
-    int n = 0, nc = 0;
-    if (int rc = count_after(it - 1, &n, &nc)) return rc;
-    if (n <= 0) { iters = it; break; }
-    // problems flagged by k_step reuse the stored factorisation (k_chord), the others factor (k_kkt2)
-    p->was_kkt[it] = n - nc > 0;
-    p->was_chord[it] = nc > 0 && p->chord_fn;
-    // Next to a factorisation of other problems the chord solve runs on the side stream: the workgroups of k_kkt2
-    // that belong to its problems leave at once and k_chord gets their CUs, so a batch whose problems are at
-    // different points of their solves pays max(k_kkt2, k_chord) per iteration, not the sum.
-    const bool fork = p->was_kkt[it] && p->was_chord[it];
-    hipStream_t cs = fork ? p->side_stream : st;
-    if (fork) {
-      HIPCHK(p, hipEventRecord(p->ev_fork, st));            // everything up to the previous k_step
-      HIPCHK(p, hipStreamWaitEvent(cs, p->ev_fork, 0));
-    }
-    if (p->was_kkt[it]) {
-      HIPCHK(p, hipEventRecord(p->ev[2 + 5 * it], st));
-      hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(p->kkt_threads), p->kkt_lds, st, D, W, B);
-      HIPCHK(p, hipEventRecord(p->ev[3 + 5 * it], st));
-    }
-    if (p->was_chord[it]) {
-      HIPCHK(p, hipEventRecord(p->ev[4 + 5 * it], cs));
-      hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), chord_lds_bytes(p->S.n_stages), cs, D, W, B);
-      HIPCHK(p, hipEventRecord(p->ev[5 + 5 * it], cs));
-    }
-    if (fork) {
-      HIPCHK(p, hipEventRecord(p->ev_join, cs));
-      HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
-    }
-    hipLaunchKernelGGL(k_step, dim3(B), dim3(ET), p->eval_lds, st, D, W, B, it);
-    HIPCHK(p, hipMemcpyAsync(p->h_active + 2 * it, W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(p, hipEventRecord(p->ev[6 + 5 * it], st));
-  }
-  hipLaunchKernelGGL(k_export, dim3(B), dim3(256), 0, st, W.x, W.status, W.iters, W.viol, D.n_vars, d_nodes_out, d_status_out, d_iters_out,
-                     d_viol_out, p->d_totals);
-  p->last_stream = st;
-  HIPCHK(p, hipEventRecord(p->ev[1], st));
-  p->last_launches = iters;   // iterations whose solve kernels qtos_last_timing sums
-  p->last_iters = iters;
-  HIPCHK(p, hipGetLastError());
+  if (int rc = qtos_plan_submit(p, B, d_start, d_goal, d_map_id, d_warm, d_nodes_out, d_status_out, d_iters_out, d_viol_out, stream_)) return rc;
+  return qtos_plan_wait(p);
+}
+
+int qtos_set_speculation(QtosPlanner *p, int max_blind_iterations) {
+  if (!p || max_blind_iterations < 0) return -1;
+  p->spec_cap = max_blind_iterations;
   return 0;
 }
 
@@ -492,9 +604,12 @@ int qtos_plan_totals(QtosPlanner *p, long long *converged, long long *iterations
   if (!p) return -1;
   HIPCHK(p, hipSetDevice(p->device));
   long long h[2] = {0, 0};
-  HIPCHK(p, hipMemcpyAsync(h, p->d_totals, sizeof(h), hipMemcpyDeviceToHost, p->last_stream));
-  if (reset) HIPCHK(p, hipMemsetAsync(p->d_totals, 0, sizeof(h), p->last_stream));
-  HIPCHK(p, hipStreamSynchronize(p->last_stream));
+  // on the planner's own stream, behind the end event of the last call (the caller's stream may be gone by now)
+  if (p->call.open) HIPCHK(p, qtos_plan_wait(p) ? hipErrorUnknown : hipSuccess);
+  HIPCHK(p, hipStreamWaitEvent(p->own_stream, p->ev[1], 0));
+  HIPCHK(p, hipMemcpyAsync(h, p->d_totals, sizeof(h), hipMemcpyDeviceToHost, p->own_stream));
+  if (reset) HIPCHK(p, hipMemsetAsync(p->d_totals, 0, sizeof(h), p->own_stream));
+  HIPCHK(p, hipStreamSynchronize(p->own_stream));
   if (converged) *converged = h[0];
   if (iterations) *iterations = h[1];
   return 0;

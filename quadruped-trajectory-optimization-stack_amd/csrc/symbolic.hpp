@@ -405,6 +405,12 @@ struct Symbolic {
       }
     }
     n_stages = (n_unknowns + PIV - 1) / PIV;
+    if (const char *dump = getenv("QTOS_DUMP_FIRST")) {   // diagnostic: envelope of the ordered matrix (position -> first coupled position, unknown id)
+      if (FILE *f = fopen(dump, "w")) {
+        for (int j = 0; j < n_unknowns; ++j) fprintf(f, "%d %d %d\n", j, first[j], order[j]);
+        fclose(f);
+      }
+    }
     // slot allocation
     var_slot.assign(n, -1);
     row_slot.assign(m, -1);

@@ -30,14 +30,26 @@ def gather_plans(nodes_local, status_local, n_total, group=None, work=None):
     """All-gather the per-rank shards (torch tensors, same device) into full (n_total, n_vars) /
     (n_total,) tensors on every rank with ONE collective: the status word of a plan travels as an
     extra column of its node row (small integers are exact in float64), shards are padded to equal
-    length (pad rows carry status -1).  work = gather_buffers(...): reused buffers (the result is a view of them)."""
+    length (pad rows carry status -1).  work = gather_buffers(...): reused buffers -- the returned tensors are then
+    VIEWS of them and the next call overwrites them (clone what must outlive it)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     per = -(-n_total // world)
     n_vars = nodes_local.shape[1]
     n_loc = nodes_local.shape[0]
+    if n_loc > per:
+        raise ValueError("gather_plans: local shard of %d plans exceeds ceil(%d / %d) = %d" % (n_loc, n_total, world, per))
     packed, gathered = work if work is not None else gather_buffers(n_total, n_vars, world, nodes_local.dtype, nodes_local.device)
+    if work is not None:
+        # reused buffers: they must fit THIS batch (a handle reused with another batch size would ship stale rows)
+        if (tuple(packed.shape) != (per, n_vars + 1) or tuple(gathered.shape) != (world * per, n_vars + 1)
+                or packed.dtype != nodes_local.dtype or gathered.dtype != nodes_local.dtype
+                or packed.device != nodes_local.device or gathered.device != nodes_local.device):
+            raise ValueError("gather_plans: work buffers do not match the batch (want %s / %s %s on %s)" %
+                             ((per, n_vars + 1), (world * per, n_vars + 1), nodes_local.dtype, nodes_local.device))
+        if n_loc < per:
+            packed[n_loc:, n_vars] = -1.0   # pad rows of a ragged shard: never a stale status 0
     packed[:n_loc, :n_vars] = nodes_local
     packed[:n_loc, n_vars] = status_local.to(nodes_local.dtype)
     dist.all_gather_into_tensor(gathered, packed, group=group)

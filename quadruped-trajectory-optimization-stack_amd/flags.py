@@ -17,6 +17,7 @@ reported back in ``LocalPlanner.last["r"]``; it does not enter the NLP.  tests/t
 strings; tests/test_gpu_parity.py::test_r_flag_does_not_change_the_plans checks statuses and plans with
 and without it.
 """
+import numpy as np
 
 FLAGS = ['-g', '-s', '-s_ang', '-s_vel', '-e1', '-e2', '-e3', '-e4', '-t', '-r', '-resolution',
          's_vel', 's_ang_vel', '-duration']
@@ -66,8 +67,10 @@ def problem_arrays(args):
     if hasattr(t0, "__len__"):
         t0 = t0[0]
     r = args.get('-r')
-    if r is not None and r != "" and not (hasattr(r, "__len__") and len(r) == 0):
-        rv = float(r[0] if hasattr(r, "__len__") else r)
+    if r is not None and not (isinstance(r, str) and r == ""):
+        r = np.ravel(np.asarray(r, dtype=float))     # scalar, list or numpy value alike
+    if r is not None and len(r) > 0:
+        rv = float(r[0])
         if not (rv > 0.0 and rv < float("inf")):
             raise ValueError("-r must be a positive finite number (see flags.py), got %r" % (r,))
     return start, goal, float(t0)

@@ -80,6 +80,9 @@ class LocalPlanner:
         order = {}
         for i, dv in enumerate(durs):
             order.setdefault(round(dv, 9), []).append(i)
+        if warm is not None and len(order) > 1 and not isinstance(warm, (list, tuple)):
+            # a warm row has the length of ITS horizon's variable vector: one array cannot serve two horizons
+            raise ValueError("solve_batch: `warm` with mixed -duration values must be a list with one node vector per problem")
         statuses = [None] * n
         nodes_o, rows_o, iters_o, viol_o, t0_o = [None] * n, [None] * n, [None] * n, [None] * n, [None] * n
         for key, idx in order.items():
@@ -96,7 +99,7 @@ class LocalPlanner:
                 nodes, status, iters, viol = P.plan(
                     np.array(starts[sl]), np.array(goals[sl]),
                     None if map_id is None else np.asarray(map_id)[ii],
-                    None if warm is None else np.asarray(warm)[ii])
+                    None if warm is None else np.stack([np.asarray(warm[i], float) for i in ii]))
                 rows = P.sample(nodes, np.array(t0s[sl]), self.cfg.hz) if sample else None
                 for j, i in enumerate(ii):
                     statuses[i] = int(status[j])

@@ -162,16 +162,44 @@ class ShiftedWindows:
         self.warm_mode = warm      # "none": towr's straight-line guess (default); "shifted": the time-shifted previous plan
         self.solved = torch.zeros((), dtype=torch.int64, device=dev)
         self.iter_sum = torch.zeros((), dtype=torch.int64, device=dev)
+        # the tensors above were filled on the caller's current stream; replan() works on self.stream (a non-blocking
+        # torch.cuda.Stream is not ordered behind the default stream): finish that work here, once.  (A host wait, not
+        # stream.wait_stream: a set's stream that has once waited on the default stream no longer ran side by side with the
+        # other sets' streams on this runtime -- four sets took 28 ms per replan instead of 17.)
+        torch.cuda.current_stream(dev).synchronize()
 
     def _call(self, rc, what):
         if rc != 0:
             raise RuntimeError("%s failed: %d %s" % (what, rc, self.P.lib.qtos_last_error(self.P.h)))
 
     def replan(self):
-        with self.torch.cuda.stream(self.stream):     # (several window sets may run side by side, each on its own stream)
-            return self._replan()
+        """One replan of every window: begin() + poll() until the call is queued to its end (results: synchronise the stream)."""
+        self.begin()
+        self.P.wait()          # (inside the library: the GIL is released, other sets' host threads are not held up)
+        self.poll()
+        return self.nodes, self.status
 
-    def _replan(self):
+    def begin(self):
+        """Queue the next replan (hand-over rows, new start / goal vectors, the whole solve) on the set's stream and return
+        at once: several sets of windows are kept in flight by ONE host thread that begins / polls them in turn."""
+        with self.torch.cuda.stream(self.stream):     # (several window sets may run side by side, each on its own stream)
+            self._begin()
+        self._pending = True
+
+    def poll(self):
+        """True once the replan begun last has been queued to its end (qtos_plan_poll); tallies its results on the stream."""
+        if not getattr(self, "_pending", False):
+            return True
+        if not self.P.poll():
+            return False
+        with self.torch.cuda.stream(self.stream):
+            self.solved.add_((self.status == 0).sum())
+            self.iter_sum.add_(self.iters.sum())
+        self.have_plan = True
+        self._pending = False
+        return True
+
+    def _begin(self):
         import ctypes as C
         torch, P, B = self.torch, self.P, self.B
         sp = C.c_void_p(self.stream.cuda_stream)
@@ -217,11 +245,7 @@ class ShiftedWindows:
                     elif mix == "base+feet":
                         self.warm[:, self._force_off:] = guess[:, self._force_off:]
                 warm_ptr = self.warm.data_ptr()
-        self._call(P.lib.qtos_plan_batch_device(P.h, B, self.start.data_ptr(), self.goal.data_ptr(),
-                                                None if self.map_id is None else self.map_id.data_ptr(), warm_ptr,
-                                                self.nodes.data_ptr(), self.status.data_ptr(), self.iters.data_ptr(),
-                                                self.viol.data_ptr(), sp), "qtos_plan_batch_device")
-        self.solved.add_((self.status == 0).sum())
-        self.iter_sum.add_(self.iters.sum())
-        self.have_plan = True
-        return self.nodes, self.status
+        self._call(P.lib.qtos_plan_submit(P.h, B, self.start.data_ptr(), self.goal.data_ptr(),
+                                          None if self.map_id is None else self.map_id.data_ptr(), warm_ptr,
+                                          self.nodes.data_ptr(), self.status.data_ptr(), self.iters.data_ptr(),
+                                          self.viol.data_ptr(), sp), "qtos_plan_submit")

@@ -1,7 +1,7 @@
 """One-off stress check: GPU vs oracle over whole batches (iterations and nodes)."""
 import sys, time; sys.path.insert(0, '.')
 import numpy as np
-from oracle.oracle import Oracle
+from oracle.oracle import Oracle, oracle_dict
 from qtos_amd import capi, workloads
 from qtos_amd.config import PlannerConfig
 def sweep(tag, cfg, start, goal, maps=None, cell=None, mid=None, n=96):
@@ -15,7 +15,7 @@ def sweep(tag, cfg, start, goal, maps=None, cell=None, mid=None, n=96):
         m = 0 if mid is None else int(mid[b])
         if m not in orc:
             h = None if maps is None else (maps if maps.ndim == 2 else maps[m])
-            orc[m] = Oracle(cfg.oracle_dict(), height=h, hcell=cell if cell else 0.1)
+            orc[m] = Oracle(oracle_dict(cfg), height=h, hcell=cell if cell else 0.1)
         O = orc[m]; s = start[b]
         xo, info = O.solve(O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), goal[b], s[18:21], s[21:24]))
         if info.status == 0 and status[b] == 0: both_ok += 1

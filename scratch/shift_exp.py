@@ -5,12 +5,12 @@ from qtos_amd import workloads
 from qtos_amd.capi import Planner
 from qtos_amd.config import PlannerConfig
 from qtos_amd.replan import ShiftedWindows
-from oracle.oracle import Oracle
+from oracle.oracle import Oracle, oracle_dict
 B = 64
 maps, cell = workloads.random_terrains()
 start, goal, map_id = workloads.mpc_goals(B, seed=5, terrains=(maps, cell))
 for tname, mk in (("knots200", PlannerConfig.knots200), ("knots100", PlannerConfig.knots100)):
-  foff = Oracle(mk().oracle_dict()).L.off_eef[0]
+  foff = Oracle(oracle_dict(mk())).L.off_eef[0]
   for push in (0.01, 0.05, 0.2):
     cfg = mk(warm_slack_push=push)
     P = Planner(cfg, max_batch=B); P.set_heightfields(maps, cell)

@@ -15,7 +15,16 @@ __global__ void k(const double *Bin, double *out, unsigned long long *cyc, int r
   if (tid < 64 * nwaves) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int r = 0; r < reps; ++r) {
-      {
+      if constexpr (VAR >= 1) {
+        const int li = tid & 15, lane = tid & 63, lk = lane >> 4;
+        double a[4], w[4], myinv;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a[g] = Bs[li * PLD + 4 * g + lk];
+        if constexpr (VAR == 1) ldlt16s(a, w, myinv, li, lk); else ldlt16p(a, w, myinv, li, lk);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { Lm[li * PLD + 4 * g + lk] = a[g]; Li[li * PLD + 4 * g + lk] = w[g]; }
+        if (lk == (li & 3)) dv[li] = myinv;
+      } else {
         const int li = tid & 15, lane = tid & 63;
         double a[PIV], v[PIV], myinv;
 #pragma unroll
@@ -48,8 +57,12 @@ int main() {
   double *dB, *dO; unsigned long long *dC;
   hipMalloc(&dB, 256 * 8); hipMalloc(&dO, 1024 * 8); hipMalloc(&dC, 8);
   hipMemcpy(dB, B.data(), 256 * 8, hipMemcpyHostToDevice);
+  for (int var = 0; var < 3; ++var)
   for (int nw = 1; nw <= 2; ++nw) {
-    hipLaunchKernelGGL(k<0>, dim3(1), dim3(128), 0, 0, dB, dO, dC, 200, nw);
+    hipMemset(dO, 0, 1024 * 8);
+    if (var == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(128), 0, 0, dB, dO, dC, 200, nw);
+    if (var == 1) hipLaunchKernelGGL(k<1>, dim3(1), dim3(128), 0, 0, dB, dO, dC, 200, nw);
+    if (var == 2) hipLaunchKernelGGL(k<2>, dim3(1), dim3(128), 0, 0, dB, dO, dC, 200, nw);
     hipDeviceSynchronize();
     unsigned long long c; hipMemcpy(&c, dC, 8, hipMemcpyDeviceToHost);
     std::vector<double> O(1024); hipMemcpy(O.data(), dO, 1024 * 8, hipMemcpyDeviceToHost);
@@ -62,7 +75,7 @@ int main() {
       e1 = fmax(e1, fabs(s - want));
       if (j > i) e2 = fmax(e2, fabs(O[256 + i * 16 + j]));
     }
-    printf("waves %d: %llu cycles per ldlt16 (err LDLt %.2e, Linv %.2e)\n", nw, c, e1, e2);
+    printf("variant %d waves %d: %llu cycles per ldlt16 (err LDLt %.2e, Linv %.2e)\n", var, nw, c, e1, e2);
   }
   return 0;
 }

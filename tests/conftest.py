@@ -33,8 +33,8 @@ def cfg():
 
 @pytest.fixture(scope="session")
 def oracle(cfg):
-    from oracle.oracle import Oracle
-    return Oracle(cfg.oracle_dict())
+    from oracle.oracle import Oracle, oracle_dict
+    return Oracle(oracle_dict(cfg))
 
 
 @pytest.fixture(scope="session")

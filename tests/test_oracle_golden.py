@@ -103,15 +103,15 @@ def test_jacobian_against_finite_differences(oracle, gv1):
 
 
 def test_terrain_bilinear_and_jacobian():
-    from oracle.oracle import Oracle
+    from oracle.oracle import Oracle, oracle_dict
     from qtos_amd import heightfield, workloads
     from qtos_amd.config import PlannerConfig
     cfg = PlannerConfig.reference_compat(terrain_mode=0)
     hxy, cell = workloads.exp5_terrain()
-    On = Oracle(PlannerConfig.reference_compat(terrain_mode=1).oracle_dict(), height=hxy, hcell=cell)
+    On = Oracle(oracle_dict(PlannerConfig.reference_compat(terrain_mode=1)), height=hxy, hcell=cell)
     assert On.terrain_height(0.33, 0.0) == 0.025 and On.terrain_height(0.1, 0.0) == 0.0  # flat ledges
     assert abs(On.terrain_height(0.33, 0.0) - float(heightfield.height_at(hxy, cell, 0.33, 0.0, mode=1))) == 0
-    O = Oracle(cfg.oracle_dict(), height=hxy, hcell=cell)
+    O = Oracle(oracle_dict(cfg), height=hxy, hcell=cell)
     rng = np.random.default_rng(0)
     for _ in range(50):
         x, y = rng.uniform(-1.2, 3.2), rng.uniform(-1.2, 1.2)
@@ -223,13 +223,13 @@ def test_oracle_stall_rule_stops_cycling_problems():
     (Footholds left free for the whole solve, hold_from = 0: with the default two-phase solve the
     foot is held after the second iteration and the same problem converges.  Chord steps off: the rule
     under test is about the cycling iterates of the plain Newton sequence.)"""
-    from oracle.oracle import Oracle
+    from oracle.oracle import Oracle, oracle_dict
     from qtos_amd import workloads
     from qtos_amd.config import PlannerConfig
     c = PlannerConfig.reference_compat()
     hxy, cell = workloads.exp5_terrain()
     start, goal = workloads.step_goals(256, seed=1, terrain=(hxy, cell))
-    O = Oracle(c.oracle_dict(), height=hxy, hcell=cell)
+    O = Oracle(oracle_dict(c), height=hxy, hcell=cell)
     s, g = start[31], goal[31]
     q = O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g, (0, 0, 0), (0, 0, 0), 0.0)
     xh, ih = O.solve(q)
@@ -251,7 +251,7 @@ def test_oracle_stall_rule_stops_cycling_problems():
 def test_oracle_knots200_on_random_heightfield():
     """BASELINE configs[4] transcription in the oracle: cold solve, then the warm-started replan from the
     row 20 ms into the plan converges in fewer iterations to a nearby plan."""
-    from oracle.oracle import Oracle
+    from oracle.oracle import Oracle, oracle_dict
     from qtos_amd import workloads
     from qtos_amd.config import PlannerConfig
     cfg = PlannerConfig.knots200()
@@ -259,7 +259,7 @@ def test_oracle_knots200_on_random_heightfield():
     assert maps.shape[0] == 8 and maps.min() == 0.0 and 0.1 < maps.max() < 0.2
     assert np.abs(maps[:, :140]).max() == 0.0 and np.ptp(maps, axis=0).max() > 0.01   # level start area, maps differ
     start, goal, mid = workloads.mpc_goals(2, terrains=(maps, cell))
-    O = Oracle(cfg.oracle_dict(), height=maps[mid[0]], hcell=cell)
+    O = Oracle(oracle_dict(cfg), height=maps[mid[0]], hcell=cell)
     assert (O.n, O.m) == (3160, 4558)
     s = start[0]
     x, info = O.solve(O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), goal[0]))

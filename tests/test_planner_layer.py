@@ -54,10 +54,10 @@ def _gait_rows():
 def test_stitcher_indices_match_reference():
     """Row selection of Combiner._state and the splice of Combiner.combine."""
     from qtos_amd.stitcher import Stitcher
-    from oracle.oracle import Oracle
+    from oracle.oracle import Oracle, oracle_dict
     from qtos_amd.config import PlannerConfig
     gv = load_gv("gv1")
-    O = Oracle(PlannerConfig.reference_compat().oracle_dict())
+    O = Oracle(oracle_dict(PlannerConfig.reference_compat()))
     rows = O.sample(gv["x"], 0.0)                    # the full 1 kHz plan (matches gait.csv to 1e-6)
     rows = np.array([[float("%g" % v) for v in r] for r in rows])   # as printed in the CSV
     for case in FIX["stitch"]:
