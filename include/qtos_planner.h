@@ -206,6 +206,11 @@ int qtos_debug_newton(QtosPlanner *p, int B, const double *start, const double *
 /* the same system once more through the chord-step kernel: the factorisation the preceding qtos_debug_newton
  * call left on the device + the right-hand side in elimination order (parity of k_chord with k_kkt2) */
 int qtos_debug_chord(QtosPlanner *p, int B, double *dx_out);
+/* a-posteriori residual of the system the preceding qtos_debug_newton call solved: res_rel_out[b] = max |b - K x| /
+ * max |b|, K applied from the problem's stream without the factorisation (k_residual).  refine != 0: first one step of
+ * iterative refinement through the stored factorisation (r = b - K x, K e = r by k_chord, x += e); dx_out (B x n_vars,
+ * may be NULL): the (refined) solution.  SURVEY.md section 7-5: accuracy of the KKT solve vs a CPU factorisation. */
+int qtos_debug_residual(QtosPlanner *p, int B, int refine, double *dx_out, double *res_rel_out);
 /* working-set description: row_kind[n_cons] (0 dropped, 1 equality, 2 inequality),
  * var_free[n_vars] (0/1), unknown order[n_unknowns] (var index, or n_vars + row for multipliers) */
 int qtos_debug_structure(const QtosPlanner *p, int *row_kind, int *var_free, int *order);

@@ -56,7 +56,7 @@ EXPORTS = [
     "qtos_debug_structure", "qtos_debug_trace", "qtos_debug_factor", "qtos_analyze",
     "qtos_set_init_table", "qtos_debug_initial_guess", "qtos_shift_warm", "qtos_shift_warm_device",
     "qtos_last_timing_chord", "qtos_debug_chord", "qtos_plan_totals",
-    "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation",
+    "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation", "qtos_debug_residual",
 ]
 
 _lib = None
@@ -112,6 +112,8 @@ def load():
     if hasattr(lib, "qtos_plan_totals"):
         lib.qtos_plan_totals.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]
         lib.qtos_debug_chord.argtypes = [vp, C.c_int, dp]
+    if hasattr(lib, "qtos_debug_residual"):
+        lib.qtos_debug_residual.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     if hasattr(lib, "qtos_plan_submit"):
         lib.qtos_plan_submit.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.qtos_plan_poll.argtypes = [vp, ip]
@@ -378,6 +380,14 @@ class Planner:
         dx = np.empty((B, self.n))
         self._chk(self.lib.qtos_debug_chord(self.h, B, _dp(dx)), "debug_chord")
         return dx
+
+    def debug_residual(self, B, refine=False):
+        """(dx, max |b - K x| / max |b| per problem) of the system of the preceding debug_newton call; refine: after one
+        step of iterative refinement through the stored factorisation."""
+        dx = np.empty((B, self.n))
+        res = np.empty(B)
+        self._chk(self.lib.qtos_debug_residual(self.h, B, int(bool(refine)), _dp(dx), _dp(res)), "debug_residual")
+        return dx, res
 
     def structure(self):
         rk = np.empty(self.m, np.int32)

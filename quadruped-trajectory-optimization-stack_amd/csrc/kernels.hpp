@@ -58,6 +58,7 @@ struct DevPlan {
   double chord_tol;
   int n_unknowns;
   const int *rhs_ptr, *rhs_gpos, *rhs_row;
+  const int *kx_ptr, *kx_col, *kx_pos;   // equality part of K by unknown position (Symbolic::kx_ptr; k_residual)
   const int *rtab;             // n_stages x 16: cell of the assembled right-hand side of every pivot (k_kkt2, Symbolic::rtab)
   const Block *blocks;
   const int *block_cols;
@@ -106,6 +107,8 @@ struct DevWork {
   int *chord;                  // per problem: the next KKT solve reuses the stored factorisation (k_chord)
   double *rhs;                 // per problem n_unknowns: right-hand side for that solve
   double *minv;                // per problem n_stages x 256: inverse of every pivot block (written by k_kkt2)
+  double *sol;                 // per problem n_stages x 16: the solution of the last KKT solve by unknown position (variables AND multipliers)
+  double *sol0, *dx0, *ur;     // iterative refinement (k_residual / k_refine_add): first solution, and sig * (Ji dx) by constraint row
 };
 
 // ---- tiny forward-mode dual (one tangent) for the rotation-dependent Jacobians ---------------

@@ -183,7 +183,7 @@ constexpr int SWD = QTOS_SWD;   // stages of factor panel in flight per wave (pr
 // caller has synchronised the workgroup.
 template <int F>
 __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *__restrict__ panel, double *__restrict__ dx,
-                                               double *xs, double *red, const int *nxp, int wv, int lane) {
+                                               double *__restrict__ sol, double *xs, double *red, const int *nxp, int wv, int lane) {
   constexpr int NT = Kkt2Cfg<F>::NT, pstride = (F + 1) * PIV;
   const int NS = P.n_stages, n = P.n_vars;
   const int j = lane & 15, q = lane >> 4;
@@ -243,6 +243,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
         const double x = t >= 0 ? bw[d] - sm - corr : 0.0;
         if (lane < PIV && t >= 0) {
           xs[bps[d]] = x;
+          sol[t * PIV + lane] = x;       // by unknown position, multipliers included (k_residual)
           if (bun[d] >= 0 && bun[d] < n) dx[bun[d]] = x;
         }
         // the block of stage t - 1 against the entries just found
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     for (int i = tid; i < NS * 4; i += KT2) nxp[i] = P.nxt_pack[i];
     for (int i = tid; i < NS * 8; i += KT2) nxp[NS * 4 + i] = (int)P.amask2[i];
     __syncthreads();
-    sweep_backward<F>(P, panel, dx, xs, red, nxp, wv, lane);
+    sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane);
   }
 #ifdef QTOS_STAMPS
   KS2(6);
@@ -942,7 +943,73 @@ __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
     }
   }
   __syncthreads();   // the w entries written above are read back below (same workgroup: visible after the barrier)
-  sweep_backward<F>(P, panel, dx, xs, red, nxp, wv, lane);
+  sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane);
+}
+
+// =================================================================================================
+// k_residual: r = b - K x for the solution the last k_kkt2 / k_chord launch left in W.sol, WITHOUT the factorisation: K
+// from the problem's stream (pivot diagonals, equality Jacobian values, inequality blocks G with their barrier weights),
+// b by k_step's formula.  r goes to W.rhs in elimination order -- the right-hand side k_chord takes --, so that one more
+// solve with the stored factorisation gives the correction of one step of iterative refinement (k_refine_add).
+//   K = [ diag + Ji' S Ji   Je' ]      variables:   r_v = b_v - diag_v x_v - sum_r G[r][v] (sig_r (Ji x)_r) - (Je' y)_v
+//       [ Je              diag  ]      multipliers: r_e = b_e - (Je x)_e - diag_e y_e
+// out[b] = max |r| / max |b|;  keep != 0: x is remembered as the solution the correction will be added to.
+__global__ __launch_bounds__(512) void k_residual(DevPlan P, DevWork W, int B, double *out, int keep) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= B) return;
+  __shared__ double red[2][512];
+  const int n = P.n_vars, m = P.n_cons, NU = P.n_unknowns, NP = P.n_stages * PIV;
+  const double *Gs = W.stream + (size_t)b * P.stream_len, *g = W.g + (size_t)b * m, *sig = W.sig + (size_t)b * m, *wr = W.w + (size_t)b * m;
+  const double *sol = W.sol + (size_t)b * NP, *dx = W.dx + (size_t)b * n;
+  double *ur = W.ur + (size_t)b * m, *res = W.rhs + (size_t)b * NU;
+  for (int i = tid; i < P.n_iq_rows; i += blockDim.x) {
+    const IqRow R = P.iq_rows[i];
+    double t = 0.0;
+    for (int a = 0; a < R.n; ++a) t = fma(Gs[R.goff + a], dx[P.block_cols[R.col_off + a]], t);
+    ur[R.row] = sig[R.row] * t;
+  }
+  __threadfence_block();
+  __syncthreads();
+  double mr = 0.0, mb = 0.0;
+  for (int p = tid; p < NU; p += blockDim.x) {
+    const int t0 = P.rhs_ptr[p], t1 = P.rhs_ptr[p + 1];
+    const bool mult = t1 - t0 == 1 && P.rhs_gpos[t0] < 0;
+    double rhs = 0.0, kx = Gs[P.drec_off[p >> 4] + (p & 15)] * sol[p];
+    if (mult) rhs = -g[P.rhs_row[t0]];
+    else
+      for (int t = t0; t < t1; ++t) {
+        const double gv = Gs[P.rhs_gpos[t]];
+        rhs = fma(-gv, wr[P.rhs_row[t]], rhs);
+        kx = fma(gv, ur[P.rhs_row[t]], kx);
+      }
+    for (int e = P.kx_ptr[p]; e < P.kx_ptr[p + 1]; ++e) kx = fma(Gs[P.kx_pos[e]], sol[P.kx_col[e]], kx);
+    const double r = rhs - kx;
+    res[p] = r;
+    mr = fmax(mr, fabs(r));
+    mb = fmax(mb, fabs(rhs));
+  }
+  red[0][tid] = mr; red[1][tid] = mb;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (tid < s) { red[0][tid] = fmax(red[0][tid], red[0][tid + s]); red[1][tid] = fmax(red[1][tid], red[1][tid + s]); }
+    __syncthreads();
+  }
+  if (tid == 0 && out) out[b] = red[0][0] / fmax(red[1][0], 1e-300);
+  if (keep) {
+    double *sol0 = W.sol0 + (size_t)b * NP, *dx0 = W.dx0 + (size_t)b * n;
+    for (int i = tid; i < NP; i += blockDim.x) sol0[i] = sol[i];
+    for (int i = tid; i < n; i += blockDim.x) dx0[i] = dx[i];
+  }
+}
+// x = x0 + correction (variables and the solution by unknown position)
+__global__ __launch_bounds__(512) void k_refine_add(DevPlan P, DevWork W, int B) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= B) return;
+  const int n = P.n_vars, NP = P.n_stages * PIV;
+  double *sol = W.sol + (size_t)b * NP, *dx = W.dx + (size_t)b * n;
+  const double *sol0 = W.sol0 + (size_t)b * NP, *dx0 = W.dx0 + (size_t)b * n;
+  for (int i = tid; i < NP; i += blockDim.x) sol[i] += sol0[i];
+  for (int i = tid; i < n; i += blockDim.x) dx[i] += dx0[i];
 }
 
 }  // namespace qtos

@@ -190,6 +190,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(S.ctab, &D.ctab));
   TRY(p->upload(S.rtab, &D.rtab));
   TRY(p->upload(S.rhs_ptr, &D.rhs_ptr)); TRY(p->upload(S.rhs_gpos, &D.rhs_gpos)); TRY(p->upload(S.rhs_row, &D.rhs_row));
+  TRY(p->upload(S.kx_ptr, &D.kx_ptr)); TRY(p->upload(S.kx_col, &D.kx_col)); TRY(p->upload(S.kx_pos, &D.kx_pos));
   D.n_unknowns = S.n_unknowns;
   D.chord_tol = M.P.chord_tol;
   D.n_cells = S.n_cells;
@@ -328,6 +329,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.chord, Bm));
   TRY(p->alloc(&W.rhs, Bm * (size_t)S.n_unknowns));
   TRY(p->alloc(&W.minv, Bm * (size_t)S.n_stages * PIV * PIV));
+  TRY(p->alloc(&W.sol, Bm * (size_t)S.n_stages * PIV)); TRY(p->alloc(&W.sol0, Bm * (size_t)S.n_stages * PIV));
+  TRY(p->alloc(&W.dx0, Bm * n)); TRY(p->alloc(&W.ur, Bm * m));
   TRY(p->alloc(&p->d_start, Bm * QTOS_START_DOUBLES)); TRY(p->alloc(&p->d_goal, Bm * 3));
   TRY(p->alloc(&p->d_nodes, Bm * n)); TRY(p->alloc(&p->d_warm, Bm * n)); TRY(p->alloc(&p->d_map, Bm));
   if (hipHostMalloc((void **)&p->h_active, 2 * sizeof(int) * ((size_t)M.P.max_iter + 1), hipHostMallocMapped) != hipSuccess) { qtos_planner_destroy(p); return -3; }
@@ -921,6 +924,10 @@ __global__ __launch_bounds__(256) void k_debug_rhs(DevPlan P, DevWork W, int B) 
   }
   if (threadIdx.x == 0) { W.chord[b] = 1; atomicAdd(W.n_active + 1, 1); }
 }
+__global__ void k_debug_flag_chord(DevWork W, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) { W.chord[b] = 1; atomicAdd(W.n_active + 1, 1); }
+}
 __global__ void k_debug_unchord(DevWork W, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) W.chord[b] = 0;
@@ -938,6 +945,33 @@ int qtos_debug_chord(QtosPlanner *p, int B, double *dx_out) {
   hipLaunchKernelGGL(k_debug_unchord, dim3((B + 63) / 64), dim3(64), 0, 0, W, B);
   HIPCHK(p, hipDeviceSynchronize());
   HIPCHK(p, hipMemcpy(dx_out, W.dx, (size_t)B * p->M.n_vars * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* A-posteriori check of the system the preceding qtos_debug_newton call solved: res_rel_out[b] = max |b - K x| / max |b|
+ * with K applied from the problem's stream (k_residual: no use of the factorisation).  refine != 0: one step of
+ * iterative refinement through the stored factorisation first -- r = b - K x, K e = r by k_chord, x += e -- and the
+ * residual of the refined solution; dx_out (B x n_vars, may be NULL) receives the solution. */
+int qtos_debug_residual(QtosPlanner *p, int B, int refine, double *dx_out, double *res_rel_out) {
+  if (!p || B < 1 || B > p->max_batch || !res_rel_out) return -1;
+  if (refine && !p->chord_fn) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  DevWork W = p->wk;
+  double *d_out = nullptr;
+  HIPCHK(p, hipMalloc((void **)&d_out, B * sizeof(double)));
+  if (refine) {
+    hipLaunchKernelGGL(k_residual, dim3(B), dim3(512), 0, 0, p->dp, W, B, (double *)nullptr, 1);   // r -> W.rhs, x remembered
+    hipLaunchKernelGGL(k_debug_flag_chord, dim3((B + 63) / 64), dim3(64), 0, 0, W, B);
+    hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), chord_lds_bytes(p->S.n_stages), 0, p->dp, W, B);
+    hipLaunchKernelGGL(k_debug_unchord, dim3((B + 63) / 64), dim3(64), 0, 0, W, B);
+    hipLaunchKernelGGL(k_refine_add, dim3(B), dim3(512), 0, 0, p->dp, W, B);
+  }
+  hipLaunchKernelGGL(k_residual, dim3(B), dim3(512), 0, 0, p->dp, W, B, d_out, 0);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(res_rel_out, d_out, B * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && dx_out) e = hipMemcpy(dx_out, W.dx, (size_t)B * p->M.n_vars * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) { p->err = std::string("qtos_debug_residual: ") + hipGetErrorString(e); return -2; }
   return 0;
 }
 

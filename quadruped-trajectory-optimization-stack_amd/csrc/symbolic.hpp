@@ -81,6 +81,9 @@ struct Symbolic {
   // stage's columns): right-hand-side entries get cells of their own too (a slot changes hands at a stage
   // boundary, a cell does not), listed per pivot in rtab, and a cell is recycled one stage later
   std::vector<int> rhs_ptr, rhs_gpos, rhs_row;   // right-hand side of K by unknown position (DevPlan::rhs_ptr ...)
+  // equality part of K by unknown position, both triangles (k_residual: K x without the factorisation): unknown p is coupled
+  // with unknown kx_col[e] through the stream value at kx_pos[e], e in [kx_ptr[p], kx_ptr[p + 1])
+  std::vector<int> kx_ptr, kx_col, kx_pos;
   int cell_mode = 2;
   std::vector<int> rtab;              // n_stages x 16: cell of the assembled right-hand side of every pivot (0 = none)
   std::vector<unsigned> amask;   // per stage 256 bits (8 words): front slots whose row of the factor panel V is stored (live, not a pivot of the stage)
@@ -582,6 +585,7 @@ struct Symbolic {
       max_stage_g = std::max(max_stage_g, S.g_len);
     }
     std::vector<std::vector<EqEntry>> ent(n_stages);
+    std::vector<std::vector<std::pair<int, int>>> ent_pp(n_stages);   // (multiplier position, variable position) of every entry
     std::vector<std::vector<EqRhs>> rhs(n_stages);
     for (Block &b : M.blocks) {
       if (b.kind != 0) continue;
@@ -596,6 +600,7 @@ struct Symbolic {
           e.slot_r = (short)sr;
           e.slot_c = (short)var_slot[var];
           ent[std::min(pr, var_pos[var]) / PIV].push_back(e);
+          ent_pp[std::min(pr, var_pos[var]) / PIV].push_back({pr, var_pos[var]});
         }
       }
     }
@@ -797,6 +802,21 @@ struct Symbolic {
         else
           for (auto &t : terms[p]) { rhs_gpos.push_back(t.first); rhs_row.push_back(t.second); }
         rhs_ptr.push_back((int)rhs_gpos.size());
+      }
+    }
+    {   // equality part of K by unknown (the entries of stage k sit behind the 16 pivot diagonals of its dynamic record)
+      std::vector<std::vector<std::pair<int, int>>> rows(n_unknowns);
+      for (int k = 0; k < n_stages; ++k)
+        for (size_t i = 0; i < ent_pp[k].size(); ++i) {
+          const int pr = ent_pp[k][i].first, pv = ent_pp[k][i].second, spos = drec_off[k] + PIV + (int)i;
+          rows[pr].push_back({pv, spos});
+          rows[pv].push_back({pr, spos});
+        }
+      kx_ptr.assign(1, 0);
+      kx_col.clear(); kx_pos.clear();
+      for (int p = 0; p < n_unknowns; ++p) {
+        for (auto &e : rows[p]) { kx_col.push_back(e.first); kx_pos.push_back(e.second); }
+        kx_ptr.push_back((int)kx_col.size());
       }
     }
     // bytes = w * [ sum_k (p + c_k) * p  +  2 M ]   (matrix once, rhs in, solution out)
