@@ -55,6 +55,10 @@ typedef struct QtosParams {
                         freshly factored KKT system is followed by ONE chord step: the stored factorisation is
                         reused with the right-hand side of the new iterate (k_chord: forward + backward sweep over
                         the factor panels, about a fifth of a factorisation); 0 = every iteration factors */
+  int reduce_base;   /* 1: inside the KKT solve the base node values are replaced by the coefficients of a clamped cubic
+                        B-spline on the same knots (a basis of the C2 splines the acceleration-continuity rows describe):
+                        no multipliers for those rows, half the base unknowns, the same Newton step; 0: every row of the
+                        reference's NLP has its multiplier (the formulation the internals' tests pin) */
 } QtosParams;
 
 typedef struct QtosDims {
@@ -206,6 +210,17 @@ int qtos_debug_newton(QtosPlanner *p, int B, const double *start, const double *
 /* the same system once more through the chord-step kernel: the factorisation the preceding qtos_debug_newton
  * call left on the device + the right-hand side in elimination order (parity of k_chord with k_kkt2) */
 int qtos_debug_chord(QtosPlanner *p, int B, double *dx_out);
+/* QtosParams.reduce_base: a solve that is given nodes (`warm`) starts from their projection onto the space of the
+ * B-spline coefficients (nodes of a C2 spline stay what they are; the reference's plans, whose acceleration continuity
+ * holds to their CSV precision, move by that much).  This is that projection (host pointers, B x n_vars); without
+ * reduce_base a copy. */
+int qtos_project_nodes(QtosPlanner *p, int B, const double *nodes, double *nodes_out);
+/* diagnostics (scratch/reduced_base_sweep.py, host-side emulations of the chain): the stage stream of problem b as the last
+ * linearisation left it (qtos_debug_stream_len doubles), and the vector behind the last qtos_debug_residual call
+ * (n_unknowns doubles, elimination order) */
+int qtos_debug_stream_len(const QtosPlanner *p);
+int qtos_debug_read_stream(QtosPlanner *p, int b, double *out);
+int qtos_debug_read_rhs(QtosPlanner *p, int b, double *out);
 /* a-posteriori residual of the system the preceding qtos_debug_newton call solved: res_rel_out[b] = max |b - K x| /
  * max |b|, K applied from the problem's stream without the factorisation (k_residual).  refine != 0: first one step of
  * iterative refinement through the stored factorisation (r = b - K x, K e = r by k_chord, x += e); dx_out (B x n_vars,

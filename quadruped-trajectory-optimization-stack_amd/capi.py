@@ -30,6 +30,7 @@ class QtosParams(C.Structure):
         ("delta_x", C.c_double), ("eps_dual", C.c_double), ("slack_push", C.c_double), ("warm_slack_push", C.c_double),
         ("stall_iters", C.c_int), ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double),
         ("chord_tol", C.c_double),
+        ("reduce_base", C.c_int),
     ]
 
 
@@ -56,7 +57,8 @@ EXPORTS = [
     "qtos_debug_structure", "qtos_debug_trace", "qtos_debug_factor", "qtos_analyze",
     "qtos_set_init_table", "qtos_debug_initial_guess", "qtos_shift_warm", "qtos_shift_warm_device",
     "qtos_last_timing_chord", "qtos_debug_chord", "qtos_plan_totals",
-    "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation", "qtos_debug_residual",
+    "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation", "qtos_debug_residual", "qtos_project_nodes",
+    "qtos_debug_stream_len", "qtos_debug_read_stream", "qtos_debug_read_rhs",
 ]
 
 _lib = None
@@ -112,6 +114,8 @@ def load():
     if hasattr(lib, "qtos_plan_totals"):
         lib.qtos_plan_totals.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]
         lib.qtos_debug_chord.argtypes = [vp, C.c_int, dp]
+    if hasattr(lib, "qtos_project_nodes"):
+        lib.qtos_project_nodes.argtypes = [vp, C.c_int, dp, dp]
     if hasattr(lib, "qtos_debug_residual"):
         lib.qtos_debug_residual.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     if hasattr(lib, "qtos_plan_submit"):
@@ -177,6 +181,7 @@ def params_from_config(cfg):
     p.stall_iters = cfg.stall_iters
     p.hold_from, p.hold_weight, p.hold_tol = cfg.foothold_hold_from, cfg.foothold_hold_weight, cfg.foothold_hold_tol
     p.chord_tol = cfg.chord_tol
+    p.reduce_base = int(cfg.reduce_base)
     return p
 
 
@@ -380,6 +385,14 @@ class Planner:
         dx = np.empty((B, self.n))
         self._chk(self.lib.qtos_debug_chord(self.h, B, _dp(dx)), "debug_chord")
         return dx
+
+    def project(self, nodes):
+        """What given nodes become when a solve starts from them (reduce_base: their projection onto the space of the base's
+        B-spline coefficients; otherwise a copy)."""
+        nodes = np.ascontiguousarray(nodes, np.float64).reshape(-1, self.n)
+        out = np.empty_like(nodes)
+        self._chk(self.lib.qtos_project_nodes(self.h, nodes.shape[0], _dp(nodes), _dp(out)), "project_nodes")
+        return out
 
     def debug_residual(self, B, refine=False):
         """(dx, max |b - K x| / max |b| per problem) of the system of the preceding debug_newton call; refine: after one

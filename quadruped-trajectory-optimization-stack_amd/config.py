@@ -98,6 +98,11 @@ class PlannerConfig:
     # followed by one step that reuses that factorisation with the new right-hand side (k_chord).  The flat batch goes
     # 27 -> 6.5 -> 0.11 -> 5.7e-4 -> (chord) 3.9e-5: three factorisations instead of four.  0 = off.
     chord_tol: float = 1e-3
+    # Reduced base: inside the KKT solve the base node values are replaced by the coefficients of a clamped cubic B-spline on
+    # the same knots -- a basis of exactly the C2 splines the acceleration-continuity rows describe --: no multipliers for
+    # those rows, half the base unknowns (2885 -> 1721 unknowns, 181 -> 108 stages on the 100-knot transcription), the same
+    # Newton step.  False: every row of the reference's NLP has its multiplier (what the internals' tests pin).
+    reduce_base: bool = True
     phase_durations: List[List[float]] = field(default=None)
 
     def __post_init__(self):

@@ -22,6 +22,16 @@ namespace qtos {
 
 struct DevPlan {
   int n_vars, n_cons, n_stages, front;
+  // solver variables (QtosParams.reduce_base): ids < n_vars = the model's variables, n_vars .. n_sol - 1 = B-spline coefficients
+  // that replace the base node values inside the KKT solve; the step in node space is recovered as dx[rec_var[i]] =
+  // sum_a rec_w[4i + a] * dx[rec_col[4i + a]] (k_recover_dx).  Without reduce_base n_sol = n_vars, n_rec = 0.
+  int n_sol, n_rec;
+  const int *rec_var, *rec_col;
+  const double *rec_w;
+  // projection of a warm start onto the space of the coefficients (model.hpp: pc_*, pz_*); n_coef = 0 without reduce_base
+  int n_coef, n_pz;
+  const int *pc_var, *pz_var, *pz_col;
+  const double *pc_w, *pz_w;
   int n_dyn, n_rom, n_terr, n_force, n_lin, n_blocks;
   const DynInst *dyn;
   const RomInst *rom;
@@ -718,6 +728,26 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     W.xbest[(size_t)b * n + v] = val;
   }
   __syncthreads();
+  if (P.n_coef && (W.warm || P.table)) {
+    // reduced base: given nodes need not be a spline of the coefficients' space (the reference's plans violate the
+    // acceleration continuity by their CSV precision, 7e-4): project them onto it -- the continuity rows that left the KKT
+    // system hold for every iterate only if they hold for the first
+    for (int c = tid; c < P.n_coef; c += blockDim.x) {
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc = fma(P.pc_w[4 * c + a], x[P.pc_var[4 * c + a]], acc);
+      evl[c] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < P.n_pz; i += blockDim.x) {
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc = fma(P.pz_w[4 * i + a], evl[P.pz_col[4 * i + a]], acc);
+      x[P.pz_var[i]] = acc;
+      W.xbest[(size_t)b * n + P.pz_var[i]] = acc;
+    }
+    __syncthreads();
+  }
   // values and linearisation of the starting point in ONE pass (the Jacobian does not depend on the slack
   // initialisation below; a problem that turns out converged or invalid has merely written a stream nobody reads)
   eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, nullptr, 0);
@@ -1017,6 +1047,8 @@ __device__ __forceinline__ double gather_term(const double *dbuf, int code) {
     const double term = rhs ? -(ga[r] * sw[r]) : sw[r] * ga[r] * gc[r];
     acc += r < qm ? term : 0.0;
   }
+  // a static contribution (c == 62: the proximal term between two B-spline coefficients of the reduced base): the value itself
+  acc = c == 62 ? ga[0] : acc;
   if (__builtin_amdgcn_ballot_w64(qm > 3) != 0ull) {
     double gb[2], gd[2], sv[2];
 #pragma unroll
@@ -1042,11 +1074,12 @@ __device__ __forceinline__ void assemble_stage(double *A, int F, const int *sbuf
   const int *rsl = eidx + n_ent;
   const double *rval = eval + n_ent;
   for (int i = t0; i < n_rhs; i += nth) A[rsl[i]] += rval[i];
-  if (n_iq == 0) return;
+  (void)n_iq;
 #ifdef QTOS_EXP_NOASM
   return;   // ablation build (timing only): the inequality blocks are not assembled
 #endif
   const int n_tgt = sbuf[5];
+  if (n_tgt == 0) return;
   const int *tg = sbuf + sbuf[4];                     // n_tgt + 1 ints: (tri << 12) | first contribution
   const int *cl = tg + n_tgt + 1;                     // one self-contained int per contribution
   for (int t = t0; t < n_tgt; t += nth) {
@@ -1066,7 +1099,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   extern __shared__ double evl[];
   const int n = P.n_vars, m = P.n_cons, tid = threadIdx.x;
   // distinct buffers: __restrict__ lets the row loops below keep several rows' loads in flight
-  double *__restrict__ x = W.x + (size_t)b * n, *__restrict__ xt = W.xt + (size_t)b * n, *__restrict__ dx = W.dx + (size_t)b * n;
+  double *__restrict__ x = W.x + (size_t)b * n, *__restrict__ xt = W.xt + (size_t)b * n, *__restrict__ dx = W.dx + (size_t)b * P.n_sol;
   double *__restrict__ g = W.g + (size_t)b * m, *__restrict__ gt = W.gt + (size_t)b * m;
   double *__restrict__ s = W.s + (size_t)b * m, *__restrict__ zl = W.zl + (size_t)b * m, *__restrict__ zu = W.zu + (size_t)b * m;
   double *__restrict__ ds = W.ds + (size_t)b * m, *__restrict__ dzl = W.dzl + (size_t)b * m, *__restrict__ dzu = W.dzu + (size_t)b * m;
@@ -1085,8 +1118,24 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
 #define KSTAMP(i) do {} while (0)
 #endif
   // ds = Ji dx + (g - s): dx staged in LDS, one thread per inequality row, independent loads
-  for (int v = tid; v < n; v += blockDim.x) evl[v] = dx[v];
+  for (int v = tid; v < P.n_sol; v += blockDim.x) evl[v] = dx[v];
   __syncthreads();
+  if (P.n_rec) {
+    // reduced base: the step of the base node values from the step of the B-spline coefficients (dx_nodes = Z dc)
+    for (int i = tid; i < P.n_rec; i += blockDim.x) {
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int col = P.rec_col[4 * i + a];
+        acc = col >= 0 ? fma(P.rec_w[4 * i + a], evl[col], acc) : acc;
+      }
+      dx[P.rec_var[i]] = acc;
+      scratch[0] = 0.0;   // (keeps the loop's stores in front of the barrier below for every thread)
+    }
+    __syncthreads();
+    for (int i = tid; i < P.n_rec; i += blockDim.x) evl[P.rec_var[i]] = dx[P.rec_var[i]];
+    __syncthreads();
+  }
   for (int i = tid; i < P.n_iq_rows; i += blockDim.x) {
     const IqRow R = P.iq_rows[i];
     const double *Gr = G + R.goff;

@@ -185,7 +185,7 @@ template <int F>
 __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *__restrict__ panel, double *__restrict__ dx,
                                                double *__restrict__ sol, double *xs, double *red, const int *nxp, int wv, int lane) {
   constexpr int NT = Kkt2Cfg<F>::NT, pstride = (F + 1) * PIV;
-  const int NS = P.n_stages, n = P.n_vars;
+  const int NS = P.n_stages, n = P.n_sol;
   const int j = lane & 15, q = lane >> 4;
   const int vcol = 4 * (j & 3) + (j >> 2);   // where column j of a V row sits
   const bool owner = wv >= 1 && wv <= NT;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   using CF = Kkt2Cfg<F>;
   using LY = Kkt2Layout<F>;
   constexpr int NT = CF::NT, NU = CF::NU, MAXT2 = CF::MAXT, NSV = CF::NSV, NH = CF::NH, FR = CF::FR, PSZ = LY::PSZ;
-  const int tid = threadIdx.x, NS = P.n_stages, n = P.n_vars;
+  const int tid = threadIdx.x, NS = P.n_stages, n = P.n_sol;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
   double *Lib = lds + LY::LIB, *dvb = lds + LY::DVB, *dgb = lds + LY::DGB, *UF = lds + LY::UF, *xs = lds + LY::XS;
   double *red = lds + LY::RED, *PB = lds + LY::PB, *dbuf = lds + LY::VAR;
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
   static_assert(NT + 1 < 16, "k_chord: waves 1..NT own the row tiles, wave NT + 1 solves with the pivot blocks");
   __shared__ double UF[FR], xs[FR], pf[2 * PIV], red[2 * 16 * PIV];
   extern __shared__ int nxp[];   // Symbolic::nxt_pack, then Symbolic::amask2
-  const int tid = threadIdx.x, NS = P.n_stages, n = P.n_vars;
+  const int tid = threadIdx.x, NS = P.n_stages, n = P.n_sol;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int j = lane & 15, q = lane >> 4;
   double *panel = W.panel + (size_t)b * P.panel_stride;
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(512) void k_residual(DevPlan P, DevWork W, int B, d
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= B) return;
   __shared__ double red[2][512];
-  const int n = P.n_vars, m = P.n_cons, NU = P.n_unknowns, NP = P.n_stages * PIV;
+  const int n = P.n_sol, m = P.n_cons, NU = P.n_unknowns, NP = P.n_stages * PIV;
   const double *Gs = W.stream + (size_t)b * P.stream_len, *g = W.g + (size_t)b * m, *sig = W.sig + (size_t)b * m, *wr = W.w + (size_t)b * m;
   const double *sol = W.sol + (size_t)b * NP, *dx = W.dx + (size_t)b * n;
   double *ur = W.ur + (size_t)b * m, *res = W.rhs + (size_t)b * NU;
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(512) void k_residual(DevPlan P, DevWork W, int B, d
 __global__ __launch_bounds__(512) void k_refine_add(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= B) return;
-  const int n = P.n_vars, NP = P.n_stages * PIV;
+  const int n = P.n_sol, NP = P.n_stages * PIV;
   double *sol = W.sol + (size_t)b * NP, *dx = W.dx + (size_t)b * n;
   const double *sol0 = W.sol0 + (size_t)b * NP, *dx0 = W.dx0 + (size_t)b * n;
   for (int i = tid; i < NP; i += blockDim.x) sol[i] += sol0[i];

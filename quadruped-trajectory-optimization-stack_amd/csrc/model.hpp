@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -137,6 +138,49 @@ inline void hermite_weights(double T, double t, int deriv, double w[4]) {
   }
 }
 
+// Cubic B-spline basis on a knot vector U: the four functions that live on span i (U[i] <= t <= U[i+1]) and their first
+// two derivatives (The NURBS Book, algorithm A2.3, degree 3).  ders[d][a] = d-th derivative of N_{i-3+a} at t.
+inline void bspline_ders(const std::vector<double> &U, int i, double t, double ders[3][4]) {
+  const int p = 3;
+  double ndu[4][4], left[4], right[4], a[2][4];
+  ndu[0][0] = 1.0;
+  for (int j = 1; j <= p; ++j) {
+    left[j] = t - U[i + 1 - j];
+    right[j] = U[i + j] - t;
+    double saved = 0.0;
+    for (int r = 0; r < j; ++r) {
+      ndu[j][r] = right[r + 1] + left[j - r];
+      const double tmp = ndu[r][j - 1] / ndu[j][r];
+      ndu[r][j] = saved + right[r + 1] * tmp;
+      saved = left[j - r] * tmp;
+    }
+    ndu[j][j] = saved;
+  }
+  for (int j = 0; j <= p; ++j) ders[0][j] = ndu[j][p];
+  for (int r = 0; r <= p; ++r) {
+    int s1 = 0, s2 = 1;
+    a[0][0] = 1.0;
+    for (int k = 1; k <= 2; ++k) {
+      double d = 0.0;
+      const int rk = r - k, pk = p - k;
+      if (r >= k) { a[s2][0] = a[s1][0] / ndu[pk + 1][rk]; d = a[s2][0] * ndu[rk][pk]; }
+      const int j1 = rk >= -1 ? 1 : -rk, j2 = (r - 1 <= pk) ? k - 1 : p - r;
+      for (int j = j1; j <= j2; ++j) {
+        a[s2][j] = (a[s1][j] - a[s1][j - 1]) / ndu[pk + 1][rk + j];
+        d += a[s2][j] * ndu[rk + j][pk];
+      }
+      if (r <= pk) { a[s2][k] = -a[s1][k - 1] / ndu[pk + 1][r]; d += a[s2][k] * ndu[r][pk]; }
+      ders[k][r] = d;
+      std::swap(s1, s2);
+    }
+  }
+  double f = p;
+  for (int k = 1; k <= 2; ++k) {
+    for (int j = 0; j <= p; ++j) ders[k][j] *= f;
+    f *= (p - k);
+  }
+}
+
 inline VecIn make_in_poly(const Spline &S, int k, double tau, int deriv) {
   VecIn v;
   hermite_weights(S.dur[k], tau, deriv, v.w);
@@ -178,6 +222,51 @@ struct HostModel {
 
   bool is_free(int v) const { return init[v].fix_src < 0; }
 
+  // ---- reduced base (QtosParams.reduce_base): the acceleration-continuity rows are linear with constant coefficients;
+  // inside the KKT solve the base node values are replaced by the coefficients of a clamped cubic B-spline on the same
+  // knots (a basis of exactly the C2 splines the rows describe): dx_nodes = Z dc.  No multipliers for those rows and half
+  // the base unknowns; the Newton step is the same (the proximal term delta |dx_nodes|^2 becomes delta dc' Z'Z dc: static
+  // entries of K).  Solver variables = the model variables (ids < n_vars; base node values are then not unknowns) followed
+  // by the coefficients (ids n_vars ..).  The iterate, the constraint evaluation and the results stay in node space.
+  int reduce_base = 0, n_sol = 0, n_coef = 0;
+  std::vector<double> knots;                 // clamped knot vector of the base splines
+  std::vector<int> span_of;                  // knot span of every base polynomial
+  std::vector<int> cvar[2][3];               // [lin / ang][dim][coefficient] -> solver variable or -1 (no freedom: fixed end state)
+  std::vector<char> replaced;                // per model variable: a base node value that the coefficients replace
+  std::vector<char> coef_unknown;            // per coefficient id (solver variable - n_vars): is an unknown of the KKT system
+  std::vector<double> sol_diag;              // per solver variable: proximal diagonal (delta_x, or delta_x (Z'Z)_jj for a coefficient)
+  struct SymEntry { int a, b; double val; }; // static entries of K between two solver variables (delta_x Z'Z off the diagonal)
+  std::vector<SymEntry> sym_static;
+  std::vector<int> rec_var, rec_col;         // recovery dx_nodes = Z dc: model variable, then 4 (solver column or -1, weight) each
+  std::vector<double> rec_w;
+  // projection of given node values (a warm start) onto the coefficients' space: coefficient c = sum_a pc_w[4c + a] *
+  // x[pc_var[4c + a]] (the blossom of one polynomial piece inside its support: exact for a spline of the space), then every
+  // free base node value = sum_a pz_w[4i + a] * c[pz_col[4i + a]]
+  std::vector<int> pc_var, pz_var, pz_col;
+  std::vector<double> pc_w, pz_w;
+  bool is_unknown(int v) const {
+    if (v < n_vars) return init[v].fix_src < 0 && !(reduce_base && replaced[v]);
+    return coef_unknown[v - n_vars] != 0;
+  }
+  // base input in solver space: the four B-spline coefficients that live on the polynomial containing t
+  VecIn make_in_sol(int which, const Spline &S, double t, int deriv) const {
+    if (!reduce_base) return make_in(S, t, deriv);
+    int k;
+    double tau;
+    S.locate(t, k, tau);
+    double ders[3][4];
+    const int sp = span_of[k];
+    bspline_ders(knots, sp, t, ders);
+    VecIn v;
+    for (int a = 0; a < 4; ++a) {
+      v.w[a] = ders[deriv][a];
+      for (int d = 0; d < 3; ++d) v.var[3 * a + d] = cvar[which][d][sp - 3 + a];
+    }
+    return v;
+  }
+  struct BaseIn { VecIn r, a, th, thd, thdd; };   // solver-space inputs of an instance (column structure and weights of its Jacobian)
+  std::vector<BaseIn> dyn_sol, rom_sol;
+
   static std::vector<double> time_grid(double T, double dt) {
     // towr time_discretization_constraint.cc: 0, dt, ..., floor(T/dt)*dt (accumulated), T
     std::vector<double> out;
@@ -197,7 +286,7 @@ struct HostModel {
     std::vector<int> cols;
     const HostModel *M;
     short add(int var) {
-      if (var < 0 || !M->is_free(var)) return -1;
+      if (var < 0 || !M->is_unknown(var)) return -1;
       for (size_t i = 0; i < cols.size(); ++i)
         if (cols[i] == var) return (short)i;
       cols.push_back(var);
@@ -265,8 +354,9 @@ struct HostModel {
       const DynInst &I = dyn[k];
       if (!I.in_kkt) continue;
       const size_t first = dyn_cols.size();
-      add(dyn_cols, first, (int)k, I.goff, I.ncol, 0, I.c_lin, &I.r, &I.a, nullptr);
-      add(dyn_cols, first, (int)k, I.goff, I.ncol, 1, I.c_ang, &I.th, &I.thd, &I.thdd);
+      const BaseIn &Bi = dyn_sol[k];
+      add(dyn_cols, first, (int)k, I.goff, I.ncol, 0, I.c_lin, &Bi.r, &Bi.a, nullptr);
+      add(dyn_cols, first, (int)k, I.goff, I.ncol, 1, I.c_ang, &Bi.th, &Bi.thd, &Bi.thdd);
       for (int e = 0; e < NEE; ++e) {
         add(dyn_cols, first, (int)k, I.goff, I.ncol, 2 + e, I.c_p[e], &I.p[e], nullptr, nullptr);
         add(dyn_cols, first, (int)k, I.goff, I.ncol, 6 + e, I.c_f[e], &I.f[e], nullptr, nullptr);
@@ -275,8 +365,9 @@ struct HostModel {
     for (size_t k = 0; k < rom.size(); ++k) {
       const RomInst &I = rom[k];
       const size_t first = rom_cols.size();
-      add(rom_cols, first, (int)k, I.goff, I.ncol, 0, I.c_lin, &I.r, nullptr, nullptr);
-      add(rom_cols, first, (int)k, I.goff, I.ncol, 1, I.c_ang, &I.th, nullptr, nullptr);
+      const BaseIn &Bi = rom_sol[k];
+      add(rom_cols, first, (int)k, I.goff, I.ncol, 0, I.c_lin, &Bi.r, nullptr, nullptr);
+      add(rom_cols, first, (int)k, I.goff, I.ncol, 1, I.c_ang, &Bi.th, nullptr, nullptr);
       add(rom_cols, first, (int)k, I.goff, I.ncol, 2, I.c_p, &I.p, nullptr, nullptr);
     }
   }
@@ -429,6 +520,164 @@ struct HostModel {
       for (int e = 0; e < NEE; ++e) init[off_eem[e] + d].fix_src = 6 + 3 * e + d;  // start feet
     }
 
+    // ---- solver variables ----
+    // (at least 20 base polynomials: on very short horizons -- 6 polynomials, both double knots next to the ends -- the
+    //  factorisation without pivoting of the reduced system lost digits, 1e-2 residual of a solve; nothing is gained there)
+    reduce_base = P.reduce_base != 0 && nb >= 20;
+    if (reduce_base) {
+      // The reduction needs towr's straight-line starting point to be a spline of the coefficients' space: C2 at every
+      // interior junction but the first and the last (those two are double knots).  Node positions start + node / n_polys *
+      // (goal - start) and node velocities (goal - start) / T are that exactly when the base polynomials have equal
+      // durations; with a shorter last polynomial (T not a multiple of dt_base) the guess has an acceleration jump at every
+      // junction and the full system is kept.
+      for (int j = 1; j + 2 < nb && reduce_base; ++j) {   // junction j + 1 between polynomials j and j + 1, no fixed end state involved
+        const VecIn prev = make_in_poly(lin, j, lin.dur[j], 2), next = make_in_poly(lin, j + 1, 0.0, 2);
+        double kappa = 0.0, scale = 0.0;
+        for (int a = 0; a < 4; ++a) {
+          const double fr_p = (double)(j + (a >> 1)) / nb, fr_n = (double)(j + 1 + (a >> 1)) / nb;
+          kappa += prev.w[a] * ((a & 1) ? 1.0 / T : fr_p) - next.w[a] * ((a & 1) ? 1.0 / T : fr_n);
+          scale = std::max(scale, std::fabs(prev.w[a]) * ((a & 1) ? 1.0 / T : 1.0));
+        }
+        if (std::fabs(kappa) > 1e-9 * scale) reduce_base = 0;
+      }
+    }
+    n_sol = n_vars;
+    n_coef = 0;
+    replaced.assign(n_vars, 0);
+    sol_diag.assign(n_vars, P.delta_x);
+    if (reduce_base) {
+      // clamped knots: t_0 x 4, the interior node times, t_nb x 4; coefficient j lives on the polynomials j-3 .. j
+      // The first and the last interior junction are DOUBLE knots (C1 there): towr's starting point -- constant node
+      // velocities, but the end velocities fixed -- has an acceleration jump exactly there, and the iterate has to stay
+      // representable.  The continuity rows of those two junctions stay in the KKT system (in the coefficients' space, see
+      // the constant-coefficient rows below); all the others hold identically.
+      knots.assign(3, 0.0);
+      for (int k = 0; k <= nb; ++k) {
+        knots.push_back(lin.node_time(k));
+        if (k == 1 || k == nb - 1) knots.push_back(lin.node_time(k));
+      }
+      for (int i = 0; i < 3; ++i) knots.push_back(T);
+      span_of.assign(nb, 0);
+      for (int k = 0, i = 3; k < nb; ++k) {
+        while (i + 1 < (int)knots.size() && knots[i + 1] <= lin.node_time(k) + 1e-12) ++i;   // last copy of the interval's left knot
+        span_of[k] = i;
+      }
+      const int ncj = (int)knots.size() - 4;
+      n_coef = 6 * ncj;
+      n_sol = n_vars + n_coef;
+      coef_unknown.assign(n_coef, 1);
+      var_time.resize(n_sol, 0.0);
+      sol_diag.assign(n_sol, 0.0);
+      for (int v = 0; v < n_vars; ++v) sol_diag[v] = P.delta_x;
+      for (int which = 0; which < 2; ++which) {
+        const Spline &S = which ? ang : lin;
+        for (int d = 0; d < 3; ++d) {
+          cvar[which][d].assign(ncj, -1);
+          for (int j = 0; j < ncj; ++j) {
+            const int id = n_vars + (which * 3 + d) * ncj + j;
+            cvar[which][d][j] = id;
+            // elimination time: the knot in the middle of the coefficient's support -- each dynamics row then finds coefficients
+            // of its polynomial eliminated in front of it (eliminated at the END of their support the multipliers of the rows
+            // come first with pivots of -eps_dual: the factorisation without pivoting breaks down)
+            var_time[id] = knots[std::min(j + 3, (int)knots.size() - 1)];
+          }
+          // end states: p(t_0) = c_0, p'(t_0) = 3 (c_1 - c_0) / h_0; p(T) = c_last, p'(T) = 3 (c_last - c_last-1) / h_last.
+          // A fixed position removes c_0 (c_last); a fixed velocity ties c_1 to c_0 (c_last-1 to c_last): no freedom if that
+          // one is gone, the same unknown otherwise.
+          auto ends = [&](int jp, int jv, int node) {
+            const bool p_fixed = !is_free(S.idx[node][d]), v_fixed = !is_free(S.idx[node][3 + d]);
+            if (p_fixed) { coef_unknown[cvar[which][d][jp] - n_vars] = 0; cvar[which][d][jp] = -1; }
+            if (v_fixed) {
+              coef_unknown[cvar[which][d][jv] - n_vars] = 0;
+              cvar[which][d][jv] = cvar[which][d][jp];
+            }
+          };
+          ends(0, 1, 0);
+          ends(ncj - 1, ncj - 2, nb);
+        }
+        for (int k = 0; k <= nb; ++k)
+          for (int q = 0; q < 2; ++q)
+            for (int d = 0; d < 3; ++d) replaced[S.idx[k][q * 3 + d]] = 1;
+      }
+      // recovery dx_nodes = Z dc and the proximal term delta |Z dc|^2 over the free node values
+      std::vector<std::vector<std::pair<int, double>>> quad;   // per node value: (solver column, weight)
+      for (int which = 0; which < 2; ++which) {
+        const Spline &S = which ? ang : lin;
+        for (int k = 0; k <= nb; ++k) {
+          const int span = span_of[std::min(k, nb - 1)] - 3;   // first coefficient of the polynomial that starts (ends, for the last node) here
+          double ders[3][4];
+          bspline_ders(knots, span + 3, S.node_time(k), ders);
+          for (int q = 0; q < 2; ++q)
+            for (int d = 0; d < 3; ++d) {
+              const int v = S.idx[k][q * 3 + d];
+              if (!is_free(v)) continue;
+              std::vector<std::pair<int, double>> row;
+              for (int a = 0; a < 4; ++a) {
+                const int col = cvar[which][d][span + a];
+                if (col < 0 || std::fabs(ders[q][a]) < 1e-14) continue;
+                bool merged = false;
+                for (auto &e : row) if (e.first == col) { e.second += ders[q][a]; merged = true; }
+                if (!merged) row.push_back({col, ders[q][a]});
+              }
+              rec_var.push_back(v);
+              for (int a = 0; a < 4; ++a) {
+                rec_col.push_back(a < (int)row.size() ? row[a].first : -1);
+                rec_w.push_back(a < (int)row.size() ? row[a].second : 0.0);
+              }
+              quad.push_back(row);
+            }
+        }
+      }
+      // projection tables
+      {
+        std::vector<int> poly_of_span(knots.size(), -1);
+        for (int k = 0; k < nb; ++k) poly_of_span[span_of[k]] = k;
+        for (int which = 0; which < 2; ++which) {
+          const Spline &S = which ? ang : lin;
+          for (int d = 0; d < 3; ++d)
+            for (int j = 0; j < ncj; ++j) {
+              int k = -1;
+              for (int i : {j + 2, j + 1, j + 3, j})
+                if (i >= 3 && i < (int)knots.size() && poly_of_span[i] >= 0) { k = poly_of_span[i]; break; }
+              const double h = S.dur[k], t0 = S.node_time(k);
+              const double s1 = knots[j + 1] - t0, s2 = knots[j + 2] - t0, s3 = knots[j + 3] - t0;
+              const double m1 = (s1 + s2 + s3) / 3, m2 = (s1 * s2 + s1 * s3 + s2 * s3) / 3, m3 = s1 * s2 * s3;
+              const double wq[4] = {1 - 3 * m2 / (h * h) + 2 * m3 / (h * h * h), m1 - 2 * m2 / h + m3 / (h * h),
+                                    3 * m2 / (h * h) - 2 * m3 / (h * h * h), -m2 / h + m3 / (h * h)};
+              const int vq[4] = {S.idx[k][d], S.idx[k][3 + d], S.idx[k + 1][d], S.idx[k + 1][3 + d]};
+              for (int a = 0; a < 4; ++a) { pc_var.push_back(vq[a]); pc_w.push_back(wq[a]); }
+            }
+          for (int k = 0; k <= nb; ++k) {
+            const int span = span_of[std::min(k, nb - 1)] - 3;
+            double ders[3][4];
+            bspline_ders(knots, span + 3, S.node_time(k), ders);
+            for (int q = 0; q < 2; ++q)
+              for (int d = 0; d < 3; ++d) {
+                const int v = S.idx[k][q * 3 + d];
+                if (!is_free(v)) continue;
+                pz_var.push_back(v);
+                for (int a = 0; a < 4; ++a) {
+                  pz_col.push_back((which * 3 + d) * ncj + span + a);
+                  pz_w.push_back(ders[q][a]);
+                }
+              }
+          }
+        }
+      }
+      std::vector<std::pair<std::pair<int, int>, double>> acc;
+      for (auto &row : quad)
+        for (size_t i = 0; i < row.size(); ++i)
+          for (size_t j = 0; j <= i; ++j) {
+            const double val = P.delta_x * row[i].second * row[j].second;
+            if (row[i].first == row[j].first) { sol_diag[row[i].first] += val; continue; }
+            const std::pair<int, int> key{std::min(row[i].first, row[j].first), std::max(row[i].first, row[j].first)};
+            bool found = false;
+            for (auto &e : acc) if (e.first == key) { e.second += val; found = true; break; }
+            if (!found) acc.push_back({key, val});
+          }
+      for (auto &e : acc) sym_static.push_back({e.first.first, e.first.second, e.second});
+    }
+
     // ---- constraint layout (logs/towr_log.out:112-129) ----
     t_dyn = time_grid(T, P.dt_dyn);
     t_rom = time_grid(T, P.dt_rom);
@@ -480,9 +729,13 @@ struct HostModel {
       di.th = make_in(ang, t, 0); di.thd = make_in(ang, t, 1); di.thdd = make_in(ang, t, 2);
       for (int e = 0; e < NEE; ++e) { di.p[e] = make_in(eem[e], t, 0); di.f[e] = make_in(eef[e], t, 0); }
       di.row0 = off_dyn + 6 * (int)k;
+      BaseIn bi;
+      bi.r = make_in_sol(0, lin, t, 0); bi.a = make_in_sol(0, lin, t, 2);
+      bi.th = make_in_sol(1, ang, t, 0); bi.thd = make_in_sol(1, ang, t, 1); bi.thdd = make_in_sol(1, ang, t, 2);
+      dyn_sol.push_back(bi);
       ColBuilder cb{{}, this};
-      cb.group(di.r, di.c_lin);
-      cb.group(di.th, di.c_ang);
+      cb.group(bi.r, di.c_lin);
+      cb.group(bi.th, di.c_ang);
       for (int e = 0; e < NEE; ++e) { cb.group(di.p[e], di.c_p[e]); cb.group(di.f[e], di.c_f[e]); }
       di.ncol = (int)cb.cols.size();
       // the grid repeats T when floor(T/dt)*dt == T: the repeated block is the same six equations
@@ -527,8 +780,12 @@ struct HostModel {
         ri.r = make_in(lin, t, 0); ri.th = make_in(ang, t, 0); ri.p = make_in(eem[e], t, 0);
         ri.ee = e;
         ri.row0 = off_rom[e] + 3 * (int)k;
+        BaseIn bi;
+        std::memset(&bi, 0, sizeof(bi));
+        bi.r = make_in_sol(0, lin, t, 0); bi.th = make_in_sol(1, ang, t, 0);
+        rom_sol.push_back(bi);
         ColBuilder cb{{}, this};
-        cb.group(ri.r, ri.c_lin); cb.group(ri.th, ri.c_ang); cb.group(ri.p, ri.c_p);
+        cb.group(bi.r, ri.c_lin); cb.group(bi.th, ri.c_ang); cb.group(ri.p, ri.c_p);
         ri.ncol = (int)cb.cols.size();
         for (int d = 0; d < 3; ++d) {
           con_lo[ri.row0 + d] = P.nominal_stance[e][d] - P.max_dev[d];
@@ -588,8 +845,39 @@ struct HostModel {
     for (const LinRow &lr : linrow) {
       std::vector<int> cols;
       std::vector<double> vals;
-      for (int i = 0; i < lr.n; ++i)
+      bool on_base = false;
+      for (int i = 0; i < lr.n; ++i) {
+        if (reduce_base && replaced[lr.var[i]]) on_base = true;
         if (is_free(lr.var[i])) { cols.push_back(lr.var[i]); vals.push_back(lr.coef[i]); }
+      }
+      if (on_base) {
+        // reduced base: the row in the coefficients' space, A Z.  It vanishes wherever the basis is C2 (the row leaves the KKT
+        // system: still evaluated, its value is zero for every iterate) and stays at the two double knots.
+        std::vector<int> ccols;
+        std::vector<double> cvals;
+        double amax = 0.0;
+        for (size_t i = 0; i < cols.size(); ++i) {
+          amax = std::max(amax, std::fabs(vals[i]));
+          for (size_t q = 0; q < rec_var.size(); ++q) {
+            if (rec_var[q] != cols[i]) continue;
+            for (int a = 0; a < 4; ++a) {
+              const int col = rec_col[4 * q + a];
+              if (col < 0) continue;
+              size_t at = 0;
+              while (at < ccols.size() && ccols[at] != col) ++at;
+              if (at == ccols.size()) { ccols.push_back(col); cvals.push_back(0.0); }
+              cvals[at] += vals[i] * rec_w[4 * q + a];
+            }
+          }
+        }
+        std::vector<int> kc;
+        std::vector<double> kv;
+        for (size_t i = 0; i < ccols.size(); ++i)
+          if (std::fabs(cvals[i]) > 1e-9 * amax) { kc.push_back(ccols[i]); kv.push_back(cvals[i]); }
+        if (kc.empty()) { row_kind[lr.row] = 0; continue; }
+        add_block(0, 1, lr.row, kc, true, kv.data());
+        continue;
+      }
       if (cols.empty()) { row_kind[lr.row] = 0; continue; }
       add_block(0, 1, lr.row, cols, true, vals.data());
     }

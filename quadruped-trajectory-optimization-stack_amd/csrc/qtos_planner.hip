@@ -154,9 +154,17 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   QtosPlanner *p = new QtosPlanner();
   p->device = device;
   p->max_batch = max_batch;
-  if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
-  p->S.cell_mode = 2;
-  if (p->S.build(p->M)) { fprintf(stderr, "qtos: %s\n", p->S.err.c_str()); delete p; return -1; }
+  // model + symbolic analysis; if the stage records and cells of the result do not fit the LDS next to the panels, again with
+  // smaller records (heavy stages then spill into continuation records): both are rebuilt, the analysis writes into the model
+  for (int cap : {0, 4096, 3072, 2048}) {
+    p->M = HostModel();
+    p->S = Symbolic();
+    if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
+    p->S.cell_mode = 2;
+    p->S.rec_cap_ints = cap;
+    if (p->S.build(p->M)) { fprintf(stderr, "qtos: %s\n", p->S.err.c_str()); delete p; return -1; }
+    if (kkt2_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) <= 160 * 1024 - 256) break;
+  }
   const HostModel &M = p->M;
   const Symbolic &S = p->S;
   int ndev = 0;
@@ -174,6 +182,11 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   DevPlan &D = p->dp;
   std::memset(&D, 0, sizeof(D));
   D.n_vars = M.n_vars; D.n_cons = M.n_cons; D.n_stages = S.n_stages; D.front = S.front;
+  D.n_sol = M.n_sol; D.n_rec = (int)M.rec_var.size();
+  TRY(p->upload(M.rec_var, &D.rec_var)); TRY(p->upload(M.rec_col, &D.rec_col)); TRY(p->upload(M.rec_w, &D.rec_w));
+  D.n_coef = M.reduce_base ? M.n_coef : 0; D.n_pz = (int)M.pz_var.size();
+  TRY(p->upload(M.pc_var, &D.pc_var)); TRY(p->upload(M.pc_w, &D.pc_w));
+  TRY(p->upload(M.pz_var, &D.pz_var)); TRY(p->upload(M.pz_col, &D.pz_col)); TRY(p->upload(M.pz_w, &D.pz_w));
   D.n_dyn = (int)M.dyn.size(); D.n_rom = (int)M.rom.size(); D.n_terr = (int)M.terr.size();
   D.n_force = (int)M.force.size(); D.n_lin = (int)M.linrow.size(); D.n_blocks = (int)M.blocks.size();
   TRY(p->upload(M.dyn, &D.dyn)); TRY(p->upload(M.rom, &D.rom)); TRY(p->upload(M.terr, &D.terr));
@@ -201,11 +214,11 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   for (int e = 0; e < NEE; ++e) D.off_eem[e] = M.off_eem[e];
   TRY(p->upload(S.cont, &D.cont));
   {  // stream positions of the pivot diagonals of every foot node's x and y (two-phase solve)
-    std::vector<int> dpos_of_var(M.n_vars, -1), td;
+    std::vector<int> dpos_of_var(M.n_sol, -1), td;
     for (int i = 0; i < (int)S.pack_src.size(); ++i)
       if ((S.pack_src[i] >> 28) == 5) {
         const int u = S.piv_unknown[S.pack_src[i] & 0x0fffffff];
-        if (u >= 0 && u < M.n_vars) dpos_of_var[u] = i;
+        if (u >= 0 && u < M.n_sol) dpos_of_var[u] = i;
       }
     for (const TerrInst &t : M.terr) { td.push_back(dpos_of_var[t.vx]); td.push_back(dpos_of_var[t.vy]); }
     if (td.empty()) td.assign(2, -1);
@@ -284,7 +297,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
   }
-  p->eval_lds = sizeof(double) * (((size_t)M.n_vars + 1) / 2 * 2 + std::max((size_t)DYN_LOC * D.dyn_chunk, (size_t)ROM_LOC * D.rom_chunk) +
+  p->eval_lds = sizeof(double) * (((size_t)M.n_sol + 1) / 2 * 2 + std::max((size_t)DYN_LOC * D.dyn_chunk, (size_t)ROM_LOC * D.rom_chunk) +
                                   std::max((size_t)DYN_VIN * D.dyn_chunk, (size_t)ROM_VIN * D.rom_chunk));
   if (p->eval_lds > 150 * 1024) {
     p->err = "too many dynamics knots for the LDS scratch";
@@ -304,7 +317,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   DevWork &W = p->wk;
   std::memset(&W, 0, sizeof(W));
   const size_t Bm = (size_t)max_batch, n = M.n_vars, m = M.n_cons;
-  TRY(p->alloc(&W.x, Bm * n)); TRY(p->alloc(&W.xt, Bm * n)); TRY(p->alloc(&W.dx, Bm * n));
+  TRY(p->alloc(&W.x, Bm * n)); TRY(p->alloc(&W.xt, Bm * n)); TRY(p->alloc(&W.dx, Bm * (size_t)M.n_sol));
   TRY(p->alloc(&W.g, Bm * m)); TRY(p->alloc(&W.gt, Bm * m)); TRY(p->alloc(&W.s, Bm * m));
   TRY(p->alloc(&W.zl, Bm * m)); TRY(p->alloc(&W.zu, Bm * m)); TRY(p->alloc(&W.ds, Bm * m));
   TRY(p->alloc(&W.dzl, Bm * m)); TRY(p->alloc(&W.dzu, Bm * m)); TRY(p->alloc(&W.sig, Bm * m));
@@ -330,7 +343,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.rhs, Bm * (size_t)S.n_unknowns));
   TRY(p->alloc(&W.minv, Bm * (size_t)S.n_stages * PIV * PIV));
   TRY(p->alloc(&W.sol, Bm * (size_t)S.n_stages * PIV)); TRY(p->alloc(&W.sol0, Bm * (size_t)S.n_stages * PIV));
-  TRY(p->alloc(&W.dx0, Bm * n)); TRY(p->alloc(&W.ur, Bm * m));
+  TRY(p->alloc(&W.dx0, Bm * (size_t)M.n_sol)); TRY(p->alloc(&W.ur, Bm * m));
   TRY(p->alloc(&p->d_start, Bm * QTOS_START_DOUBLES)); TRY(p->alloc(&p->d_goal, Bm * 3));
   TRY(p->alloc(&p->d_nodes, Bm * n)); TRY(p->alloc(&p->d_warm, Bm * n)); TRY(p->alloc(&p->d_map, Bm));
   if (hipHostMalloc((void **)&p->h_active, 2 * sizeof(int) * ((size_t)M.P.max_iter + 1), hipHostMallocMapped) != hipSuccess) { qtos_planner_destroy(p); return -3; }
@@ -353,7 +366,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
 
 static void fill_dims(const HostModel &M, const Symbolic &S, QtosDims *d) {
   std::memset(d, 0, sizeof(*d));
-  d->n_vars = M.n_vars; d->n_cons = M.n_cons; d->n_free = S.n_free;
+  d->n_vars = M.n_vars; d->n_cons = M.n_cons;
+  d->n_free = 0;
+  for (int v = 0; v < M.n_vars; ++v) d->n_free += M.is_free(v) ? 1 : 0;   // (the NLP's count; with reduce_base the KKT system has fewer: n_unknowns)
   for (int r = 0; r < M.n_cons; ++r) {
     const bool eq = M.con_lo[r] == M.con_hi[r];
     if (eq) d->n_eq++;
@@ -807,6 +822,38 @@ __global__ __launch_bounds__(256) void k_debug_guess(DevPlan P, DevWork W, int B
   for (int v = threadIdx.x; v < P.n_vars; v += blockDim.x) out[(size_t)b * P.n_vars + v] = initial_value(P, W, b, v, st, gl, map, tc);
 }
 
+// reduced base: what given nodes become when a solve starts from them (k_start's projection onto the coefficients' space)
+__global__ __launch_bounds__(256) void k_project_nodes(DevPlan P, const double *in, double *out, int B) {
+  extern __shared__ double cf[];
+  const int b = blockIdx.x, n = P.n_vars;
+  if (b >= B) return;
+  const double *x = in + (size_t)b * n;
+  double *y = out + (size_t)b * n;
+  for (int v = threadIdx.x; v < n; v += blockDim.x) y[v] = x[v];
+  for (int c = threadIdx.x; c < P.n_coef; c += blockDim.x) {
+    double acc = 0.0;
+    for (int a = 0; a < 4; ++a) acc = fma(P.pc_w[4 * c + a], x[P.pc_var[4 * c + a]], acc);
+    cf[c] = acc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < P.n_pz; i += blockDim.x) {
+    double acc = 0.0;
+    for (int a = 0; a < 4; ++a) acc = fma(P.pz_w[4 * i + a], cf[P.pz_col[4 * i + a]], acc);
+    y[P.pz_var[i]] = acc;
+  }
+}
+
+int qtos_project_nodes(QtosPlanner *p, int B, const double *nodes, double *nodes_out) {
+  if (!p || B < 1 || B > p->max_batch || !nodes || !nodes_out) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  const size_t bytes = (size_t)B * p->M.n_vars * sizeof(double);
+  HIPCHK(p, hipMemcpy(p->d_warm, nodes, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_project_nodes, dim3(B), dim3(256), sizeof(double) * std::max(p->dp.n_coef, 1), 0, p->dp, p->d_warm, p->d_nodes, B);
+  HIPCHK(p, hipDeviceSynchronize());
+  HIPCHK(p, hipMemcpy(nodes_out, p->d_nodes, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int qtos_debug_initial_guess(QtosPlanner *p, int B, const double *start, const double *goal, const int *map_id, double *nodes_out) {
   if (!p || B < 1 || B > p->max_batch || !start || !goal || !nodes_out) return -1;
   HIPCHK(p, hipSetDevice(p->device));
@@ -850,6 +897,29 @@ __global__ __launch_bounds__(256) void k_debug_pack(DevPlan P, DevWork W, int B)
   }
 }
 
+// reduced base: the step of the base node values from the step of the coefficients (what k_step does at its start), for
+// the entry points that hand dx out
+__global__ __launch_bounds__(256) void k_recover_dx(DevPlan P, DevWork W, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  double *dx = W.dx + (size_t)b * P.n_sol;
+  for (int i = threadIdx.x; i < P.n_rec; i += blockDim.x) {
+    double acc = 0.0;
+    for (int a = 0; a < 4; ++a) {
+      const int col = P.rec_col[4 * i + a];
+      if (col >= 0) acc = fma(P.rec_w[4 * i + a], dx[col], acc);
+    }
+    dx[P.rec_var[i]] = acc;
+  }
+}
+// dx (node space, B x n_vars) of the last debug solve to the host
+static int copy_dx_out(QtosPlanner *p, const DevWork &W, int B, double *dx_out) {
+  if (p->dp.n_rec) hipLaunchKernelGGL(k_recover_dx, dim3(B), dim3(256), 0, 0, p->dp, W, B);
+  HIPCHK(p, hipDeviceSynchronize());
+  HIPCHK(p, hipMemcpy2D(dx_out, p->M.n_vars * sizeof(double), W.dx, p->M.n_sol * sizeof(double), p->M.n_vars * sizeof(double), B, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 static int debug_upload(QtosPlanner *p, int B, const double *start, const double *goal, const int *map_id, const double *nodes, DevWork *W) {
   if (!p || B < 1 || B > p->max_batch || !start || !goal || !nodes) return -1;
   HIPCHK(p, hipSetDevice(p->device));
@@ -867,6 +937,7 @@ static int debug_upload(QtosPlanner *p, int B, const double *start, const double
 
 int qtos_debug_eval(QtosPlanner *p, int B, const double *start, const double *goal, const int *map_id,
                     const double *nodes, double *g_out, double *J_out) {
+  if (J_out && p && p->M.reduce_base) { p->err = "qtos_debug_eval: the Jacobian in node space is not formed with reduce_base (create the planner without it)"; return -1; }
   DevWork W;
   int rc = debug_upload(p, B, start, goal, map_id, nodes, &W);
   if (rc) return rc;
@@ -903,7 +974,7 @@ int qtos_debug_newton(QtosPlanner *p, int B, const double *start, const double *
   hipLaunchKernelGGL(k_debug_pack, dim3(B), dim3(256), 0, 0, p->dp, W, B);
   hipLaunchKernelGGL(p->kkt_fn, dim3(B), dim3(p->kkt_threads), p->kkt_lds, 0, p->dp, W, B);
   HIPCHK(p, hipDeviceSynchronize());
-  HIPCHK(p, hipMemcpy(dx_out, W.dx, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost));
+  if (int rc = copy_dx_out(p, W, B, dx_out)) return rc;
   return 0;
 }
 
@@ -944,7 +1015,7 @@ int qtos_debug_chord(QtosPlanner *p, int B, double *dx_out) {
   hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), chord_lds_bytes(p->S.n_stages), 0, p->dp, W, B);
   hipLaunchKernelGGL(k_debug_unchord, dim3((B + 63) / 64), dim3(64), 0, 0, W, B);
   HIPCHK(p, hipDeviceSynchronize());
-  HIPCHK(p, hipMemcpy(dx_out, W.dx, (size_t)B * p->M.n_vars * sizeof(double), hipMemcpyDeviceToHost));
+  if (int rc = copy_dx_out(p, W, B, dx_out)) return rc;
   return 0;
 }
 
@@ -969,9 +1040,25 @@ int qtos_debug_residual(QtosPlanner *p, int B, int refine, double *dx_out, doubl
   hipLaunchKernelGGL(k_residual, dim3(B), dim3(512), 0, 0, p->dp, W, B, d_out, 0);
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy(res_rel_out, d_out, B * sizeof(double), hipMemcpyDeviceToHost);
-  if (e == hipSuccess && dx_out) e = hipMemcpy(dx_out, W.dx, (size_t)B * p->M.n_vars * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && dx_out && copy_dx_out(p, W, B, dx_out)) e = hipErrorUnknown;
   (void)hipFree(d_out);
   if (e != hipSuccess) { p->err = std::string("qtos_debug_residual: ") + hipGetErrorString(e); return -2; }
+  return 0;
+}
+
+/* diagnostic: the stage stream of problem b (qtos_debug_stream_len doubles) */
+int qtos_debug_stream_len(const QtosPlanner *p) { return p ? (int)p->S.pack_src.size() : -1; }
+int qtos_debug_read_stream(QtosPlanner *p, int b, double *out) {
+  if (!p || !out || b < 0 || b >= p->max_batch) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  HIPCHK(p, hipMemcpy(out, p->wk.stream + (size_t)b * p->S.pack_src.size(), p->S.pack_src.size() * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+/* diagnostic: the vector W.rhs of problem b (n_unknowns doubles, elimination order): after qtos_debug_residual the residual */
+int qtos_debug_read_rhs(QtosPlanner *p, int b, double *out) {
+  if (!p || !out || b < 0 || b >= p->max_batch) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  HIPCHK(p, hipMemcpy(out, p->wk.rhs + (size_t)b * p->S.n_unknowns, p->S.n_unknowns * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -13,6 +13,7 @@
 // of eliminated pivots are recycled).
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -188,15 +189,19 @@ struct Symbolic {
   //  per record; larger fronts -- three panels of up to 85 KB -- get 4096 / 1280 and spill the rest of a heavy
   //  stage into continuation records)
   int REC_MAX_DOUBLES = 2048, REC_MAX_INTS = 6144;
+  int rec_cap_ints = 0;   // optional upper limit of a record's ints (qtos_planner_create retries with smaller records if the LDS budget is exceeded)
   std::vector<int> cont;   // continuation records: {srec offset, ints, stream offset, doubles} each
   // dynamic part (per block G, sig, w) and gather table of the blocks `blks` of stage k, appended to the
   // record that starts at srec[s0] / pack_src[d0]; patches the record's header ints [4], [5]
   // the longest prefix of `blks` that fits a record which already holds `dyn` doubles and `fixed` ints
   template <class TRS>
   int split_blocks(const StageDesc &S, const std::vector<int> &blks, int dyn, int fixed, TRS trs,
-                   std::vector<int> &mine, std::vector<int> &rest) {
+                   std::vector<int> &mine, std::vector<int> &rest, int reserve = 0) {
+    // (reserve: static contributions emitted with this record -- one double, one contribution and at most one target each)
     std::set<int> targets;
-    int contrib = 0;
+    int contrib = reserve;
+    dyn += reserve;
+    fixed += reserve;
     for (int q : blks) {
       const IqBlock &Q = iq_blocks[S.iq_begin + q];
       if (Q.m > 5 || Q.n > 32) { err = "inequality block too large for the packed gather records"; return -1; }
@@ -214,8 +219,10 @@ struct Symbolic {
     }
     return 0;
   }
+  std::vector<std::array<int, 3>> sym_pp;   // static contributions as emitted: {position a, position b, stream position of the value}
   template <class TRS>
-  int emit_blocks(int k, const StageDesc &S, const std::vector<int> &blks, int s0, int d0, TRS trs) {
+  int emit_blocks(int k, const StageDesc &S, const std::vector<int> &blks, int s0, int d0, TRS trs,
+                  const std::vector<std::array<int, 5>> *syms = nullptr) {
     (void)k;
     std::vector<int> blk_goff(blks.size());
     for (size_t bi = 0; bi < blks.size(); ++bi) {
@@ -238,6 +245,15 @@ struct Symbolic {
         tmap[front * (front + 1) / 2 + sa].push_back(((int)bi << 16) | (a << 8) | 255);
       }
     }
+    // static contributions: code = offset of the value in the dynamic record | 62 << 18 (a one-by-one "block")
+    if (syms)
+      for (const auto &e : *syms) {
+        const int off = (int)pack_src.size() - d0;
+        if (off >= 4096) { err = "static entry beyond the reach of the packed gather records"; return -1; }
+        sym_pp.push_back({e[3], e[4], (int)pack_src.size()});
+        pack_src.push_back((1 << 28) | e[2]);
+        tmap[trs(e[0], e[1])].push_back(-(off + 1));   // (marked: rewritten below)
+      }
     srec[s0 + 4] = (int)srec.size() - s0;
     srec[s0 + 5] = (int)tmap.size();
     // one int per target (tri << 12 | first contribution), then one self-contained int per
@@ -255,6 +271,7 @@ struct Symbolic {
       srec.push_back((kv.first << 12) | cpos);
       cpos += (int)kv.second.size();
       for (int code : kv.second) {
+        if (code < 0) { codes.push_back((-code - 1) | (62 << 18)); continue; }   // static contribution
         const int bi = code >> 16, a = (code >> 8) & 255, c = code & 255;
         const IqBlock &Q = iq_blocks[S.iq_begin + blks[bi]];
         codes.push_back(blk_goff[bi] | (a << 12) | ((c == 255 ? 63 : c) << 18) | ((Q.n - 1) << 24) | (int)((unsigned)(Q.m - 1) << 29));
@@ -320,7 +337,7 @@ struct Symbolic {
       int *e = &srec[s0 + SHDR_INTS + PIV];
       for (int i = 0; i < n_ent; ++i) if ((e[i] = target(k, e[i])) < 0) return -1;
       for (int i = 0; i < n_rhs; ++i) if ((e[n_ent + i] = target(k, ntri_rhs + e[n_ent + i])) < 0) return -1;
-      if (srec[s0 + 2] == 0) return 0;
+      if (srec[s0 + 5] == 0) return 0;
       int *tg = &srec[s0 + srec[s0 + 4]];
       for (int t = 0; t < srec[s0 + 5]; ++t) {
         const int c = target(k, tg[t] >> 12);
@@ -354,11 +371,13 @@ struct Symbolic {
   }
 
   int build(HostModel &M) {
-    const int n = M.n_vars, m = M.n_cons;
+    // (solver variables: the model's variables, then -- QtosParams.reduce_base -- the B-spline coefficients that replace the
+    //  base node values inside the solve, model.hpp)
+    const int n = M.n_sol, m = M.n_cons;
     struct Key { double t; int id; };
     std::vector<Key> keys;
     for (int v = 0; v < n; ++v)
-      if (M.is_free(v)) keys.push_back({M.var_time[v], v});
+      if (M.is_unknown(v)) keys.push_back({M.var_time[v], v});
     n_free = (int)keys.size();
     // only rows that ended up in an equality block are multipliers
     std::vector<char> is_eq(m, 0);
@@ -406,6 +425,12 @@ struct Symbolic {
           }
         }
       }
+    }
+    for (const HostModel::SymEntry &e : M.sym_static) {
+      const int pa = var_pos[e.a], pb = var_pos[e.b];
+      if (pa < 0 || pb < 0) continue;
+      const int lo = std::min(pa, pb), hi = std::max(pa, pb);
+      first[hi] = std::min(first[hi], lo);
     }
     n_stages = (n_unknowns + PIV - 1) / PIV;
     if (const char *dump = getenv("QTOS_DUMP_FIRST")) {   // diagnostic: envelope of the ordered matrix (position -> first coupled position, unknown id)
@@ -515,7 +540,7 @@ struct Symbolic {
         if (i < hi) {
           piv_slot[q] = slot_of[i];
           piv_unknown[q] = order[i];
-          piv_diag[q] = order[i] < n ? M.P.delta_x : -M.P.eps_dual;
+          piv_diag[q] = order[i] < n ? M.sol_diag[order[i]] : -M.P.eps_dual;
         } else {
           piv_slot[q] = dummies[i - hi];
           piv_unknown[q] = -1;
@@ -552,6 +577,8 @@ struct Symbolic {
       }
     front = ((n_slots + PIV - 1) / PIV) * PIV;
     if (front > 128 && cell_mode == 2) { REC_MAX_INTS = 4096; REC_MAX_DOUBLES = 1280; }
+    // (the caller found the records too large for the LDS it has left: heavy stages spill into continuation records earlier)
+    if (rec_cap_ints > 0) { REC_MAX_INTS = std::min(REC_MAX_INTS, rec_cap_ints); REC_MAX_DOUBLES = std::min(REC_MAX_DOUBLES, rec_cap_ints / 3); }
     for (int j = 0; j < n_unknowns; ++j) {
       if (order[j] < n) var_slot[order[j]] = slot_of[j];
       else row_slot[order[j] - n] = slot_of[j];
@@ -604,6 +631,19 @@ struct Symbolic {
         }
       }
     }
+    // static entries between two variable unknowns (the proximal term of the reduced base: delta_x Z'Z off the diagonal).
+    // They share cells with the entries the inequality blocks assemble (J' S J of the same coefficient pairs), so they are
+    // NOT equality-type entries (added by other threads of the same assembly pass: a race on the cell): each becomes one more
+    // contribution of its target in the gather table of the stage that eliminates the earlier of the two -- the target's
+    // thread sums all of them in a fixed order.  {slot a, slot b, index into g_static, position a, position b}
+    std::vector<std::vector<std::array<int, 5>>> sym_of(n_stages);
+    for (const HostModel::SymEntry &se : M.sym_static) {
+      const int pa = var_pos[se.a], pb = var_pos[se.b];
+      if (pa < 0 || pb < 0) continue;
+      sym_of[std::min(pa, pb) / PIV].push_back({var_slot[se.a], var_slot[se.b], (int)M.g_static.size(), pa, pb});
+      M.g_static.push_back(se.val);
+    }
+    sym_pp.clear();
     for (int k = 0; k < n_stages; ++k) {
       stages[k].ent_begin = (int)eq_entries.size();
       eq_entries.insert(eq_entries.end(), ent[k].begin(), ent[k].end());
@@ -648,9 +688,9 @@ struct Symbolic {
       {
         std::vector<int> all(n_iq);
         std::iota(all.begin(), all.end(), 0);
-        if (split_blocks(S, all, (int)pack_src.size() - drec_off[k], (int)srec.size() - srec_off[k], trs, mine, rest)) return -1;
+        if (split_blocks(S, all, (int)pack_src.size() - drec_off[k], (int)srec.size() - srec_off[k], trs, mine, rest, (int)sym_of[k].size())) return -1;
       }
-      if (emit_blocks(k, S, mine, srec_off[k], drec_off[k], trs)) return -1;
+      if (emit_blocks(k, S, mine, srec_off[k], drec_off[k], trs, &sym_of[k])) return -1;
       srec[srec_off[k] + 2] = (int)mine.size();
       pending.push_back(rest);
       max_srec = std::max(max_srec, (int)srec.size() - srec_off[k]);
@@ -812,6 +852,10 @@ struct Symbolic {
           rows[pr].push_back({pv, spos});
           rows[pv].push_back({pr, spos});
         }
+      for (const auto &e : sym_pp) {
+        rows[e[0]].push_back({e[1], e[2]});
+        rows[e[1]].push_back({e[0], e[2]});
+      }
       kx_ptr.assign(1, 0);
       kx_col.clear(); kx_pos.clear();
       for (int p = 0; p < n_unknowns; ++p) {

@@ -82,8 +82,14 @@ def test_planner_dimensions_match_reference_log(hip_lib, cfg):
     """Same NLP as logs/towr_log.out:40-52: 1040 variables (1005 free), 706 + 1024 constraints,
     bound split 112 / 816 / 96 -- computed by the product's own host code."""
     from qtos_amd import capi
+    import dataclasses
     dims = json.load(open(os.path.join(GOLDEN, "nlp_dims.json")))
-    d, act = capi.analyze(cfg)
+    # (the NLP's own counts do not depend on how the KKT system is formed; the unknowns of the system do)
+    dr, actr = capi.analyze(dataclasses.replace(cfg, reduce_base=True))
+    assert (dr.n_vars, dr.n_cons, dr.n_free, dr.n_eq, dr.n_ineq) == (1040, 1730, dims["n_vars_free"], dims["n_eq"], dims["n_ineq"])
+    assert (dr.n_unknowns, dr.n_stages, dr.front) == (1121, 71, 96) and actr.max() <= dr.front
+    d, act = capi.analyze(dataclasses.replace(cfg, reduce_base=False))
+    assert (d.n_unknowns, d.n_stages, d.front) == (1685, 106, 112)
     assert (d.n_vars, d.n_cons, d.n_free) == (1040, 1730, dims["n_vars_free"])
     assert (d.n_eq, d.n_ineq) == (dims["n_eq"], dims["n_ineq"])
     assert (d.n_ineq_lower, d.n_ineq_both, d.n_ineq_upper) == (112, 816, 96)
@@ -110,10 +116,13 @@ def test_knots200_structure(hip_lib):
     cfg = PlannerConfig.knots200()
     assert [len(f) for f in cfg.phase_durations] == [17] * 4
     assert all(abs(sum(f) - 10.0) < 1e-12 for f in cfg.phase_durations)
-    d, act = capi.analyze(cfg)
+    import dataclasses
+    d, act = capi.analyze(dataclasses.replace(cfg, reduce_base=False))
     assert (d.n_base_nodes, d.n_dyn_times, d.n_vars, d.n_cons) == (201, 202, 3160, 4558)
     assert act.max() <= d.front == 128 and d.n_stages == 356
-    d2, _ = capi.analyze(PlannerConfig.knots100(duration=10.0))
+    dr, actr = capi.analyze(cfg)     # reduced base (the default): 5685 -> 3321 unknowns
+    assert (dr.n_vars, dr.n_cons) == (3160, 4558) and actr.max() <= dr.front == 128 and dr.n_stages == 208
+    d2, _ = capi.analyze(PlannerConfig.knots100(duration=10.0, reduce_base=False))
     assert d2.front > 128
 
 

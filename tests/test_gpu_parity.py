@@ -27,6 +27,18 @@ def planner(cfg):
     p.close()
 
 
+@pytest.fixture(scope="module")
+def planner_full(cfg):
+    """The planner with every row of the reference's NLP in the KKT system (reduce_base off): the tests that pin the
+    internals -- the node-space Jacobian, one KKT solve against a dense factorisation, the factor panels -- are written
+    for that system."""
+    import dataclasses
+    from qtos_amd.capi import Planner
+    p = Planner(dataclasses.replace(cfg, reduce_base=False), max_batch=256)
+    yield p
+    p.close()
+
+
 def _random_problems(n, seed, hard=False):
     from qtos_amd import workloads
     start, goal = workloads.flat_goals(n, seed)
@@ -53,18 +65,18 @@ def test_dims_match_reference_log(planner):
     assert (d.n_ineq_lower, d.n_ineq_both, d.n_ineq_upper) == (112, 816, 96)
 
 
-def test_constraints_and_jacobian_match_oracle(planner, oracle, gv1):
+def test_constraints_and_jacobian_match_oracle(planner_full, oracle, gv1):
     rng = np.random.default_rng(0)
     inp = gv1["inputs"]
     B = 6
-    x = gv1["x"][None] + 0.02 * rng.standard_normal((B, planner.n))
+    x = gv1["x"][None] + 0.02 * rng.standard_normal((B, planner_full.n))
     lo, hi = oracle.var_bounds(oracle_problem(oracle, inp))
     fx = lo == hi
     x[:, fx] = lo[fx]
     start = np.repeat(start_vector(inp)[None], B, 0)
     goal = np.repeat(np.array(inp["g"])[None], B, 0)
-    g, J = planner.debug_eval(start, goal, x)
-    rk, vf, _ = planner.structure()
+    g, J = planner_full.debug_eval(start, goal, x)
+    rk, vf, _ = planner_full.structure()
     assert np.array_equal(vf == 0, fx)
     for b in range(B):
         go, Jo = oracle.constraints(x[b]), oracle.jacobian(x[b])
@@ -80,7 +92,7 @@ def test_terrain_constraints_and_jacobian_match_oracle(gv1):
     from qtos_amd import workloads
     from qtos_amd.capi import Planner
     from qtos_amd.config import PlannerConfig
-    cfg = PlannerConfig.reference_compat(terrain_mode=0)   # bilinear: slopes enter the Jacobian
+    cfg = PlannerConfig.reference_compat(terrain_mode=0, reduce_base=False)   # bilinear: slopes enter the Jacobian; node-space Jacobian: the full system
     hxy, cell = workloads.exp5_terrain()
     O = Oracle(oracle_dict(cfg), height=hxy, hcell=cell)
     P = Planner(cfg, max_batch=4)
@@ -105,31 +117,31 @@ def test_terrain_constraints_and_jacobian_match_oracle(gv1):
     P.close()
 
 
-def test_kkt_solve_matches_dense_reference(planner, oracle, gv1, cfg):
+def test_kkt_solve_matches_dense_reference(planner_full, oracle, gv1, cfg):
     """One condensed KKT solve with random barrier weights vs LAPACK and vs the oracle's LDL^T."""
     import ctypes as C
     from oracle.oracle import lib as olib
     rng = np.random.default_rng(1)
     inp = gv1["inputs"]
     B = 4
-    x = gv1["x"][None] + 0.01 * rng.standard_normal((B, planner.n))
+    x = gv1["x"][None] + 0.01 * rng.standard_normal((B, planner_full.n))
     lo, hi = oracle.var_bounds(oracle_problem(oracle, inp))
     fx = lo == hi
     x[:, fx] = lo[fx]
     start = np.repeat(start_vector(inp)[None], B, 0)
     goal = np.repeat(np.array(inp["g"])[None], B, 0)
-    rk, _, _ = planner.structure()
+    rk, _, _ = planner_full.structure()
     I = rk == 2
-    sig = np.zeros((B, planner.m))
-    w = np.zeros((B, planner.m))
+    sig = np.zeros((B, planner_full.m))
+    w = np.zeros((B, planner_full.m))
     sig[:, I] = 10.0 ** rng.uniform(-3, 3, (B, I.sum()))
     w[:, I] = rng.standard_normal((B, I.sum()))
-    dx = planner.debug_newton(start, goal, x, sig, w)
+    dx = planner_full.debug_newton(start, goal, x, sig, w)
     # a-posteriori residual of the same solve (k_residual: K applied from the stream, no use of the factorisation), then one
     # step of iterative refinement through the stored factorisation (k_chord) and its residual
-    dx_same, res_plain = planner.debug_residual(B, refine=False)
+    dx_same, res_plain = planner_full.debug_residual(B, refine=False)
     assert np.array_equal(dx_same, dx)
-    dx_ref, res_ref = planner.debug_residual(B, refine=True)
+    dx_ref, res_ref = planner_full.debug_residual(B, refine=True)
     free, E, Ii = np.nonzero(~fx)[0], np.nonzero(rk == 1)[0], np.nonzero(I)[0]
     nf, nE = len(free), len(E)
     achieved = []
@@ -181,7 +193,47 @@ def test_kkt_solve_matches_dense_reference(planner, oracle, gv1, cfg):
         json.dump(achieved, open(os.path.join(out, "kkt_accuracy.json"), "w"), indent=1)
 
 
-def test_chord_step_kernel_matches_the_factorising_kernel(planner, oracle, gv1, cfg):
+def test_reduced_base_system_gives_the_newton_step_of_the_full_system(cfg):
+    """QtosParams.reduce_base: inside the KKT solve the base node values are replaced by the coefficients of a clamped cubic
+    B-spline on the same knots (a basis of the C2 splines the acceleration-continuity rows describe): 2885 -> 1721 unknowns,
+    181 -> 108 stages on the 100-knot transcription.  At a point of that space (towr's straight-line guess) one Newton step
+    of the reduced system equals the step of the full system -- random barrier weights, same right-hand side -- to 1e-7 of its
+    largest entry (the full system regularises the multipliers of the eliminated rows with eps_dual = 1e-8, the reduced one
+    has no such multipliers), the reduced system's own residual is at rounding level, and the recovered step keeps the
+    acceleration continuity."""
+    import dataclasses
+    from qtos_amd import capi, workloads
+    from qtos_amd.config import PlannerConfig
+    rng = np.random.default_rng(3)
+    B = 2
+    s, g = workloads.flat_goals(B, 0)
+    for base in (cfg, PlannerConfig.knots100()):
+        out, dims = {}, {}
+        sig = w = None
+        for rb in (False, True):
+            P = capi.Planner(dataclasses.replace(base, reduce_base=rb), max_batch=B)
+            dims[rb] = (P.dims.n_unknowns, P.dims.n_stages)
+            x0 = P.initial_guess(s, g)
+            rk, _, _ = P.structure()
+            I = rk == 2
+            if sig is None:
+                sig = np.zeros((B, P.m)); w = np.zeros((B, P.m))
+                sig[:, I] = 10.0 ** rng.uniform(-2, 2, (B, I.sum())); w[:, I] = rng.standard_normal((B, I.sum()))
+            dx = P.debug_newton(s, g, x0, sig, w)
+            _, res = P.debug_residual(B, refine=False)
+            dxr, res1 = P.debug_residual(B, refine=True)
+            out[rb] = dxr
+            assert res1.max() < 1e-11
+            if rb:
+                assert res.max() < 1e-8          # (the full system's first solve: 1e-6, see test_kkt_solve_matches_dense_reference)
+            P.close()
+        assert dims[True][0] < 0.7 * dims[False][0] and dims[True][1] < 0.7 * dims[False][1]
+        scale = np.abs(out[False]).max()
+        assert np.abs(out[True] - out[False]).max() < 1e-7 * scale
+    assert dims == {False: (2885, 181), True: (1721, 108)}
+
+
+def test_chord_step_kernel_matches_the_factorising_kernel(planner_full, oracle, gv1, cfg):
     """k_chord (QtosParams.chord_tol: reuse of the stored factorisation with a new right-hand side) solves the system
     of the preceding factorisation to the accuracy of that factorisation; and a solve with chord steps uses one
     factorisation less than one without, in the same number of iterations (the oracle applies the same rule)."""
@@ -190,22 +242,22 @@ def test_chord_step_kernel_matches_the_factorising_kernel(planner, oracle, gv1, 
     rng = np.random.default_rng(3)
     inp = gv1["inputs"]
     B = 4
-    x = gv1["x"][None] + 0.01 * rng.standard_normal((B, planner.n))
+    x = gv1["x"][None] + 0.01 * rng.standard_normal((B, planner_full.n))
     start = np.repeat(start_vector(inp)[None], B, 0)
     goal = np.repeat(np.array(inp["g"])[None], B, 0)
-    rk, _, _ = planner.structure()
+    rk, _, _ = planner_full.structure()
     I = rk == 2
-    sig = np.zeros((B, planner.m))
-    w = np.zeros((B, planner.m))
+    sig = np.zeros((B, planner_full.m))
+    w = np.zeros((B, planner_full.m))
     sig[:, I] = 10.0 ** rng.uniform(-3, 3, (B, I.sum()))
     w[:, I] = rng.standard_normal((B, I.sum()))
-    dx = planner.debug_newton(start, goal, x, sig, w)
-    dc = planner.debug_chord(B)
+    dx = planner_full.debug_newton(start, goal, x, sig, w)
+    dc = planner_full.debug_chord(B)
     assert np.abs(dc - dx).max() <= 1e-7 * np.abs(dx).max()
     # full solves: 3 factorisations + 1 chord step instead of 4 factorisations on the benchmark goals
     s, g = _random_problems(12, seed=11)
-    n1, st1, it1, _ = planner.plan(s, g)
-    t1 = planner.timing()
+    n1, st1, it1, _ = planner_full.plan(s, g)
+    t1 = planner_full.timing()
     P0 = Planner(dataclasses.replace(cfg, chord_tol=0.0), max_batch=12)
     n0, st0, it0, _ = P0.plan(s, g)
     t0 = P0.timing()
@@ -674,7 +726,8 @@ def test_shifted_windows_match_oracle_over_five_replans():
         nodes, status = W.replan()
         torch.cuda.synchronize()
         st, gl = W.start.cpu().numpy(), W.goal.cpu().numpy()
-        warm = W.warm.cpu().numpy() if k >= 4 else [None] * 4
+        # (a solve that is given nodes starts from their projection onto the reduced base's spline space: the oracle gets the same)
+        warm = P.project(W.warm.cpu().numpy()) if k >= 4 else [None] * 4
         it = W.iters.cpu().numpy()
         if k > 0:   # hand-over rows: all four feet carry force, a few hundred rows after `advance`
             assert (W.offset.cpu().numpy() >= 2.5).all() and (W.offset.cpu().numpy() <= 2.9).all()
@@ -715,7 +768,7 @@ def test_mixed_terrain_batch_with_map_ids(cfg):
     P.close()
 
 
-def _batch_vs_oracle(cfg, start, goal, sel, maps=None, cell=None, map_id=None, status=None, iters=None, nodes=None):
+def _batch_vs_oracle(cfg, start, goal, sel, maps=None, cell=None, map_id=None, status=None, iters=None, nodes=None, tol=1e-6):
     """The problems `sel` of a batch solved by the oracle (OpenMP over the problems, one oracle per heightfield): returns
     the number of problems whose status and iteration count equal the GPU's and whose nodes agree to 1e-6, and the
     worst node difference among them."""
@@ -734,29 +787,33 @@ def _batch_vs_oracle(cfg, start, goal, sel, maps=None, cell=None, map_id=None, s
         for j, b in enumerate(idx):
             if infos[j].status == int(status[b]) and infos[j].iters == int(iters[b]):
                 e = float(np.abs(nodes[b] - xo[j]).max())
-                if e < 1e-6:
+                if e < tol:
                     same += 1
                     worst = max(worst, e)
     return same, worst
 
 
-def test_trot_gait_batch_matches_oracle():
+@pytest.mark.parametrize("reduce_base", [False, True])
+def test_trot_gait_batch_matches_oracle(reduce_base):
     """The gait BASELINE.json's metric names (diagonal-pair trot, config.TROT_UNNORMALISED; the reference's committed
     plans are the walk), at the benchmark's transcription and batch size: all 256 seeded flat goals converge, and the
-    first 32 take the oracle's iterations to the oracle's nodes (1e-6)."""
+    first 32 take the oracle's iterations to the oracle's nodes: to 1e-6 with every row of the NLP in the KKT system, to
+    5e-6 with the reduced base (the default) -- the oracle regularises the multipliers of the acceleration-continuity rows
+    with eps_dual = 1e-8 (its plans keep a continuity residual of eps_dual times those multipliers), the reduced system
+    satisfies the rows identically; over the trot's 4 .. 5 iterations the two drift 1e-6 apart (the walk: 2e-8)."""
     from qtos_amd import workloads
     from qtos_amd.capi import Planner
     from qtos_amd.config import PlannerConfig
-    cfg = PlannerConfig.knots100(gait="trot")
+    cfg = PlannerConfig.knots100(gait="trot", reduce_base=reduce_base)
     B = 256
     P = Planner(cfg, max_batch=B)
-    assert (P.dims.n_vars, P.dims.n_stages) == (1880, 200)
+    assert (P.dims.n_vars, P.dims.n_stages) == (1880, 127 if reduce_base else 200)
     start, goal = workloads.flat_goals(B, seed=0)
     nodes, status, iters, viol = P.plan(start, goal)
     P.close()
     assert (status == 0).all() and viol.max() <= cfg.tol
     assert iters.max() <= 6
-    same, worst = _batch_vs_oracle(cfg, start, goal, range(32), status=status, iters=iters, nodes=nodes)
+    same, worst = _batch_vs_oracle(cfg, start, goal, range(32), status=status, iters=iters, nodes=nodes, tol=5e-6 if reduce_base else 1e-6)
     assert same == 32, (same, worst)
 
 
@@ -912,25 +969,25 @@ def test_stall_detection_returns_best_iterate(cfg):
 
 
 @pytest.mark.gpu
-def test_factor_panels_match_block_elimination(planner, oracle, gv1, cfg):
+def test_factor_panels_match_block_elimination(planner_full, oracle, gv1, cfg):
     """The factor panels k_kkt leaves in HBM (per stage w = L^-T D^-1 y_F and V = Y D^-1 L^-1) against
-    an independent numpy block elimination of the same KKT matrix in the planner's elimination order
+    an independent numpy block elimination of the same KKT matrix in the planner_full's elimination order
     (16 pivots per stage, unpivoted LDL^T of the pivot block, explicit L^-1), stage by stage: this
     pins the chain itself, not only the solution it produces.  Tolerance 1e-6 relative to the stage's
     largest entry (the factors reach 1e8 where a multiplier is eliminated)."""
     rng = np.random.default_rng(5)
     inp = gv1["inputs"]
-    x = gv1["x"][None] + 0.01 * rng.standard_normal((1, planner.n))
+    x = gv1["x"][None] + 0.01 * rng.standard_normal((1, planner_full.n))
     lo, hi = oracle.var_bounds(oracle_problem(oracle, inp))
     fx = lo == hi
     x[:, fx] = lo[fx]
     start, goal = start_vector(inp)[None], np.array(inp["g"])[None]
-    rk, _, order = planner.structure()
+    rk, _, order = planner_full.structure()
     I = rk == 2
-    sig = np.zeros((1, planner.m)); w = np.zeros((1, planner.m))
+    sig = np.zeros((1, planner_full.m)); w = np.zeros((1, planner_full.m))
     sig[:, I] = 10.0 ** rng.uniform(-3, 3, (1, I.sum())); w[:, I] = rng.standard_normal((1, I.sum()))
-    dx = planner.debug_newton(start, goal, x, sig, w)
-    pan, ps = planner.factor(0)
+    dx = planner_full.debug_newton(start, goal, x, sig, w)
+    pan, ps = planner_full.factor(0)
     free, E, Ii = np.nonzero(~fx)[0], np.nonzero(rk == 1)[0], np.nonzero(I)[0]
     nf, nE = len(free), len(E)
     Jo, go = oracle.jacobian(x[0]), oracle.constraints(x[0])
@@ -941,7 +998,7 @@ def test_factor_panels_match_block_elimination(planner, oracle, gv1, cfg):
     rhs = np.concatenate([-JI.T @ w[0, Ii], -go[E]])
     pos_of_var = {v: i for i, v in enumerate(free)}
     pos_of_row = {r: nf + i for i, r in enumerate(E)}
-    perm = np.array([pos_of_var[u] if u < planner.n else pos_of_row[u - planner.n] for u in order])
+    perm = np.array([pos_of_var[u] if u < planner_full.n else pos_of_row[u - planner_full.n] for u in order])
     N = len(perm); NS = (N + 15) // 16; Np = NS * 16
     S = np.eye(Np); S[:N, :N] = K[np.ix_(perm, perm)]
     y = np.zeros(Np); y[:N] = rhs[perm]
@@ -989,7 +1046,7 @@ def test_knots200_receding_window_on_random_heightfields():
     cfg = PlannerConfig.knots200(honor_start_velocity=True)   # a replan continues the motion it starts in
     B, NCHK = 64, 3
     P = Planner(cfg, max_batch=B)
-    assert (P.dims.n_dyn_times, P.dims.front, P.dims.n_stages) == (202, 128, 356)
+    assert (P.dims.n_dyn_times, P.dims.front, P.dims.n_stages) == (202, 128, 208)   # (356 stages with every continuity row in the system)
     maps, cell = workloads.random_terrains()
     P.set_heightfields(maps, cell)
     start, goal, mid = workloads.mpc_goals(B, terrains=(maps, cell))
@@ -1036,7 +1093,7 @@ def test_knots200_receding_window_on_random_heightfields():
         ok = status == 0
         assert ok.mean() >= 0.9
         assert np.median(iters[ok]) < np.median(cold_iters)            # the warm start pays
-        assert check(chk, nodes, status, iters, nstart, warm) >= NCHK - 1
+        assert check(chk, nodes, status, iters, nstart, P.project(warm)) >= NCHK - 1   # (what the solve starts from: the nodes' projection onto the reduced base's spline space)
         start = nstart
     # (the 20 ms look-ahead loop of round 1 drifts after ~28 replans -- replanning from one's own first 20 ms -- and is not
     #  the reference's loop: the reference's hand-over rule, 2.5 s ahead with all feet down, is exercised over 20 replans
@@ -1045,6 +1102,7 @@ def test_knots200_receding_window_on_random_heightfields():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("reduce_base", [False, True])
 @pytest.mark.parametrize("kw,front,heavy", [
     (dict(duration=12.0), 160, True),                                  # default-TOWR mode on a 3-tile experiment: `-duration 4.0 * tiles`
                                                                        # (scripts/main.py:119-120): a 160-slot front, `k_kkt2<160>`
@@ -1060,16 +1118,18 @@ def test_knots200_receding_window_on_random_heightfields():
     (dict(duration=1.0, dt_dynamic=0.5, dt_base=0.5, dt_range_of_motion=0.5), 64, False),              # a 64-slot front: `k_kkt<64>`, four
                                                                        # of the eight waves without a panel tile
 ])
-def test_other_horizons_match_oracle(kw, front, heavy):
+def test_other_horizons_match_oracle(kw, front, heavy, reduce_base):
     """Horizons other than 5 s (the reference's `-duration` flag rescales the gait schedule): other
     front sizes (other `k_kkt<F>` instantiations) and, for long stance phases, stages whose inequality
     blocks spill into continuation records.  GPU vs oracle, same iterates."""
     from oracle.oracle import Oracle, oracle_dict
     from qtos_amd import capi, workloads
     from qtos_amd.config import PlannerConfig
-    cfg = PlannerConfig.reference_compat(**kw)
+    cfg = PlannerConfig.reference_compat(reduce_base=reduce_base, **kw)
     d, _ = capi.analyze(cfg)
-    assert d.front == front
+    # fronts of the full system as listed; with the reduced base (half the base unknowns, no continuity multipliers) they are
+    # the same or smaller -- 12 s: 128 instead of 160, 20 s: 176 instead of 208
+    assert d.front == front if not reduce_base else d.front <= front
     P = capi.Planner(cfg, max_batch=8)
     O = Oracle(oracle_dict(cfg))
     assert (P.n, P.m) == (O.n, O.m)
@@ -1082,7 +1142,10 @@ def test_other_horizons_match_oracle(kw, front, heavy):
     xo, infos = _oracle_solve(O, start[:4], goal[:4])
     assert [i[0] for i in infos] == [0] * 4
     assert [int(i) for i in iters[:4]] == [i[1] for i in infos]
-    assert np.abs(nodes[:4] - xo).max() < 1e-6
+    # (reduced base, 12 .. 14 iterations of the 20 s horizons: the oracle's full system regularises the multipliers of the
+    #  continuity rows with eps_dual = 1e-8, the reduced one has none -- the iterates drift apart by 1e-7 of their size per
+    #  iteration on these ill-conditioned horizons)
+    assert np.abs(nodes[:4] - xo).max() < (1e-5 if reduce_base and cfg.duration >= 10.0 else 1e-6)
     P.close()
 
 
