@@ -43,8 +43,8 @@ REF_LOG_PLANS_PER_S = 1.0 / 0.745  # logs/towr_log.out:81-82, unknown CPU -- not
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="plans per GPU per step")
     ap.add_argument("--transcription", default="knots100", choices=["knots100", "reference_compat", "knots200"])
     ap.add_argument("--gait", default="walk", choices=["walk", "trot"],
@@ -73,6 +73,9 @@ def parse_args():
     ap.add_argument("--advance", type=float, default=2.5,
                     help="mpc_random: seconds into its newest plan at which a window's next plan starts (the reference's "
                          "f_steps = 2500 rows, scripts/main.py:177; moved on until all feet are in contact)")
+    ap.add_argument("--full-system", action="store_true",
+                    help="every row of the reference's NLP in the KKT system (PlannerConfig.reduce_base off: 2885 unknowns / 181 "
+                         "stages instead of 1721 / 108 on the 100-knot transcription) -- the system rounds 1 and 2 solved")
     ap.add_argument("--force-torchrun", action="store_true",
                     help="launch the ranks through torch.distributed.run even for --gpus 1 (exercises the child-process path "
                          "and the RCCL all-gather at world size 1)")
@@ -197,6 +200,8 @@ def main():
         kw["chord_tol"] = 0.0
     if args.gait == "trot":
         kw["gait"] = "trot"
+    if args.full_system:
+        kw["reduce_base"] = False
     if mpc and args.inflight > 1 and args.batch % args.inflight:
         raise SystemExit("--inflight must divide --batch for mpc_random (the windows are split into that many sets)")
     cfg = {"knots100": PlannerConfig.knots100, "knots200": PlannerConfig.knots200,
@@ -438,7 +443,7 @@ def main():
             "iterations_max_last_step": int(itn.max()),
             "iterations_mean": round(float(iters_dev.item()) / max(B * args.steps, 1), 3) if (solved_inflight is None or lanes) else None,
             "parallelism": "batch-shard x%d + 1 %s" % (world, "RCCL all-gather" if use_dist else "all-gather (not launched under torch.distributed: single process)"),
-            "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front,
+            "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front, "reduce_base": bool(cfg.reduce_base),
             "batches_in_flight": args.inflight, "max_iter": cfg.max_iter, "chord_tol": cfg.chord_tol,
             "initial_guess": "towr straight line" if args.init == "straight_line" else
                              "interpolated table of %d nominal plans (solved before the timed region)" % (P.init_table[2].shape[0] * P.init_table[2].shape[1]),
@@ -472,6 +477,14 @@ def main():
     if kkt_n:
         avg = kkt_s / kkt_n
         alg_bytes = float(B) * d.kkt_algorithmic_bytes
+        full_sys = None
+        if cfg.reduce_base:
+            import dataclasses
+            from qtos_amd.capi import analyze
+            dfull, _ = analyze(dataclasses.replace(cfg, reduce_base=False))
+            full_sys = {"kkt_unknowns": dfull.n_unknowns, "kkt_stages": dfull.n_stages, "bytes_per_launch": float(B) * dfull.kkt_algorithmic_bytes,
+                        "achieved_if_priced_with_its_bytes": round(B * dfull.kkt_algorithmic_bytes / avg / 1e9, 2),
+                        "frac_if_priced_with_its_bytes": round(B * dfull.kkt_algorithmic_bytes / avg / 1e9 / HBM_PEAK_GBS, 5)}
         achieved = alg_bytes / avg / 1e9
         out["roofline"] = {
             "kernel": "k_kkt2", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -479,6 +492,10 @@ def main():
             "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
             "bytes_per_launch": alg_bytes, "avg_launch_ms": round(1e3 * avg, 4), "launches": kkt_n,
             "fp64_tflops": round(B * d.kkt_flops / avg / 1e12, 3), "fp64_peak_tflops": 78.6,
+            # the same launch priced with the bytes of the FULL KKT system of the reference's NLP (every acceleration-continuity
+            # row with its multiplier: what rounds 1 and 2 factored): the reduced base solves that system's Newton step with
+            # 1721 instead of 2885 unknowns, so `achieved` above (the SURVEY.md 8d formula on the stages actually run) counts fewer bytes
+            "full_system": full_sys,
             "kkt_share_of_device_time": round(kkt_s / max(tot_s, 1e-12), 3),
             "launches_per_step": round(kkt_n / max(args.steps, 1), 2),
             # k_chord: a solve that re-uses the factor panels of the preceding k_kkt2 launch (no assembly,

@@ -55,6 +55,7 @@ struct QtosPlanner {
     double *nodes_out = nullptr, *viol_out = nullptr;
     int *status_out = nullptr, *iters_out = nullptr;
   } call;
+  bool counts_by_copy = false;       // the counts of unfinished problems reach the host by hipMemcpyAsync instead of k_post_counts (QTOS_COUNTS_COPY=1)
   int spec_next = 1;                 // blind iterations of the next call: the iterations the last one took
   int spec_cap = 1;                  // limit of the blind iterations (qtos_set_speculation): 1 = off, the measured optimum
   std::atomic<int> busy{0};
@@ -354,7 +355,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   if (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   if (hipMalloc(&p->d_totals, 2 * sizeof(long long)) != hipSuccess || hipMemset(p->d_totals, 0, 2 * sizeof(long long)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
   p->last_stream = p->own_stream;
-  if (const char *e = getenv("QTOS_SPEC_CAP")) p->spec_cap = std::max(0, atoi(e));   // (diagnostic: limit of the blind iterations)
+  if (const char *e = getenv("QTOS_SPEC_CAP")) p->spec_cap = std::max(0, atoi(e));
+  if (const char *e = getenv("QTOS_COUNTS_COPY")) p->counts_by_copy = atoi(e) != 0;   // (diagnostic: limit of the blind iterations)
   if (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   p->ev.resize(5 * (size_t)M.P.max_iter + 3);
   for (auto &e : p->ev)
@@ -497,7 +499,8 @@ static int queue_iteration(QtosPlanner *p, int it, bool informed, int n, int nc)
     HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
   }
   hipLaunchKernelGGL(k_step, dim3(c.B), dim3(ET), p->eval_lds, st, D, c.W, c.B, it);
-  hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * it);
+  if (p->counts_by_copy) HIPCHK(p, hipMemcpyAsync(p->h_active + 2 * it, c.W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * it);
   HIPCHK(p, hipEventRecord(p->ev[6 + 5 * it], st));
   return 0;
 }
@@ -532,7 +535,8 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
   hipLaunchKernelGGL(k_start, dim3(B), dim3(ET), p->eval_lds, st, D, c.W, B);
   // counts after k_start (slot max_iter of the pinned array), event ev_start
   const int ev_start = 2 + 5 * D.max_iter;
-  hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * D.max_iter);
+  if (p->counts_by_copy) SUBCHK(hipMemcpyAsync(p->h_active + 2 * D.max_iter, c.W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * D.max_iter);
   SUBCHK(hipEventRecord(p->ev[ev_start], st));
 #undef SUBCHK
   // Blind iterations: as many as the previous call of this handle needed (its slowest problem), queued without a host

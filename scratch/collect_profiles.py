@@ -1,14 +1,15 @@
-"""Copy the artefacts of scratch/final_measure2.sh (gpurun_out/*_<tag>*) into profiles/ as the round's set and derive
+"""Copy the artefacts of scratch/final_measure3.sh (gpurun_out/*_<tag>*) into profiles/ as the round's set and derive
 the per-launch HBM traffic and the SQ-counter summary of the KKT kernel from the PMC passes.
 usage: python scratch/collect_profiles.py <tag> [r02]"""
 import csv, collections, json, os, shutil, sys
 tag = sys.argv[1]
-R = sys.argv[2] if len(sys.argv) > 2 else "r02"
+R = sys.argv[2] if len(sys.argv) > 2 else "r03"
 G = "gpurun_out/"
 names = {"default": "bench", "compat": "bench_reference_compat", "exp5": "bench_exp5", "mixed": "bench_mixed", "trot": "bench_trot",
          "tol1e-3": "bench_tol1e-3", "batch512": "bench_batch512", "batch1024": "bench_batch1024", "knots200": "bench_knots200",
          "mpc": "bench_knots200_mpc_random", "mpc_1set": "bench_knots200_mpc_random_one_set", "table": "bench_init_table", "inflight2": "bench_flat_inflight2",
-         "nochord": "bench_no_chord_step", "torchrun1": "bench_torchrun_1rank"}
+         "nochord": "bench_no_chord_step", "torchrun1": "bench_torchrun_1rank", "full_system": "bench_full_system",
+         "exp5_lanes3": "bench_exp5_lanes3", "mixed_lanes3": "bench_mixed_lanes3", "lanes2": "bench_flat_lanes2", "steps500": "bench_steps500"}
 for src, dst in names.items():
     f = G + "bench_%s_%s.json" % (tag, src)
     if not os.path.exists(f):
@@ -34,7 +35,7 @@ for name, f in (("FETCH_SIZE", G + "pmc_fetch_%s/runc_counter_collection.csv" % 
 kk = [k for k in out["FETCH_SIZE"] if "k_kkt" in k][0]
 f, w = out["FETCH_SIZE"][kk]["mean_KB"], out["WRITE_SIZE"][kk]["mean_KB"]
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of `python3 bench.py --steps 3 --warmup 1 "
-               "--cpu-sample 0 --no-parity` (batch 256, knots100). KB per dispatch. gfx950: FETCH_SIZE reports 1/2 of the bytes of wide "
+               "--cpu-sample 0 --no-parity --no-trot` (batch 256, knots100). KB per dispatch. gfx950: FETCH_SIZE reports 1/2 of the bytes of wide "
                "coalesced reads (calibrated for 16 B/lane; the kernel reads 8-16 B/lane) -> HBM bytes per launch between (F+W)*1024 and "
                "(2F+W)*1024; bench.py reports the larger.")
 out["k_kkt_traffic_bytes_per_launch"] = {"raw": (f + w) * 1024, "fetch_x2": (2 * f + w) * 1024}
@@ -57,7 +58,7 @@ for sub in ("pmc_sq_%s" % tag, "pmc_sq2_%s" % tag):
         for c, x in v.items():
             d[c] = sum(x) / len(x)
             d["dispatches"] = len(x)
-summ = {"note": "rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-parity`; means per dispatch, "
+summ = {"note": "rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-parity --no-trot`; means per dispatch, "
                 "summed over the chip by the profiler. SQ_*_CYCLES / SQ_WAIT* / SQ_ACTIVE_INST_* count quad-cycles (x4 = cycles); "
                 "SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD. 256 CUs x 4 SIMDs, 16 waves per CU.",
         "raw": sq}
