@@ -20,6 +20,20 @@
 
 namespace qtos {
 
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+
+// a terrain row for the evaluation kernels: TerrInst with everything that depends on the symbolic analysis resolved on the
+// host -- stream positions of its three Jacobian entries (equality block of a stance row: Symbolic::eq_pos; inequality
+// block: its offset; -1 = not in the KKT system) and of the pivot diagonals of the foot node's x, y (two-phase solve, -1 = none)
+struct TerrDev {
+  int vx, vy, vz, row;
+  int px, py, pz;
+  int d0, d1;
+  int pad;
+};
+
 struct DevPlan {
   int n_vars, n_cons, n_stages, front;
   // solver variables (QtosParams.reduce_base): ids < n_vars = the model's variables, n_vars .. n_sol - 1 = B-spline coefficients
@@ -35,13 +49,19 @@ struct DevPlan {
   int n_dyn, n_rom, n_terr, n_force, n_lin, n_blocks;
   const DynInst *dyn;
   const RomInst *rom;
-  const TerrInst *terr;
+  // spline inputs of the dynamics knots / range-of-motion instances, one record per (instance, input vector, component) in the
+  // order of the pre-pass: the four variables and the four Hermite weights of VecIn, flat (vec_prepass)
+  const i4_t *pre_dyn_var, *pre_rom_var;
+  const d2_t *pre_dyn_wa, *pre_dyn_wb, *pre_rom_wa, *pre_rom_wb;
+  const TerrDev *terr;         // (TerrInst with its stream positions resolved on the host)
   const ForceInst *force;
   const LinRow *lin;
   // iterate-dependent Jacobian entries of the dynamics / range-of-motion columns as linear forms over
   // the local Jacobians in LDS, in stream order (model.hpp: LinTerm1 / LinTerm3)
-  const LinTerm1 *dyn_t1, *rom_t1;
-  const LinTerm3 *dyn_t3;
+  const PackedTerm1 *dyn_t1, *rom_t1;
+  const PackedTerm3 *dyn_t3;
+  const double *lin_coef;      // the distinct coefficients of the three lists
+  int n_lin_coef;
   const int *dyn_t1_off, *dyn_t3_off;   // first entry of every knot chunk (+ end)
   int n_rom_t1;
   int rom_chunk;               // range-of-motion instances evaluated per pass (LDS scratch bound)
@@ -54,7 +74,6 @@ struct DevPlan {
   int off_lin, off_ang, off_eem[NEE];   // first variable of the base / foot motion node sets
   const int *cont;             // continuation records of heavy stages: {srec offset, ints, stream offset, doubles} each
   int n_cont;                  // how many there are in the whole plan (0 for the standard transcriptions)
-  const int *terr_dpos;        // n_terr x 2: stream positions of the pivot diagonals of a foot node's x and y (-1: none)
   int hold_from;               // two-phase solve: stance footholds are held once an iterate >= hold_from has violation <= hold_tol (0: never)
   double hold_weight, hold_tol;
   const unsigned *amask;       // n_stages x 8: rows of the factor panel that are stored / read back (Symbolic::amask)
@@ -68,6 +87,7 @@ struct DevPlan {
   double chord_tol;
   int n_unknowns;
   const int *rhs_ptr, *rhs_gpos, *rhs_row;
+  int n_rhs_ent, rhs_chunk;    // entries of the three lists; entries per pass through the LDS scratch of k_step (a multiple of ET)
   const int *kx_ptr, *kx_col, *kx_pos;   // equality part of K by unknown position (Symbolic::kx_ptr; k_residual)
   const int *rtab;             // n_stages x 16: cell of the assembled right-hand side of every pivot (k_kkt2, Symbolic::rtab)
   const Block *blocks;
@@ -108,7 +128,7 @@ struct DevPlan {
 struct DevWork {
   const double *start, *goal, *warm;
   const int *map_id;
-  double *x, *xt, *g, *gt, *s, *zl, *zu, *ds, *dzl, *dzu, *sig, *w, *G, *panel, *dx, *stream;
+  double *x, *g, *gt, *s, *zl, *zu, *ds, *dzl, *dzu, *sig, *w, *G, *panel, *dx, *stream;
   double *mu, *viol, *trace;
   double *best_viol, *xbest;   // stall detection: lowest violation seen and the iterate that had it
   int *held;                   // two-phase solve: 1 once the problem's footholds are held
@@ -225,31 +245,29 @@ __device__ inline void vec_eval(const VecIn &in, const double *x, double out[3])
   }
 }
 
-// Pre-pass of the spline inputs: one work item per (instance, input vector, component), so that the
-// instance descriptors (about 1 KB per dynamics knot) are read coalesced by the whole workgroup
-// instead of being chased by one thread per instance.  The VecIn records are the leading members of
-// the instance structs.  Same summation order as vec_eval.
-__device__ inline void vec_prepass(const void *inst0, int inst_bytes, int n_inst, int n_vec, const double *x,
-                                   double *out) {
-  const int per = 3 * n_vec, total = n_inst * per, nt = blockDim.x;
-  constexpr int UN = 4;   // work items per thread and round: all descriptor reads of a round are in flight together
+// Pre-pass of the spline inputs: one work item per (instance, input vector, component); the items' variables and weights come
+// from flat tables in item order (DevPlan::pre_*: three 16-byte loads per item, consecutive items consecutive -- the VecIn
+// records inside the instance descriptors cost five times the cache-line visits).  Same summation order as vec_eval.
+__device__ inline void vec_prepass(const i4_t *__restrict__ V, const d2_t *__restrict__ Wa, const d2_t *__restrict__ Wb, int total,
+                                   const double *x, double *out) {
+  const int nt = blockDim.x;
+  constexpr int UN = 8;   // work items per thread and round: all table reads of a round are in flight together (one round
+                          // for the 100 knots / 256 foot instances of the benchmark: 4 k items on 512 threads)
   for (int base = threadIdx.x; base < total; base += UN * nt) {
-    int var[UN][4];
-    double w[UN][4];
+    i4_t var[UN];
+    d2_t wa[UN], wb[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int idx = min(base + u * nt, total - 1);
-      const int i = idx / per, rem = idx - i * per, v = rem / 3, d = rem - 3 * v;
-      const VecIn &in = *(const VecIn *)((const char *)inst0 + (size_t)i * inst_bytes + (size_t)v * sizeof(VecIn));
-#pragma unroll
-      for (int a = 0; a < 4; ++a) { var[u][a] = in.var[3 * a + d]; w[u][a] = in.w[a]; }
+      var[u] = V[idx]; wa[u] = Wa[idx]; wb[u] = Wb[idx];
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
+      const double w[4] = {wa[u][0], wa[u][1], wb[u][0], wb[u][1]};
       double acc = 0;
 #pragma unroll
       for (int a = 0; a < 4; ++a)
-        if (var[u][a] >= 0) acc += w[u][a] * x[var[u][a]];
+        if (var[u][a] >= 0) acc += w[a] * x[var[u][a]];
       if (base + u * nt < total) out[base + u * nt] = acc;
     }
   }
@@ -365,35 +383,37 @@ __device__ inline void eval_dyn_pass(const DevPlan &P, const DynInst &I, double 
 }
 
 #ifndef TERM1_UNROLL
-#define TERM1_UNROLL 12
+#define TERM1_UNROLL 24
 #endif
 #ifndef TERM3_UNROLL
-#define TERM3_UNROLL 4
+#define TERM3_UNROLL 8
 #endif
-// G[pos] = a * loc[off] for the entries [i0, i1) of a LinTerm1 list, TERM1_UNROLL per thread and round (all
-// descriptor reads of a round in flight together); consecutive threads write consecutive positions
-__device__ inline void write_terms1(const LinTerm1 *T, int i0, int i1, const double *loc, double *G) {
+// G[pos] = a * loc[off] for the entries [i0, i1) of a PackedTerm1 list, TERM1_UNROLL per thread and round (all
+// descriptor reads of a round in flight together); consecutive threads write consecutive positions.  coef = the table
+// of coefficients in LDS.
+__device__ inline void write_terms1(const PackedTerm1 *T, int i0, int i1, const double *loc, const double *coef, double *G) {
   const int nt = blockDim.x;
   constexpr int UN = TERM1_UNROLL;   // descriptor reads in flight per thread: the lists are read at memory latency
   for (int i = i0 + threadIdx.x; i < i1; i += UN * nt) {
-    LinTerm1 t[UN];
+    PackedTerm1 t[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) t[u] = T[min(i + u * nt, i1 - 1)];
 #pragma unroll
     for (int u = 0; u < UN; ++u)
-      if (i + u * nt < i1) G[t[u].pos] = t[u].a * loc[t[u].off];
+      if (i + u * nt < i1) G[t[u].pos] = coef[t[u].ai] * loc[t[u].off];
   }
 }
-__device__ inline void write_terms3(const LinTerm3 *T, int i0, int i1, const double *loc, double *G) {
+__device__ inline void write_terms3(const PackedTerm3 *T, int i0, int i1, const double *loc, const double *coef, double *G) {
   const int nt = blockDim.x;
   constexpr int UN = TERM3_UNROLL;
   for (int i = i0 + threadIdx.x; i < i1; i += UN * nt) {
-    LinTerm3 t[UN];
+    PackedTerm3 t[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) t[u] = T[min(i + u * nt, i1 - 1)];
 #pragma unroll
     for (int u = 0; u < UN; ++u)
-      if (i + u * nt < i1) G[t[u].pos] = loc[t[u].off[0]] * t[u].a[0] + loc[t[u].off[1]] * t[u].a[1] + loc[t[u].off[2]] * t[u].a[2];
+      if (i + u * nt < i1)
+        G[t[u].pos] = loc[t[u].off[0]] * coef[t[u].ai[0]] + loc[t[u].off[1]] * coef[t[u].ai[1]] + loc[t[u].off[2]] * coef[t[u].ai[2]];
   }
 }
 
@@ -424,30 +444,19 @@ __device__ inline void eval_rom(const DevPlan &P, const RomInst &I, const double
 }
 
 template <bool JAC>
-__device__ inline void eval_terr(const DevPlan &P, const TerrInst &I, int map, const double *x, double *g, double *Gp,
-                                 int hold = -1, const int *dpos = nullptr) {
+__device__ inline void eval_terr(const DevPlan &P, const TerrDev &I, int map, const double *x, double *g, double *Gp, int hold = -1) {
   const Terr t = terrain_at(P, map, x[I.vx], x[I.vy]);
   g[I.row] = x[I.vz] - t.h;
-  if (JAC && I.in_kkt) {
-    if (P.hold_from > 0 && P.row_kind[I.row] == 1 && dpos) {
-      // two-phase solve (QtosParams.hold_from): the proximal weight of a stance foothold's x, y for the
-      // KKT system of this iterate -- delta_x while the feet are being placed, hold_weight afterwards
-      // (hold = -1, the introspection calls: delta_x)
-      const double wgt = hold > 0 ? P.hold_weight : P.delta_x;
-      if (dpos[0] >= 0) Gp[dpos[0]] = wgt;
-      if (dpos[1] >= 0) Gp[dpos[1]] = wgt;
-    }
-    if (P.row_kind[I.row] == 1) {   // stance row: equality block, entries at their stream positions
-      const int *pos = P.eq_pos + I.goff;
-      if (I.cx >= 0) Gp[pos[I.cx]] = -t.hx;
-      if (I.cy >= 0) Gp[pos[I.cy]] = -t.hy;
-      if (I.cz >= 0) Gp[pos[I.cz]] = 1.0;
-    } else {
-      double *G = Gp + I.goff;
-      if (I.cx >= 0) G[I.cx] = -t.hx;
-      if (I.cy >= 0) G[I.cy] = -t.hy;
-      if (I.cz >= 0) G[I.cz] = 1.0;
-    }
+  if (JAC) {
+    // two-phase solve (QtosParams.hold_from): the proximal weight of a stance foothold's x, y for the
+    // KKT system of this iterate -- delta_x while the feet are being placed, hold_weight afterwards
+    // (hold = -1, the introspection calls: delta_x)
+    const double wgt = hold > 0 ? P.hold_weight : P.delta_x;
+    if (I.d0 >= 0) Gp[I.d0] = wgt;
+    if (I.d1 >= 0) Gp[I.d1] = wgt;
+    if (I.px >= 0) Gp[I.px] = -t.hx;
+    if (I.py >= 0) Gp[I.py] = -t.hy;
+    if (I.pz >= 0) Gp[I.pz] = 1.0;
   }
 }
 
@@ -498,30 +507,39 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
 #endif
   double *x = lds, *loc = lds + eval_loc_offset(P.n_vars);
   double *vin = loc + max(DYN_LOC * P.dyn_chunk, ROM_LOC * P.rom_chunk);
-  for (int v = tid; v < P.n_vars; v += nt) x[v] = xg[v];
+  double *coef = vin + max(DYN_VIN * P.dyn_chunk, ROM_VIN * P.rom_chunk);   // coefficients of the entry lists (JAC only)
+  if (xg)   // (null: the caller has left the nodes in lds[0 .. n_vars) already)
+    for (int v = tid; v < P.n_vars; v += nt) x[v] = xg[v];
+  if (JAC)
+    for (int v = tid; v < P.n_lin_coef; v += nt) coef[v] = P.lin_coef[v];
   __syncthreads();
   // the dynamics knots go through the LDS scratch in chunks of P.dyn_chunk (one chunk up to 128 knots)
   for (int c0 = 0, ch = 0; c0 < P.n_dyn; c0 += P.dyn_chunk, ++ch) {
     const int cnt = min(P.dyn_chunk, P.n_dyn - c0);
     if (c0) __syncthreads();   // the previous chunk is done with vin / loc
-    vec_prepass(P.dyn + c0, (int)sizeof(DynInst), cnt, 13, x, vin);
+    vec_prepass(P.pre_dyn_var + c0 * DYN_VIN, P.pre_dyn_wa + c0 * DYN_VIN, P.pre_dyn_wb + c0 * DYN_VIN, cnt * DYN_VIN, x, vin);
     __syncthreads();
     ESTAMP();
     if (JAC) {
-      for (int i = tid; i < cnt; i += nt) {
+      // four work items per knot -- the value pass and the three groups of forward-mode passes --, a whole number of
+      // waves per kind (a chunk of 128 knots is one item per thread)
+      const int cpad = (cnt + 63) & ~63;
+      for (int it = tid; it < 4 * cpad; it += nt) {
+        const int what = it / cpad, i = it - what * cpad;
+        if (i >= cnt) continue;
         double *li = loc + (size_t)i * DYN_LOC;
         const DynInst &I = P.dyn[c0 + i];
         const double *vi = vin + (size_t)i * DYN_VIN, *th = vi + 6, *thd = vi + 9, *thdd = vi + 12;
-        const Trig tg = trig_of(th);   // shared by the value pass and the nine forward-mode passes
-        eval_dyn<true>(P, I, vi, g, li, th, thd, thdd, tg);
-        eval_dyn_pass<0>(P, I, li, th, thd, thdd, tg);
-        eval_dyn_pass<1>(P, I, li, th, thd, thdd, tg);
-        eval_dyn_pass<2>(P, I, li, th, thd, thdd, tg);
+        const Trig tg = trig_of(th);
+        if (what == 0) eval_dyn<true>(P, I, vi, g, li, th, thd, thdd, tg);
+        else if (what == 1) eval_dyn_pass<0>(P, I, li, th, thd, thdd, tg);
+        else if (what == 2) eval_dyn_pass<1>(P, I, li, th, thd, thdd, tg);
+        else eval_dyn_pass<2>(P, I, li, th, thd, thdd, tg);
       }
       __syncthreads();
       ESTAMP();
-      write_terms1(P.dyn_t1, P.dyn_t1_off[ch], P.dyn_t1_off[ch + 1], loc, G);
-      write_terms3(P.dyn_t3, P.dyn_t3_off[ch], P.dyn_t3_off[ch + 1], loc, G);
+      write_terms1(P.dyn_t1, P.dyn_t1_off[ch], P.dyn_t1_off[ch + 1], loc, coef, G);
+      write_terms3(P.dyn_t3, P.dyn_t3_off[ch], P.dyn_t3_off[ch + 1], loc, coef, G);
       __syncthreads();
       ESTAMP();
     } else {
@@ -536,24 +554,46 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
   for (int c0 = 0, ch = 0; c0 < P.n_rom; c0 += P.rom_chunk, ++ch) {
     const int cnt = min(P.rom_chunk, P.n_rom - c0);
     __syncthreads();   // the dynamics knots / the previous chunk are done with vin and loc
-    vec_prepass(P.rom + c0, (int)sizeof(RomInst), cnt, 3, x, vin);
+    vec_prepass(P.pre_rom_var + c0 * ROM_VIN, P.pre_rom_wa + c0 * ROM_VIN, P.pre_rom_wb + c0 * ROM_VIN, cnt * ROM_VIN, x, vin);
     __syncthreads();
     for (int i = tid; i < cnt; i += nt) eval_rom<JAC>(P, P.rom[c0 + i], vin + (size_t)i * ROM_VIN, g, JAC ? loc + (size_t)i * ROM_LOC : nullptr);
     if (!JAC) ESTAMP();
     if (JAC) {
       __syncthreads();
       ESTAMP();
-      write_terms1(P.rom_t1, P.rom_t1_off[ch], P.rom_t1_off[ch + 1], loc, G);
+      write_terms1(P.rom_t1, P.rom_t1_off[ch], P.rom_t1_off[ch + 1], loc, coef, G);
       ESTAMP();
     }
   }
-  for (int i = tid; i < P.n_force; i += nt) eval_force<JAC>(P, P.force[i], map, x, g, G);
-  for (int i = tid; i < P.n_terr; i += nt) eval_terr<JAC>(P, P.terr[i], map, x, g, G, hold, P.terr_dpos + 2 * i);
-  for (int i = tid; i < P.n_lin; i += nt) {
-    const LinRow &L = P.lin[i];
-    double acc = 0;
-    for (int k = 0; k < L.n; ++k) acc += L.coef[k] * x[L.var[k]];
-    g[L.row] = acc;
+  // force, terrain and constant-coefficient rows: the descriptors of a thread's items are read before the first of them is
+  // used (three loops in a row are three memory round trips in a row: the stores of one may alias the loads of the
+  // next); force rows from the last thread down, terrain rows below them, two linear rows per thread from the first up
+  {
+    const int rt = nt - 1 - tid;
+    for (int base = 0; base < max(max(P.n_force + P.n_terr, 1), (P.n_lin + 1) / 2); base += nt) {
+      const int fi = base + rt, ti = base + rt - P.n_force, l0 = 2 * (base + tid), l1 = l0 + 1;
+      const bool hf = fi < P.n_force, ht = ti >= 0 && ti < P.n_terr, h0 = l0 < P.n_lin, h1 = l1 < P.n_lin;
+      ForceInst FI;
+      TerrDev TI;
+      LinRow L0, L1;
+      if (hf) FI = P.force[fi];
+      if (ht) TI = P.terr[ti];
+      if (h0) L0 = P.lin[l0];
+      if (h1) L1 = P.lin[l1];
+      if (hf) eval_force<JAC>(P, FI, map, x, g, G);
+      if (ht) eval_terr<JAC>(P, TI, map, x, g, G, hold);
+      auto lin_row = [&](const LinRow &L) __attribute__((always_inline)) {   // (the row sits in registers: constant indices only)
+        double xv[8], acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xv[k] = x[k < L.n ? L.var[k] : 0];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < L.n) acc += L.coef[k] * xv[k];
+        g[L.row] = acc;
+      };
+      if (h0) lin_row(L0);
+      if (h1) lin_row(L1);
+    }
   }
   ESTAMP();
 }
@@ -750,7 +790,11 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
   }
   // values and linearisation of the starting point in ONE pass (the Jacobian does not depend on the slack
   // initialisation below; a problem that turns out converged or invalid has merely written a stream nobody reads)
+#ifdef QTOS_STAMPS
+  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, W.trace ? W.trace + ((size_t)b * (P.max_iter + 1) + 72) * 4 : nullptr, 0);
+#else
   eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, nullptr, 0);
+#endif
   __syncthreads();
   // slack initialisation: push strictly inside the bounds (Ipopt bound_push / bound_frac)
   for (int r = tid; r < m; r += blockDim.x) {
@@ -837,9 +881,6 @@ __device__ __forceinline__ int trs(int a, int b) { return a >= b ? tri(a, b) : t
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-typedef double d4_t __attribute__((ext_vector_type(4)));
-typedef double d2_t __attribute__((ext_vector_type(2)));
-typedef int i4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
@@ -1091,6 +1132,16 @@ __device__ __forceinline__ void assemble_stage(double *A, int F, const int *sbuf
   }
 }
 
+// sum over the four lanes of a quad, on every lane of it
+__device__ __forceinline__ double quadsum(double t) {
+  double o = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(t), 0xB1, 0xf, 0xf, false),
+                              __builtin_amdgcn_update_dpp(0, __double2loint(t), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  t += o;
+  o = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(t), 0x4E, 0xf, 0xf, false),
+                       __builtin_amdgcn_update_dpp(0, __double2loint(t), 0x4E, 0xf, 0xf, false));          // quad_perm [2,3,0,1]
+  return t + o;
+}
+
 // =================================================================================================
 __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it) {
   const int b = blockIdx.x;
@@ -1099,7 +1150,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   extern __shared__ double evl[];
   const int n = P.n_vars, m = P.n_cons, tid = threadIdx.x;
   // distinct buffers: __restrict__ lets the row loops below keep several rows' loads in flight
-  double *__restrict__ x = W.x + (size_t)b * n, *__restrict__ xt = W.xt + (size_t)b * n, *__restrict__ dx = W.dx + (size_t)b * P.n_sol;
+  double *__restrict__ x = W.x + (size_t)b * n, *__restrict__ dx = W.dx + (size_t)b * P.n_sol;
   double *__restrict__ g = W.g + (size_t)b * m, *__restrict__ gt = W.gt + (size_t)b * m;
   double *__restrict__ s = W.s + (size_t)b * m, *__restrict__ zl = W.zl + (size_t)b * m, *__restrict__ zu = W.zu + (size_t)b * m;
   double *__restrict__ ds = W.ds + (size_t)b * m, *__restrict__ dzl = W.dzl + (size_t)b * m, *__restrict__ dzu = W.dzu + (size_t)b * m;
@@ -1117,39 +1168,99 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
 #else
 #define KSTAMP(i) do {} while (0)
 #endif
-  // ds = Ji dx + (g - s): dx staged in LDS, one thread per inequality row, independent loads
-  for (int v = tid; v < P.n_sol; v += blockDim.x) evl[v] = dx[v];
+  // ds = Ji dx + (g - s), dx staged in LDS.  Every pass over a table below is a chain of memory round trips (index ->
+  // value -> ...) of a microsecond each: the table reads that depend on nothing this kernel computes are issued first.
+  const int nt = blockDim.x;
+  // (a) reduced base: the step of the base node values from the step of the B-spline coefficients (dx_nodes = Z dc),
+  //     RR rows per thread and batch
+  constexpr int RR = 3;
+  int rcol[RR][4], rvar[RR];
+  double rw[RR][4];
+  auto rec_load = [&](int i0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      const int i = min(i0 + r * nt, P.n_rec - 1);
+      rvar[r] = P.rec_var[i];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { rcol[r][a] = P.rec_col[4 * i + a]; rw[r][a] = P.rec_w[4 * i + a]; }
+    }
+  };
+  // (b) rows of the inequality blocks, four lanes per row: lane q takes the entries q, q + 4, ... of the whole groups of
+  //     four (lane 0 the up to three entries behind them as well); the lanes of a quad read 32 consecutive bytes of the
+  //     row.  TP lane tasks per thread and round, the row descriptors of the next round in flight during this one.
+  constexpr int TP = 2, RU = 8;
+  const int ntask = (4 * P.n_iq_rows + 63) & ~63, q = tid & 3;
+  auto row_of = [&](int i4) __attribute__((always_inline)) { return P.iq_rows[min(i4 >> 2, P.n_iq_rows - 1)]; };
+  IqRow Rn[TP];
+  if (P.n_rec) rec_load(tid);
+#pragma unroll
+  for (int t = 0; t < TP; ++t) Rn[t] = row_of(tid + t * nt);
+  for (int v = tid; v < P.n_sol; v += nt) evl[v] = dx[v];
   __syncthreads();
   if (P.n_rec) {
-    // reduced base: the step of the base node values from the step of the B-spline coefficients (dx_nodes = Z dc)
-    for (int i = tid; i < P.n_rec; i += blockDim.x) {
-      double acc = 0.0;
+    for (int i0 = tid;;) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int col = P.rec_col[4 * i + a];
-        acc = col >= 0 ? fma(P.rec_w[4 * i + a], evl[col], acc) : acc;
+      for (int r = 0; r < RR; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc = rcol[r][a] >= 0 ? fma(rw[r][a], evl[max(rcol[r][a], 0)], acc) : acc;
+        if (i0 + r * nt < P.n_rec) {
+          dx[rvar[r]] = acc;
+          evl[rvar[r]] = acc;   // (node values: no thread reads them in this loop, the sources are coefficients)
+        }
       }
-      dx[P.rec_var[i]] = acc;
-      scratch[0] = 0.0;   // (keeps the loop's stores in front of the barrier below for every thread)
+      i0 += RR * nt;
+      if (i0 - tid >= P.n_rec) break;   // (uniform: the whole workgroup leaves together)
+      rec_load(i0);
     }
-    __syncthreads();
-    for (int i = tid; i < P.n_rec; i += blockDim.x) evl[P.rec_var[i]] = dx[P.rec_var[i]];
     __syncthreads();
   }
-  for (int i = tid; i < P.n_iq_rows; i += blockDim.x) {
-    const IqRow R = P.iq_rows[i];
-    const double *Gr = G + R.goff;
-    const int *cols = P.block_cols + R.col_off;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    int a = 0;
-    for (; a + 4 <= R.n; a += 4) {
-      a0 = fma(Gr[a], evl[cols[a]], a0);
-      a1 = fma(Gr[a + 1], evl[cols[a + 1]], a1);
-      a2 = fma(Gr[a + 2], evl[cols[a + 2]], a2);
-      a3 = fma(Gr[a + 3], evl[cols[a + 3]], a3);
+  for (int base = 0; base < ntask; base += TP * nt) {
+    IqRow R[TP];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) R[t] = Rn[t];
+    if (base + TP * nt < ntask) {
+#pragma unroll
+      for (int t = 0; t < TP; ++t) Rn[t] = row_of(base + TP * nt + t * nt + tid);
     }
-    for (; a < R.n; ++a) a0 = fma(Gr[a], evl[cols[a]], a0);
-    ds[R.row] = ((a0 + a1) + (a2 + a3)) + (g[R.row] - s[R.row]);
+    double gv[TP][RU], gr[TP][3], g_row[TP], s_row[TP];
+    int cv[TP][RU], cr[TP][3];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      g_row[t] = g[R[t].row];
+      s_row[t] = s[R[t].row];
+      const double *Gr = G + R[t].goff;
+      const int *cols = P.block_cols + R[t].col_off;
+      const int n4 = R[t].n & ~3;
+#pragma unroll
+      for (int u = 0; u < RU; ++u) { const int e = max(min(q + 4 * u, n4 - 4 + q), 0); gv[t][u] = Gr[e]; cv[t][u] = cols[e]; }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { const int e = min(n4 + u, R[t].n - 1); gr[t][u] = Gr[e]; cr[t][u] = cols[e]; }
+    }
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      const int i4 = base + t * nt + tid;
+      if (i4 >= ntask) continue;   // (whole waves)
+      const int n4 = R[t].n & ~3;
+      double ev[RU], er[3];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) ev[u] = evl[cv[t][u]];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) er[u] = evl[cr[t][u]];
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < RU; ++u) acc = q + 4 * u < n4 ? fma(gv[t][u], ev[u], acc) : acc;
+      // (rows of more than 35 entries: the rest of the whole groups, at memory latency)
+      const double *Gr = G + R[t].goff;
+      const int *cols = P.block_cols + R[t].col_off;
+      for (int a = q + 4 * RU; a < n4; a += 4) acc = fma(Gr[a], evl[cols[a]], acc);
+      if (q == 0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) acc = n4 + u < R[t].n ? fma(gr[t][u], er[u], acc) : acc;
+      }
+      acc = quadsum(acc);   // (a0 + a1) + (a2 + a3) of the four running sums
+      if (q == 0 && (i4 >> 2) < P.n_iq_rows) ds[R[t].row] = acc + (g_row[t] - s_row[t]);
+    }
   }
   __syncthreads();
   KSTAMP(0);
@@ -1178,9 +1289,11 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   // backtracking on the l1 infeasibility of (c_E, c_I - s)
   double al = amax, th = 0;
   for (int ls = 0; ls < 6; ++ls) {
-    for (int v = tid; v < n; v += blockDim.x) xt[v] = x[v] + al * dx[v];
+    // the trial point goes to LDS directly (and stays there for the linearisation below if it is accepted): written to
+    // memory and staged back it would cost two memory round trips
+    for (int v = tid; v < n; v += blockDim.x) evl[v] = x[v] + al * dx[v];
     __syncthreads();
-    eval_all<false>(P, map, xt, gt, nullptr, evl, (W.trace && it == 1 && ls == 0) ? W.trace + ((size_t)b * (P.max_iter + 1) + 76) * 4 : nullptr);
+    eval_all<false>(P, map, nullptr, gt, nullptr, evl, (W.trace && it == 1 && ls == 0) ? W.trace + ((size_t)b * (P.max_iter + 1) + 76) * 4 : nullptr);
     __syncthreads();
     th = l1_infeasibility(P, gt, s, ds, al, scratch);
     if (th <= (1.0 - 1e-4 * al) * th0 || th < 1e-9) break;
@@ -1193,7 +1306,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   const bool reject = was_chord && al != 1.0;
   if (reject) { al = 0.0; az = 0.0; th = 0.0; }
   else {
-    for (int v = tid; v < n; v += blockDim.x) x[v] = xt[v];
+    for (int v = tid; v < n; v += blockDim.x) x[v] = evl[v];   // (the trial point of the last evaluation)
 #pragma unroll 4
     for (int r = tid; r < m; r += blockDim.x) g[r] = gt[r];
   }
@@ -1252,7 +1365,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   const int held = (W.held[b] || (P.hold_from > 0 && it + 1 >= P.hold_from && viol <= P.hold_tol)) ? 1 : 0;
   __syncthreads();
   if (tid == 0) W.held[b] = held;
-  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, (W.trace && it == 1) ? W.trace + ((size_t)b * (P.max_iter + 1) + 72) * 4 : nullptr,
+  eval_all<true>(P, map, reject ? x : nullptr, g, W.stream + (size_t)b * P.stream_len, evl, (W.trace && it == 1) ? W.trace + ((size_t)b * (P.max_iter + 1) + 72) * 4 : nullptr,
                  held);
   __syncthreads();
   KSTAMP(4);
@@ -1263,31 +1376,53 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     if (next_chord) atomicAdd(W.n_active + 1, 1);
   }
   if (next_chord) {
-    // right-hand side of the KKT system at the new iterate, in elimination order, for k_chord
+    // right-hand side of the KKT system at the new iterate, in elimination order, for k_chord: rhs[p] = -g[row] for a
+    // multiplier, -sum_t G[gpos[t]] w[row[t]] over the unknown's list for a variable (a base coefficient has sixty entries
+    // and every one is two dependent memory round trips: a list walked by its own thread costs a hundred of them).  The
+    // factors of rhs_chunk entries at a time go to LDS with every load of the pass in flight, then every unknown sums its
+    // part of the pass in list order.
     __syncthreads();   // the stream and w of this launch are complete
     const double *__restrict__ Gs = W.stream + (size_t)b * P.stream_len, *__restrict__ wr = W.w + (size_t)b * m;
     double *__restrict__ rhs = W.rhs + (size_t)b * P.n_unknowns;
-    for (int p = tid; p < P.n_unknowns; p += blockDim.x) {
-      const int t0 = P.rhs_ptr[p], t1 = P.rhs_ptr[p + 1];
-      double acc = 0.0;
-      if (t1 - t0 == 1 && P.rhs_gpos[t0] < 0) acc = -g[P.rhs_row[t0]];
-      else {
-        // eight entries per round: their index pairs, then their values, in flight together (a base node has a
-        // hundred entries and every one is two dependent memory round trips); summed in list order
-        constexpr int RU = 8;
-        for (int t = t0; t < t1; t += RU) {
-          int gp[RU], rw[RU];
+    const int NUK = P.n_unknowns, CH = P.rhs_chunk;
+    double *accL = evl;
+    int *ptrL = (int *)(accL + ((NUK + 1) & ~1));
+    double *gvL = (double *)(ptrL + ((NUK + 4) & ~3)), *wvL = gvL + CH;
+    for (int p = tid; p <= NUK; p += nt) { ptrL[p] = P.rhs_ptr[p]; if (p < NUK) accL[p] = 0.0; }
+    constexpr int SU = 12;   // entries per thread in flight
+    for (int c0 = 0; c0 < P.n_rhs_ent; c0 += CH) {
+      const int c1 = min(c0 + CH, P.n_rhs_ent);
+      for (int t = c0 + tid; t < c1; t += SU * nt) {
+        int gp[SU], rw[SU];
 #pragma unroll
-          for (int u = 0; u < RU; ++u) { const int tt = min(t + u, t1 - 1); gp[u] = P.rhs_gpos[tt]; rw[u] = P.rhs_row[tt]; }
-          double gv[RU], wv[RU];
+        for (int u = 0; u < SU; ++u) { const int tt = min(t + u * nt, c1 - 1); gp[u] = P.rhs_gpos[tt]; rw[u] = P.rhs_row[tt]; }
+        double gv[SU], wv[SU];
 #pragma unroll
-          for (int u = 0; u < RU; ++u) { gv[u] = Gs[gp[u]]; wv[u] = wr[rw[u]]; }
-#pragma unroll
-          for (int u = 0; u < RU; ++u) acc = t + u < t1 ? fma(-gv[u], wv[u], acc) : acc;
+        for (int u = 0; u < SU; ++u) {   // (a multiplier's single entry: 1 * g[row])
+          gv[u] = gp[u] >= 0 ? Gs[max(gp[u], 0)] : 1.0;
+          wv[u] = (gp[u] >= 0 ? wr : g)[rw[u]];
         }
+#pragma unroll
+        for (int u = 0; u < SU; ++u)
+          if (t + u * nt < c1) { gvL[t + u * nt - c0] = gv[u]; wvL[t + u * nt - c0] = wv[u]; }
       }
-      rhs[p] = acc;
+      __syncthreads();
+      for (int p = tid; p < NUK; p += nt) {
+        const int t0 = max(ptrL[p], c0), t1 = min(ptrL[p + 1], c1);
+        if (t0 >= t1) continue;
+        double acc = accL[p];
+        for (int t = t0; t < t1; t += 8) {   // eight LDS round trips together, summed in list order
+          double gq[8], wq[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int tt = min(t + u, t1 - 1) - c0; gq[u] = gvL[tt]; wq[u] = wvL[tt]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc = t + u < t1 ? fma(-gq[u], wq[u], acc) : acc;
+        }
+        accL[p] = acc;
+      }
+      __syncthreads();
     }
+    for (int p = tid; p < NUK; p += nt) rhs[p] = accL[p];
   }
 #ifdef QTOS_STAMPS
   if (tid == 0 && W.trace && it == 1) for (int i = 0; i < 8; ++i) W.trace[((size_t)b * (P.max_iter + 1) + 70) * 4 + i] = (double)ks[i];

@@ -148,15 +148,6 @@ __device__ __forceinline__ double rowsum4(double p) {
   auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
   return __hiloint2double(h2[0], l2[0]) + __hiloint2double(h2[1], l2[1]);
 }
-// sum over the four lanes of a quad, on every lane of it
-__device__ __forceinline__ double quadsum(double t) {
-  double o = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(t), 0xB1, 0xf, 0xf, false),
-                              __builtin_amdgcn_update_dpp(0, __double2loint(t), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-  t += o;
-  o = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(t), 0x4E, 0xf, 0xf, false),
-                       __builtin_amdgcn_update_dpp(0, __double2loint(t), 0x4E, 0xf, 0xf, false));          // quad_perm [2,3,0,1]
-  return t + o;
-}
 // acc += (lane K of the 16-lane row of x) * b on the rows of the wave selected by RM
 template <int K, int RM>
 __device__ __forceinline__ void fma_bc_rows(double &acc, double x, double b) {
@@ -685,8 +676,13 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
         const int R = rc < 0 ? 0 : rc >> 8, C = rc < 0 ? 0 : rc & 255;
         const int oR = __builtin_amdgcn_readfirstlane(R * (16 * PLD * 8)), oC = __builtin_amdgcn_readfirstlane(C * (16 * PLD * 8));
         const char *wrow = (const char *)Yk + (tile_lane + oR), *prow2 = (const char *)Bop + (tile_lane + oC);
+#ifdef QTOS_EXP_NOLOADS
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { w[s4] = (double)(long long)wrow; pq[s4] = (double)(long long)prow2; }   // ablation: no operand loads
+#else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) { w[s4] = *(const double *)(wrow + 32 * s4); pq[s4] = *(const double *)(prow2 + 32 * s4); }
+#endif
       };
       // pivot indices of the columns (li) and of the four rows (lk + 4g) this lane holds in each tile: fetched ahead of
       // the products (the extraction behind them starts with no LDS round trip of its own: -5.5 % per launch)

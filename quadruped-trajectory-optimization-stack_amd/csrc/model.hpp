@@ -71,6 +71,11 @@ struct ColDesc {
 // stream once, with the other constants, when the planner is created.
 struct LinTerm1 { int pos, off; double a; };
 struct LinTerm3 { int pos, off[3]; double a[3]; };
+// the same lists as the evaluation kernels read them (every workgroup streams them from L2 in every linearisation: bytes
+// matter): 16-bit offsets into the local Jacobians, coefficients as indices into a table of the distinct values (a few
+// thousand: the Hermite weights of the knot times), which the kernels keep in LDS
+struct PackedTerm1 { unsigned pos; unsigned short off, ai; };
+struct PackedTerm3 { unsigned pos; unsigned short off[3], ai[3]; };
 // K2 assembly block: m consecutive constraint rows sharing one dense column list
 struct Block {
   int kind;  // 0 equality, 1 inequality

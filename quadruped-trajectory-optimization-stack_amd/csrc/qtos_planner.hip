@@ -7,6 +7,7 @@
 #include <cstring>
 #include <atomic>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "kernels.hpp"
@@ -184,15 +185,69 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   std::memset(&D, 0, sizeof(D));
   D.n_vars = M.n_vars; D.n_cons = M.n_cons; D.n_stages = S.n_stages; D.front = S.front;
   D.n_sol = M.n_sol; D.n_rec = (int)M.rec_var.size();
+  {  // k_step writes a recovered node step next to the coefficient steps it is formed from: the two sets must not meet
+    std::vector<char> is_rec(M.n_sol, 0);
+    for (int v : M.rec_var) is_rec[v] = 1;
+    for (int c : M.rec_col)
+      if (c >= 0 && is_rec[c]) { p->err = "reduced base: a recovered node value is the source of another"; fprintf(stderr, "qtos: %s\n", p->err.c_str()); delete p; return -1; }
+  }
   TRY(p->upload(M.rec_var, &D.rec_var)); TRY(p->upload(M.rec_col, &D.rec_col)); TRY(p->upload(M.rec_w, &D.rec_w));
   D.n_coef = M.reduce_base ? M.n_coef : 0; D.n_pz = (int)M.pz_var.size();
   TRY(p->upload(M.pc_var, &D.pc_var)); TRY(p->upload(M.pc_w, &D.pc_w));
   TRY(p->upload(M.pz_var, &D.pz_var)); TRY(p->upload(M.pz_col, &D.pz_col)); TRY(p->upload(M.pz_w, &D.pz_w));
   D.n_dyn = (int)M.dyn.size(); D.n_rom = (int)M.rom.size(); D.n_terr = (int)M.terr.size();
   D.n_force = (int)M.force.size(); D.n_lin = (int)M.linrow.size(); D.n_blocks = (int)M.blocks.size();
-  TRY(p->upload(M.dyn, &D.dyn)); TRY(p->upload(M.rom, &D.rom)); TRY(p->upload(M.terr, &D.terr));
+  TRY(p->upload(M.dyn, &D.dyn)); TRY(p->upload(M.rom, &D.rom));
+  {  // flat tables of the spline inputs in pre-pass order (the VecIn records lead the instance structs)
+    auto flat = [&](const void *inst0, size_t inst_bytes, size_t n_inst, int n_vec, const i4_t **var, const d2_t **wa, const d2_t **wb) {
+      std::vector<i4_t> v;
+      std::vector<d2_t> a, b;
+      for (size_t i = 0; i < n_inst; ++i)
+        for (int k = 0; k < n_vec; ++k) {
+          const VecIn &in = ((const VecIn *)((const char *)inst0 + i * inst_bytes))[k];
+          for (int d = 0; d < 3; ++d) {
+            v.push_back(i4_t{in.var[d], in.var[3 + d], in.var[6 + d], in.var[9 + d]});
+            a.push_back(d2_t{in.w[0], in.w[1]});
+            b.push_back(d2_t{in.w[2], in.w[3]});
+          }
+        }
+      int rc2 = p->upload(v, var);
+      if (!rc2) rc2 = p->upload(a, wa);
+      if (!rc2) rc2 = p->upload(b, wb);
+      return rc2;
+    };
+    static_assert(DYN_VIN == 39 && ROM_VIN == 9, "13 / 3 input vectors of three components");
+    TRY(flat(M.dyn.data(), sizeof(DynInst), M.dyn.size(), 13, &D.pre_dyn_var, &D.pre_dyn_wa, &D.pre_dyn_wb));
+    TRY(flat(M.rom.data(), sizeof(RomInst), M.rom.size(), 3, &D.pre_rom_var, &D.pre_rom_wa, &D.pre_rom_wb));
+  }
   TRY(p->upload(M.force, &D.force)); TRY(p->upload(M.linrow, &D.lin));
-  TRY(p->upload(S.dyn_t1, &D.dyn_t1)); TRY(p->upload(S.dyn_t3, &D.dyn_t3)); TRY(p->upload(S.rom_t1, &D.rom_t1));
+  {  // entry lists of the iterate-dependent Jacobian values, packed (model.hpp: PackedTerm1 / PackedTerm3)
+    std::map<unsigned long long, int> idx_of;
+    std::vector<double> coefs;
+    bool fits = true;
+    auto ci = [&](double a) {
+      unsigned long long bits;
+      std::memcpy(&bits, &a, 8);
+      auto it = idx_of.find(bits);
+      if (it == idx_of.end()) { it = idx_of.emplace(bits, (int)coefs.size()).first; coefs.push_back(a); }
+      return (unsigned short)it->second;
+    };
+    auto off16 = [&](int off) { if (off < 0 || off > 65535) fits = false; return (unsigned short)off; };
+    std::vector<PackedTerm1> d1, r1;
+    std::vector<PackedTerm3> d3;
+    for (const LinTerm1 &t : S.dyn_t1) d1.push_back({(unsigned)t.pos, off16(t.off), ci(t.a)});
+    for (const LinTerm1 &t : S.rom_t1) r1.push_back({(unsigned)t.pos, off16(t.off), ci(t.a)});
+    for (const LinTerm3 &t : S.dyn_t3)
+      d3.push_back({(unsigned)t.pos, {off16(t.off[0]), off16(t.off[1]), off16(t.off[2])}, {ci(t.a[0]), ci(t.a[1]), ci(t.a[2])}});
+    if (!fits || coefs.size() > 65535) {
+      p->err = "Jacobian entry lists exceed the packed format (16-bit offsets / coefficient indices)";
+      fprintf(stderr, "qtos: %s\n", p->err.c_str());
+      qtos_planner_destroy(p);
+      return -4;
+    }
+    D.n_lin_coef = (int)coefs.size();
+    TRY(p->upload(d1, &D.dyn_t1)); TRY(p->upload(d3, &D.dyn_t3)); TRY(p->upload(r1, &D.rom_t1)); TRY(p->upload(coefs, &D.lin_coef));
+  }
   TRY(p->upload(S.dyn_t1_off, &D.dyn_t1_off)); TRY(p->upload(S.dyn_t3_off, &D.dyn_t3_off));
   D.n_rom_t1 = (int)S.rom_t1.size();
   D.dyn_chunk = M.dyn_chunk;
@@ -214,16 +269,26 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.off_lin = M.off_lin; D.off_ang = M.off_ang;
   for (int e = 0; e < NEE; ++e) D.off_eem[e] = M.off_eem[e];
   TRY(p->upload(S.cont, &D.cont));
-  {  // stream positions of the pivot diagonals of every foot node's x and y (two-phase solve)
-    std::vector<int> dpos_of_var(M.n_sol, -1), td;
+  {  // terrain rows with their stream positions: the row's Jacobian entries, and the pivot diagonals of the foot node's x and
+     // y (two-phase solve: stance rows only)
+    std::vector<int> dpos_of_var(M.n_sol, -1);
     for (int i = 0; i < (int)S.pack_src.size(); ++i)
       if ((S.pack_src[i] >> 28) == 5) {
         const int u = S.piv_unknown[S.pack_src[i] & 0x0fffffff];
         if (u >= 0 && u < M.n_sol) dpos_of_var[u] = i;
       }
-    for (const TerrInst &t : M.terr) { td.push_back(dpos_of_var[t.vx]); td.push_back(dpos_of_var[t.vy]); }
-    if (td.empty()) td.assign(2, -1);
-    TRY(p->upload(td, &D.terr_dpos));
+    std::vector<TerrDev> td;
+    for (const TerrInst &t : M.terr) {
+      TerrDev d = {t.vx, t.vy, t.vz, t.row, -1, -1, -1, -1, -1, 0};
+      if (t.in_kkt) {
+        const bool stance = M.row_kind[t.row] == 1;   // equality block: entries at their own stream positions
+        auto pos = [&](int c) { return c < 0 ? -1 : (stance ? S.eq_pos[t.goff + c] : t.goff + c); };
+        d.px = pos(t.cx); d.py = pos(t.cy); d.pz = pos(t.cz);
+        if (M.P.hold_from > 0 && stance) { d.d0 = dpos_of_var[t.vx]; d.d1 = dpos_of_var[t.vy]; }
+      }
+      td.push_back(d);
+    }
+    TRY(p->upload(td, &D.terr));
     D.hold_from = M.P.hold_from;
     D.hold_weight = M.P.hold_weight > 0 ? M.P.hold_weight : 1e6;
     D.hold_tol = M.P.hold_tol;
@@ -299,7 +364,13 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
   }
   p->eval_lds = sizeof(double) * (((size_t)M.n_sol + 1) / 2 * 2 + std::max((size_t)DYN_LOC * D.dyn_chunk, (size_t)ROM_LOC * D.rom_chunk) +
-                                  std::max((size_t)DYN_VIN * D.dyn_chunk, (size_t)ROM_VIN * D.rom_chunk));
+                                  std::max((size_t)DYN_VIN * D.dyn_chunk, (size_t)ROM_VIN * D.rom_chunk) + (size_t)D.n_lin_coef);
+  {  // k_step's pass over the chord right-hand side: unknown sums and list bounds, then the factors of rhs_chunk entries
+    D.n_rhs_ent = (int)S.rhs_gpos.size();
+    D.rhs_chunk = std::min((D.n_rhs_ent + ET - 1) / ET, 12) * ET;
+    const size_t nuk = (size_t)S.n_unknowns, need = ((nuk + 1) & ~(size_t)1) + ((nuk + 4) & ~(size_t)3) / 2 + 2 * (size_t)std::max(D.rhs_chunk, ET);
+    p->eval_lds = std::max(p->eval_lds, need * sizeof(double));
+  }
   if (p->eval_lds > 150 * 1024) {
     p->err = "too many dynamics knots for the LDS scratch";
     fprintf(stderr, "qtos: evaluation kernels need %zu B of LDS\n", p->eval_lds);
@@ -318,7 +389,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   DevWork &W = p->wk;
   std::memset(&W, 0, sizeof(W));
   const size_t Bm = (size_t)max_batch, n = M.n_vars, m = M.n_cons;
-  TRY(p->alloc(&W.x, Bm * n)); TRY(p->alloc(&W.xt, Bm * n)); TRY(p->alloc(&W.dx, Bm * (size_t)M.n_sol));
+  TRY(p->alloc(&W.x, Bm * n)); TRY(p->alloc(&W.dx, Bm * (size_t)M.n_sol));
   TRY(p->alloc(&W.g, Bm * m)); TRY(p->alloc(&W.gt, Bm * m)); TRY(p->alloc(&W.s, Bm * m));
   TRY(p->alloc(&W.zl, Bm * m)); TRY(p->alloc(&W.zu, Bm * m)); TRY(p->alloc(&W.ds, Bm * m));
   TRY(p->alloc(&W.dzl, Bm * m)); TRY(p->alloc(&W.dzu, Bm * m)); TRY(p->alloc(&W.sig, Bm * m));
