@@ -61,7 +61,7 @@ struct DevPlan {
   const PackedTerm1 *dyn_t1, *rom_t1;
   const PackedTerm3 *dyn_t3;
   const double *lin_coef;      // the distinct coefficients of the three lists
-  int n_lin_coef;
+  int n_lin_coef, coef_in_lds; // the evaluation kernels copy the table to LDS when it fits next to their scratch
   const int *dyn_t1_off, *dyn_t3_off;   // first entry of every knot chunk (+ end)
   int n_rom_t1;
   int rom_chunk;               // range-of-motion instances evaluated per pass (LDS scratch bound)
@@ -507,11 +507,12 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
 #endif
   double *x = lds, *loc = lds + eval_loc_offset(P.n_vars);
   double *vin = loc + max(DYN_LOC * P.dyn_chunk, ROM_LOC * P.rom_chunk);
-  double *coef = vin + max(DYN_VIN * P.dyn_chunk, ROM_VIN * P.rom_chunk);   // coefficients of the entry lists (JAC only)
+  double *coef_lds = vin + max(DYN_VIN * P.dyn_chunk, ROM_VIN * P.rom_chunk);   // coefficients of the entry lists (JAC only)
+  const double *coef = P.coef_in_lds ? coef_lds : P.lin_coef;
   if (xg)   // (null: the caller has left the nodes in lds[0 .. n_vars) already)
     for (int v = tid; v < P.n_vars; v += nt) x[v] = xg[v];
-  if (JAC)
-    for (int v = tid; v < P.n_lin_coef; v += nt) coef[v] = P.lin_coef[v];
+  if (JAC && P.coef_in_lds)
+    for (int v = tid; v < P.n_lin_coef; v += nt) coef_lds[v] = P.lin_coef[v];
   __syncthreads();
   // the dynamics knots go through the LDS scratch in chunks of P.dyn_chunk (one chunk up to 128 knots)
   for (int c0 = 0, ch = 0; c0 < P.n_dyn; c0 += P.dyn_chunk, ++ch) {

@@ -364,12 +364,17 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
   }
   p->eval_lds = sizeof(double) * (((size_t)M.n_sol + 1) / 2 * 2 + std::max((size_t)DYN_LOC * D.dyn_chunk, (size_t)ROM_LOC * D.rom_chunk) +
-                                  std::max((size_t)DYN_VIN * D.dyn_chunk, (size_t)ROM_VIN * D.rom_chunk) + (size_t)D.n_lin_coef);
+                                  std::max((size_t)DYN_VIN * D.dyn_chunk, (size_t)ROM_VIN * D.rom_chunk));
+  // the coefficient table of the entry lists joins the scratch when it fits (schedules with irregular phase durations have
+  // ten thousand distinct Hermite weights: those read it from memory)
+  D.coef_in_lds = p->eval_lds + sizeof(double) * (size_t)D.n_lin_coef <= 150 * 1024;
+  if (D.coef_in_lds) p->eval_lds += sizeof(double) * (size_t)D.n_lin_coef;
   {  // k_step's pass over the chord right-hand side: unknown sums and list bounds, then the factors of rhs_chunk entries
     D.n_rhs_ent = (int)S.rhs_gpos.size();
-    D.rhs_chunk = std::min((D.n_rhs_ent + ET - 1) / ET, 12) * ET;
-    const size_t nuk = (size_t)S.n_unknowns, need = ((nuk + 1) & ~(size_t)1) + ((nuk + 4) & ~(size_t)3) / 2 + 2 * (size_t)std::max(D.rhs_chunk, ET);
-    p->eval_lds = std::max(p->eval_lds, need * sizeof(double));
+    const size_t nuk = (size_t)S.n_unknowns, fixed = ((nuk + 1) & ~(size_t)1) + ((nuk + 4) & ~(size_t)3) / 2;
+    const size_t room = 150 * 1024 / sizeof(double) > fixed ? (150 * 1024 / sizeof(double) - fixed) / (2 * (size_t)ET) : 0;   // passes of ET entries that fit
+    D.rhs_chunk = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((D.n_rhs_ent + ET - 1) / ET, 12), room)) * ET;
+    p->eval_lds = std::max(p->eval_lds, (fixed + 2 * (size_t)D.rhs_chunk) * sizeof(double));
   }
   if (p->eval_lds > 150 * 1024) {
     p->err = "too many dynamics knots for the LDS scratch";
