@@ -766,10 +766,12 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
   for (int v = tid; v < n; v += blockDim.x) {
     const double val = initial_value(P, W, b, v, st, gl, map, tc);
     x[v] = val;
-    W.xbest[(size_t)b * n + v] = val;
+    W.xbest[(size_t)b * n + v] = val;   // best iterate so far: the starting point
+    evl[v] = val;                       // (the evaluation below reads the nodes from LDS)
   }
   __syncthreads();
-  if (P.n_coef && (W.warm || P.table)) {
+  const bool project = P.n_coef && (W.warm || P.table);
+  if (project) {
     // reduced base: given nodes need not be a spline of the coefficients' space (the reference's plans violate the
     // acceleration continuity by their CSV precision, 7e-4): project them onto it -- the continuity rows that left the KKT
     // system hold for every iterate only if they hold for the first
@@ -791,10 +793,11 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
   }
   // values and linearisation of the starting point in ONE pass (the Jacobian does not depend on the slack
   // initialisation below; a problem that turns out converged or invalid has merely written a stream nobody reads)
+  // (a projected start is staged from memory again: the projection used the scratch)
 #ifdef QTOS_STAMPS
-  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, W.trace ? W.trace + ((size_t)b * (P.max_iter + 1) + 72) * 4 : nullptr, 0);
+  eval_all<true>(P, map, project ? x : nullptr, g, W.stream + (size_t)b * P.stream_len, evl, W.trace ? W.trace + ((size_t)b * (P.max_iter + 1) + 72) * 4 : nullptr, 0);
 #else
-  eval_all<true>(P, map, x, g, W.stream + (size_t)b * P.stream_len, evl, nullptr, 0);
+  eval_all<true>(P, map, project ? x : nullptr, g, W.stream + (size_t)b * P.stream_len, evl, nullptr, 0);
 #endif
   __syncthreads();
   // slack initialisation: push strictly inside the bounds (Ipopt bound_push / bound_frac)
@@ -836,7 +839,6 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     record_trace(P, W, b, 0, viol, theta, 0.0, mu);
   }
   if (conv || bad) return;
-  for (int v = tid; v < n; v += blockDim.x) W.xbest[(size_t)b * n + v] = x[v];   // best iterate so far: the starting point
   __syncthreads();
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
 }

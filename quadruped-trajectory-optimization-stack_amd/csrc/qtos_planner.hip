@@ -51,6 +51,7 @@ struct QtosPlanner {
   struct Call {
     bool open = false;
     int B = 0, spec = 0, enq = 0, chk = 0;   // iterations queued blind / queued in all / whose preceding counts have been read
+    unsigned spins = 0;                      // polls that found no counts yet
     hipStream_t st = nullptr;
     DevWork W;
     double *nodes_out = nullptr, *viol_out = nullptr;
@@ -536,7 +537,11 @@ __global__ void k_export(const double *x, const int *status, const int *iters, c
 // streams than hardware queues that wait holds up the other streams of the queue too: four sets of receding windows
 // then ran one after the other.)
 __global__ void k_post_counts(const int *n_active, int *host_slot) {
-  if (threadIdx.x < 2) host_slot[threadIdx.x] = n_active[threadIdx.x];
+  // both counts in ONE eight-byte store: the host spins on the slot (qtos_plan_poll) and must never see half of it
+  if (threadIdx.x == 0) {
+    const unsigned long long v = (unsigned long long)(unsigned)n_active[0] | ((unsigned long long)(unsigned)n_active[1] << 32);
+    *(volatile unsigned long long *)host_slot = v;
+  }
   __threadfence_system();
 }
 
@@ -606,6 +611,7 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
   c.nodes_out = d_nodes_out; c.status_out = d_status_out; c.iters_out = d_iters_out; c.viol_out = d_viol_out;
   const DevPlan &D = p->dp;
 #define SUBCHK(call_) do { hipError_t e_ = (call_); if (e_ != hipSuccess) { p->err = std::string(#call_) + ": " + hipGetErrorString(e_); return fail(e_ == hipErrorOutOfMemory ? -3 : -2); } } while (0)
+  std::memset(p->h_active, 0xff, 2 * sizeof(int) * ((size_t)D.max_iter + 1));   // no counts yet (the handle's previous call is over)
   SUBCHK(hipMemsetAsync(c.W.n_active, 0, 2 * sizeof(int), st));
   SUBCHK(hipEventRecord(p->ev[0], st));
   hipLaunchKernelGGL(k_start, dim3(B), dim3(ET), p->eval_lds, st, D, c.W, B);
@@ -638,12 +644,28 @@ int qtos_plan_poll(QtosPlanner *p, int *done) {
   bool device_set = false;     // (only in front of launches: hipSetDevice in a spin loop of several host threads is a lock fight)
   const int ev_start = 2 + 5 * D.max_iter;
   for (;;) {
-    // counts in front of iteration c.chk (behind k_start / iteration c.chk - 1)
-    const hipError_t q = hipEventQuery(p->ev[c.chk == 0 ? ev_start : 6 + 5 * (c.chk - 1)]);
-    if (q == hipErrorNotReady) return 0;
-    if (q != hipSuccess) { p->err = std::string("hipEventQuery: ") + hipGetErrorString(q); c.open = false; p->busy.store(0); return -2; }
+    // counts in front of iteration c.chk (behind k_start / iteration c.chk - 1): the slot itself says when they are there
+    // (k_post_counts stores into mapped host memory; qtos_plan_submit left -1 in every slot) -- an event query on top of
+    // it is a driver call and waits for the end-of-kernel signal of the command processor
     const int *h = p->h_active + 2 * (c.chk == 0 ? D.max_iter : c.chk - 1);
-    const int n = h[0], nc = h[1];
+    int n, nc;
+    if (p->counts_by_copy) {
+      const hipError_t q = hipEventQuery(p->ev[c.chk == 0 ? ev_start : 6 + 5 * (c.chk - 1)]);
+      if (q == hipErrorNotReady) return 0;
+      if (q != hipSuccess) { p->err = std::string("hipEventQuery: ") + hipGetErrorString(q); c.open = false; p->busy.store(0); return -2; }
+      n = h[0]; nc = h[1];
+    } else {
+      const unsigned long long v = __atomic_load_n((const unsigned long long *)h, __ATOMIC_ACQUIRE);
+      if (v == ~0ull) {
+        // (a failed launch never fills the slot: look at the stream now and then)
+        if ((++c.spins & 0xfffff) == 0) {
+          const hipError_t q = hipStreamQuery(c.st);
+          if (q != hipSuccess && q != hipErrorNotReady) { p->err = std::string("hipStreamQuery: ") + hipGetErrorString(q); c.open = false; p->busy.store(0); return -2; }
+        }
+        return 0;
+      }
+      n = (int)(unsigned)(v & 0xffffffffull); nc = (int)(unsigned)(v >> 32);
+    }
     if (n <= 0 || c.chk >= D.max_iter) {
       // finished in front of iteration c.chk.  The blind export ran iff the blind iterations were enough.
       const int iters = c.chk;
