@@ -133,18 +133,20 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
  * reference's pool of `docker exec ./main` workers pulling probes from a queue (QTOS/generateHeightField.py:344-352,
  * 375-377; scripts/main.py:49-50 for the single call):
  *
- *   qtos_plan_submit   queues the initial guess, the first Newton iteration(s) and an export of the results that runs
- *                      only if they were enough, and returns at once.  With qtos_set_speculation(n > 1) it queues as
+ *   qtos_plan_submit   queues the initial guess and the first Newton iteration(s), and returns at once (a problem's
+ *                      result is written to the output buffers by the kernel that finishes it -- converged, stalled,
+ *                      failed or out of iterations --: there is no export step).  With qtos_set_speculation(n > 1) it queues as
  *                      many iterations as the previous call of this handle needed, up to n, without a host round
  *                      trip ("blind" iterations: both solve kernels are launched, the workgroups of problems that
  *                      are finished or belong to the other kernel leave at once).
  *   qtos_plan_poll     non-blocking: reads the counts of unfinished problems the iterations sent back; a batch that
- *                      needs more iterations gets them queued one by one (only the kernels with work), then the
- *                      export; *done = 1 once everything the call needs is on the stream.
+ *                      needs more iterations gets them queued one by one (only the kernels with work);
+ *                      *done = 1 once the counts say that every problem is finished (the results are then in the
+ *                      output buffers: the counts travel behind the kernel that wrote them).
  *   qtos_plan_wait     polls until done.
  *
- * qtos_plan_batch_device = submit + wait: it returns when the last kernel of the call has been QUEUED; the results are
- * in the output buffers once `stream` has been synchronised.  For a batch whose problems all finish within the blind
+ * qtos_plan_batch_device = submit + wait: it returns when the last iteration has reported that no problem is left; work
+ * queued on `stream` afterwards sees the results, and so does the host after synchronising `stream`.  For a batch whose problems all finish within the blind
  * iterations (qtos_set_speculation; off by default) the host does nothing between the submit and the end.  One planner handle serves one call at a time (a second submit before the first is done returns -5);
  * handles are independent: several handles on their own streams keep several batches in flight from ONE host thread
  * (qtos_amd.pool.PlannerPool: submit to a free handle, poll the others) -- a batch that waits for its slowest problem

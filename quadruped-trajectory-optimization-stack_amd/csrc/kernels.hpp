@@ -139,6 +139,11 @@ struct DevWork {
   double *minv;                // per problem n_stages x 256: inverse of every pivot block (written by k_kkt2)
   double *sol;                 // per problem n_stages x 16: the solution of the last KKT solve by unknown position (variables AND multipliers)
   double *sol0, *dx0, *ur;     // iterative refinement (k_residual / k_refine_add): first solution, and sig * (Ji dx) by constraint row
+  // where a finished problem leaves its result (the caller's buffers of this call; status / iters / viol may be null) and the
+  // handle's running totals {converged problems, iterations}: written by the kernel that finishes the problem (export_problem)
+  double *nodes_out, *viol_out;
+  int *status_out, *iters_out;
+  unsigned long long *totals;
 };
 
 // ---- tiny forward-mode dual (one tangent) for the rotation-dependent Jacobians ---------------
@@ -691,6 +696,21 @@ __device__ inline void record_trace(const DevPlan &P, const DevWork &W, int b, i
   }
 }
 
+// A problem that is finished (converged, stalled, failed, or out of iterations) hands its result over on the spot: no export
+// kernel behind the last iteration, whose launch the host could only queue after reading that it was the last.  x = the
+// nodes as the workgroup's threads left them in memory (the caller has synchronised the workgroup).
+__device__ inline void export_problem(const DevPlan &P, const DevWork &W, int b, const double *x, int status, int iters, double viol) {
+  const size_t n = P.n_vars;
+  for (int v = threadIdx.x; v < P.n_vars; v += blockDim.x) W.nodes_out[(size_t)b * n + v] = x[v];
+  if (threadIdx.x == 0) {
+    if (W.status_out) W.status_out[b] = status;
+    if (W.iters_out) W.iters_out[b] = iters;
+    if (W.viol_out) W.viol_out[b] = viol;
+    if (status == 0) atomicAdd(W.totals, 1ull);
+    atomicAdd(W.totals + 1, (unsigned long long)iters);
+  }
+}
+
 // ---- starting point of a solve ---------------------------------------------------------------------
 // With a table of nominal plans: bilinear interpolation over the goal displacement (clamped to the
 // grid), then every position-like variable is shifted by the difference between the problem's start
@@ -838,7 +858,11 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     if (!conv && !bad) atomicAdd(W.n_active, 1);
     record_trace(P, W, b, 0, viol, theta, 0.0, mu);
   }
-  if (conv || bad) return;
+  if (conv || bad || P.max_iter <= 0) {
+    __syncthreads();   // (x of the other threads)
+    export_problem(P, W, b, x, conv ? 0 : (bad ? 2 : 1), 0, viol);
+    if (conv || bad) return;
+  }
   __syncthreads();
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
 }
@@ -1357,6 +1381,12 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
       W.chord[b] = 0;
       atomicAdd(W.n_active, -1);
     }
+  }
+  // finished, or out of iterations: the result leaves now (x as restored above; a problem out of iterations keeps the status
+  // k_start gave it: 1)
+  if (conv || bad || stalled || it + 1 >= P.max_iter) {
+    __syncthreads();
+    export_problem(P, W, b, x, conv ? 0 : (bad ? 2 : 1), it + 1, restore ? best_viol : viol);
   }
   if (conv || bad || stalled) return;
   // chord step next?  (an iterate this close, reached by a full step of a freshly factored system)

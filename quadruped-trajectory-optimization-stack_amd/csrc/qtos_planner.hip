@@ -510,28 +510,6 @@ int qtos_set_heightfields(QtosPlanner *p, int n_maps, const double *height, int 
 
 // results of a batch to the caller's buffers (one launch instead of four copies) and the running totals of
 // qtos_plan_totals
-__global__ void k_export(const double *x, const int *status, const int *iters, const double *viol, int n, double *nodes_out,
-                         int *status_out, int *iters_out, double *viol_out, long long *tot, const int *only_if_zero) {
-  // (queued behind iterations that were launched without knowing whether they would be the last: it runs only if they were)
-  if (only_if_zero && *only_if_zero != 0) return;
-  const int b = blockIdx.x;
-  const d2_t *src = (const d2_t *)(x + (size_t)b * n);
-  d2_t *dst = (d2_t *)(nodes_out + (size_t)b * n);
-  if ((n & 1) == 0 && ((((size_t)nodes_out) & 15) == 0)) {
-    for (int i = threadIdx.x; i < n / 2; i += blockDim.x) dst[i] = src[i];
-  } else {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) nodes_out[(size_t)b * n + i] = x[(size_t)b * n + i];
-  }
-  if (threadIdx.x == 0) {
-    const int st = status[b], it = iters[b];
-    if (status_out) status_out[b] = st;
-    if (iters_out) iters_out[b] = it;
-    if (viol_out) viol_out[b] = viol[b];
-    if (st == 0) atomicAdd((unsigned long long *)tot, 1ull);
-    atomicAdd((unsigned long long *)(tot + 1), (unsigned long long)it);
-  }
-}
-
 // The counts of unfinished problems to the host: a store into mapped pinned memory by a one-wave kernel.  (A copy
 // (hipMemcpyAsync) between two kernels of a stream makes the compute queue wait on the copy engine's signal; with more
 // streams than hardware queues that wait holds up the other streams of the queue too: four sets of receding windows
@@ -586,14 +564,6 @@ static int queue_iteration(QtosPlanner *p, int it, bool informed, int n, int nc)
   return 0;
 }
 
-static int queue_export(QtosPlanner *p, bool conditional) {
-  QtosPlanner::Call &c = p->call;
-  hipLaunchKernelGGL(k_export, dim3(c.B), dim3(256), 0, c.st, c.W.x, c.W.status, c.W.iters, c.W.viol, p->dp.n_vars, c.nodes_out,
-                     c.status_out, c.iters_out, c.viol_out, p->d_totals, conditional ? c.W.n_active : nullptr);
-  HIPCHK(p, hipGetLastError());
-  return 0;
-}
-
 int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
                      const int *d_map_id, const double *d_warm, double *d_nodes_out,
                      int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream_) {
@@ -609,6 +579,9 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
   c.W = p->wk;
   c.W.start = d_start; c.W.goal = d_goal; c.W.map_id = d_map_id; c.W.warm = d_warm;
   c.nodes_out = d_nodes_out; c.status_out = d_status_out; c.iters_out = d_iters_out; c.viol_out = d_viol_out;
+  // (the kernel that finishes a problem writes its result: kernels.hpp export_problem)
+  c.W.nodes_out = d_nodes_out; c.W.status_out = d_status_out; c.W.iters_out = d_iters_out; c.W.viol_out = d_viol_out;
+  c.W.totals = (unsigned long long *)p->d_totals;
   const DevPlan &D = p->dp;
 #define SUBCHK(call_) do { hipError_t e_ = (call_); if (e_ != hipSuccess) { p->err = std::string(#call_) + ": " + hipGetErrorString(e_); return fail(e_ == hipErrorOutOfMemory ? -3 : -2); } } while (0)
   std::memset(p->h_active, 0xff, 2 * sizeof(int) * ((size_t)D.max_iter + 1));   // no counts yet (the handle's previous call is over)
@@ -622,14 +595,12 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
   SUBCHK(hipEventRecord(p->ev[ev_start], st));
 #undef SUBCHK
   // Blind iterations: as many as the previous call of this handle needed (its slowest problem), queued without a host
-  // round trip; the results leave through an export that runs only if they were enough.  A batch that needs more is
-  // continued by qtos_plan_poll from the counts the iterations send back.
+  // round trip (qtos_set_speculation; 1 by default: the first iteration).  A batch that needs more is continued by
+  // qtos_plan_poll from the counts the iterations send back; blind launches behind the end find every problem done.
   c.spec = std::max(0, std::min(std::min(p->spec_next, p->spec_cap), D.max_iter));
   for (int it = 0; it < c.spec; ++it)
     if (int rc = queue_iteration(p, it, false, 0, 0)) return fail(rc);
   c.enq = c.spec;
-  if (c.spec > 0)
-    if (int rc = queue_export(p, true)) return fail(rc);
   if (hipEventRecord(p->ev[1], st) != hipSuccess) return fail(-2);
   p->last_stream = st;
   return 0;
@@ -667,15 +638,10 @@ int qtos_plan_poll(QtosPlanner *p, int *done) {
       n = (int)(unsigned)(v & 0xffffffffull); nc = (int)(unsigned)(v >> 32);
     }
     if (n <= 0 || c.chk >= D.max_iter) {
-      // finished in front of iteration c.chk.  The blind export ran iff the blind iterations were enough.
+      // finished in front of iteration c.chk (every problem has handed its result over: export_problem)
       const int iters = c.chk;
       for (int j = iters; j < c.enq; ++j) { p->was_kkt[j] = 0; p->was_chord[j] = 0; }   // blind launches behind the end: no work
-      const bool blind_export_ran = c.spec > 0 && (iters < c.spec || (iters == c.spec && n <= 0));
-      if (!blind_export_ran) {
-        if (!device_set) { HIPCHK(p, hipSetDevice(p->device)); device_set = true; }
-        if (int rc = queue_export(p, false)) { c.open = false; p->busy.store(0); return rc; }
-        HIPCHK(p, hipEventRecord(p->ev[1], c.st));
-      }
+      // (the end-of-call event ev[1] sits behind the last launch already: submit and every continuation record it)
       p->last_launches = iters;
       p->last_iters = iters;
       p->spec_next = std::max(1, iters);
