@@ -132,7 +132,7 @@ __device__ __forceinline__ void sload2(const int *p, int &a, int &b) {
 // A triangular solve with the chain of fronts is a chain of NS dependent steps: x_k needs x_{k+1} (backward), p_k needs
 // p_{k-1} (forward).  Per stage only a 16 x 16 block carries that dependence -- the rows of V_k that belong to the
 // pivots of stage k+1 (Symbolic::nxt_pack) --; every other row of V_k meets values that are one stage older.  Wave 0
-// carries the chain (the block product, in registers), NT helper waves apply the other rows one stage behind it
+// carries the chain (the block product, in registers), waves 1..NT apply the other rows one stage behind it
 // (Symbolic::amask2) and hand their partial sums over through LDS: one barrier per stage, and between two barriers
 // the chain costs one reduction of 16 partials and 16 row-broadcast multiply-adds.
 
@@ -163,10 +163,6 @@ __device__ __forceinline__ double dot4_by_row(double x, const double (&c)[4]) {
   fma_bc_rows<12, 1>(a3, x, c[3]); fma_bc_rows<13, 2>(a3, x, c[3]); fma_bc_rows<14, 4>(a3, x, c[3]); fma_bc_rows<15, 8>(a3, x, c[3]);
   return (a0 + a1) + (a2 + a3);
 }
-// helper index of a wave in the sweeps (-1: the chain wave)
-__device__ __forceinline__ int sweep_helper_of_wave(int wv) {
-  return (wv & 3) ? wv - 1 - (wv >> 2) : (wv == 0 ? -1 : 11 + (wv >> 2));
-}
 #ifndef QTOS_SWD
 #define QTOS_SWD 4
 #endif
@@ -183,31 +179,19 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
   const int NS = P.n_stages, n = P.n_sol;
   const int j = lane & 15, q = lane >> 4;
   const int vcol = 4 * (j & 3) + (j >> 2);   // where column j of a V row sits
-  // the waves that own a row tile: those that do not share the chain wave's SIMD first (waves w, w + 4, w + 8, w + 12 share
-  // a SIMD and its one vector ALU: what a helper executes there is time the chain does not get) -- helper h = 0 .. 11 on wave
-  // h + 1 + h / 3, helpers 12 .. 14 (fronts above 192 slots) on waves 4, 8, 12
-  const int hlp = sweep_helper_of_wave(wv);
-  const bool owner = hlp >= 0 && hlp < NT;
-  const int R = owner ? hlp : 0;
+  const bool owner = wv >= 1 && wv <= NT;
+  const int R = owner ? wv - 1 : 0;
   // ring slot of a stage: four doubles -- the chain block on wave 0, the rows of the wave's tile on waves 1..NT --, and on
   // wave 0 the stage's w, pivot slots and unknowns
   double bv[SWD][4], bw[SWD];
   int bps[SWD], bun[SWD];
-  unsigned bam[SWD], bnp[SWD];
-  // the two table words of a stage (LDS): the slots of the next stage's pivots, the row mask of the wave's tile.  They form
-  // the addresses of the stage's panel loads and are read one step AHEAD of them (carried through the loop in registers):
-  // read where they are used they put an LDS round trip -- two, one per word -- between the barrier and the loads of
-  // every step of every wave
-  auto words = [&](int s, unsigned &np, unsigned &amw) __attribute__((always_inline)) {
-    const int kk = max(s, 0);
-    np = (unsigned)nxp[kk * 4 + q];
-    amw = owner ? (unsigned)nxp[NS * 4 + kk * 8 + (R >> 1)] : 0u;
-  };
-  auto load = [&](int s, unsigned np, unsigned amw, double (&v)[4], unsigned &am, unsigned &npo, double &wj, int &psj, int &unkj) __attribute__((always_inline)) {
+  unsigned bam[SWD];
+  auto load = [&](int s, double (&v)[4], unsigned &am, double &wj, int &psj, int &unkj) __attribute__((always_inline)) {
     const int kk = max(s, 0);
     const double *pk = panel + (size_t)kk * pstride;
-    am = owner ? (amw >> ((R & 1) * 16)) & 0xffffu : 0u;
-    npo = np;
+    // (the masks and slots below are addresses of the loads: from LDS)
+    am = owner ? ((unsigned)nxp[NS * 4 + kk * 8 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu : 0u;
+    const unsigned np = (unsigned)nxp[kk * 4 + q];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = q + 4 * i;
@@ -224,7 +208,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
   if (lane < PIV) { red[wv * PIV + lane] = 0.0; red[256 + wv * PIV + lane] = 0.0; }   // (the last stage has no rows besides its pivots)
   // waves NT+1 .. 15 have no rows: they only meet the barriers (a SIMD has one vector ALU: what they would execute on
   // dummies is time the working waves of their SIMD do not get)
-  const bool active = wv == 0 || owner;
+  const bool active = wv <= NT;
   if (!active) {
     lds_barrier();
     for (int k0 = NS - 1; k0 >= 0; k0 -= SWD)
@@ -233,13 +217,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
     return;
   }
 #pragma unroll
-  for (int d = 0; d < SWD; ++d) {
-    unsigned np0, amw0;
-    words(NS - 1 - d, np0, amw0);
-    load(NS - 1 - d, np0, amw0, bv[d], bam[d], bnp[d], bw[d], bps[d], bun[d]);
-  }
-  unsigned np_nx, amw_nx;   // table words of the stage the next step loads
-  words(NS - 1 - SWD, np_nx, amw_nx);
+  for (int d = 0; d < SWD; ++d) load(NS - 1 - d, bv[d], bam[d], bw[d], bps[d], bun[d]);
   double corr = 0.0;
   lds_barrier();
   for (int k0 = NS - 1; k0 >= 0; k0 -= SWD) {
@@ -259,33 +237,28 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
           sol[t * PIV + lane] = x;       // by unknown position, multipliers included (k_residual)
           if (bun[d] >= 0 && bun[d] < n) dx[bun[d]] = x;
         }
-        // the block of stage t - 1 against the entries just found (its table word came with its loads)
-        const unsigned np = bnp[dn];
+        // the block of stage t - 1 against the entries just found
+        const unsigned np = (unsigned)nxp[max(t - 1, 0) * 4 + q];
         double c[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) c[m] = ((np >> (8 * m)) & 255u) != 255u && t >= 1 ? bv[dn][m] : 0.0;
         corr = rowsum4(dot4_by_row(x, c));
       }
-      // the other rows of stage t - 1 (they meet entries that are at least one barrier old): the four entries are read
-      // together and unconditionally -- a read under its row's mask bit is a branch, and four of them are four LDS round trips
-      // in a row
-      if (owner) {
-        const unsigned am = bam[dn];
-        double xv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = xs[16 * R + q + 4 * i];
+      // the other rows of stage t - 1 (they meet entries that are at least one barrier old)
+      if (wv >= 1) {
         double pp = 0.0;
+        const unsigned am = bam[dn];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const double tq = fma(bv[dn][i], xv[i], pp);
-          pp = ((am >> (q + 4 * i)) & 1u) ? tq : pp;
+          const int row = q + 4 * i;
+          const double xv = xs[16 * R + row];
+          pp = ((am >> row) & 1u) ? fma(bv[dn][i], xv, pp) : pp;
         }
         pp = rowsum4(pp);
-        if (lane < PIV) red[((t - 1) & 1) * 256 + (hlp + 1) * PIV + j] = t >= 1 ? pp : 0.0;
+        if (lane < PIV) red[((t - 1) & 1) * 256 + wv * PIV + j] = t >= 1 ? pp : 0.0;
       }
       lds_barrier();
-      load(t - SWD, np_nx, amw_nx, bv[d], bam[d], bnp[d], bw[d], bps[d], bun[d]);
-      words(t - SWD - 1, np_nx, amw_nx);
+      load(t - SWD, bv[d], bam[d], bw[d], bps[d], bun[d]);
     }
   }
 }
@@ -892,8 +865,8 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
 // with the right-hand side in elimination order from k_step.  Both sweeps run with the one-stage look-ahead described
 // above: one barrier per stage; the launch streams the panels twice and is bound by that.
 //   wave 0          the chain: p_k, and the block of V_k that feeds p_{k+1}
-//   NT helpers      u -= V_{k-1} p_{k-1} on the other rows of their row tile, one stage behind (sweep_helper_of_wave)
-//   helper NT       w_{k-1} = B_{k-1}^-1 p_{k-1}
+//   waves 1 .. NT   u -= V_{k-1} p_{k-1} on the other rows of row tile wv - 1, one stage behind
+//   wave NT + 1     w_{k-1} = B_{k-1}^-1 p_{k-1}
 constexpr int KTC = 1024;
 inline size_t chord_lds_bytes(int NS) { return sizeof(int) * (size_t)NS * 12; }
 template <int F>
@@ -921,28 +894,20 @@ __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
   __syncthreads();
   // ---- forward -------------------------------------------------------------------------------------
   {
-    const int hlp = sweep_helper_of_wave(wv);   // (helpers off the chain wave's SIMD first: sweep_backward)
-    const bool owner = hlp >= 0 && hlp < NT, solver = hlp == NT;
-    const int R = owner ? hlp : 0;
+    const bool owner = wv >= 1 && wv <= NT, solver = wv == NT + 1;
+    const int R = owner ? wv - 1 : 0;
     const int rowl = lane >> 2, jq = lane & 3;   // bulk rows: lane = (row of the tile, four columns jq + 4 m: one 32-byte piece of the V row)
     // ring slot of a stage: one 32-byte piece -- of the chain block on wave 0 (V_k[slot of pivot j of stage k+1][q + 4 m]), of
     // the wave's rows on waves 1..NT, of B_k^-1 on wave NT + 1 --, and on wave 0 the stage's right-hand side and pivot slots
     d4_t fv[SWD];
     double frhs[SWD];
     int fps[SWD];
-    unsigned fam[SWD], fnr[SWD];
-    // the two table words of a stage (LDS), read one step ahead of the loads whose addresses they form (sweep_backward)
-    auto fwords = [&](int s, unsigned &nrw, unsigned &amw) __attribute__((always_inline)) {
-      const int kk = min(s, NS - 1);
-      nrw = (unsigned)nxp[kk * 4 + (j & 3)];
-      amw = owner ? (unsigned)nxp[NS * 4 + kk * 8 + (R >> 1)] : 0u;
-    };
-    auto load = [&](int s, unsigned nrw, unsigned amw, d4_t &v, unsigned &am, unsigned &nro, double &rk, int &psj) __attribute__((always_inline)) {
+    unsigned fam[SWD];
+    auto load = [&](int s, d4_t &v, unsigned &am, double &rk, int &psj) __attribute__((always_inline)) {
       const int kk = min(s, NS - 1);
       const double *pk = panel + (size_t)kk * pstride;
-      am = owner ? (amw >> ((R & 1) * 16)) & 0xffffu : 0u;
-      const unsigned nr = (nrw >> (8 * (j >> 2))) & 255u;   // slot of pivot j of stage kk + 1
-      nro = nr;
+      am = owner ? ((unsigned)nxp[NS * 4 + kk * 8 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu : 0u;
+      const unsigned nr = ((unsigned)nxp[kk * 4 + (j & 3)] >> (8 * (j >> 2))) & 255u;   // slot of pivot j of stage kk + 1
       const double *src = wv == 0 ? pk + (nr != 255u ? PIV + (int)nr * PIV + 4 * q : 0)
                         : solver  ? minv + (size_t)kk * (PIV * PIV) + j * PIV + 4 * q
                                   : pk + (((am >> rowl) & 1u) ? PIV + (16 * R + rowl) * PIV + 4 * jq : 0);
@@ -953,13 +918,7 @@ __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
       }
     };
 #pragma unroll
-    for (int d = 0; d < SWD; ++d) {
-      unsigned nrw0, amw0;
-      fwords(d, nrw0, amw0);
-      load(d, nrw0, amw0, fv[d], fam[d], fnr[d], frhs[d], fps[d]);
-    }
-    unsigned nrw_nx, amw_nx;   // table words of the stage the next step loads
-    fwords(SWD, nrw_nx, amw_nx);
+    for (int d = 0; d < SWD; ++d) load(d, fv[d], fam[d], frhs[d], fps[d]);
     double corr = 0.0;
     for (int k0 = 0; k0 <= NS; k0 += SWD) {
 #pragma unroll
@@ -969,7 +928,7 @@ __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
           const bool real = k * PIV + j < P.n_unknowns;     // (dummy pivots of a short last stage)
           const double p = (real ? frhs[d] : 0.0) + UF[fps[d]] - corr;
           if (lane < PIV) { pf[(k & 1) * PIV + j] = p; UF[fps[d]] = 0.0; }   // (the slots are retired)
-          const unsigned nr = fnr[d];
+          const unsigned nr = ((unsigned)nxp[k * 4 + (j & 3)] >> (8 * (j >> 2))) & 255u;
           double c[4];
 #pragma unroll
           for (int m = 0; m < 4; ++m) c[m] = nr != 255u ? fv[d][m] : 0.0;
@@ -998,10 +957,7 @@ __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
         }
         lds_barrier();
         // ring slot dp (stage k - 1) is free now
-        if (k >= 1) {
-          load(k - 1 + SWD, nrw_nx, amw_nx, fv[dp], fam[dp], fnr[dp], frhs[dp], fps[dp]);
-          fwords(k + SWD, nrw_nx, amw_nx);
-        }
+        if (k >= 1) load(k - 1 + SWD, fv[dp], fam[dp], frhs[dp], fps[dp]);
       }
     }
   }
