@@ -631,6 +631,50 @@ struct Symbolic {
         }
       }
     }
+    // Order of a stage's entries in its record (and with it in the problem's stream): the values the evaluation kernels
+    // write in every linearisation first and grouped by the pass that writes them -- one-term dynamics entries, three-term
+    // dynamics entries, terrain rows --, then everything that is written once (structural zeros and constants of the dynamics
+    // blocks, static rows).  Interleaved as the blocks list them, the entries of one pass are runs of two among constants: 8-byte
+    // stores scattered over every cache line of the stream (25 of the 39 k cycles of that pass).  Which
+    // cell an entry is added to does not depend on its place in the list.
+    {
+      std::vector<char> cls((size_t)std::max<long long>(g_doubles, 1), 3);
+      for (const DynInst &I : M.dyn) {
+        if (!I.in_kkt || I.goff < 0) continue;
+        const Block &b = M.blocks[I.goff];          // (instances hold their block id until finalize_goff)
+        if (b.kind != 0 || b.gstatic) continue;
+        auto mark = [&](const short cmap[12], int kind) {
+          for (int sl = 0; sl < 4; ++sl)
+            for (int d = 0; d < 3; ++d) {
+              const int c = cmap[3 * sl + d];
+              if (c < 0) continue;
+              for (int i = 0; i < 3; ++i)           // (rows 3..5 of a column are constants: build_linear_terms)
+                if (kind == 1) cls[b.goff + c + i * b.n] = 1;
+                else if (i != d) cls[b.goff + c + i * b.n] = 0;
+            }
+        };
+        mark(I.c_lin, 0);
+        mark(I.c_ang, 1);
+        for (int e = 0; e < NEE; ++e) { mark(I.c_p[e], 2 + e); mark(I.c_f[e], 6 + e); }
+      }
+      for (const TerrInst &T : M.terr) {
+        if (!T.in_kkt || T.goff < 0) continue;
+        const Block &b = M.blocks[T.goff];
+        if (b.kind != 0 || b.gstatic) continue;
+        for (int a = 0; a < b.n; ++a) cls[b.goff + a] = 2;
+      }
+      for (int k = 0; k < n_stages; ++k) {
+        std::vector<int> perm(ent[k].size());
+        std::iota(perm.begin(), perm.end(), 0);
+        auto key = [&](int i) { return ent[k][i].src >= 0 ? (int)cls[ent[k][i].src] : 4; };
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b2) { return key(a) < key(b2); });
+        std::vector<EqEntry> e2(ent[k].size());
+        std::vector<std::pair<int, int>> p2(ent[k].size());
+        for (size_t i = 0; i < perm.size(); ++i) { e2[i] = ent[k][perm[i]]; p2[i] = ent_pp[k][perm[i]]; }
+        ent[k].swap(e2);
+        ent_pp[k].swap(p2);
+      }
+    }
     // static entries between two variable unknowns (the proximal term of the reduced base: delta_x Z'Z off the diagonal).
     // They share cells with the entries the inequality blocks assemble (J' S J of the same coefficient pairs), so they are
     // NOT equality-type entries (added by other threads of the same assembly pass: a race on the cell): each becomes one more
