@@ -2,9 +2,9 @@
 //
 //   k_start : initial guess (or warm start), constraint values, slack / barrier initialisation,
 //             first linearisation (per-instance dense Jacobian blocks G, barrier weights)
-//   k_kkt   : fused front assembly + block LDL^T (Schur-complement chain, 16 pivots per stage,
-//             assembled entries in LDS, Schur updates in MFMA accumulator registers) +
-//             forward/backward substitution  -> Newton step dx
+//   k_kkt2 / k_chord (kkt2.hpp): fused front assembly + block LDL^T (Schur-complement chain, 16 pivots per
+//             stage, assembled entries in LDS cells, Schur updates in MFMA accumulator registers) +
+//             forward/backward substitution  -> Newton step dx; a solve with the stored factorisation
 //   k_step  : slack/dual steps, fraction-to-the-boundary, backtracking on the l1 infeasibility,
 //             state update, convergence test, next linearisation
 //   k_sample: 1 kHz spline sampling into the 37-column CSV row layout
@@ -868,37 +868,10 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
 }
 
 // =================================================================================================
-// k_kkt: one workgroup (KT threads = 8 waves) per problem: fused assembly + block LDL^T of the
-// condensed KKT chain (16 pivots per stage) + forward/backward substitution.
-//
-// Where the data lives
-//   LDS   A      lower triangle of the ASSEMBLED entries of the front (original matrix entries only;
-//                rows 0..F-1 by front slot, row F = assembled right-hand side)
-//         PB[3]  three (F+1) x 17 panels: the pivot columns P_k of the current stage, Y_k = P_k L^-T,
-//                and the columns of the next stage under construction
-//         UF     accumulated right-hand-side updates by front slot
-//   VGPR  U      the accumulated Schur updates  -sum_k Y_k D_k^-1 Y_k^T  as 16 x 16 tiles in the
-//                f64 MFMA accumulator layout, six tiles on each of waves 1..6 (36 = lower triangle
-//                of a 128-slot front); they never touch LDS except for the 16 columns a stage
-//                extracts
-//   HBM   per stage V_k = Y_k D^-1 L^-1 (hi x 16) and w_k = L^-T D^-1 y_F: all the backward pass needs
-//
-// Two phases per stage, two LDS-only barriers:
-//   AB(k)  every wave owns one 16-row tile R of the panel, three chained products of 4 MFMAs (an MFMA
-//          accumulator IS a valid A/B operand of the next MFMA: no LDS round trip, no barrier between
-//          them): Y^T = L^-1 P^T;  V^T = (D^-1 L^-1)^T Y^T, which in accumulator layout is V as an A
-//          operand (and goes to HBM);  P_{k+1} = A[:, piv] + U[:, piv] - V P_k[piv]^T, because
-//          Y D^-1 Y[piv]^T = V P[piv]^T: the raw rows of the next pivots are the B operand.
-//   C(k)   wave 0: in-register LDL^T + L^-1 of the next 16 x 16 pivot block (DPP row broadcasts);
-//          waves 1..6: U -= Y D^-1 Y^T on the matrix cores, retire the next pivots' rows/columns,
-//          extract the columns of stage k+2;  wave 7: right-hand-side row (y_F, w, updates);
-//          every wave ends with its share of the assembly of stage k+2's records into A.
-// The backward pass is one barrier per stage: every wave reduces its 16 rows of V^T x against the
-// solution, partial sums meet in LDS, every wave forms the 16 new solution entries redundantly.
-constexpr int KT = 512;
+// Building blocks of the KKT kernels (kkt2.hpp: k_kkt2, k_chord): LDS-only barrier, the in-register LDL^T of a 16 x 16 pivot
+// block, the assembly of a stage's records.
+constexpr int KT = 512;    // (record limits of the prefetch path are stated in units of it: qtos_planner_create)
 constexpr int PLD = PIV + 1;
-constexpr int MAXT = 6;   // U tiles per update wave
-constexpr int TB = 2;     // tiles processed together in the update phase
 __device__ __forceinline__ int tri(int r, int c) { return ((r * (r + 1)) >> 1) + c; }  // c <= r
 __device__ __forceinline__ int trs(int a, int b) { return a >= b ? tri(a, b) : tri(b, a); }
 
@@ -923,55 +896,6 @@ __device__ __forceinline__ double bc16(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-// a += bcast_K(a) * b as ONE DP-ALU DPP instruction (v_fmac_f64 is the VOP2 form that can carry DPP;
-// the broadcast source is the accumulator itself).  Callers keep two instructions between a VALU
-// write of `a` and this cross-lane read.
-template <int K>
-__device__ __forceinline__ void fma_bc_self(double &a, double b) {
-  asm volatile("v_fmac_f64 %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b), "n"(K));
-}
-template <int K, int J, int END>
-__device__ __forceinline__ void bc_update(double (&r)[PIV], double m) {
-  if constexpr (J < END) {
-    fma_bc_self<K>(r[J], m);
-    bc_update<K, J + 1, END>(r, m);
-  }
-}
-template <int K>
-__device__ __forceinline__ void ldlt16_steps(double (&a)[PIV], double (&v)[PIV], double &myinv, int i) {
-  if constexpr (K < PIV) {
-    const double inv = fast_rcp(bc16<K>(a[K]));   // 1 / d_K
-    if (i == K) myinv = inv;
-    if constexpr (K < PIV - 1) {
-      const double li = i > K ? a[K] * inv : 0.0;  // L[i][K] for rows i > K, 0 for finished rows
-      const double nli = -li;
-      bc_update<K, K + 1, PIV>(a, nli);   // trailing block: a[j] -= L[i][K] B[K][j], j > K
-      bc_update<K, 0, K>(v, nli);         // inverse: row i -= L[i][K] * (row K of L^-1), columns < K
-      v[K] = nli;                         // (L^-1)[K][K] = 1
-      asm volatile("s_nop 1" : "+v"(v[K]));   // DPP hazard: two wait states between this VALU write and the row read
-    }
-    ldlt16_steps<K + 1>(a, v, myinv, i);
-  }
-}
-// In-register LDL^T of a symmetric 16 x 16 block by one wave, no pivoting (the KKT matrix is
-// quasi-definite and the elimination order is fixed), plus the inverse of the unit lower-triangular
-// factor, so that every other product of the stage is a plain matrix product on the matrix cores.
-// Lane i of every 16-lane DPP row holds ROW i of the block in a[0..15]; the wave-uniform row K is
-// read with DPP row broadcasts folded into the f64 FMAs: no LDS traffic and no scalar round trips
-// on the 16-step dependency chain.  On return v[j] = (L^-1)[i][j] for j < i, myinv = 1 / d_i.
-__device__ __forceinline__ void ldlt16(double (&a)[PIV], double (&v)[PIV], double &myinv, int i) {
-#pragma unroll
-  for (int j = 0; j < PIV; ++j) v[j] = 0.0;
-  myinv = 0.0;
-  // pin the 32 row registers before the DPP chain starts (EXEC / VALU-write hazards of the hand-written
-  // DPP instructions are not tracked by the compiler)
-#define QTOS_PIN16(r) asm volatile("s_nop 4" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]))
-  QTOS_PIN16(a);
-  QTOS_PIN16(v);
-#undef QTOS_PIN16
-  ldlt16_steps<0>(a, v, myinv, i);
-}
-
 // ---- LDL^T of a 16 x 16 block in the split layout (round 3) --------------------------------------------------------
 // The block is held ONCE by the wave, not once per 16-lane row: lane (li, lk) = (lane & 15, lane >> 4) keeps
 // a[g] = B[li][4 g + lk], g = 0..3 -- row li, the four columns = lk (mod 4); this is also the accumulator layout of the
@@ -1038,42 +962,6 @@ __device__ __forceinline__ void ldlt16s(double (&a)[4], double (&w)[4], double &
   myinv = 0.0;
   asm volatile("s_nop 4" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
   ldlt16s_steps<0>(a, w, myinv, li, lk);
-}
-
-// The same factorisation with the row-group crossing taken off the dependency chain: the next two pivot columns are
-// kept replicated on all four row groups (cK: column K after the steps before K; cN: column K + 1 after the steps
-// before K); a step forms its multipliers from cK with no crossing, brings cN up to date with one more FMA, and fetches
-// column K + 2 from the split matrix for the step after next.
-template <int K>
-__device__ __forceinline__ void ldlt16p_steps(double (&a)[4], double (&w)[4], double &myinv, double cK, double cN, int li, int lk) {
-  if constexpr (K < PIV) {
-    constexpr int gK = K >> 2, qK = K & 3;
-    const double inv = fast_rcp(bc16_safe<K>(cK));
-    if (li == K && lk == qK) myinv = inv;
-    if constexpr (K < PIV - 1) {
-      const double nl = li > K ? -(cK * inv) : 0.0;
-      fma_bc_self_rows<K, 0xF>(cN, nl);             // column K + 1 after step K: the next step's pivot column
-      fma_bc_self_rows<K, (0xF << (qK + 1)) & 0xF>(a[gK], nl);
-      if constexpr (gK + 1 < 4) fma_bc_self_rows<K, 0xF>(a[gK + 1 < 4 ? gK + 1 : 3], nl);
-      if constexpr (gK + 2 < 4) fma_bc_self_rows<K, 0xF>(a[gK + 2 < 4 ? gK + 2 : 3], nl);
-      if constexpr (gK + 3 < 4) fma_bc_self_rows<K, 0xF>(a[gK + 3 < 4 ? gK + 3 : 3], nl);
-      if constexpr (gK >= 1) fma_bc_self_rows<K, 0xF>(w[0], nl);
-      if constexpr (gK >= 2) fma_bc_self_rows<K, 0xF>(w[1], nl);
-      if constexpr (gK >= 3) fma_bc_self_rows<K, 0xF>(w[2], nl);
-      fma_bc_self_rows<K, (1 << (qK + 1)) - 1>(w[gK], nl);
-      double c2 = 0.0;
-      if constexpr (K + 2 < PIV) c2 = bcast_rowgroup<(K + 2) & 3>(a[(K + 2) >> 2]);   // column K + 2 after step K
-      ldlt16p_steps<K + 1>(a, w, myinv, cN, c2, li, lk);
-    }
-  }
-}
-__device__ __forceinline__ void ldlt16p(double (&a)[4], double (&w)[4], double &myinv, int li, int lk) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) w[g] = li == 4 * g + lk ? 1.0 : 0.0;
-  myinv = 0.0;
-  double c0 = bcast_rowgroup<0>(a[0]), c1 = bcast_rowgroup<1>(a[0]);
-  asm volatile("s_nop 4" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(c0), "+v"(c1));
-  ldlt16p_steps<0>(a, w, myinv, c0, c1, li, lk);
 }
 
 #ifdef QTOS_STAMPS

@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../../quadruped-trajectory-optimization-stack_amd/csrc/kernels.hpp"
+#include "ldlt_variants.hpp"
 using namespace qtos;
 
 template <int VAR>
