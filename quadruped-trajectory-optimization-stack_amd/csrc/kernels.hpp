@@ -1110,6 +1110,26 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   if (P.n_rec) rec_load(tid);
 #pragma unroll
   for (int t = 0; t < TP; ++t) Rn[t] = row_of(tid + t * nt);
+  // (c) the rows of the working set this thread owns: inequality rows tid + k nt (k < KR) and equality rows tid + k nt
+  //     (k < KE) with their bounds, slacks, multipliers and values live in registers from here to the end of the kernel -- every
+  //     pass below (ratio test, merit function, update, convergence test, barrier weights) read them through the row lists
+  //     again: two memory round trips per pass and ten array passes of traffic per launch.  Rows beyond KR nt / KE nt (longer
+  //     horizons) go through memory as before.
+  constexpr int KR = 2, KE = 2;
+  int rr[KR], er[KE];
+  double rl[KR], ru[KR], rs[KR], rzl[KR], rzu[KR], rg[KR], eg[KE];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const int ic = min(tid + k * nt, max(P.n_iq - 1, 0));
+    rr[k] = P.iq_idx[ic]; rl[k] = P.iq_lo[ic]; ru[k] = P.iq_hi[ic];
+  }
+#pragma unroll
+  for (int k = 0; k < KE; ++k) er[k] = P.eq_idx[min(tid + k * nt, max(P.n_eqw - 1, 0))];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) { rs[k] = s[rr[k]]; rzl[k] = zl[rr[k]]; rzu[k] = zu[rr[k]]; rg[k] = g[rr[k]]; }
+#pragma unroll
+  for (int k = 0; k < KE; ++k) eg[k] = g[er[k]];
+  const bool rows_in_regs = P.n_iq <= KR * nt && P.n_eqw <= KE * nt;
   for (int v = tid; v < P.n_sol; v += nt) evl[v] = dx[v];
   __syncthreads();
   if (P.n_rec) {
@@ -1181,28 +1201,55 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   KSTAMP(0);
   const double tau = fmax(0.99, 1.0 - mu);
   double amax = 1.0, az = 1.0;
-#pragma unroll 4
-  for (int i = tid; i < P.n_iq; i += blockDim.x) {
-    const int r = P.iq_idx[i];
-    const double l = P.iq_lo[i], u = P.iq_hi[i];
+  double rds[KR], rdzl[KR], rdzu[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) rds[k] = ds[rr[k]];
+  // ratio tests and the step of the multipliers (one row; the formulas of the passes below are these lambdas, on registers
+  // for the thread's own rows and on memory for the rest)
+  auto ratio_row = [&](double l, double u, double sv, double d, double zlv, double zuv, double &a, double &c) __attribute__((always_inline)) {
     const bool hl = l > -1e19, hu = u < 1e19;
-    const double dl = hl ? s[r] - l : 1.0, du = hu ? u - s[r] : 1.0;
-    const double d = ds[r];
-    const double a = hl ? mu / dl - zl[r] - zl[r] / dl * d : 0.0;
-    const double c = hu ? mu / du - zu[r] + zu[r] / du * d : 0.0;
-    dzl[r] = a;
-    dzu[r] = c;
+    const double dl = hl ? sv - l : 1.0, du = hu ? u - sv : 1.0;
+    a = hl ? mu / dl - zlv - zlv / dl * d : 0.0;
+    c = hu ? mu / du - zuv + zuv / du * d : 0.0;
     if (hl && d < 0) amax = fmin(amax, tau * dl / -d);
     if (hu && d > 0) amax = fmin(amax, tau * du / d);
-    if (hl && a < 0) az = fmin(az, tau * zl[r] / -a);
-    if (hu && c < 0) az = fmin(az, tau * zu[r] / -c);
+    if (hl && a < 0) az = fmin(az, tau * zlv / -a);
+    if (hu && c < 0) az = fmin(az, tau * zuv / -c);
+  };
+#pragma unroll
+  for (int k = 0; k < KR; ++k)
+    if (tid + k * nt < P.n_iq) ratio_row(rl[k], ru[k], rs[k], rds[k], rzl[k], rzu[k], rdzl[k], rdzu[k]);
+  for (int i = tid + KR * nt; i < P.n_iq; i += nt) {
+    const int r = P.iq_idx[i];
+    double a, c;
+    ratio_row(P.iq_lo[i], P.iq_hi[i], s[r], ds[r], zl[r], zu[r], a, c);
+    dzl[r] = a;
+    dzu[r] = c;
   }
   amax = wg_reduce<2>(amax, scratch);
   az = wg_reduce<2>(az, scratch);
-  const double th0 = l1_infeasibility(P, g, s, ds, 0.0, scratch);
+  // l1 infeasibility of (c_E, c_I - (s + alpha ds)) for constraint values gI / gE (registers) and gm (memory), summed in the
+  // order of l1_infeasibility: the thread's equality rows, then its inequality rows
+  auto l1_rows = [&](const double (&gI)[KR], const double (&gE)[KE], const double *__restrict__ gm, double alq) __attribute__((always_inline)) {
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < KE; ++k)
+      if (tid + k * nt < P.n_eqw) t += fabs(gE[k]);
+    for (int i = tid + KE * nt; i < P.n_eqw; i += nt) t += fabs(gm[P.eq_idx[i]]);
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+      if (tid + k * nt < P.n_iq) t += fabs(gI[k] - (rs[k] + alq * rds[k]));
+    for (int i = tid + KR * nt; i < P.n_iq; i += nt) {
+      const int r = P.iq_idx[i];
+      t += fabs(gm[r] - (s[r] + alq * ds[r]));
+    }
+    return wg_reduce<0>(t, scratch);
+  };
+  const double th0 = l1_rows(rg, eg, g, 0.0);
   KSTAMP(1);
   // backtracking on the l1 infeasibility of (c_E, c_I - s)
   double al = amax, th = 0;
+  double rgt[KR], egt[KE];
   for (int ls = 0; ls < 6; ++ls) {
     // the trial point goes to LDS directly (and stays there for the linearisation below if it is accepted): written to
     // memory and staged back it would cost two memory round trips
@@ -1210,7 +1257,11 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     __syncthreads();
     eval_all<false>(P, map, nullptr, gt, nullptr, evl, (W.trace && it == 1 && ls == 0) ? W.trace + ((size_t)b * (P.max_iter + 1) + 76) * 4 : nullptr);
     __syncthreads();
-    th = l1_infeasibility(P, gt, s, ds, al, scratch);
+#pragma unroll
+    for (int k = 0; k < KR; ++k) rgt[k] = gt[rr[k]];
+#pragma unroll
+    for (int k = 0; k < KE; ++k) egt[k] = gt[er[k]];
+    th = l1_rows(rgt, egt, gt, al);
     if (th <= (1.0 - 1e-4 * al) * th0 || th < 1e-9) break;
     if (ls < 5) al *= 0.5;
   }
@@ -1222,27 +1273,70 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   if (reject) { al = 0.0; az = 0.0; th = 0.0; }
   else {
     for (int v = tid; v < n; v += blockDim.x) x[v] = evl[v];   // (the trial point of the last evaluation)
+#pragma unroll
+    for (int k = 0; k < KR; ++k) rg[k] = rgt[k];
+#pragma unroll
+    for (int k = 0; k < KE; ++k) eg[k] = egt[k];
+    // (the constraint values in memory: rewritten by the linearisation below whenever the solve goes on; copied here only
+    //  for the rows that are read from memory before that)
+    if (!rows_in_regs) {
 #pragma unroll 4
-    for (int r = tid; r < m; r += blockDim.x) g[r] = gt[r];
+      for (int r = tid; r < m; r += blockDim.x) g[r] = gt[r];
+    }
   }
-#pragma unroll 4
-  for (int i = tid; i < P.n_iq; i += blockDim.x) {
-    const int r = P.iq_idx[i];
-    const double l = P.iq_lo[i], u = P.iq_hi[i];
+  auto update_row = [&](double l, double u, double &sv, double d, double &zlv, double &zuv, double dl_, double du_) __attribute__((always_inline)) {
     const bool hl = l > -1e19, hu = u < 1e19;
-    const double sn = s[r] + al * ds[r];
-    s[r] = sn;
-    double a = zl[r] + az * dzl[r], c = zu[r] + az * dzu[r];
+    const double sn = sv + al * d;
+    sv = sn;
+    double a = zlv + az * dl_, c = zuv + az * du_;
     const double kap = 1e10;
     if (hl) a = fmin(fmax(a, mu / (kap * (sn - l))), kap * mu / (sn - l));
     if (hu) c = fmin(fmax(c, mu / (kap * (u - sn))), kap * mu / (u - sn));
-    zl[r] = a;
-    zu[r] = c;
+    zlv = a;
+    zuv = c;
+  };
+#pragma unroll
+  for (int k = 0; k < KR; ++k)
+    if (tid + k * nt < P.n_iq) {
+      update_row(rl[k], ru[k], rs[k], rds[k], rzl[k], rzu[k], rdzl[k], rdzu[k]);
+      s[rr[k]] = rs[k]; zl[rr[k]] = rzl[k]; zu[rr[k]] = rzu[k];
+    }
+  for (int i = tid + KR * nt; i < P.n_iq; i += nt) {
+    const int r = P.iq_idx[i];
+    double sv = s[r], zlv = zl[r], zuv = zu[r];
+    update_row(P.iq_lo[i], P.iq_hi[i], sv, ds[r], zlv, zuv, dzl[r], dzu[r]);
+    s[r] = sv; zl[r] = zlv; zu[r] = zuv;
   }
   if (al > 0.3) mu = fmax(P.mu_min, 0.2 * mu);
   __syncthreads();
+  // max violation of the working rows (viol) and of the slack form (theta): infeasibility() on the rows in registers
   double viol, theta;
-  infeasibility(P, g, s, scratch, viol, theta);
+  {
+    double v = 0, t = 0;
+    auto eq_row = [&](double gr) __attribute__((always_inline)) {
+      if (!(gr == gr)) { v = t = INFINITY; return; }   // fmax would swallow a NaN
+      v = fmax(v, fabs(gr));
+      t = fmax(t, fabs(gr));
+    };
+    auto iq_row = [&](double gr, double sr, double l, double u) __attribute__((always_inline)) {
+      if (!(gr == gr) || !(sr == sr)) { v = t = INFINITY; return; }
+      v = fmax(v, fmax(l - gr, gr - u));
+      t = fmax(t, fabs(gr - sr));
+    };
+#pragma unroll
+    for (int k = 0; k < KE; ++k)
+      if (tid + k * nt < P.n_eqw) eq_row(eg[k]);
+    for (int i = tid + KE * nt; i < P.n_eqw; i += nt) eq_row(g[P.eq_idx[i]]);
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+      if (tid + k * nt < P.n_iq) iq_row(rg[k], rs[k], rl[k], ru[k]);
+    for (int i = tid + KR * nt; i < P.n_iq; i += nt) {
+      const int r = P.iq_idx[i];
+      iq_row(g[r], s[r], P.iq_lo[i], P.iq_hi[i]);
+    }
+    viol = wg_reduce<1>(v, scratch);
+    theta = wg_reduce<1>(t, scratch);
+  }
   KSTAMP(3);
   const bool conv = viol <= P.tol && theta <= P.tol;
   const bool bad = !(viol < INFINITY) || !(th < INFINITY);
@@ -1290,7 +1384,38 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
                  held);
   __syncthreads();
   KSTAMP(4);
-  barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
+  {
+    // barrier weights of every inequality row, right-hand sides of the equality rows (barrier_terms, on the rows in registers;
+    // their constraint values as the linearisation above has just written them: the same point as the last line-search
+    // evaluation, but the two evaluation passes need not round alike)
+#pragma unroll
+    for (int k = 0; k < KR; ++k) rg[k] = g[rr[k]];
+#pragma unroll
+    for (int k = 0; k < KE; ++k) eg[k] = g[er[k]];
+    double *__restrict__ sigp = W.sig + (size_t)b * m, *__restrict__ wp = W.w + (size_t)b * m, *__restrict__ strm = W.stream + (size_t)b * P.stream_len;
+    auto bar_row = [&](int r, double l, double u, double sv, double zlv, double zuv, double gv) __attribute__((always_inline)) {
+      const bool hl = l > -1e19, hu = u < 1e19;
+      const double dl = hl ? sv - l : 1.0, du = hu ? u - sv : 1.0;
+      const double sg = (hl ? zlv / dl : 0.0) + (hu ? zuv / du : 0.0);
+      const double gmu = -(hl ? mu / dl : 0.0) + (hu ? mu / du : 0.0);
+      const double wrv = sg * (gv - sv) + gmu;
+      sigp[r] = sg;
+      wp[r] = wrv;
+      strm[P.sig_pos[r]] = sg;
+      strm[P.w_pos[r]] = wrv;
+    };
+#pragma unroll
+    for (int k = 0; k < KE; ++k)
+      if (tid + k * nt < P.n_eqw) strm[P.rhs_pos[er[k]]] = -eg[k];
+    for (int i = tid + KE * nt; i < P.n_eqw; i += nt) { const int r = P.eq_idx[i]; strm[P.rhs_pos[r]] = -g[r]; }
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+      if (tid + k * nt < P.n_iq) bar_row(rr[k], rl[k], ru[k], rs[k], rzl[k], rzu[k], rg[k]);
+    for (int i = tid + KR * nt; i < P.n_iq; i += nt) {
+      const int r = P.iq_idx[i];
+      bar_row(r, P.iq_lo[i], P.iq_hi[i], s[r], zl[r], zu[r], g[r]);
+    }
+  }
   KSTAMP(5);
   if (tid == 0) {
     W.chord[b] = next_chord ? 1 : (chord_off ? 2 : 0);
