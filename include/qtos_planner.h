@@ -52,13 +52,17 @@ typedef struct QtosParams {
                         place the feet, the rest of the solve is a fixed-foothold problem; 0 = never */
   double hold_weight, hold_tol;
   double chord_tol;  /* an iterate with violation <= chord_tol that was reached by a full step (alpha = 1) of a
-                        freshly factored KKT system is followed by ONE chord step: the stored factorisation is
+                        freshly factored KKT system is followed by a chord step: the stored factorisation is
                         reused with the right-hand side of the new iterate (k_chord: forward + backward sweep over
                         the factor panels, about a fifth of a factorisation); 0 = every iteration factors */
   int reduce_base;   /* 1: inside the KKT solve the base node values are replaced by the coefficients of a clamped cubic
                         B-spline on the same knots (a basis of the C2 splines the acceleration-continuity rows describe):
                         no multipliers for those rows, half the base unknowns, the same Newton step; 0: every row of the
                         reference's NLP has its multiplier (the formulation the internals' tests pin) */
+  int chord_max;     /* chord steps in a row with one factorisation (0 = 1): a further one follows a full chord step that
+                        brought the violation down to chord_shrink times what it was (and to chord_tol) -- a solve that a
+                        chord step leaves just above the tolerance finishes with a second one instead of a factorisation */
+  double chord_shrink; /* (0 = 1/3) */
 } QtosParams;
 
 typedef struct QtosDims {

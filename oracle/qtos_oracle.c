@@ -914,7 +914,9 @@ void qo_default_options(qo_options *o) {
   o->eps_dual = 1e-8;
   o->slack_push = 0.2;
   o->warm_slack_push = 0.01;
-  o->chord_tol = 1e-3;
+  o->chord_tol = 4e-3;
+  o->chord_max = 2;
+  o->chord_shrink = 1.0 / 3.0;
   o->stall_iters = 5;
   o->hold_from = 2;
   o->hold_weight = 1e6;
@@ -1138,6 +1140,9 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
   int best_it = 0;
   double *xbest = (double *)malloc(sizeof(double) * n);
   int chord_ok = 0;      /* the last step was a full step (alpha = 1) of a freshly factored system */
+  int chord_again = 0;   /* the last step was a full chord step and the factorisation has chord steps left */
+  int chord_run = 0;     /* chord steps taken with the current factorisation */
+  double viol_prev = INFINITY;   /* violation in front of the last step */
   int chord_banned = 0;  /* a chord step of this solve was discarded: every later iteration factors */
   int n_chord = 0;
   for (it = 0; it < o->max_iter; ++it) {
@@ -1162,7 +1167,8 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     eval_all(p, M, x, NULL, J);
     t_eval += now_s() - t0;
     t0 = now_s();
-    const int chord = o->chord_tol > 0 && chord_ok && !chord_banned && viol <= o->chord_tol;
+    const int chord = o->chord_tol > 0 && !chord_banned && viol <= o->chord_tol &&
+                      (chord_ok || (chord_again && viol <= o->chord_shrink * viol_prev));
     chord_ok = 0;
     n_chord += chord;
     if (!chord) memset(K.a, 0, sizeof(double) * K.start[N]);
@@ -1276,6 +1282,9 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     }
     if (al > 0.3) mu = fmax(o->mu_min, 0.2 * mu);
     chord_ok = !chord && al == 1.0;
+    chord_run = chord ? chord_run + 1 : 0;
+    chord_again = chord && al == 1.0 && chord_run < o->chord_max;
+    viol_prev = viol;
   }
   info->status = status;
   info->iters = it;

@@ -106,8 +106,11 @@ typedef struct {
                           delta_x for the rest of the solve; 0 = never              */
   double hold_weight, hold_tol;
   double chord_tol;    /* an iterate with violation <= chord_tol that was reached by a full step of a freshly
-                          factored system is followed by ONE chord step: the same factorisation, the right-hand
+                          factored system is followed by a chord step: the same factorisation, the right-hand
                           side of the new iterate; 0 = every iteration factors */
+  int chord_max;       /* chord steps in a row with one factorisation: a further one follows a full chord step that
+                          brought the violation down to chord_shrink times what it was (and to chord_tol)      */
+  double chord_shrink;
 } qo_options;
 
 typedef struct {

@@ -31,6 +31,7 @@ class QtosParams(C.Structure):
         ("stall_iters", C.c_int), ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double),
         ("chord_tol", C.c_double),
         ("reduce_base", C.c_int),
+        ("chord_max", C.c_int), ("chord_shrink", C.c_double),
     ]
 
 
@@ -182,6 +183,7 @@ def params_from_config(cfg):
     p.hold_from, p.hold_weight, p.hold_tol = cfg.foothold_hold_from, cfg.foothold_hold_weight, cfg.foothold_hold_tol
     p.chord_tol = cfg.chord_tol
     p.reduce_base = int(cfg.reduce_base)
+    p.chord_max, p.chord_shrink = int(cfg.chord_max), float(cfg.chord_shrink)
     return p
 
 

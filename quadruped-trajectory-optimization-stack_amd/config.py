@@ -96,8 +96,15 @@ class PlannerConfig:
     foothold_hold_tol: float = 0.25
     # Chord step: an iterate with violation <= chord_tol reached by a full step of a freshly factored KKT system is
     # followed by one step that reuses that factorisation with the new right-hand side (k_chord).  The flat batch goes
-    # 27 -> 6.5 -> 0.11 -> 5.7e-4 -> (chord) 3.9e-5: three factorisations instead of four.  0 = off.
-    chord_tol: float = 1e-3
+    # 27 -> 6.5 -> 0.11 -> 5.7e-4 -> (chord) 3.9e-5: three factorisations instead of four.  0 = off.  (4e-3 with a second
+    # chord step in reserve, below: a chord step takes the violation down to 6-22 % -- 1e-3 sent the problems of a batch that
+    # arrive at 1.0e-3 ... 4e-3 to a factorisation the whole batch then waited for: knots200 -16 %, exp_5 -12 % per batch.)
+    chord_tol: float = 4e-3
+    # A full chord step that brought the violation down to chord_shrink of what it was (and to chord_tol) may be followed by
+    # another one with the same factorisation, chord_max in a row: the trot batch goes 0.5 -> 5e-4 -> (chord) 1.1e-4 ->
+    # (chord) 2.5e-5 instead of paying a fourth factorisation for the last 10 % above the tolerance.
+    chord_max: int = 2
+    chord_shrink: float = 1.0 / 3.0
     # Reduced base: inside the KKT solve the base node values are replaced by the coefficients of a clamped cubic B-spline on
     # the same knots -- a basis of exactly the C2 splines the acceleration-continuity rows describe --: no multipliers for
     # those rows, half the base unknowns (2885 -> 1721 unknowns, 181 -> 108 stages on the 100-knot transcription), the same

@@ -84,7 +84,8 @@ struct DevPlan {
   // chord step (QtosParams.chord_tol): right-hand side of the KKT system in elimination order, formed by k_step:
   // unknown p is a multiplier (rhs_ptr[p+1] - rhs_ptr[p] == 1, rhs_gpos < 0: rhs = -g[rhs_row]) or a variable
   // (rhs = -sum G[rhs_gpos] * w[rhs_row] over the inequality rows that contain it)
-  double chord_tol;
+  double chord_tol, chord_shrink;
+  int chord_max;               // chord steps in a row with one factorisation (QtosParams.chord_max)
   int n_unknowns;
   const int *rhs_ptr, *rhs_gpos, *rhs_row;
   int n_rhs_ent, rhs_chunk;    // entries of the three lists; entries per pass through the LDS scratch of k_step (a multiple of ET)
@@ -135,6 +136,7 @@ struct DevWork {
   int *best_it;
   int *status, *iters, *done, *n_active;   // n_active[0]: unfinished problems, n_active[1]: of those, flagged for a chord step
   int *chord;                  // per problem: the next KKT solve reuses the stored factorisation (k_chord)
+  int *chord_run;              // per problem: chord steps taken with the stored factorisation
   double *rhs;                 // per problem n_unknowns: right-hand side for that solve
   double *minv;                // per problem n_stages x 256: inverse of every pivot block (written by k_kkt2)
   double *sol;                 // per problem n_stages x 16: the solution of the last KKT solve by unknown position (variables AND multipliers)
@@ -855,6 +857,7 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     W.best_it[b] = 0;
     W.held[b] = 0;
     W.chord[b] = 0;
+    W.chord_run[b] = 0;
     if (!conv && !bad) atomicAdd(W.n_active, 1);
     record_trace(P, W, b, 0, viol, theta, 0.0, mu);
   }
@@ -1076,6 +1079,8 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   const int best_it = W.best_it[b];
   const int chord_state = W.chord[b];        // 1: this iteration's dx came from a chord step; 2: chord steps are off for this solve
   const bool was_chord = chord_state == 1;
+  const int chord_run = W.chord_run[b];
+  const double prev_viol = W.viol[b];        // violation in front of this step
 #ifdef QTOS_STAMPS
   unsigned long long ks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kt0 = 0;
 #define KSTAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ks[i] += t_ - kt0; kt0 = t_; } } while (0)
@@ -1375,7 +1380,9 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   // (one discarded chord step and the solve factors every iteration from then on: near a terrain edge the attempt
   //  fails again and again, and every failure is an iteration the whole batch waits for)
   const bool chord_off = chord_state == 2 || reject;
-  const bool next_chord = P.chord_tol > 0 && !was_chord && !chord_off && al == 1.0 && viol <= P.chord_tol;
+  // (a full chord step that brought the violation down to chord_shrink of what it was may be followed by another one)
+  const bool next_chord = P.chord_tol > 0 && !chord_off && al == 1.0 && viol <= P.chord_tol &&
+                          (!was_chord || (chord_run < P.chord_max && viol <= P.chord_shrink * prev_viol));
   // two-phase solve: latch the hold once this iterate is close enough
   const int held = (W.held[b] || (P.hold_from > 0 && it + 1 >= P.hold_from && viol <= P.hold_tol)) ? 1 : 0;
   __syncthreads();
@@ -1419,6 +1426,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   KSTAMP(5);
   if (tid == 0) {
     W.chord[b] = next_chord ? 1 : (chord_off ? 2 : 0);
+    W.chord_run[b] = next_chord ? (was_chord ? chord_run + 1 : 1) : 0;
     if (next_chord) atomicAdd(W.n_active + 1, 1);
   }
   if (next_chord) {

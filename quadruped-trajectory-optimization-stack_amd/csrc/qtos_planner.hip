@@ -263,6 +263,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(S.kx_ptr, &D.kx_ptr)); TRY(p->upload(S.kx_col, &D.kx_col)); TRY(p->upload(S.kx_pos, &D.kx_pos));
   D.n_unknowns = S.n_unknowns;
   D.chord_tol = M.P.chord_tol;
+  D.chord_max = M.P.chord_max > 0 ? M.P.chord_max : 1;
+  D.chord_shrink = M.P.chord_shrink > 0 ? M.P.chord_shrink : 1.0 / 3.0;
   D.n_cells = S.n_cells;
   D.n_cont = 0;
   for (int k = 0; k < S.n_stages; ++k) D.n_cont += S.srec[S.srec_off[k] + 6];
@@ -418,6 +420,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.status, Bm)); TRY(p->alloc(&W.iters, Bm)); TRY(p->alloc(&W.done, Bm));
   TRY(p->alloc(&W.n_active, 2));
   TRY(p->alloc(&W.chord, Bm));
+  TRY(p->alloc(&W.chord_run, Bm));
   TRY(p->alloc(&W.rhs, Bm * (size_t)S.n_unknowns));
   TRY(p->alloc(&W.minv, Bm * (size_t)S.n_stages * PIV * PIV));
   TRY(p->alloc(&W.sol, Bm * (size_t)S.n_stages * PIV)); TRY(p->alloc(&W.sol0, Bm * (size_t)S.n_stages * PIV));

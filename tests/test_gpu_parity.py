@@ -1092,7 +1092,7 @@ def test_knots200_receding_window_on_random_heightfields():
         nodes, status, iters, viol = P.plan(nstart, goal, map_id=mid, warm=warm)
         ok = status == 0
         assert ok.mean() >= 0.9
-        assert np.median(iters[ok]) < np.median(cold_iters)            # the warm start pays
+        assert iters[ok].mean() < cold_iters.mean() - 0.25             # the warm start pays (cold: 4-5 iterations, warm: 3-4)
         assert check(chk, nodes, status, iters, nstart, P.project(warm)) >= NCHK - 1   # (what the solve starts from: the nodes' projection onto the reduced base's spline space)
         start = nstart
     # (the 20 ms look-ahead loop of round 1 drifts after ~28 replans -- replanning from one's own first 20 ms -- and is not
