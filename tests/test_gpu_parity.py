@@ -793,6 +793,33 @@ def _batch_vs_oracle(cfg, start, goal, sel, maps=None, cell=None, map_id=None, s
     return same, worst
 
 
+def test_second_chord_step_finishes_the_trot_batch():
+    """Half of a trot batch leaves its chord step at 1.1e-4, ten per cent above the tolerance: a second chord step with the same
+    factorisation (PlannerConfig.chord_max = 2: allowed behind a full chord step that cut the violation to a third) finishes
+    them -- three factorisations and two chord solves per batch; with one chord step per factorisation the whole batch pays a
+    fourth factorisation for those problems.  The problems the first chord step finishes get bit-identical plans."""
+    import dataclasses
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig.knots100(gait="trot")
+    assert cfg.chord_max == 2
+    start, goal = workloads.flat_goals(128, seed=0)
+    out = {}
+    for cm in (2, 1):
+        P = Planner(dataclasses.replace(cfg, chord_max=cm), max_batch=128)
+        nodes, status, iters, viol = P.plan(start, goal)
+        t = P.timing()
+        P.close()
+        assert (status == 0).all() and viol.max() <= cfg.tol
+        out[cm] = (nodes, iters, t["kkt_launches"], t["chord_launches"])
+    assert out[2][2:] == (3, 2) and out[1][2:] == (4, 1)
+    assert np.array_equal(out[2][1], out[1][1]) and set(np.unique(out[2][1])) == {4, 5}
+    same = out[2][1] == 4           # (finished by the first chord step: the second never ran)
+    assert same.sum() >= 32 and np.array_equal(out[2][0][same], out[1][0][same])
+    assert np.abs(out[2][0] - out[1][0]).max() < 5e-2   # (two points of the feasible set, both within the tolerance: forces of ~7 N differ by ~1e-2)
+
+
 @pytest.mark.parametrize("reduce_base", [False, True])
 def test_trot_gait_batch_matches_oracle(reduce_base):
     """The gait BASELINE.json's metric names (diagonal-pair trot, config.TROT_UNNORMALISED; the reference's committed
