@@ -1126,10 +1126,10 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
 #pragma unroll
   for (int k = 0; k < KR; ++k) {
     const int ic = min(tid + k * nt, max(P.n_iq - 1, 0));
-    rr[k] = P.iq_idx[ic]; rl[k] = P.iq_lo[ic]; ru[k] = P.iq_hi[ic];
+    rr[k] = P.n_iq > 0 ? P.iq_idx[ic] : 0; rl[k] = P.iq_lo[ic]; ru[k] = P.iq_hi[ic];   // (an empty list is one unset element)
   }
 #pragma unroll
-  for (int k = 0; k < KE; ++k) er[k] = P.eq_idx[min(tid + k * nt, max(P.n_eqw - 1, 0))];
+  for (int k = 0; k < KE; ++k) er[k] = P.n_eqw > 0 ? P.eq_idx[min(tid + k * nt, max(P.n_eqw - 1, 0))] : 0;
 #pragma unroll
   for (int k = 0; k < KR; ++k) { rs[k] = s[rr[k]]; rzl[k] = zl[rr[k]]; rzu[k] = zu[rr[k]]; rg[k] = g[rr[k]]; }
 #pragma unroll
