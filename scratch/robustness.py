@@ -28,3 +28,7 @@ P.close()
 P = capi.Planner(PlannerConfig.knots200(), max_batch=B)
 maps, cell = workloads.random_terrains(); P.set_heightfields(maps, cell)
 stats("random, 200 knots", lambda sd: workloads.mpc_goals(B, seed=sd, terrains=(maps, cell)), range(5, 10))
+P.close()
+P = capi.Planner(PlannerConfig.knots100(gait="trot"), max_batch=B)
+P.set_heightfields(h1, c1)
+stats("flat, trot", lambda sd: workloads.flat_goals(B, sd), range(10))
