@@ -63,6 +63,9 @@ typedef struct QtosParams {
                         brought the violation down to chord_shrink times what it was (and to chord_tol) -- a solve that a
                         chord step leaves just above the tolerance finishes with a second one instead of a factorisation */
   double chord_shrink; /* (0 = 1/3) */
+  double stall_alpha;  /* a problem whose step length stays below stall_alpha for two iterations in a row is jammed against its
+                          bounds (it would sit there until a division overflows, and its batch with it): it stops like a
+                          stalled one -- status 1, best iterate returned; 0 = never */
 } QtosParams;
 
 typedef struct QtosDims {

@@ -58,7 +58,7 @@ class QoOptions(C.Structure):
         ("mu_min", C.c_double), ("delta_x", C.c_double), ("eps_dual", C.c_double), ("slack_push", C.c_double), ("warm_slack_push", C.c_double),
         ("warm_start", C.c_int), ("verbose", C.c_int), ("stall_iters", C.c_int),
         ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double), ("chord_tol", C.c_double),
-        ("chord_max", C.c_int), ("chord_shrink", C.c_double),
+        ("stall_alpha", C.c_double), ("chord_max", C.c_int), ("chord_shrink", C.c_double),
     ]
 
 
@@ -129,6 +129,7 @@ def oracle_options(cfg, O):
     o.stall_iters, o.hold_from, o.hold_weight, o.hold_tol = (cfg.stall_iters, cfg.foothold_hold_from,
                                                              cfg.foothold_hold_weight, cfg.foothold_hold_tol)
     o.chord_tol, o.chord_max, o.chord_shrink = cfg.chord_tol, cfg.chord_max, cfg.chord_shrink
+    o.stall_alpha = cfg.stall_alpha
     return o
 
 

@@ -915,6 +915,7 @@ void qo_default_options(qo_options *o) {
   o->slack_push = 0.2;
   o->warm_slack_push = 0.01;
   o->chord_tol = 4e-3;
+  o->stall_alpha = 1e-2;
   o->chord_max = 2;
   o->chord_shrink = 1.0 / 3.0;
   o->stall_iters = 5;
@@ -1145,6 +1146,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
   double viol_prev = INFINITY;   /* violation in front of the last step */
   int chord_banned = 0;  /* a chord step of this solve was discarded: every later iteration factors */
   int n_chord = 0;
+  int jam = 0;           /* steps in a row shorter than stall_alpha */
   for (it = 0; it < o->max_iter; ++it) {
     double theta = 0;
     viol = 0;
@@ -1159,6 +1161,11 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     if (viol <= o->tol && theta <= o->tol) { status = 0; break; }
     if (viol < best_viol) { best_viol = viol; best_it = it; memcpy(xbest, x, sizeof(double) * n); }
     else if (o->stall_iters > 0 && it - best_it >= o->stall_iters) {
+      memcpy(x, xbest, sizeof(double) * n);
+      eval_all(p, M, x, g, NULL);
+      break;
+    }
+    if (jam >= 2) {   /* jammed against its bounds: stop like a stalled problem */
       memcpy(x, xbest, sizeof(double) * n);
       eval_all(p, M, x, g, NULL);
       break;
@@ -1260,6 +1267,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     /* a chord step is taken whole or not at all: cut by the fraction-to-the-boundary rule or by the line search
      * it is discarded (the iterate stays, the next iteration factors) -- a damped chord step can park a slack
      * right on its bound, and the KKT matrix of that point is too badly scaled for the block elimination */
+    jam = (o->stall_alpha > 0 && !(chord && al != 1.0) && al < o->stall_alpha) ? jam + 1 : 0;
     if (chord && al != 1.0) {
       chord_banned = 1;   /* one discarded chord step and the solve factors every iteration from then on */
       al = 0.0;

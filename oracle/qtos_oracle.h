@@ -108,6 +108,9 @@ typedef struct {
   double chord_tol;    /* an iterate with violation <= chord_tol that was reached by a full step of a freshly
                           factored system is followed by a chord step: the same factorisation, the right-hand
                           side of the new iterate; 0 = every iteration factors */
+  double stall_alpha;  /* a problem whose step length stays below stall_alpha for two iterations in a row is jammed against
+                          its bounds (the fraction-to-the-boundary rule leaves it no room: it would sit there until a
+                          division overflows): it stops like a stalled one, status 1, best iterate returned; 0 = never */
   int chord_max;       /* chord steps in a row with one factorisation: a further one follows a full chord step that
                           brought the violation down to chord_shrink times what it was (and to chord_tol)      */
   double chord_shrink;

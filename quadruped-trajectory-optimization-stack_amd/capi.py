@@ -31,7 +31,7 @@ class QtosParams(C.Structure):
         ("stall_iters", C.c_int), ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double),
         ("chord_tol", C.c_double),
         ("reduce_base", C.c_int),
-        ("chord_max", C.c_int), ("chord_shrink", C.c_double),
+        ("chord_max", C.c_int), ("chord_shrink", C.c_double), ("stall_alpha", C.c_double),
     ]
 
 
@@ -184,6 +184,7 @@ def params_from_config(cfg):
     p.chord_tol = cfg.chord_tol
     p.reduce_base = int(cfg.reduce_base)
     p.chord_max, p.chord_shrink = int(cfg.chord_max), float(cfg.chord_shrink)
+    p.stall_alpha = float(cfg.stall_alpha)
     return p
 
 

@@ -84,6 +84,10 @@ class PlannerConfig:
     slack_push: float = 0.2            # cold-start slack push (fraction of the bound range)
     warm_slack_push: float = 0.01      # slack push of a solve started from given nodes (Ipopt's bound_push)
     stall_iters: int = 5               # stop after this many iterations without a new lowest violation (0 = off)
+    # A problem whose step length stays below stall_alpha for two iterations in a row is jammed against its bounds (one window in
+    # 250 on the randomized heightfields: alpha 0.02, 0.00, 0.00 ... at a violation of 2.5 until a division overflows in the
+    # ninth iteration -- and its set of windows waits for it): it stops like a stalled one, status 1, best iterate.  0 = off.
+    stall_alpha: float = 1e-2
     # Two-phase solve: the first Newton iterations place the feet; once an iterate (number >=
     # `foothold_hold_from`) has a constraint violation <= `foothold_hold_tol`, the stance footholds are
     # held where they are (proximal weight on their x, y) and the rest of the solve is a

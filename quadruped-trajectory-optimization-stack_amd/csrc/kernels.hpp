@@ -120,6 +120,7 @@ struct DevPlan {
   double nominal[NEE][3];
   double tol, mu_init, mu_min, delta_x, eps_dual, slack_push, warm_slack_push;
   int max_iter, stall_iters;
+  double stall_alpha;          // QtosParams.stall_alpha
   const double *height;
   int n_maps, hnx, hny, terrain_mode;
   double hcell, hx0, hy0;
@@ -137,6 +138,7 @@ struct DevWork {
   int *status, *iters, *done, *n_active;   // n_active[0]: unfinished problems, n_active[1]: of those, flagged for a chord step
   int *chord;                  // per problem: the next KKT solve reuses the stored factorisation (k_chord)
   int *chord_run;              // per problem: chord steps taken with the stored factorisation
+  int *jam;                    // per problem: steps in a row shorter than stall_alpha
   double *rhs;                 // per problem n_unknowns: right-hand side for that solve
   double *minv;                // per problem n_stages x 256: inverse of every pivot block (written by k_kkt2)
   double *sol;                 // per problem n_stages x 16: the solution of the last KKT solve by unknown position (variables AND multipliers)
@@ -858,6 +860,7 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     W.held[b] = 0;
     W.chord[b] = 0;
     W.chord_run[b] = 0;
+    W.jam[b] = 0;
     if (!conv && !bad) atomicAdd(W.n_active, 1);
     record_trace(P, W, b, 0, viol, theta, 0.0, mu);
   }
@@ -1080,6 +1083,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   const int chord_state = W.chord[b];        // 1: this iteration's dx came from a chord step; 2: chord steps are off for this solve
   const bool was_chord = chord_state == 1;
   const int chord_run = W.chord_run[b];
+  const int jam_prev = W.jam[b];
   const double prev_viol = W.viol[b];        // violation in front of this step
 #ifdef QTOS_STAMPS
   unsigned long long ks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kt0 = 0;
@@ -1349,7 +1353,10 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   // it for stall_iters iterations (cycling on a discontinuous terrain edge) stops with status 1 and
   // returns that iterate
   const bool improved = !conv && !bad && viol < best_viol;
-  const bool stalled = !conv && !bad && !improved && P.stall_iters > 0 && it + 1 - best_it >= P.stall_iters;
+  // jammed against its bounds (two steps in a row shorter than stall_alpha; a discarded chord step does not count): stops
+  // like a stalled problem
+  const int jam = (P.stall_alpha > 0 && !reject && al < P.stall_alpha) ? jam_prev + 1 : 0;
+  const bool stalled = !conv && !bad && ((!improved && P.stall_iters > 0 && it + 1 - best_it >= P.stall_iters) || jam >= 2);
   if (improved)
     for (int v = tid; v < n; v += blockDim.x) W.xbest[(size_t)b * n + v] = x[v];
   // a numerical failure (NaN / inf after a step from a finite iterate) hands back that best iterate too
@@ -1360,6 +1367,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     W.mu[b] = mu;
     W.viol[b] = restore ? best_viol : viol;
     W.iters[b] = it + 1;
+    W.jam[b] = jam;
     if (improved) { W.best_viol[b] = viol; W.best_it[b] = it + 1; }
     record_trace(P, W, b, it + 1, viol, theta, al, mu);
     if (conv || bad || stalled) {

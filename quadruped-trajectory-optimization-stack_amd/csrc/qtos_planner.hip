@@ -335,7 +335,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   for (int e = 0; e < NEE; ++e)
     for (int d = 0; d < 3; ++d) D.nominal[e][d] = M.P.nominal_stance[e][d];
   D.tol = M.P.tol; D.mu_init = M.P.mu_init; D.mu_min = M.P.mu_min; D.delta_x = M.P.delta_x;
-  D.eps_dual = M.P.eps_dual; D.max_iter = M.P.max_iter; D.stall_iters = M.P.stall_iters;
+  D.eps_dual = M.P.eps_dual; D.max_iter = M.P.max_iter; D.stall_iters = M.P.stall_iters; D.stall_alpha = M.P.stall_alpha;
   D.slack_push = M.P.slack_push > 0 ? M.P.slack_push : 0.01;
   D.warm_slack_push = M.P.warm_slack_push > 0 ? M.P.warm_slack_push : 0.01;
   D.terrain_mode = M.P.terrain_mode;
@@ -421,6 +421,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.n_active, 2));
   TRY(p->alloc(&W.chord, Bm));
   TRY(p->alloc(&W.chord_run, Bm));
+  TRY(p->alloc(&W.jam, Bm));
   TRY(p->alloc(&W.rhs, Bm * (size_t)S.n_unknowns));
   TRY(p->alloc(&W.minv, Bm * (size_t)S.n_stages * PIV * PIV));
   TRY(p->alloc(&W.sol, Bm * (size_t)S.n_stages * PIV)); TRY(p->alloc(&W.sol0, Bm * (size_t)S.n_stages * PIV));
