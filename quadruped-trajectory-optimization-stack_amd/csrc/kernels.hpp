@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     for (int v = tid; v < n; v += blockDim.x) x[v] = W.xbest[(size_t)b * n + v];
   if (tid == 0) {
     W.mu[b] = mu;
-    W.viol[b] = restore ? best_viol : viol;
+    W.viol[b] = restore ? (improved ? viol : best_viol) : viol;   // (a jammed problem may have improved in its last step)
     W.iters[b] = it + 1;
     W.jam[b] = jam;
     if (improved) { W.best_viol[b] = viol; W.best_it[b] = it + 1; }
@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   // k_start gave it: 1)
   if (conv || bad || stalled || it + 1 >= P.max_iter) {
     __syncthreads();
-    export_problem(P, W, b, x, conv ? 0 : (bad ? 2 : 1), it + 1, restore ? best_viol : viol);
+    export_problem(P, W, b, x, conv ? 0 : (bad ? 2 : 1), it + 1, restore ? (improved ? viol : best_viol) : viol);
   }
   if (conv || bad || stalled) return;
   // chord step next?  (an iterate this close, reached by a full step of a freshly factored system)

@@ -793,6 +793,44 @@ def _batch_vs_oracle(cfg, start, goal, sel, maps=None, cell=None, map_id=None, s
     return same, worst
 
 
+def test_jammed_problem_stops_like_a_stalled_one():
+    """One window in 250 on the randomized heightfields is left no room by the fraction-to-the-boundary rule: step lengths
+    0.02, 0.00, 0.00 ... at a violation of 2.5.  It used to sit there until a division overflowed in its ninth iteration
+    (status 2) while its batch waited; two steps in a row shorter than PlannerConfig.stall_alpha now stop it like a stalled
+    problem -- status 1, best iterate, iteration 5 -- in the product and in the oracle alike."""
+    import dataclasses
+    from oracle.oracle import Oracle, oracle_dict, oracle_options
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig.knots200(chord_tol=0.0)
+    assert cfg.stall_alpha == 1e-2
+    maps, cell = workloads.random_terrains()
+    start, goal, mid = workloads.mpc_goals(256, seed=5, terrains=(maps, cell))
+    P = Planner(cfg, max_batch=256)
+    P.set_heightfields(maps, cell)
+    nodes, status, iters, viol = P.plan(start, goal, map_id=mid)
+    jam = np.nonzero(status != 0)[0]
+    assert len(jam) >= 1 and (status[jam] == 1).all() and (iters[jam] <= 6).all()   # (no numerical failure, no ninth iteration)
+    b = int(jam[0])
+    tr = np.asarray(P.trace(b))[:iters[b] + 1]
+    assert (tr[-2:, 2] < cfg.stall_alpha).all() and tr[-3, 2] >= cfg.stall_alpha      # the two short steps that stopped it
+    assert viol[b] == tr[:, 0].min()                                                   # the best iterate came back
+    P.close()
+    P0 = Planner(dataclasses.replace(cfg, stall_alpha=0.0), max_batch=256)
+    P0.set_heightfields(maps, cell)
+    _, status0, iters0, _ = P0.plan(start, goal, map_id=mid)
+    P0.close()
+    assert status0[b] != 0 and iters0[b] > iters[b] + 2                                # without the rule: iterations later
+    ok = status == 0
+    assert np.array_equal(status0[ok], status[ok]) and np.array_equal(iters0[ok], iters[ok])
+    O = Oracle(oracle_dict(cfg), height=maps[mid[b]], hcell=cell)
+    s = start[b]
+    xo, info = O.solve(O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), goal[b], (0, 0, 0), (0, 0, 0), 0.0), opts=oracle_options(cfg, O))
+    assert (info.status, info.iters) == (1, int(iters[b]))
+    assert np.abs(nodes[b] - xo).max() < 1e-5
+
+
 def test_second_chord_step_finishes_the_trot_batch():
     """Half of a trot batch leaves its chord step at 1.1e-4, ten per cent above the tolerance: a second chord step with the same
     factorisation (PlannerConfig.chord_max = 2: allowed behind a full chord step that cut the violation to a third) finishes
