@@ -1066,7 +1066,10 @@ __device__ __forceinline__ double quadsum(double t) {
 // =================================================================================================
 __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it) {
   const int b = blockIdx.x;
-  if (b >= B || W.done[b]) return;
+  if (b >= B) return;
+  // (a finished problem leaves behind the first barrier, not here: the test of its flag is a memory round trip, and everything
+  //  the kernel reads first would queue behind it)
+  const int done_flag = W.done[b];
   __shared__ double scratch[ET];
   extern __shared__ double evl[];
   const int n = P.n_vars, m = P.n_cons, tid = threadIdx.x;
@@ -1134,13 +1137,15 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   }
 #pragma unroll
   for (int k = 0; k < KE; ++k) er[k] = P.n_eqw > 0 ? P.eq_idx[min(tid + k * nt, max(P.n_eqw - 1, 0))] : 0;
+  const bool rows_in_regs = P.n_iq <= KR * nt && P.n_eqw <= KE * nt;
+  for (int v = tid; v < P.n_sol; v += nt) evl[v] = dx[v];
+  // (behind the staging, whose stores waited for every load above: the row indices are there)
 #pragma unroll
   for (int k = 0; k < KR; ++k) { rs[k] = s[rr[k]]; rzl[k] = zl[rr[k]]; rzu[k] = zu[rr[k]]; rg[k] = g[rr[k]]; }
 #pragma unroll
   for (int k = 0; k < KE; ++k) eg[k] = g[er[k]];
-  const bool rows_in_regs = P.n_iq <= KR * nt && P.n_eqw <= KE * nt;
-  for (int v = tid; v < P.n_sol; v += nt) evl[v] = dx[v];
-  __syncthreads();
+  lds_barrier();   // (LDS only: the loads of the thread's rows stay in flight across it)
+  if (done_flag) return;
   if (P.n_rec) {
     for (int i0 = tid;;) {
 #pragma unroll
