@@ -444,7 +444,7 @@ def main():
             "iterations_mean": round(float(iters_dev.item()) / max(B * args.steps, 1), 3) if (solved_inflight is None or lanes) else None,
             "parallelism": "batch-shard x%d + 1 %s" % (world, "RCCL all-gather" if use_dist else "all-gather (not launched under torch.distributed: single process)"),
             "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front, "reduce_base": bool(cfg.reduce_base),
-            "batches_in_flight": args.inflight, "max_iter": cfg.max_iter, "chord_tol": cfg.chord_tol,
+            "batches_in_flight": args.inflight, "max_iter": cfg.max_iter, "chord_tol": cfg.chord_tol, "chord_max": cfg.chord_max,
             "initial_guess": "towr straight line" if args.init == "straight_line" else
                              "interpolated table of %d nominal plans (solved before the timed region)" % (P.init_table[2].shape[0] * P.init_table[2].shape[1]),
         },
