@@ -260,8 +260,12 @@ __device__ inline void vec_eval(const VecIn &in, const double *x, double out[3])
 __device__ inline void vec_prepass(const i4_t *__restrict__ V, const d2_t *__restrict__ Wa, const d2_t *__restrict__ Wb, int total,
                                    const double *x, double *out) {
   const int nt = blockDim.x;
-  constexpr int UN = 8;   // work items per thread and round: all table reads of a round are in flight together (one round
-                          // for the 100 knots / 256 foot instances of the benchmark: 4 k items on 512 threads)
+#ifndef PREPASS_UNROLL
+#define PREPASS_UNROLL 4
+#endif
+  constexpr int UN = PREPASS_UNROLL;   // work items per thread and round: all table reads of a round are in flight together (two rounds
+                          // for the 100 knots of the benchmark -- 4 k items on 512 threads; measured: 2: +0 %, 4: best, 6: +2 %, 8: +0.8 %
+                          // of the evaluation kernels' time)
   for (int base = threadIdx.x; base < total; base += UN * nt) {
     i4_t var[UN];
     d2_t wa[UN], wb[UN];
