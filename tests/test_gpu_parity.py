@@ -587,7 +587,7 @@ def test_step_terrain_batch(cfg):
         xo, info = O.solve(O.problem(s[0:3], s[3:6], s[6:18].reshape(4, 3), g, (0, 0, 0), (0, 0, 0), 0.0))
         if info.status == 0 and status[b] == 0 and info.iters == iters[b]:
             same += np.abs(nodes[b] - xo).max() < 1e-5
-    assert same >= 7   # (4 of 8 before the two-phase solve: free footholds near a cell edge branch differently)
+    assert same == 8   # (4 of 8 before the two-phase solve: free footholds near a cell edge branched differently; 7 the gate of round 2)
     P.close()
 
 
@@ -1259,7 +1259,7 @@ def test_two_phase_solve_holds_the_footholds():
         if info.iters == iters[b]:
             assert np.abs(nodes[b] - xo).max() < 1e-5
             same += 1
-    assert same >= 5
+    assert same == 6   # (round 2 gated 5 of 6)
     # flat ground: same iteration count with and without the hold
     Pf = Planner(dataclasses.replace(cfg, foothold_hold_from=0), max_batch=64)
     sf, gf = workloads.flat_goals(64, seed=0)
