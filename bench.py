@@ -89,12 +89,37 @@ def parse_args():
     return ap.parse_args()
 
 
+def count_gpus_without_hip():
+    """GPUs of this node, counted without loading the HIP runtime into this process: the KFD topology in sysfs (a node
+    with SIMDs is a GPU), cut down to the visible-devices lists; if sysfs is not there, a short-lived child process asks
+    torch.  (torch.cuda.device_count() in THIS process may fall back to hipGetDeviceCount, which initialises HIP -- and
+    the launcher must not have touched the GPU when it starts its torchrun child.)"""
+    have = None
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        have = n
+    except (OSError, ValueError):
+        pass
+    if have is None:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+        have = int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            have = min(have, len([x for x in v.split(",") if x.strip() != ""]))
+    return have
+
+
 def relaunch_under_torchrun(args):
-    """--gpus N > 1 (or --force-torchrun) outside a torch.distributed launch: become the launcher.  No GPU call has
-    been made by this process (torch.cuda.device_count() does not initialise the runtime) and none is made: the ranks
-    run in a child process whose exit code becomes ours."""
-    import torch
-    have = torch.cuda.device_count()
+    """--gpus N > 1 (or --force-torchrun) outside a torch.distributed launch: become the launcher.  This process makes
+    no GPU call and does not load the HIP runtime (count_gpus_without_hip): the ranks run in a child process whose exit
+    code becomes ours."""
+    have = count_gpus_without_hip()
     if have < args.gpus:
         print("bench.py: --gpus %d but this node has %d GPU(s)" % (args.gpus, have), file=sys.stderr)
         sys.exit(2)

@@ -52,11 +52,13 @@ struct QtosPlanner {
     bool open = false;
     int B = 0, spec = 0, enq = 0, chk = 0;   // iterations queued blind / queued in all / whose preceding counts have been read
     unsigned spins = 0;                      // polls that found no counts yet
+    unsigned seq = 0;                        // sequence number of the call, stamped into the count words (k_post_counts)
     hipStream_t st = nullptr;
     DevWork W;
     double *nodes_out = nullptr, *viol_out = nullptr;
     int *status_out = nullptr, *iters_out = nullptr;
   } call;
+  unsigned call_seq = 0;             // sequence number of the last call submitted
   bool counts_by_copy = false;       // the counts of unfinished problems reach the host by hipMemcpyAsync instead of k_post_counts (QTOS_COUNTS_COPY=1)
   int spec_next = 1;                 // blind iterations of the next call: the iterations the last one took
   int spec_cap = 1;                  // limit of the blind iterations (qtos_set_speculation): 1 = off, the measured optimum
@@ -152,7 +154,7 @@ void qtos_planner_destroy(QtosPlanner *p) {
 }
 
 int qtos_planner_create(const QtosParams *params, int max_batch, int device, QtosPlanner **out) {
-  if (!params || !out || max_batch < 1) return -1;
+  if (!params || !out || max_batch < 1 || max_batch >= (1 << 24)) return -1;   // (the count words of k_post_counts hold 24 bits per count)
   *out = nullptr;
   QtosPlanner *p = new QtosPlanner();
   p->device = device;
@@ -518,10 +520,14 @@ int qtos_set_heightfields(QtosPlanner *p, int n_maps, const double *height, int 
 // (hipMemcpyAsync) between two kernels of a stream makes the compute queue wait on the copy engine's signal; with more
 // streams than hardware queues that wait holds up the other streams of the queue too: four sets of receding windows
 // then ran one after the other.)
-__global__ void k_post_counts(const int *n_active, int *host_slot) {
+// The word carries the sequence number of the call that queued the launch: blind iterations a call queued beyond its end
+// still store into their slots AFTER the next call of the handle has reset them (qtos_plan_submit), and a word of another
+// call must read as "no counts yet", not as "nothing left to do" (24 bits per count: qtos_planner_create limits max_batch).
+__global__ void k_post_counts(const int *n_active, int *host_slot, unsigned seq) {
   // both counts in ONE eight-byte store: the host spins on the slot (qtos_plan_poll) and must never see half of it
   if (threadIdx.x == 0) {
-    const unsigned long long v = (unsigned long long)(unsigned)n_active[0] | ((unsigned long long)(unsigned)n_active[1] << 32);
+    const unsigned long long v = (unsigned long long)((unsigned)n_active[0] & 0xffffffu) | ((unsigned long long)((unsigned)n_active[1] & 0xffffffu) << 24) |
+                                 ((unsigned long long)(seq & 0xffffu) << 48);
     *(volatile unsigned long long *)host_slot = v;
   }
   __threadfence_system();
@@ -563,7 +569,7 @@ static int queue_iteration(QtosPlanner *p, int it, bool informed, int n, int nc)
   }
   hipLaunchKernelGGL(k_step, dim3(c.B), dim3(ET), p->eval_lds, st, D, c.W, c.B, it);
   if (p->counts_by_copy) HIPCHK(p, hipMemcpyAsync(p->h_active + 2 * it, c.W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * it);
+  else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * it, c.seq);
   HIPCHK(p, hipEventRecord(p->ev[6 + 5 * it], st));
   return 0;
 }
@@ -580,6 +586,8 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
   if (hipSetDevice(p->device) != hipSuccess) return fail(-2);
   c = QtosPlanner::Call();
   c.open = true; c.B = B; c.st = st;
+  p->call_seq = p->call_seq >= 0xfffeu ? 1u : p->call_seq + 1u;   // (0xffff = the reset pattern of the slots)
+  c.seq = p->call_seq;
   c.W = p->wk;
   c.W.start = d_start; c.W.goal = d_goal; c.W.map_id = d_map_id; c.W.warm = d_warm;
   c.nodes_out = d_nodes_out; c.status_out = d_status_out; c.iters_out = d_iters_out; c.viol_out = d_viol_out;
@@ -595,7 +603,7 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
   // counts after k_start (slot max_iter of the pinned array), event ev_start
   const int ev_start = 2 + 5 * D.max_iter;
   if (p->counts_by_copy) SUBCHK(hipMemcpyAsync(p->h_active + 2 * D.max_iter, c.W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * D.max_iter);
+  else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * D.max_iter, c.seq);
   SUBCHK(hipEventRecord(p->ev[ev_start], st));
 #undef SUBCHK
   // Blind iterations: as many as the previous call of this handle needed (its slowest problem), queued without a host
@@ -631,7 +639,7 @@ int qtos_plan_poll(QtosPlanner *p, int *done) {
       n = h[0]; nc = h[1];
     } else {
       const unsigned long long v = __atomic_load_n((const unsigned long long *)h, __ATOMIC_ACQUIRE);
-      if (v == ~0ull) {
+      if (v == ~0ull || (unsigned)(v >> 48) != c.seq) {   // nothing yet, or the late store of a blind launch of an earlier call
         // (a failed launch never fills the slot: look at the stream now and then)
         if ((++c.spins & 0xfffff) == 0) {
           const hipError_t q = hipStreamQuery(c.st);
@@ -639,7 +647,7 @@ int qtos_plan_poll(QtosPlanner *p, int *done) {
         }
         return 0;
       }
-      n = (int)(unsigned)(v & 0xffffffffull); nc = (int)(unsigned)(v >> 32);
+      n = (int)(unsigned)(v & 0xffffffull); nc = (int)(unsigned)((v >> 24) & 0xffffffull);
     }
     if (n <= 0 || c.chk >= D.max_iter) {
       // finished in front of iteration c.chk (every problem has handed its result over: export_problem)

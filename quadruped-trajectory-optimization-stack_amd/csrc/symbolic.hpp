@@ -839,6 +839,25 @@ struct Symbolic {
         for (auto &kv : bh) fprintf(stderr, " %dx%d:%d", kv.first.first, kv.first.second, kv.second);
         fprintf(stderr, "\ncontributions %lld, row-weighted %lld", con, conw);
       }
+      {   // inequality rows and touched 16-slot groups per stage record (MFMA condensation study)
+        fprintf(stderr, "\niq rows per stage (rows/chunks4/groups/tiles):");
+        long long tot_mf = 0, tot_ent = 0; int mxr = 0;
+        for (int k = 0; k < n_stages; ++k) {
+          const StageDesc &S = stages[k];
+          int rows = 0, ch = 0; long long mf = 0; unsigned gall = 0;
+          for (int q = S.iq_begin; q < S.iq_end; ++q) {
+            const IqBlock &Q = iq_blocks[q];
+            unsigned gm = 0;
+            for (int a = 0; a < Q.n; ++a) gm |= 1u << (iq_slots[Q.slot_off + a] >> 4);
+            const int g = __builtin_popcount(gm), c4 = (Q.m + 3) / 4;
+            rows += Q.m; ch += c4; mf += (long long)c4 * g * (g + 1) / 2; gall |= gm; tot_ent += Q.m * Q.n;
+          }
+          mxr = std::max(mxr, rows);
+          tot_mf += mf;
+          fprintf(stderr, " %d/%d/%d/%lld", rows, ch, __builtin_popcount(gall), mf);
+        }
+        fprintf(stderr, "\niq MFMAs total %lld (per stage %.1f), G entries %lld, max rows/stage %d", tot_mf, (double)tot_mf / n_stages, tot_ent, mxr);
+      }
       fprintf(stderr, "\nenter per stage:");
       for (int k = 0; k < n_stages; ++k) fprintf(stderr, " %d", (int)enter[k].size());
       fprintf(stderr, "\n");

@@ -3,9 +3,11 @@
 The reference keeps 32 ``docker exec ./main`` processes busy from a queue of probes
 (QTOS/generateHeightField.py:344-352: ``while not queue.empty(): data = queue.get()``, 375-377): a slow solve never
 holds the other workers.  Here a *lane* is a planner handle with its own workspace and HIP stream; a batch is submitted
-to a free lane with ``qtos_plan_submit`` (the whole solve is queued without a host round trip, include/qtos_planner.h) and
-the lanes are polled round-robin with ``qtos_plan_poll``: a batch that waits for its slowest problems keeps a few CUs
-busy while the next batches run on the others.  No host threads, nothing blocks but ``drain``.
+to a free lane with ``qtos_plan_submit`` (which queues the start of the solve and returns; include/qtos_planner.h) and
+the lanes are polled round-robin with ``qtos_plan_poll``, which reads the counts of unfinished problems an iteration
+sends back and queues the next one -- the host drives every Newton iteration, it just never blocks on one: a batch
+that waits for its slowest problems keeps a few CUs busy while the next batches run on the others.  No host threads,
+nothing blocks but ``drain``.
 """
 import ctypes as C
 
@@ -80,14 +82,17 @@ class PlannerPool:
             self._reap(block=True)
         lane = next(ln for ln in self.lanes if not ln.busy)
         B = start.shape[0]
+        if B < 1 or B > lane.B:
+            raise ValueError("batch of %d problems on lanes of %d" % (B, lane.B))
         # The inputs must be complete when they are submitted (synchronise the stream that produced them, or produce them
         # on a stream of your own and pass after=event).  The lanes' streams are never made to wait on the default stream:
         # on this runtime a stream that has once waited on it no longer runs side by side with the others.
         if after is not None:
             lane.stream.wait_event(after)
-        lane.tag, lane.busy, lane.n = tag, True, B
         lane.P.submit(B, self._ptr(start), self._ptr(goal), self._ptr(map_id), self._ptr(warm), lane.nodes.data_ptr(),
                       lane.status.data_ptr(), lane.iters.data_ptr(), lane.viol.data_ptr(), lane.stream.cuda_stream)
+        # (only a submit that went through occupies the lane: one that raised leaves it free)
+        lane.tag, lane.busy, lane.n = tag, True, B
         self._order.append(lane)
         return lane
 

@@ -417,7 +417,32 @@ def test_pool_of_handles_equals_one_call_after_the_other(cfg):
     again = [P.plan(s, g, map_id=m) for s, g, m in batches]   # from the second call on: as many blind iterations as the last call took
     for a, b in zip(ref, again):
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
-    assert len({int(r[2].max()) for r in ref}) > 1 or True   # (batches differ in their slowest problem)
+    # device-pointer path, ONE handle and ONE stream reused back to back without a stream synchronisation between the calls,
+    # blind iterations on: a call that needs fewer iterations than its predecessor leaves launches queued behind its end
+    # (first of all a warm start that k_start finds converged), and their late count words must not end the next call early
+    # (sequence number in the word, qtos_planner.hip k_post_counts).  Results bit for bit those of the synchronous calls.
+    warm0 = ref[0][0]
+    ref_w = P.plan(batches[0][0], batches[0][1], map_id=batches[0][2], warm=warm0)
+    P.set_speculation(1)
+    ref_w1 = P.plan(batches[0][0], batches[0][1], map_id=batches[0][2], warm=warm0)
+    assert all(np.array_equal(x, y) for x, y in zip(ref_w, ref_w1))
+    assert int(ref_w[2].max()) < min(int(r[2].max()) for r in ref)     # the premise: the calls below differ in their length
+    P.set_speculation(8)
+    seq = [(0, None), (1, None), (0, warm0), (2, None), (0, warm0), (0, warm0), (3, None), (4, None), (0, warm0), (5, None)]
+    dt = [[torch.as_tensor(np.ascontiguousarray(x), device=dev) for x in (s, g, m.astype(np.int32))] for s, g, m in batches]
+    dwarm = torch.as_tensor(np.ascontiguousarray(warm0), device=dev)
+    outs = [(torch.empty((B, P.n), dtype=torch.float64, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+             torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.float64, device=dev)) for _ in seq]
+    st2 = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    for (i, w), o in zip(seq, outs):
+        P.submit(B, dt[i][0].data_ptr(), dt[i][1].data_ptr(), dt[i][2].data_ptr(), None if w is None else dwarm.data_ptr(),
+                 o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), st2.cuda_stream)
+        P.wait()                                          # (drives the polls; does not wait for the stream)
+    st2.synchronize()
+    for (i, w), o in zip(seq, outs):
+        want = ref[i] if w is None else ref_w
+        assert np.array_equal(o[0].cpu().numpy(), want[0]) and np.array_equal(o[1].cpu().numpy(), want[1]) and np.array_equal(o[2].cpu().numpy(), want[2])
     # a busy handle refuses a second call
     t = [torch.as_tensor(x, device=dev) for x in (batches[0][0], batches[0][1], batches[0][2].astype(np.int32))]
     out = (torch.empty((B, P.n), dtype=torch.float64, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
