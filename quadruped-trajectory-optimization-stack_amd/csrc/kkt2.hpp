@@ -36,15 +36,7 @@ struct Kkt2Cfg {
   // waves w, w+4, w+8, w+12 of a workgroup share a SIMD: the twelve waves that do not sit on the factor wave's
   // SIMD come first (update index u -> wave u + 1 + u / 3), waves 4 and 8 join only when a large front needs
   // them (u = 12, 13); wave 12 publishes headers.  As many update waves as divide the tiles evenly.
-  static constexpr int pick_nu() {
-    int best = 14, best_t = (NTILE + 13) / 14;
-    for (int nu = 14; nu >= 8; --nu) {
-      const int t = (NTILE + nu - 1) / nu;
-      if (t < best_t || (t == best_t && nu * t - NTILE <= best * best_t - NTILE)) { best = nu; best_t = t; }
-    }
-    return NTILE < 8 ? (NTILE < 1 ? 1 : NTILE) : best;
-  }
-  static constexpr int NU = pick_nu();
+  static constexpr int NU = kkt_pick_nu(NTILE);
   static constexpr int MAXT = (NTILE + NU - 1) / NU;
   static constexpr int NSV = 16 - NT;            // service waves of the AB phase
   static constexpr int NH = NT <= 8 ? 2 : 1;     // backward pass: waves per row tile

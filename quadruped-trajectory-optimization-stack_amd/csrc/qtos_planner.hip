@@ -12,6 +12,7 @@
 
 #include "kernels.hpp"
 #include "kkt2.hpp"
+#include "kkt3.hpp"
 
 using namespace qtos;
 
@@ -59,6 +60,7 @@ struct QtosPlanner {
     int *status_out = nullptr, *iters_out = nullptr;
   } call;
   unsigned call_seq = 0;             // sequence number of the last call submitted
+  bool use_kkt3 = false;             // k_kkt3 (kkt3.hpp) instead of k_kkt2: chosen by qtos_planner_create
   bool counts_by_copy = false;       // the counts of unfinished problems reach the host by hipMemcpyAsync instead of k_post_counts (QTOS_COUNTS_COPY=1)
   int spec_next = 1;                 // blind iterations of the next call: the iterations the last one took
   int spec_cap = 1;                  // limit of the blind iterations (qtos_set_speculation): 1 = off, the measured optimum
@@ -103,6 +105,13 @@ static void (*kkt2_kernel(int F, bool cont))(DevPlan, DevWork, int) {
 #endif
   }
 #undef QTOS_KKT2
+  return nullptr;
+}
+// k_kkt3 (inequality blocks condensed on the matrix core): fronts up to 128 slots
+static void (*kkt3_kernel(int F))(DevPlan, DevWork, int) {
+#define QTOS_KKT3(f) case f: return k_kkt3<f>;
+  switch (F) { QTOS_KKT3(16) QTOS_KKT3(32) QTOS_KKT3(48) QTOS_KKT3(64) QTOS_KKT3(80) QTOS_KKT3(96) QTOS_KKT3(112) QTOS_KKT3(128) }
+#undef QTOS_KKT3
   return nullptr;
 }
 static void (*chord_kernel(int F))(DevPlan, DevWork, int) {
@@ -161,7 +170,29 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   p->max_batch = max_batch;
   // model + symbolic analysis; if the stage records and cells of the result do not fit the LDS next to the panels, again with
   // smaller records (heavy stages then spill into continuation records): both are rebuilt, the analysis writes into the model
+  // First choice: k_kkt3 (inequality blocks condensed on the matrix core; fronts of up to 128 slots, every stage's blocks in
+  // its own record, at most IQ_MAX_ROWS inequality rows per record, everything in LDS).  QTOS_KKT=2 keeps k_kkt2.
+  p->use_kkt3 = false;
+  {
+    const char *e = getenv("QTOS_KKT");
+    if (!e || atoi(e) != 2) {
+      p->M = HostModel();
+      p->S = Symbolic();
+      if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
+      p->S.cell_mode = 2;
+      p->S.iq_mfma = true;
+      bool ok = p->S.build(p->M) == 0 && p->S.front <= 128 && !(p->S.pack_src.size() & 1);
+      if (ok) {
+        int n_cont = 0;
+        for (int k = 0; k < p->S.n_stages; ++k) n_cont += p->S.srec[p->S.srec_off[k] + 6];
+        ok = n_cont == 0 && kkt3_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) <= 160 * 1024 - 256;
+      }
+      p->use_kkt3 = ok;
+      if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: k_kkt3 %s (%s)\n", ok ? "selected" : "not applicable", p->S.err.c_str());
+    }
+  }
   for (int cap : {0, 4096, 3072, 2048}) {
+    if (p->use_kkt3) break;
     p->M = HostModel();
     p->S = Symbolic();
     if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
@@ -345,7 +376,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.panel_stride = (long long)S.n_stages * (S.front + 1) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  p->kkt_lds = kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
+  p->kkt_lds = p->use_kkt3 ? kkt3_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
   p->kkt_threads = KT2;
   const int max_front = 208;
   if (S.max_drec > 2 * 2 * KT || S.max_srec > 3 * 4 * KT || F > max_front || (S.pack_src.size() & 1)) {
@@ -362,7 +393,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     return -4;
   }
   {
-    p->kkt_fn = kkt2_kernel(F, D.n_cont > 0);
+    p->kkt_fn = p->use_kkt3 ? kkt3_kernel(F) : kkt2_kernel(F, D.n_cont > 0);
     p->chord_fn = chord_kernel(F);
     if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);

@@ -27,6 +27,22 @@ namespace qtos {
 
 constexpr int PIV = 16;
 
+// Which update wave holds which 16 x 16 tile of the Schur complement (k_kkt2 / k_kkt3): update index u holds the tiles
+// t = u + NU i of the lower triangle, row by row.  Shared by the kernels and by the analysis (the per-wave chunk masks of the
+// inequality blocks, Symbolic::iq_mfma).
+constexpr int kkt_pick_nu(int ntile) {
+  int best = 14, best_t = (ntile + 13) / 14;
+  for (int nu = 14; nu >= 8; --nu) {
+    const int t = (ntile + nu - 1) / nu;
+    if (t < best_t || (t == best_t && nu * t - ntile <= best * best_t - ntile)) { best = nu; best_t = t; }
+  }
+  return ntile < 8 ? (ntile < 1 ? 1 : ntile) : best;
+}
+constexpr int kkt_tile_row(int t) { int R = 0; while (((R + 1) * (R + 2)) >> 1 <= t) ++R; return R; }
+constexpr int IQ_LDG = 34;        // doubles per slot of the dense copy of a record's inequality rows (k_kkt3: Gd[slot][row], 32 rows + 2: bank spread)
+constexpr int IQ_MAX_ROWS = 32;   // rows of one record (8 chunks of four: one f64 matrix instruction of K = 4 each)
+constexpr int IQ_SEC_HDR = 20;    // header ints of a record's inequality section: rows (padded), chunks, list entries, 0, 16 per-wave masks
+
 struct StageDesc {
   int n_active;            // pivots + border (for the algorithmic byte / flop count)
   int g_begin, g_len;      // this stage's slice of the per-problem Jacobian-block buffer G
@@ -86,6 +102,13 @@ struct Symbolic {
   // with unknown kx_col[e] through the stream value at kx_pos[e], e in [kx_ptr[p], kx_ptr[p + 1])
   std::vector<int> kx_ptr, kx_col, kx_pos;
   int cell_mode = 2;
+  // k_kkt3: the inequality blocks J' S J are not summed entry by entry into cells (gather table) but condensed on the matrix
+  // core straight into the Schur tiles: a record lists, row by row, where the entries of its G blocks go in a dense
+  // [slot][row] copy (Gd), the rows in chunks of four with the 16-slot groups they touch, and per update wave which
+  // (tile, chunk) products have work.  The gather table keeps the static entries only.  Header int [2] of a record = offset
+  // of that section.
+  bool iq_mfma = false;
+  int iq_max_rows = 0;
   std::vector<int> rtab;              // n_stages x 16: cell of the assembled right-hand side of every pivot (0 = none)
   std::vector<unsigned> amask;   // per stage 256 bits (8 words): front slots whose row of the factor panel V is stored (live, not a pivot of the stage)
   // substitution sweeps with a one-stage look-ahead (k_chord, backward pass of k_kkt2): the rows of V_k that belong to
@@ -212,8 +235,13 @@ struct Symbolic {
         for (int cc = 0; cc <= a; ++cc) t2.insert(trs(sa, iq_slots[Q.slot_off + cc]));
         t2.insert(front * (front + 1) / 2 + sa);
       }
-      const bool fits = rest.empty() && dyn < 4096 && dyn + d <= REC_MAX_DOUBLES - 2 && contrib + c < 4096 &&
-                        fixed + (int)t2.size() + 1 + contrib + c <= REC_MAX_INTS - 8;
+      bool fits = rest.empty() && dyn < 4096 && dyn + d <= REC_MAX_DOUBLES - 2 && contrib + c < 4096 &&
+                  fixed + (int)t2.size() + 1 + contrib + c <= REC_MAX_INTS - 8;
+      if (iq_mfma) {   // (no gather table: what limits a record is the rows of the dense copy)
+        int rows = Q.m;
+        for (int q2 : mine) rows += iq_blocks[S.iq_begin + q2].m;
+        fits = rest.empty() && dyn < 4096 && dyn + d <= REC_MAX_DOUBLES - 2 && rows <= IQ_MAX_ROWS;
+      }
       if (fits) { mine.push_back(q); dyn += d; contrib += c; targets.swap(t2); }
       else rest.push_back(q);
     }
@@ -237,7 +265,7 @@ struct Symbolic {
     // contribution of column a).  One thread owns one target, so the blocks of a record are assembled
     // in ONE pass without conflicts and in a fixed order.
     std::map<int, std::vector<int>> tmap;
-    for (size_t bi = 0; bi < blks.size(); ++bi) {
+    for (size_t bi = 0; bi < blks.size() && !iq_mfma; ++bi) {
       const IqBlock &Q = iq_blocks[S.iq_begin + blks[bi]];
       for (int a = 0; a < Q.n; ++a) {
         const int sa = iq_slots[Q.slot_off + a];
@@ -280,6 +308,63 @@ struct Symbolic {
     if (cpos >= 4096) { err = "gather table overflow"; return -1; }
     srec.push_back(cpos);   // sentinel: end of the last target's contributions
     srec.insert(srec.end(), codes.begin(), codes.end());
+    if (iq_mfma && emit_iq_section(S, blks, blk_goff, s0)) return -1;
+    return 0;
+  }
+  // Inequality section of a record (iq_mfma): rows of the record's blocks, ordered so that rows touching the same 16-slot groups
+  // share chunks of four; per row where its sig / w sit in the dynamic record and its slice of the scatter list (source offset
+  // in the dynamic record | destination slot * IQ_LDG + row << 12); per update wave the (tile, chunk) pairs with work.
+  int emit_iq_section(const StageDesc &S, const std::vector<int> &blks, const std::vector<int> &blk_goff, int s0) {
+    struct Row { int bi, r; unsigned mask; };
+    std::vector<Row> rows;
+    for (size_t bi = 0; bi < blks.size(); ++bi) {
+      const IqBlock &Q = iq_blocks[S.iq_begin + blks[bi]];
+      unsigned gm = 0;
+      for (int a = 0; a < Q.n; ++a) gm |= 1u << (iq_slots[Q.slot_off + a] >> 4);
+      for (int r = 0; r < Q.m; ++r) rows.push_back({(int)bi, r, gm});
+    }
+    std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.mask < b.mask; });
+    const int n_rows = (int)rows.size(), n_pad = (n_rows + 3) & ~3, n_ch = n_pad / 4;
+    if (n_pad > IQ_MAX_ROWS) { err = "too many inequality rows in one record for the dense copy"; return -1; }
+    iq_max_rows = std::max(iq_max_rows, n_pad);
+    const int q0 = (int)srec.size();
+    srec[s0 + 2] = q0 - s0;
+    srec.push_back(n_pad); srec.push_back(n_ch); srec.push_back(0); srec.push_back(0);
+    const int NT = front / 16, NTILE = NT * (NT + 1) / 2, NU = kkt_pick_nu(NTILE), MAXT = (NTILE + NU - 1) / NU;
+    if (MAXT * 8 > 32) { err = "front too large for the per-wave chunk masks"; return -1; }
+    std::vector<unsigned> cmask(n_ch, 0u);
+    for (int i = 0; i < n_rows; ++i) cmask[i >> 2] |= rows[i].mask;
+    for (int u = 0; u < 16; ++u) {
+      unsigned em = 0;
+      for (int i = 0; i < MAXT && u < NU; ++i) {
+        const int t = u + NU * i;
+        if (t >= NTILE) continue;
+        const int R = kkt_tile_row(t), C = t - R * (R + 1) / 2;
+        for (int c = 0; c < n_ch; ++c)
+          if (((cmask[c] >> R) & 1u) && ((cmask[c] >> C) & 1u)) em |= 1u << (8 * i + c);
+      }
+      srec.push_back((int)em);
+    }
+    for (int i = 0; i < n_pad; ++i) {
+      if (i >= n_rows) { srec.push_back(-1); continue; }
+      const IqBlock &Q = iq_blocks[S.iq_begin + blks[rows[i].bi]];
+      const int so = blk_goff[rows[i].bi] + Q.m * Q.n + rows[i].r, wo = so + Q.m;
+      if (wo >= 4096) { err = "inequality block beyond the reach of the packed row table"; return -1; }
+      srec.push_back(so | (wo << 16));
+    }
+    int e = 0;
+    for (int i = 0; i <= n_pad; ++i) {
+      srec.push_back(e);
+      if (i < n_rows) e += iq_blocks[S.iq_begin + blks[rows[i].bi]].n;
+    }
+    for (int i = 0; i < n_rows; ++i) {
+      const IqBlock &Q = iq_blocks[S.iq_begin + blks[rows[i].bi]];
+      for (int a = 0; a < Q.n; ++a) {
+        const int src = blk_goff[rows[i].bi] + rows[i].r * Q.n + a, dst = iq_slots[Q.slot_off + a] * IQ_LDG + i;
+        srec.push_back(src | (dst << 12));
+      }
+    }
+    srec[q0 + 2] = e;
     return 0;
   }
 
@@ -735,7 +820,7 @@ struct Symbolic {
         if (split_blocks(S, all, (int)pack_src.size() - drec_off[k], (int)srec.size() - srec_off[k], trs, mine, rest, (int)sym_of[k].size())) return -1;
       }
       if (emit_blocks(k, S, mine, srec_off[k], drec_off[k], trs, &sym_of[k])) return -1;
-      srec[srec_off[k] + 2] = (int)mine.size();
+      if (!iq_mfma) srec[srec_off[k] + 2] = (int)mine.size();
       pending.push_back(rest);
       max_srec = std::max(max_srec, (int)srec.size() - srec_off[k]);
       max_drec = std::max(max_drec, (int)pack_src.size() - drec_off[k]);
