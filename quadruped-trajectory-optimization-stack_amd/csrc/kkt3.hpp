@@ -1,70 +1,163 @@
 // kkt3.hpp -- k_kkt3: the factor + solve kernel of round 4 for fronts of up to 128 slots (larger fronts and records with
-// continuation parts stay with k_kkt2).  Same chain of fronts, same panels, sweeps and k_chord as kkt2.hpp; what changed:
+// continuation parts stay with k_kkt2).  Same chain of fronts, cells, panels, sweeps and k_chord as kkt2.hpp; what changed:
 //
-//   * The inequality blocks J' S J are condensed ON THE MATRIX CORE, straight into the Schur tiles.  k_kkt2 summed them entry
-//     by entry into LDS cells through a gather table (one thread per target: a third of the kernel's vector instructions).
-//     Here a record's G blocks are copied into a dense [slot][row] array (Gd) by the waves that have no job in phase AB, row
-//     by row (the wave that clears a row of the previous record writes the row of the next one: no synchronisation), and the
-//     update waves add  U[R][C] += (S G)[:, R]' G[:, C]  for the (tile, chunk of four rows) pairs the record lists for them --
-//     one f64 matrix instruction each -- in front of the Schur update of the stage.  Contributions land in U two stages before
-//     their pivot columns are extracted, exactly when k_kkt2 put them into cells; a slot that changes hands is dead in U by
-//     then (the rows of a stage's pivots are blanked in both operands of every later update).  Right-hand sides -G' w go to
-//     the accumulated right-hand side by slot (UF) by one multiply-add pass over Gd.
-//   * Cells hold what is left: equality Jacobian entries, multiplier right-hand sides, static entries (a tenth of the cells).
+//   * The inequality blocks J' S J are condensed ON THE MATRIX CORE by one wave.  k_kkt2 summed them entry by entry into the
+//     cells through a gather table -- one thread per target, three barrier weights, six Jacobian values and a decoded
+//     contribution word per term: a third of the kernel's vector instructions, spread over fifteen waves.  Here wave 15, which
+//     has no job in phase AB, takes a record's blocks one after the other in that phase: G' S G of a block of
+//     up to 32 columns is three 16 x 16 tiles (one for up to 16 columns), one f64 matrix instruction per four rows each; a
+//     lane then holds four entries of the lower triangle and adds each to its cell with ds_add_f64 -- the cells come from a
+//     table in the record (Symbolic::emit_iq_section), entries above the diagonal go to a trash cell.  One wave, LDS
+//     operations in program order: the summation order of a cell is fixed.  Right-hand sides -G' w by a row sum across the
+//     wave's four row groups.  (Round 2 tried the products with read-modify-write cells: three to four LDS round trips per
+//     block in sequence; the atomic add has none.  Experiment A1 of this round condensed into the Schur tiles instead: 48
+//     products per stage, slower -- profiles/r04_experiments.)
 //   * No special prologue: the stage loop starts two stages early (k = -2, -1 build the panels of stages 0 and 1 through the
-//     same extraction path as every other stage).
+//     same path as every other stage).
 #pragma once
 #include "kkt2.hpp"
 
 namespace qtos {
 
-template <int F>
-struct Kkt3Layout {
-  using CF = Kkt2Cfg<F>;
-  static constexpr int PSZ = (F + 1) * PLD;
-  static constexpr int LIB = 0;                          // 2 x 16 x PLD   L^-1 (current / next)
-  static constexpr int DVB = LIB + 2 * PIV * PLD;        // 2 x 16         1 / d
-  static constexpr int DGB = DVB + 2 * PIV;              // 3 x 16         pivot diagonals (ring)
-  static constexpr int UF = DGB + 3 * PIV;               // FR             accumulated rhs updates
-  static constexpr int XS = UF + CF::FR;                 // FR             solution by slot (backward)
-  static constexpr int RED = XS + CF::FR;                // 2 x 16 x 16 partial sums + 64 dummy slots
-  static constexpr int PSB = RED + 2 * 16 * PIV + 64;    // 3 x 16 ints    pivot slots (ring)
-  static constexpr int HIB = PSB + 3 * PIV / 2;          // 4 ints
-  static constexpr int JM = HIB + 2;                     // 2 x FR bytes   slot -> pivot index
-  static constexpr int PM = JM + CF::FR;                 // 2 x 8 ints     pivot-slot bit masks
-  static constexpr int MIV = PM + 8;                     // 16 x PLD       (L D L^T)^-1 of the current pivot block
-  static constexpr int PB = MIV + PIV * PLD;             // 3 panels of (F+1) x PLD: P_k / P_k+1 alternate in 0 and 2, 1 = operand A of the update
-  static constexpr int PMB = PB + 3 * PSZ;               // F x PLD: rows of P_k with those of the next pivots blanked
-  static constexpr int SIG = (PMB + F * PLD + 1) & ~1;   // IQ_MAX_ROWS barrier weights, then IQ_MAX_ROWS right-hand-side factors w
-  static constexpr int GD = SIG + 2 * IQ_MAX_ROWS;       // F x IQ_LDG     dense copy of the record's inequality rows, [slot][row]
-  static constexpr int VAR = GD + F * IQ_LDG;            // dbuf x 2, then (ints) sbuf x 2, hiall, then the cells A
-};
-inline size_t kkt3_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells) {
-  const int FR = (F + 63) & ~63, PSZ = (F + 1) * PLD;
-  const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 2 * (size_t)FR + 2 * 16 * PIV + 64 + 3 * PIV / 2 + 2 + FR + 8 + PIV * PLD;
-  size_t o = ((fixed + 3 * (size_t)PSZ + (size_t)F * PLD + 1) & ~(size_t)1) + 2 * IQ_MAX_ROWS + (size_t)F * IQ_LDG;
-  o += 2 * kkt2_dbuf_doubles(F, max_drec);
-  size_t oi = 2 * o + 2 * kkt2_sbuf_ints(F, max_srec) + (((size_t)NS + 4) & ~(size_t)3);
-  oi += 2 * (((size_t)n_cells + 1) & ~(size_t)1);
-  const size_t sweep = fixed * sizeof(double) + (size_t)NS * 12 * sizeof(int);
-  return oi * sizeof(int) > sweep ? oi * sizeof(int) : sweep;
+inline size_t kkt3_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells) { return kkt2_lds_bytes(F, NS, max_srec, max_drec, n_cells); }
+
+// The inequality blocks of one record, by ONE wave (section layout: Symbolic::emit_iq_section).  abase = LDS byte address of
+// the cells.
+// The inequality blocks and static entries of one record (section layout: Symbolic::emit_iq_section), shared by THREE waves:
+// wave TY takes the 16 x 16 tiles of type TY of every block -- (0,0): class-0 columns x class-0 columns, (1,0): class 1 x
+// class 0, (2 = (1,1)): class 1 x class 1 -- and the static entries of that type.  A pair of variables has the same type in
+// every block (Symbolic::color_columns), so the three waves' cells never meet and each wave's adds (LDS atomics: no value
+// comes back, nothing waits for them) are executed in its own program order: the summation order of a cell is fixed.
+// abase = LDS byte address of the cells.  Two-stage software pipeline over the blocks: tables of block b + 2 and Jacobian
+// values of block b + 1 are in flight while block b is multiplied.
+struct IqS1 { int colt, rct, ta, tb; };
+struct IqS2 { IqS1 s; double gA, gB, sg, ww, hA, hB, sh, wh; };
+template <int TY>
+__device__ __forceinline__ void condense_type(unsigned abase, const int *sbuf, const double *dbuf, int lane, int part, unsigned long long *stp = nullptr) {
+#ifdef QTOS_STAMPS
+  unsigned long long tq_ = 0;
+#define IQ_ST0() do { if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq_) :: "memory"); } while (0)
+#define IQ_ST(i) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stp[i] += t_ - tq_; tq_ = t_; } } while (0)
+#else
+#define IQ_ST0() do {} while (0)
+#define IQ_ST(i) do {} while (0)
+#endif
+  IQ_ST0();
+  const int li = lane & 15, lk = lane >> 4;
+  const int *q = sbuf + sbuf[2];
+  const int hv = q[8 + lane];        // the headers of up to 16 blocks, one int per lane
+  // part 0 (phase AB): the static entries and the first QTOS_IQ_SPLIT-th of the blocks; part 1 (phase C, another wave: the
+  // barrier between the phases orders the two): the rest
+#ifndef QTOS_IQ_SPLIT
+#define QTOS_IQ_SPLIT 2
+#endif
+  const int nb_all = __builtin_amdgcn_readfirstlane(q[0]), nb_ab = (nb_all + QTOS_IQ_SPLIT - 1) / QTOS_IQ_SPLIT;
+  const int b_first = part == 0 ? 0 : nb_ab, nb = part == 0 ? nb_ab : nb_all;
+  const int nst = part == 0 ? __builtin_amdgcn_readfirstlane(q[1 + TY]) : 0, sto = __builtin_amdgcn_readfirstlane(q[4 + TY]);
+  for (int i = lane; i < nst; i += 64) {
+    const int v = q[sto + i];
+    const unsigned a = abase + 8u * (unsigned)(v >> 12);
+    const double x = dbuf[v & 4095];
+    asm volatile("ds_add_f64 %0, %1" :: "v"(a), "v"(x));
+  }
+  IQ_ST(9);
+  auto present = [&](int b) { return b < nb && ((__builtin_amdgcn_readlane(hv, 4 * b + 1) >> (16 + TY)) & 1); };
+  auto stage1 = [&](int b, IqS1 &o) __attribute__((always_inline)) {
+    o.colt = 0xffff; o.rct = 0; o.ta = 0; o.tb = 0;
+    if (!present(b)) return;
+    const int pres = (__builtin_amdgcn_readlane(hv, 4 * b + 1) >> 16) & 7;
+    const int *d = q + __builtin_amdgcn_readlane(hv, 4 * b + 2);
+    typedef int i2_t __attribute__((ext_vector_type(2)));
+    const i2_t t = ((const i2_t *)(d + 32 + 128 * __builtin_popcount(pres & ((1 << TY) - 1))))[lane];
+    o.colt = d[li]; o.rct = d[16 + li]; o.ta = t[0]; o.tb = t[1];
+  };
+  auto stage2 = [&](int b, const IqS1 &s1, IqS2 &o) __attribute__((always_inline)) {
+    o.s = s1;
+    o.gA = o.gB = o.sg = o.ww = o.hA = o.hB = o.sh = o.wh = 0.0;
+    if (!present(b)) return;
+    const int mn = __builtin_amdgcn_readlane(hv, 4 * b + 1), m = mn & 255, n = (mn >> 8) & 255;
+    const double *G = dbuf + __builtin_amdgcn_readlane(hv, 4 * b);
+    const int a0 = s1.colt & 255, a1 = (s1.colt >> 8) & 255;
+    const int cA = TY == 0 ? a0 : a1, cB = TY == 2 ? a1 : a0;
+    const bool rv = lk < m, rv2 = 4 + lk < m;
+    if (rv && cA != 255) o.gA = G[lk * n + cA];
+    if (rv2 && cA != 255) o.hA = G[(4 + lk) * n + cA];       // rows 4 .. 7 (friction pyramids: five rows)
+    if (TY == 1) {
+      if (rv && cB != 255) o.gB = G[lk * n + cB];
+      if (rv2 && cB != 255) o.hB = G[(4 + lk) * n + cB];
+    }
+    if (rv) { o.sg = G[m * n + lk]; o.ww = G[m * n + m + lk]; }
+    if (rv2) { o.sh = G[m * n + 4 + lk]; o.wh = G[m * n + m + 4 + lk]; }
+  };
+  auto multiply_add = [&](int b, const IqS2 &o) __attribute__((always_inline)) {
+    if (!present(b)) return;
+    const int m = __builtin_amdgcn_readlane(hv, 4 * b + 1) & 255;
+    const double gB = TY == 1 ? o.gB : o.gA, hB = TY == 1 ? o.hB : o.hA;
+    double zero = 0.0;
+    asm volatile("" : "+v"(zero));
+    d4_t D = {zero, zero, zero, zero};
+    D = __builtin_amdgcn_mfma_f64_16x16x4f64(o.sg * o.gA, gB, D, 0, 0, 0);
+    if (m > 4) D = __builtin_amdgcn_mfma_f64_16x16x4f64(o.sh * o.hA, hB, D, 0, 0, 0);
+    const unsigned c0 = abase + 8u * ((unsigned)o.s.ta & 0xffffu), c1 = abase + 8u * ((unsigned)o.s.ta >> 16);
+    const unsigned c2 = abase + 8u * ((unsigned)o.s.tb & 0xffffu), c3 = abase + 8u * ((unsigned)o.s.tb >> 16);
+    asm volatile("ds_add_f64 %0, %1" :: "v"(c0), "v"(D[0]));
+    asm volatile("ds_add_f64 %0, %1" :: "v"(c1), "v"(D[1]));
+    asm volatile("ds_add_f64 %0, %1" :: "v"(c2), "v"(D[2]));
+    asm volatile("ds_add_f64 %0, %1" :: "v"(c3), "v"(D[3]));
+    if (TY != 1) {
+      // right-hand sides of the class's columns: -sum_r G[r][c] w_r, column c on lane li of every row group
+      double r = o.gA * o.ww;
+      if (m > 4) r = fma(o.hA, o.wh, r);
+      r = -rowsum4(r);
+      if (lk == 0) {
+        const unsigned ar = abase + 8u * (TY == 0 ? (unsigned)o.s.rct & 0xffffu : (unsigned)o.s.rct >> 16);
+        asm volatile("ds_add_f64 %0, %1" :: "v"(ar), "v"(r));
+      }
+    }
+  };
+  if (nb > b_first) {
+    IqS1 s1a, s1b;
+    IqS2 s2;
+    stage1(b_first, s1a);
+    stage1(b_first + 1, s1b);
+    stage2(b_first, s1a, s2);
+    for (int b = b_first; b < nb; ++b) {
+      IqS1 s1c;
+      IqS2 s2n;
+      stage1(b + 2, s1c);
+      stage2(b + 1, s1b, s2n);
+      multiply_add(b, s2);
+      s2 = s2n; s1b = s1c;
+    }
+  }
+  IQ_ST(10);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the cells are read and written by ordinary accesses from here on
+  IQ_ST(11);
 }
 
+// The rest of a record: equality Jacobian entries and multiplier right-hand sides are distinct cells of their own (any thread).
+__device__ __forceinline__ void assemble_eq(double *A, const int *sbuf, const double *dbuf, int t0, int nth) {
+  const int n_ent = sbuf[0], n_rhs = sbuf[1];
+  const int *eidx = sbuf + SHDR + PIV;
+  const double *eval = dbuf + PIV;
+  for (int i = t0; i < n_ent; i += nth) A[eidx[i]] += eval[i];
+  const int *rsl = eidx + n_ent;
+  const double *rval = eval + n_ent;
+  for (int i = t0; i < n_rhs; i += nth) A[rsl[i]] += rval[i];
+}
 template <int F>
 __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
-  static_assert(F <= 128 && F % 16 == 0, "k_kkt3: fronts of up to 128 slots");
+  static_assert(F <= 128 && F % 16 == 0, "k_kkt3: fronts of up to 128 slots (waves 9 .. 15 must be free in phase AB)");
   const int b = blockIdx.x;
   if (b >= B || W.done[b] || W.chord[b] == 1) return;   // (a problem flagged for a chord step is k_chord's)
   extern __shared__ double lds[];
   using CF = Kkt2Cfg<F>;
-  using LY = Kkt3Layout<F>;
+  using LY = Kkt2Layout<F>;
   constexpr int NT = CF::NT, NU = CF::NU, MAXT2 = CF::MAXT, FR = CF::FR, PSZ = LY::PSZ;
-  static_assert(NT < 15, "phase AB needs a wave for the right-hand-side row and at least one for the dense copy");
-  constexpr int NI = 15 - NT;   // waves without a job in phase AB: they keep the dense copy of the inequality rows
   const int tid = threadIdx.x, NS = P.n_stages, n = P.n_sol;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
   double *Lib = lds + LY::LIB, *dvb = lds + LY::DVB, *dgb = lds + LY::DGB, *UF = lds + LY::UF, *xs = lds + LY::XS;
-  double *red = lds + LY::RED, *PB = lds + LY::PB, *Gd = lds + LY::GD, *SIG = lds + LY::SIG, *WW = SIG + IQ_MAX_ROWS;
+  double *red = lds + LY::RED, *PB = lds + LY::PB;
   int *psb = (int *)(lds + LY::PSB), *hib = (int *)(lds + LY::HIB), *jm = (int *)(lds + LY::JM);
   unsigned *pm = (unsigned *)(lds + LY::PM);
   unsigned char *jmb = (unsigned char *)jm;   // slot -> pivot index of stages k+2 / k+3 (layout: kkt2.hpp)
@@ -104,7 +197,6 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
   for (int g = 0; g < 4; ++g) { ge4_keep |= (lk + 4 * g >= li ? 1u : 0u) << (4 * g); gt4_keep |= (lk + 4 * g > li ? 1u : 0u) << (4 * g); }
   for (int i = tid; i < P.n_cells; i += KT2) A[i] = 0.0;
   for (int i = tid; i < 3 * PSZ + F * PLD; i += KT2) PB[i] = 0.0;   // (the three panels and the blanked copy behind them)
-  for (int i = tid; i < F * IQ_LDG + 2 * IQ_MAX_ROWS; i += KT2) SIG[i] = 0.0;   // (SIG, WW and Gd are contiguous)
   for (int i = tid; i < PIV * PLD; i += KT2) Minv[i] = 0.0;
   for (int i = tid; i < FR; i += KT2) { UF[i] = 0.0; xs[i] = 0.0; }
   if (tid < 16) pm[tid] = 0u;
@@ -283,36 +375,26 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
         }
       }
      }
-    } else {
-      // ---- the waves without a job in this phase keep the dense copy of the inequality rows: row pair p belongs to wave
-      //      p mod NI in both passes, so the zeros of the record that leaves (k+1) and the entries of the one that comes (k+2)
-      //      reach a row in program order of one wave.  Section layout: Symbolic::emit_iq_section.
-      const int iw = wv - NT - 1;
-      const int hl = lane >> 5, l32 = lane & 31;
-      if (k + 1 >= 0 && k + 1 < NS) {
-        const int *sb = sbuf0 + ((k + 1) & 1) * sstride;
-        const int *q = sb + sb[2];
-        const int nr = q[0];
-        const int *rp = q + IQ_SEC_HDR + nr, *ls = rp + nr + 1;
-        for (int p2 = iw; 2 * p2 < nr; p2 += NI) {
-          const int r = 2 * p2 + hl, e = rp[r] + l32;
-          if (e < rp[r + 1]) Gd[ls[e] >> 12] = 0.0;
-        }
-      }
-      if (k + 2 < NS) {
-        const int *q = sbuf + sbuf[2];
-        const int nr = q[0];
-        const int *rt = q + IQ_SEC_HDR, *rp = rt + nr, *ls = rp + nr + 1;
-        for (int p2 = iw; 2 * p2 < nr; p2 += NI) {
-          const int r = 2 * p2 + hl, e = rp[r] + l32;
-          if (e < rp[r + 1]) { const int v = ls[e]; Gd[v >> 12] = dbuf[v & 4095]; }
-          if (l32 == 0) {
-            const int rw = rt[r];
-            SIG[r] = rw < 0 ? 0.0 : dbuf[rw & 0xffff];
-            WW[r] = rw < 0 ? 0.0 : dbuf[(rw >> 16) & 0xffff];
-          }
-        }
-      }
+    }
+    else if (k + 2 < NS) {
+      // ---- the waves without a job in this phase assemble record k+2 into the cells.  None of the cells they touch is read
+      //      or retired by the tile waves here: those belong to the columns of stage k+1, and a retired cell is handed out
+      //      again two stages later (Symbolic::compact_cells).  Waves 13 .. 15: the inequality blocks and static entries, one
+      //      tile type each (condense_type); the others: equality entries and multiplier right-hand sides.
+      typedef __attribute__((address_space(3))) double lds_double;
+      const unsigned abase = (unsigned)(size_t)(lds_double *)A;
+#if !(defined(QTOS_IQ_ABL) && (QTOS_IQ_ABL & 4))
+#ifdef QTOS_STAMPS
+      unsigned long long *stp = &st2[wv][0];
+#else
+      unsigned long long *stp = nullptr;
+#endif
+      if (wv == 13) condense_type<0>(abase, sbuf, dbuf, lane, 0, stp);
+      else if (wv == 14) condense_type<1>(abase, sbuf, dbuf, lane, 0, stp);
+      else if (wv == 15) condense_type<2>(abase, sbuf, dbuf, lane, 0, stp);
+      else
+#endif
+        assemble_eq(A, sbuf, dbuf, (wv - NT - 1) * 64 + lane, (12 - NT) * 64);
     }
     KS2(0);
     lds_barrier();
@@ -332,28 +414,6 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
       int rcs[MAXT2];
 #pragma unroll
       for (int t = 0; t < MAXT2; ++t) { rcs[t] = tRC[t]; asm volatile("" : "+s"(rcs[t])); }
-      // inequality blocks of record k+2 for this wave's tiles: U[R][C] += (S G)[chunk, R]' G[chunk, C], one matrix instruction
-      // per (tile, chunk of four rows) the record lists (bit 8 t + c of the wave's mask)
-      if (k + 2 < NS) {
-        const int *q = sbuf + sbuf[2];
-        const unsigned em = (unsigned)__builtin_amdgcn_readfirstlane(q[4 + uw]);
-        if (em) {
-#pragma unroll
-          for (int t = 0; t < MAXT2; ++t) {
-            if ((em >> (8 * t)) & 0xffu) {
-              const int R = rcs[t] >> 8, C = rcs[t] & 255;
-              const double *ga = Gd + (16 * R + li) * IQ_LDG + lk, *gb = Gd + (16 * C + li) * IQ_LDG + lk;
-#pragma unroll
-              for (int c = 0; c < IQ_MAX_ROWS / 4; ++c)
-                if ((em >> (8 * t + c)) & 1u) {
-                  const double sg = SIG[4 * c + lk];
-                  U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * c] * sg, gb[4 * c], U[t], 0, 0, 0);
-                }
-            }
-          }
-        }
-      }
-      KS2(9);
       double wa[2][4], pbv[2][4];
       // operand addresses: a lane part that never changes (tile_lane, bytes) plus a wave-uniform tile offset formed on the
       // scalar unit
@@ -422,31 +482,10 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
       }
     }
     KS2(2);
-    // right-hand sides of the inequality blocks of record k+2: UF[slot] -= sum_r G[r][slot] w_r, one lane per slot (waves 4
-    // and 8: no other wave touches UF in this phase)
-    if ((wv == 4 || (wv == 8 && F > 64)) && k + 2 < NS) {
-      const int *q = sbuf + sbuf[2];
-      const int nr = q[0], slot = (wv == 4 ? 0 : 64) + lane;
-      if (nr > 0 && slot < F) {
-        const d2_t *g2 = (const d2_t *)(Gd + slot * IQ_LDG);
-        double acc = 0.0;
-        for (int r = 0; r < nr; r += 2) {
-          const d2_t g = g2[r >> 1];
-          acc = fma(g[0], WW[r], acc);
-          acc = fma(g[1], WW[r + 1], acc);
-        }
-        UF[slot] -= acc;
-      }
-    }
-    // every wave but the factor wave ends the phase with its share of the assembly of stage k+2's records into the cells:
-    // equality entries, multiplier right-hand sides, static entries (few: the waves without Schur tiles first)
-    const int apos = is_upd ? (15 - NU) + uw : uw - NU;   // (wave 12, the header wave, is the last of the free ones)
-    if (wv >= 1 && k + 2 < NS) assemble_stage(A, F, sbuf, dbuf, apos * 64 + lane, 15 * 64);
-    // LDS-DMA of the records of stage k+3 into the other buffer, by the three waves without Schur tiles once
-    // their assembly is done (1 KB per instruction, chunk c of a record by wave c mod 3; wave 12 takes the
-    // chunks with the header it publishes below); the loads are waited for before the phase's barrier
-    if (!(wv & 3) && wv != 0 && k + 3 < NS) {
-      const int s = k + 3, wi = wv == 12 ? 0 : wv >> 2;
+    // LDS-DMA of the records of stage k+3 into the other buffer by waves 8 and 12 (1 KB per instruction, chunk c of a record
+    // by wave c mod 2; wave 12 takes the chunks with the header it publishes below)
+    if ((wv == 8 || wv == 12) && k + 3 < NS) {
+      const int s = k + 3, wi = wv == 12 ? 0 : 1;
       int d0, d1, s0, s1;
       sload2(P.drec_off + s, d0, d1);
       sload2(P.srec_off + s, s0, s1);
@@ -454,16 +493,30 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
       const char *gd = (const char *)(stream + d0), *gs = (const char *)(P.srec + s0);
       typedef __attribute__((address_space(3))) char lds_char;
       lds_char *ld = (lds_char *)(dbuf0 + (s & 1) * dstride), *ls = (lds_char *)(sbuf0 + (s & 1) * sstride);
-      for (int c = wi; c * 1024 < nbd; c += 3)
+      for (int c = wi; c * 1024 < nbd; c += 2)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gd + min(c * 1024 + lane * 16, nbd - 16)), (__attribute__((address_space(3))) void *)(ld + c * 1024), 16, 0, 0);
-      for (int c = wi; c * 1024 < nbs; c += 3)
+      for (int c = wi; c * 1024 < nbs; c += 2)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gs + min(c * 1024 + lane * 16, nbs - 16)), (__attribute__((address_space(3))) void *)(ls + c * 1024), 16, 0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    // the second part of the inequality blocks of record k+2, one tile type per wave (condense_type), while the records travel
+    if (!(wv & 3) && wv != 0 && k + 2 < NS) {
+      typedef __attribute__((address_space(3))) double lds_double;
+      const unsigned abase = (unsigned)(size_t)(lds_double *)A;
+#ifdef QTOS_STAMPS
+      unsigned long long *stp = &st2[wv][0];
+#else
+      unsigned long long *stp = nullptr;
+#endif
+#if !(defined(QTOS_IQ_ABL) && (QTOS_IQ_ABL & 4))
+      if (wv == 4) condense_type<0>(abase, sbuf, dbuf, lane, 1, stp);
+      else if (wv == 8) condense_type<1>(abase, sbuf, dbuf, lane, 1, stp);
+      else condense_type<2>(abase, sbuf, dbuf, lane, 1, stp);
+#endif
+    }
+    if (wv == 8 || wv == 12) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wv == 12) {
       // header of stage k+3, published to the LDS rings (their slots have no reader left in this phase: stage k's pivot
-      // slots / diagonals, stage k+1's slot map and mask) from the first chunks of the record, which this wave has just
-      // waited for
+      // slots / diagonals, stage k+1's slot map and mask) from the first chunks of the record, which this wave has just waited for
       const int hs = k + 3;
       if (hs < NS) {
         if (lane < 8) pm[(hs & 1) * 8 + lane] = 0u;

@@ -170,12 +170,13 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   p->max_batch = max_batch;
   // model + symbolic analysis; if the stage records and cells of the result do not fit the LDS next to the panels, again with
   // smaller records (heavy stages then spill into continuation records): both are rebuilt, the analysis writes into the model
-  // First choice: k_kkt3 (inequality blocks condensed on the matrix core; fronts of up to 128 slots, every stage's blocks in
-  // its own record, at most IQ_MAX_ROWS inequality rows per record, everything in LDS).  QTOS_KKT=2 keeps k_kkt2.
+  // QTOS_KKT=3 selects k_kkt3 (round-4 experiment, kkt3.hpp: inequality blocks condensed on the matrix core by three waves per
+  // phase; fronts of up to 128 slots, every stage's blocks in its own record, everything in LDS).  Correct -- the parity tests
+  // pass with it -- and 11 % slower than k_kkt2 on the benchmark (profiles/r04_experiments): not the default.
   p->use_kkt3 = false;
   {
     const char *e = getenv("QTOS_KKT");
-    if (!e || atoi(e) != 2) {
+    if (e && atoi(e) == 3) {
       p->M = HostModel();
       p->S = Symbolic();
       if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }

@@ -1,4 +1,4 @@
-# A/B of the KKT kernels inside ONE library: QTOS_KKT=2 (k_kkt2) against the default (k_kkt3 where it applies).
+# A/B of the KKT kernels inside ONE library: the default (k_kkt2) against QTOS_KKT=3 (k_kkt3 where it applies).
 # usage: python scratch/ab4.py [lib ...]   (each lib is run with QTOS_KKT=2 and without)
 import sys, subprocess, os
 code = r'''
@@ -14,15 +14,15 @@ s, g = workloads.flat_goals(256, 0)
 ts, tt, tc = [], [], []
 for i in range(12):
     nodes, status, iters, viol = P.plan(s, g); t = P.timing(); ts.append(t["kkt_seconds"] / max(t["kkt_launches"], 1)); tt.append(t["total_seconds"]); tc.append(t["chord_seconds"])
-print("%-28s KKT=%s %s kkt ms/launch %.4f (x%d); whole solve ms %.4f; chord %.4f; conv %d/256 iters max %d; sha %s" % (os.environ.get("QTOS_LIB", "default"), os.environ.get("QTOS_KKT", "3"), gait,
+print("%-28s KKT=%s %s kkt ms/launch %.4f (x%d); whole solve ms %.4f; chord %.4f; conv %d/256 iters max %d; sha %s" % (os.environ.get("QTOS_LIB", "default"), os.environ.get("QTOS_KKT", "2"), gait,
       1e3 * np.median(ts[2:]), t["kkt_launches"], 1e3 * np.median(tt[2:]), 1e3 * np.median(tc[2:]), int((status == 0).sum()), int(iters.max()), hashlib.sha1(nodes.tobytes()).hexdigest()[:10]))
-np.save("/tmp/ab4_nodes_%s_%s.npy" % (os.environ.get("QTOS_KKT", "3"), gait), nodes)
+np.save("/tmp/ab4_nodes_%s_%s.npy" % (os.environ.get("QTOS_KKT", "2"), gait), nodes)
 '''
 libs = sys.argv[1:] or [""]
 for gait in os.environ.get("AB_GAITS", "walk").split(","):
     for rep in range(2):
         for lib in libs:
-            for kkt in ("2", ""):
+            for kkt in ("", "3"):
                 env = dict(os.environ, AB_GAIT=gait)
                 if lib: env["QTOS_LIB"] = lib
                 if kkt: env["QTOS_KKT"] = kkt

@@ -18,7 +18,7 @@ for b in (0, 5, NB - 1):
 acc /= 3 * NS
 print("cycles per stage by wave: 0 AB work | 1 AB wait | 2 C role work (after prefetch issue; update waves: extraction only) | 3 assembly | 4 C wait | 5 update MFMA loop | 6 backward/NS | 7 top | 8 prefetch issue | 9 inequality products (k_kkt3)")
 for w in range(16):
-    print("wave %2d: " % w + " ".join("%6.0f" % v for v in acc[w][:10]))
+    print("wave %2d: " % w + " ".join("%6.0f" % v for v in acc[w][:12]))
 print("stage total (wave 0):", acc[0][[0, 1, 2, 3, 4, 7, 8]].sum(), "timing", P.timing())
 ks = np.zeros(8)
 for b in (0, 5, NB - 1):
