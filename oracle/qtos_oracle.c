@@ -11,6 +11,7 @@
 #include "qtos_oracle.h"
 
 #include <complex.h>
+#include <malloc.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -543,11 +544,19 @@ int qo_initial_guess(const qo_params *p, const qo_problem *q, double *x) {
 /* ============================================================================================ */
 static int stance_var(const qo_model *M, int e, int s) { return M->L.off_eem[e] + 8 * s; }
 
-static void eval_all(const qo_params *p, const qo_model *M, const double *x, double *g, double *J) {
+/* zrp / zci: CSR pattern (free columns) of the Jacobian, or NULL.  With a pattern only ITS entries of J are cleared before the
+ * evaluation -- the solver reads J through that pattern and nothing else (the dense clear is 30 MB per evaluation on the
+ * 100-knot problem: at one problem per thread a many-core host spends its memory bandwidth on zeros; bench.py cpu_baseline). */
+static void eval_all_z(const qo_params *p, const qo_model *M, const double *x, double *g, double *J, const int *zrp, const int *zci) {
   const qo_layout *L = &M->L;
   const int n = L->n_vars;
   const double hcs = 1e-30;
-  if (J) memset(J, 0, sizeof(double) * (size_t)L->n_cons * n);
+  if (J && !zrp) memset(J, 0, sizeof(double) * (size_t)L->n_cons * n);
+  if (J && zrp)
+    for (int r = 0; r < L->n_cons; ++r) {
+      double *Jr = J + (size_t)r * n;
+      for (int a = zrp[r]; a < zrp[r + 1]; ++a) Jr[zci[a]] = 0.0;
+    }
 
   /* ---- terrain: z - h(x,y) at ee-motion nodes 1..N (UPSTREAM terrain_constraint.cc) -------- */
   for (int e = 0; e < QO_NEE; ++e) {
@@ -741,6 +750,10 @@ static void eval_all(const qo_params *p, const qo_model *M, const double *x, dou
     }
   }
 }
+static void eval_all(const qo_params *p, const qo_model *M, const double *x, double *g, double *J) {
+  eval_all_z(p, M, x, g, J, NULL, NULL);
+}
+
 
 int qo_constraints(const qo_params *p, const double *x, double *g) {
   qo_model *M = (qo_model *)malloc(sizeof(qo_model));
@@ -1000,7 +1013,16 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
     if (xl[i] == xh[i]) x[i] = xl[i];
 
   double *g = (double *)malloc(sizeof(double) * m), *gt = (double *)malloc(sizeof(double) * m);
-  double *J = (double *)malloc(sizeof(double) * (size_t)m * n);
+  /* the dense Jacobian (30 MB on the 100-knot problem) is kept per thread between solves: allocated and freed per solve
+   * it is an mmap / munmap pair with page faults and TLB shoot-downs across every thread of the process (qo_solve_batch) */
+  static _Thread_local double *tls_J = NULL;
+  static _Thread_local size_t tls_J_cap = 0;
+  if (tls_J_cap < (size_t)m * n) {
+    free(tls_J);
+    tls_J = (double *)malloc(sizeof(double) * (size_t)m * n);
+    tls_J_cap = tls_J ? (size_t)m * n : 0;
+  }
+  double *J = tls_J;
   double *xt = (double *)malloc(sizeof(double) * n);
 
   /* ---- working sets: free variables, de-duplicated equality rows, inequality rows ---------- */
@@ -1171,7 +1193,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
       break;
     }
     t0 = now_s();
-    eval_all(p, M, x, NULL, J);
+    eval_all_z(p, M, x, NULL, J, rp, ci);   /* (everything the solver reads of J lies in the pattern rp / ci) */
     t_eval += now_s() - t0;
     t0 = now_s();
     const int chord = o->chord_tol > 0 && !chord_banned && viol <= o->chord_tol &&
@@ -1303,7 +1325,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
   (void)wv;
   sky_free(&K);
   free(first); free(epos); free(ks); free(tv); free(tc); free(Er); free(Ir); free(ci); free(rp);
-  free(rowtype); free(vpos); free(xt); free(J); free(gt); free(g); free(cl); free(xl); free(s);
+  free(rowtype); free(vpos); free(xt); free(gt); free(g); free(cl); free(xl); free(s);
   free(rhs); free(dx); free(M); free(xbest);
   return status;
 }
@@ -1315,6 +1337,10 @@ int qo_solve_batch(const qo_params *p, int n_problems, const qo_problem *q, cons
   qo_layout L;
   if (qo_get_layout(p, &L)) return -1;
   int bad = 0;
+  /* a solve allocates and frees a few MB in blocks above glibc's mmap threshold: each would be an mmap / munmap pair -- page
+   * faults on fresh pages and a TLB shoot-down across every thread of the process per munmap.  Keep them in the threads' arenas. */
+  mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : bad)

@@ -1041,9 +1041,6 @@ __device__ __forceinline__ void assemble_stage(double *A, int F, const int *sbuf
   const double *rval = eval + n_ent;
   for (int i = t0; i < n_rhs; i += nth) A[rsl[i]] += rval[i];
   (void)n_iq;
-#ifdef QTOS_EXP_NOASM
-  return;   // ablation build (timing only): the inequality blocks are not assembled
-#endif
   const int n_tgt = sbuf[5];
   if (n_tgt == 0) return;
   const int *tg = sbuf + sbuf[4];                     // n_tgt + 1 ints: (tri << 12) | first contribution

@@ -344,13 +344,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     for (int g = 0; g < 4; ++g) pc[g] = ps[4 * g + lk];
 #pragma unroll
     for (int g = 0; g < 4; ++g) a[g] = 4 * g + lk > li ? Pn[pc[g] * PLD + li] : prow_p[4 * g];
-#ifdef QTOS_EXP_NOFACTOR
-#pragma unroll
-    for (int g = 0; g < 4; ++g) wi[g] = a[g];   // ablation: no factorisation
-    myinv = 1.0;
-#else
     ldlt16s(a, wi, myinv, li, lk);
-#endif
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       Lin[li * PLD + 4 * g + lk] = wi[g];
@@ -494,13 +488,8 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
       asm volatile("" : "+v"(zero));   // (a loop-invariant zero pair would be kept across the loop -- and spilled)
       // V = P (L D L^T)^-1 in accumulator layout: vt[g] = V[16R+li][lk+4g] -- V itself as the A operand of the next product
       d4_t vt = {zero, zero, zero, zero};
-#ifdef QTOS_EXP_NOABMFMA
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) { vt[s4] = lm[s4] + pr[s4]; }
-#else
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) vt = __builtin_amdgcn_mfma_f64_16x16x4f64(lm[s4], pr[s4], vt, 0, 0, 0);
-#endif
       // next pivot columns: assembled entries (cell table: 0 = the zero cell), extracted Schur updates, pivot
       // diagonal, minus V P[piv]^T (= Y D^-1 Y[piv]^T: the raw rows of the next pivots are the B operand)
       double npp[4], xv[4], av[4];
@@ -521,13 +510,8 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
         acc[g] = xv[g] + av[g] + (r == prow ? dgn : 0.0);
         npp[g] = -npp[g];
       }
-#ifdef QTOS_EXP_NOABMFMA
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) acc[s4] += vt[s4] * npp[s4];
-#else
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[s4], npp[s4], acc, 0, 0, 0);   // acc -= V P[piv]^T
-#endif
 #pragma unroll
       for (int g = 0; g < 4; ++g) A[aidx[g]] = 0.0;   // retired (the zero cell stays zero)
       if constexpr (LY::VP) {
@@ -565,11 +549,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     } else {
       // ---- service waves ------------------------------------------------------------------------------
       const int sv = wv - NT;
-#ifdef QTOS_EXP_NORHS
-      if (false) {
-#else
       if (sv == 0) {
-#endif
         // right-hand-side row: w = (L D L^T)^-1 p_F; rhs -= P w; right-hand side of the next pivots
         double part = 0.0;
 #pragma unroll
@@ -668,13 +648,8 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
         const int R = rc < 0 ? 0 : rc >> 8, C = rc < 0 ? 0 : rc & 255;
         const int oR = __builtin_amdgcn_readfirstlane(R * (16 * PLD * 8)), oC = __builtin_amdgcn_readfirstlane(C * (16 * PLD * 8));
         const char *wrow = (const char *)Yk + (tile_lane + oR), *prow2 = (const char *)Bop + (tile_lane + oC);
-#ifdef QTOS_EXP_NOLOADS
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { w[s4] = (double)(long long)wrow; pq[s4] = (double)(long long)prow2; }   // ablation: no operand loads
-#else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) { w[s4] = *(const double *)(wrow + 32 * s4); pq[s4] = *(const double *)(prow2 + 32 * s4); }
-#endif
       };
       // pivot indices of the columns (li) and of the four rows (lk + 4g) this lane holds in each tile: fetched ahead of
       // the products (the extraction behind them starts with no LDS round trip of its own: -5.5 % per launch)
@@ -689,21 +664,12 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
 #pragma unroll
       for (int t = 0; t < MAXT2; ++t) {
         if (t + 1 < MAXT2) tile_loads(rcs[t + 1], wa[(t + 1) & 1], pbv[(t + 1) & 1]);
-#ifdef QTOS_EXP_NOUPD
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) asm volatile("" :: "v"(wa[t & 1][s4]), "v"(pbv[t & 1][s4]));   // ablation: loads kept, no matrix instructions
-#else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
           U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(LY::VP ? wa[t & 1][s4] : wa[t & 1][s4] * dv4[s4], pbv[t & 1][s4], U[t], 0, 0, 0);
-#endif
       }
       KS2(5);
-#ifdef QTOS_EXP_NOEXTRACT
-      if (false) {
-#else
       if (extract) {
-#endif
         int jcs[MAXT2], jrs[MAXT2][4];
 #pragma unroll
         for (int t = 0; t < MAXT2; ++t) {
@@ -836,9 +802,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     for (int i = tid; i < NS * 4; i += KT2) nxp[i] = P.nxt_pack[i];
     for (int i = tid; i < NS * 8; i += KT2) nxp[NS * 4 + i] = (int)P.amask2[i];
     __syncthreads();
-#ifndef QTOS_EXP_NOBACK
     sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane);
-#endif
   }
 #ifdef QTOS_STAMPS
   KS2(6);

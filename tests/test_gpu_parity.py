@@ -475,6 +475,36 @@ def test_pool_of_handles_equals_one_call_after_the_other(cfg):
     pool.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [["--workload", "mixed", "--steps", "10", "--warmup", "2"],
+                                   ["--transcription", "knots200", "--workload", "mpc_random", "--steps", "6", "--warmup", "2"]])
+def test_bench_on_two_gpus_when_the_node_has_them(flags):
+    """The first box with more than one GPU exercises what world size 1 cannot: RCCL between ranks, ragged shards of the
+    mixed batch (BASELINE configs[3]) and the gather of the receding windows (configs[4]).  `bench.py --gpus 2` starts its two
+    ranks as a child process (torch.distributed.run) and prints ONE JSON line with n_gpus = 2 and the whole job's rate.
+    Skipped on a one-GPU box."""
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % torch.cuda.device_count())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-sample", "0", "--no-parity", "--no-trot",
+                        "--child-timeout", "900"] + flags, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert "RCCL all-gather" in out["config"]["parallelism"]
+    pr = out["per_rank_plans_per_s"]
+    assert 0 < pr["min"] <= pr["max"]
+
+
+@pytest.mark.gpu
 def test_bench_relaunches_itself_under_torchrun_on_one_gpu():
     """bench.py --force-torchrun: the launcher path of `--gpus N` (bench.py starts `python -m torch.distributed.run`
     as a CHILD before it touches the GPU and exits with the child's code) exercised with one rank: one JSON line,
@@ -746,13 +776,16 @@ def test_shifted_windows_match_oracle_over_five_replans():
     start, goal, map_id = workloads.mpc_goals(4, seed=5, terrains=(maps, cell))
     W = ShiftedWindows(P, start, goal - start[:, 0:3], map_id, advance=2.5)
     oracles = [Oracle(oracle_dict(cfg), height=maps[m], hcell=cell) for m in map_id]
+    from oracle.projection import project_nodes
+    var_free = P.structure()[1]
     for k in range(6):
         W.warm_mode = "shifted" if k >= 4 else "none"
         nodes, status = W.replan()
         torch.cuda.synchronize()
         st, gl = W.start.cpu().numpy(), W.goal.cpu().numpy()
         # (a solve that is given nodes starts from their projection onto the reduced base's spline space: the oracle gets the same)
-        warm = P.project(W.warm.cpu().numpy()) if k >= 4 else [None] * 4
+        # ... through the numpy / scipy restatement of the projection (oracle/projection.py), not the product's own
+        warm = project_nodes(W.warm.cpu().numpy(), oracles[0].L, var_free) if k >= 4 else [None] * 4
         it = W.iters.cpu().numpy()
         if k > 0:   # hand-over rows: all four feet carry force, a few hundred rows after `advance`
             assert (W.offset.cpu().numpy() >= 2.5).all() and (W.offset.cpu().numpy() <= 2.9).all()
@@ -793,7 +826,7 @@ def test_mixed_terrain_batch_with_map_ids(cfg):
     P.close()
 
 
-def _batch_vs_oracle(cfg, start, goal, sel, maps=None, cell=None, map_id=None, status=None, iters=None, nodes=None, tol=1e-6):
+def _batch_vs_oracle(cfg, start, goal, sel, maps=None, cell=None, map_id=None, status=None, iters=None, nodes=None, tol=1e-6, eps_dual=None):
     """The problems `sel` of a batch solved by the oracle (OpenMP over the problems, one oracle per heightfield): returns
     the number of problems whose status and iteration count equal the GPU's and whose nodes agree to 1e-6, and the
     worst node difference among them."""
@@ -808,6 +841,8 @@ def _batch_vs_oracle(cfg, start, goal, sel, maps=None, cell=None, map_id=None, s
         O = Oracle(oracle_dict(cfg), height=h, hcell=cell if cell else 0.1)
         qs = [O.problem(start[b][0:3], start[b][3:6], start[b][6:18].reshape(4, 3), goal[b], start[b][18:21], start[b][21:24]) for b in idx]
         opts = oracle_options(cfg, O)
+        if eps_dual is not None:
+            opts.eps_dual = eps_dual          # (the oracle's regularisation of the multipliers only: the product keeps its own)
         xo, infos = O.solve_batch(qs, n_threads=os.cpu_count() or 1, opts=opts)
         for j, b in enumerate(idx):
             if infos[j].status == int(status[b]) and infos[j].iters == int(iters[b]):
@@ -905,6 +940,48 @@ def test_trot_gait_batch_matches_oracle(reduce_base):
     assert iters.max() <= 6
     same, worst = _batch_vs_oracle(cfg, start, goal, range(32), status=status, iters=iters, nodes=nodes, tol=5e-6 if reduce_base else 1e-6)
     assert same == 32, (same, worst)
+
+
+@pytest.mark.gpu
+def test_trot_gap_to_the_oracle_is_rounding_sensitivity_not_the_oracles_regularisation():
+    """Where the 5e-6 of the trot (2e-8 on the walk) comes from.  Round 3 blamed the oracle's eps_dual = 1e-8 on the
+    multipliers of the acceleration-continuity rows (the reduced base satisfies those rows identically).  Measured here, that
+    is NOT it: with the ORACLE's eps_dual taken to 1e-10 (the product untouched) the gap stays where it was.  What the gap is:
+    the sensitivity of the iterates of a cost-free NLP to rounding -- the two KKT kernels of the product (k_kkt2, and k_kkt3
+    through QTOS_KKT=3: the same system, the same algorithm, the inequality blocks summed in another order) already differ
+    by a good part of it on the trot and by 1e-8 on the walk.  Both kernels' plans are feasible to the tolerance and take the
+    same iterations; neither side of the comparison is 'the wrong one' at this level."""
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    res = {}
+    for gait in ("trot", "walk"):
+        cfg = PlannerConfig.knots100(gait=gait)
+        B = 32
+        start, goal = workloads.flat_goals(B, seed=0)
+        plans = {}
+        for kkt in ("2", "3"):
+            os.environ["QTOS_KKT"] = kkt
+            try:
+                P = Planner(cfg, max_batch=B)
+            finally:
+                del os.environ["QTOS_KKT"]
+            plans[kkt] = P.plan(start, goal)
+            P.close()
+        (n2, s2, i2, v2), (n3, s3, i3, v3) = plans["2"], plans["3"]
+        assert (s2 == 0).all() and (s3 == 0).all() and np.array_equal(i2, i3) and max(v2.max(), v3.max()) <= cfg.tol
+        order_gap = float(np.abs(n2 - n3).max())
+        gaps = {}
+        for eps in (1e-8, 1e-10):
+            same, worst = _batch_vs_oracle(cfg, start, goal, range(16), status=s2, iters=i2, nodes=n2, tol=1e-4, eps_dual=eps)
+            assert same == 16, (gait, eps, same)
+            gaps[eps] = worst
+        res[gait] = (order_gap, gaps)
+    (ot, gt), (ow, gw) = res["trot"], res["walk"]
+    assert gt[1e-8] < 5e-6 and gw[1e-8] < 1e-6, res
+    assert 0.3 < gt[1e-10] / gt[1e-8] < 3.0, res                 # the regularisation does not move the gap
+    assert ot > 0.02 * gt[1e-8] and ot < 5e-6, res               # another order of summation alone gives a good part of it
+    assert ow < 1e-6, res
 
 
 @pytest.mark.gpu
@@ -1170,6 +1247,9 @@ def test_knots200_receding_window_on_random_heightfields():
     assert (status == 0).mean() >= 0.9 and viol[status == 0].max() <= cfg.tol   # nearest-cell terrain: a few stall on a cell edge
     assert len({int(mid[b]) for b in range(B)}) == 8 and np.ptp(maps, axis=0).max() > 0.01   # the maps differ
     cold_iters = iters.copy()
+    from oracle.oracle import Oracle as _O, oracle_dict as _od
+    from oracle.projection import project_nodes
+    proj_layout, var_free = _O(_od(cfg)).L, P.structure()[1]
     chk = [int(b) for b in np.nonzero((status == 0) & (iters <= 5))[0][:NCHK + 3]]
     assert check(chk, nodes, status, iters, start, None) >= NCHK
     # five replans of the receding window: the next start is the row 20 ms into the current plan, the
@@ -1183,7 +1263,9 @@ def test_knots200_receding_window_on_random_heightfields():
         ok = status == 0
         assert ok.mean() >= 0.9
         assert iters[ok].mean() < cold_iters.mean() - 0.25             # the warm start pays (cold: 4-5 iterations, warm: 3-4)
-        assert check(chk, nodes, status, iters, nstart, P.project(warm)) >= NCHK - 1   # (what the solve starts from: the nodes' projection onto the reduced base's spline space)
+        # (what the solve starts from: the nodes' projection onto the reduced base's spline space -- handed to the oracle from
+        #  the numpy / scipy restatement, oracle/projection.py; test_projection.py holds the product's to it)
+        assert check(chk, nodes, status, iters, nstart, project_nodes(warm, proj_layout, var_free)) >= NCHK - 1
         start = nstart
     # (the 20 ms look-ahead loop of round 1 drifts after ~28 replans -- replanning from one's own first 20 ms -- and is not
     #  the reference's loop: the reference's hand-over rule, 2.5 s ahead with all feet down, is exercised over 20 replans
