@@ -40,25 +40,35 @@ struct QtosPlanner {
   hipStream_t own_stream = nullptr;   // stream of the host-pointer entry points (non-blocking: other handles / streams are not synchronised)
   long long *d_totals = nullptr;      // converged problems, iterations: tallied at the end of every plan call (qtos_plan_totals)
   hipStream_t last_stream = nullptr;
-  hipStream_t side_stream = nullptr;  // k_chord of an iteration in which other problems of the batch factor: the two kernels run side by side
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *d_table = nullptr, *d_tab_dx = nullptr, *d_tab_dy = nullptr;   // nominal-plan table (qtos_set_init_table)
-  int *h_active = nullptr;  // pinned + mapped, two words per Newton iteration: unfinished problems after it, of those flagged for a chord step
-  int *h_active_dev = nullptr;   // the same memory as the device sees it (k_post_counts stores there: no copy engine between two kernels)
-  std::vector<hipEvent_t> ev;  // 3 per iteration (kkt begin / end, count read back) + 2 (total)
-  int last_launches = 0, last_iters = 0;
-  // the call in flight (qtos_plan_submit .. qtos_plan_poll): what was queued without knowing the counts, what has been
-  // looked at.  One call per handle at a time (`busy`).
-  struct Call {
+  // A call is served by one or more LANES.  A lane owns everything one host-driven Newton loop needs: the stream its kernels
+  // run on (lane 0: the caller's; the others: streams of the planner), a side stream for the chord solve that runs next to a
+  // factorisation, the pinned count slots its iterations report to, its events and its two device counters.  A call of more
+  // problems than the GPU has compute units is cut into contiguous parts, one per lane: the late iterations of a part's
+  // stragglers then run side by side with the other parts' full grids instead of holding the whole call -- the reference's
+  // queue of probes (QTOS/generateHeightField.py:375-377) inside ONE call.  The parts never meet: the plans are bit for bit
+  // those of a single lane (QTOS_LANES=1).
+  struct Lane {
     bool open = false;
-    int B = 0, spec = 0, enq = 0, chk = 0;   // iterations queued blind / queued in all / whose preceding counts have been read
+    int B = 0, b0 = 0, spec = 0, enq = 0, chk = 0;   // problems, first problem; iterations queued blind / queued in all / whose preceding counts have been read
     unsigned spins = 0;                      // polls that found no counts yet
-    unsigned seq = 0;                        // sequence number of the call, stamped into the count words (k_post_counts)
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;                // where this lane's kernels go in the call in flight
+    hipStream_t own = nullptr, side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
     DevWork W;
-    double *nodes_out = nullptr, *viol_out = nullptr;
-    int *status_out = nullptr, *iters_out = nullptr;
-  } call;
+    int *h_active = nullptr;      // pinned + mapped, two words per Newton iteration: unfinished problems after it, of those flagged for a chord step
+    int *h_active_dev = nullptr;  // the same memory as the device sees it (k_post_counts stores there: no copy engine between two kernels)
+    int *d_n_active = nullptr;    // the lane's two device counters
+    std::vector<hipEvent_t> ev;   // 5 per iteration (kkt begin / end, chord begin / end, counts posted) + 3
+    std::vector<char> was_kkt, was_chord;   // per iteration of the last call: which solve kernels were launched
+    int last_launches = 0, last_iters = 0;
+  };
+  std::vector<Lane> lanes;
+  int lanes_used = 1, lane_chunk = 256;      // lanes of the call in flight; problems per lane above which a call is cut (the GPU's compute units)
+  bool call_open = false;
+  unsigned seq = 0;                          // sequence number of the call in flight, stamped into the count words (k_post_counts)
+  hipStream_t call_stream = nullptr;
+  hipEvent_t ev_in = nullptr;                // the caller's stream at submit time: the other lanes start behind it
   unsigned call_seq = 0;             // sequence number of the last call submitted
   bool use_kkt3 = false;             // k_kkt3 (kkt3.hpp) instead of k_kkt2: chosen by qtos_planner_create
   bool counts_by_copy = false;       // the counts of unfinished problems reach the host by hipMemcpyAsync instead of k_post_counts (QTOS_COUNTS_COPY=1)
@@ -67,7 +77,6 @@ struct QtosPlanner {
   std::atomic<int> busy{0};
   size_t kkt_lds = 0, eval_lds = 0;
   void (*chord_fn)(DevPlan, DevWork, int) = nullptr; // k_chord instantiated for this front size (null: chord steps off)
-  std::vector<char> was_kkt, was_chord;              // per iteration of the last call: which solve kernels were launched
   void (*kkt_fn)(DevPlan, DevWork, int) = nullptr;   // k_kkt / k_kkt2 instantiated for this front size
   int kkt_threads = KT;
   std::string err;
@@ -150,15 +159,19 @@ void qtos_planner_destroy(QtosPlanner *p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
   for (void *a : p->allocs) (void)hipFree(a);
-  for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+  for (auto &L : p->lanes) {
+    for (hipEvent_t e : L.ev) (void)hipEventDestroy(e);
+    if (L.h_active) (void)hipHostFree(L.h_active);
+    if (L.own) (void)hipStreamDestroy(L.own);
+    if (L.side) (void)hipStreamDestroy(L.side);
+    for (hipEvent_t e : {L.ev_fork, L.ev_join, L.ev_done})
+      if (e) (void)hipEventDestroy(e);
+  }
+  if (p->ev_in) (void)hipEventDestroy(p->ev_in);
   for (void *q : {(void *)p->d_table, (void *)p->d_tab_dx, (void *)p->d_tab_dy, (void *)p->d_height})
     if (q) (void)hipFree(q);
-  if (p->h_active) (void)hipHostFree(p->h_active);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
-  if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
   if (p->d_totals) (void)hipFree(p->d_totals);
-  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   delete p;
 }
 
@@ -452,7 +465,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
 #endif
   TRY(p->alloc(&W.trace, Bm * (size_t)(M.P.max_iter + 1) * 4));
   TRY(p->alloc(&W.status, Bm)); TRY(p->alloc(&W.iters, Bm)); TRY(p->alloc(&W.done, Bm));
-  TRY(p->alloc(&W.n_active, 2));
+  TRY(p->alloc(&W.n_active, 2 * 4));   // two counters per lane
   TRY(p->alloc(&W.chord, Bm));
   TRY(p->alloc(&W.chord_run, Bm));
   TRY(p->alloc(&W.jam, Bm));
@@ -462,20 +475,39 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.dx0, Bm * (size_t)M.n_sol)); TRY(p->alloc(&W.ur, Bm * m));
   TRY(p->alloc(&p->d_start, Bm * QTOS_START_DOUBLES)); TRY(p->alloc(&p->d_goal, Bm * 3));
   TRY(p->alloc(&p->d_nodes, Bm * n)); TRY(p->alloc(&p->d_warm, Bm * n)); TRY(p->alloc(&p->d_map, Bm));
-  if (hipHostMalloc((void **)&p->h_active, 2 * sizeof(int) * ((size_t)M.P.max_iter + 1), hipHostMallocMapped) != hipSuccess) { qtos_planner_destroy(p); return -3; }
-  if (hipHostGetDevicePointer((void **)&p->h_active_dev, p->h_active, 0) != hipSuccess) { qtos_planner_destroy(p); return -2; }
-  p->was_kkt.assign(M.P.max_iter + 1, 0);
-  p->was_chord.assign(M.P.max_iter + 1, 0);
   if (hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
-  if (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   if (hipMalloc(&p->d_totals, 2 * sizeof(long long)) != hipSuccess || hipMemset(p->d_totals, 0, 2 * sizeof(long long)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
   p->last_stream = p->own_stream;
   if (const char *e = getenv("QTOS_SPEC_CAP")) p->spec_cap = std::max(0, atoi(e));
   if (const char *e = getenv("QTOS_COUNTS_COPY")) p->counts_by_copy = atoi(e) != 0;   // (diagnostic: limit of the blind iterations)
-  if (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) { qtos_planner_destroy(p); return -2; }
-  p->ev.resize(5 * (size_t)M.P.max_iter + 3);
-  for (auto &e : p->ev)
-    if (hipEventCreate(&e) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+  {  // lanes: one per part of a call that is larger than the GPU -- QTOS_LANES: at most that many; default ONE: measured at 1024
+     // problems per call (round 4, profiles/r04_lanes.txt), parts that start together also reach their stragglers together, and
+     // four lock-step loops of 256 pay four tails where one loop of 1024 pays one (exp_5 75.8 K plans/s on four lanes, 84.0 K
+     // on two, 84.2 K on one)
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    p->lane_chunk = cus;
+    int want = 1;
+    if (const char *e = getenv("QTOS_LANES")) want = std::max(1, std::min(4, atoi(e)));
+    const int n_lanes = std::max(1, std::min(want, (max_batch + cus - 1) / cus));
+    p->lanes.resize(n_lanes);
+    if (hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+    for (int j = 0; j < n_lanes; ++j) {
+      QtosPlanner::Lane &L = p->lanes[j];
+      if (hipHostMalloc((void **)&L.h_active, 2 * sizeof(int) * ((size_t)M.P.max_iter + 1), hipHostMallocMapped) != hipSuccess) { qtos_planner_destroy(p); return -3; }
+      if (hipHostGetDevicePointer((void **)&L.h_active_dev, L.h_active, 0) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+      L.was_kkt.assign(M.P.max_iter + 1, 0);
+      L.was_chord.assign(M.P.max_iter + 1, 0);
+      L.d_n_active = W.n_active + 2 * j;
+      if (j > 0 && hipStreamCreateWithFlags(&L.own, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+      if (hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+      if (hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+      L.ev.resize(5 * (size_t)M.P.max_iter + 3);
+      for (auto &e : L.ev)
+        if (hipEventCreate(&e) != hipSuccess) { qtos_planner_destroy(p); return -2; }
+    }
+  }
 #undef TRY
   *out = p;
   return 0;
@@ -571,39 +603,56 @@ __global__ void k_post_counts(const int *n_active, int *host_slot, unsigned seq)
 // to its problems leave at once and k_chord gets their CUs: the batch pays max(k_kkt2, k_chord), not the sum).  Blind
 // (queued before the counts of the preceding iteration have come back): both solve kernels are launched, each leaves at
 // once for the problems that are not its own (a launch whose workgroups all leave costs a few microseconds).
-static int queue_iteration(QtosPlanner *p, int it, bool informed, int n, int nc) {
-  QtosPlanner::Call &c = p->call;
+static int queue_iteration(QtosPlanner *p, QtosPlanner::Lane &c, int it, bool informed, int n, int nc) {
   const DevPlan &D = p->dp;
   hipStream_t st = c.st;
   const bool do_kkt = informed ? n - nc > 0 : true;
   const bool do_chord = p->chord_fn && (informed ? nc > 0 : it >= 1);
-  p->was_kkt[it] = do_kkt;       // (blind iterations: corrected once their counts are known)
-  p->was_chord[it] = do_chord;
+  c.was_kkt[it] = do_kkt;       // (blind iterations: corrected once their counts are known)
+  c.was_chord[it] = do_chord;
   const bool fork = do_kkt && do_chord;
-  hipStream_t cs = fork ? p->side_stream : st;
+  hipStream_t cs = fork ? c.side : st;
   if (fork) {
-    HIPCHK(p, hipEventRecord(p->ev_fork, st));            // everything up to the previous k_step
-    HIPCHK(p, hipStreamWaitEvent(cs, p->ev_fork, 0));
+    HIPCHK(p, hipEventRecord(c.ev_fork, st));            // everything up to the previous k_step
+    HIPCHK(p, hipStreamWaitEvent(cs, c.ev_fork, 0));
   }
   if (do_kkt) {
-    HIPCHK(p, hipEventRecord(p->ev[2 + 5 * it], st));
+    HIPCHK(p, hipEventRecord(c.ev[2 + 5 * it], st));
     hipLaunchKernelGGL(p->kkt_fn, dim3(c.B), dim3(p->kkt_threads), p->kkt_lds, st, D, c.W, c.B);
-    HIPCHK(p, hipEventRecord(p->ev[3 + 5 * it], st));
+    HIPCHK(p, hipEventRecord(c.ev[3 + 5 * it], st));
   }
   if (do_chord) {
-    HIPCHK(p, hipEventRecord(p->ev[4 + 5 * it], cs));
+    HIPCHK(p, hipEventRecord(c.ev[4 + 5 * it], cs));
     hipLaunchKernelGGL(p->chord_fn, dim3(c.B), dim3(KTC), chord_lds_bytes(p->S.n_stages), cs, D, c.W, c.B);
-    HIPCHK(p, hipEventRecord(p->ev[5 + 5 * it], cs));
+    HIPCHK(p, hipEventRecord(c.ev[5 + 5 * it], cs));
   }
   if (fork) {
-    HIPCHK(p, hipEventRecord(p->ev_join, cs));
-    HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
+    HIPCHK(p, hipEventRecord(c.ev_join, cs));
+    HIPCHK(p, hipStreamWaitEvent(st, c.ev_join, 0));
   }
   hipLaunchKernelGGL(k_step, dim3(c.B), dim3(ET), p->eval_lds, st, D, c.W, c.B, it);
-  if (p->counts_by_copy) HIPCHK(p, hipMemcpyAsync(p->h_active + 2 * it, c.W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * it, c.seq);
-  HIPCHK(p, hipEventRecord(p->ev[6 + 5 * it], st));
+  if (p->counts_by_copy) HIPCHK(p, hipMemcpyAsync(c.h_active + 2 * it, c.W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, c.h_active_dev + 2 * it, p->seq);
+  HIPCHK(p, hipEventRecord(c.ev[6 + 5 * it], st));
   return 0;
+}
+
+// The part [b0, b0 + B) of the planner's workspace and of the caller's buffers, as a workspace of its own (every array is
+// indexed by the problem's number inside its launch).  Strides: the allocations in qtos_planner_create.
+static DevWork work_slice(const QtosPlanner *p, const DevWork &w, int b0, int *n_active) {
+  DevWork s = w;
+  const size_t n = p->M.n_vars, m = p->M.n_cons, ns = p->M.n_sol, NS = p->S.n_stages, b = (size_t)b0;
+  auto off = [&](auto *&ptr, size_t stride) { if (ptr) ptr += b * stride; };
+  off(s.start, QTOS_START_DOUBLES); off(s.goal, 3); off(s.warm, n); off(s.map_id, 1);
+  off(s.x, n); off(s.g, m); off(s.gt, m); off(s.s, m); off(s.zl, m); off(s.zu, m); off(s.ds, m); off(s.dzl, m); off(s.dzu, m);
+  off(s.sig, m); off(s.w, m); off(s.panel, (size_t)p->dp.panel_stride); off(s.dx, ns); off(s.stream, (size_t)p->dp.stream_len);
+  off(s.mu, 1); off(s.viol, 1); off(s.trace, ((size_t)p->dp.max_iter + 1) * 4); off(s.best_viol, 1); off(s.xbest, n);
+  off(s.held, 1); off(s.best_it, 1); off(s.status, 1); off(s.iters, 1); off(s.done, 1);
+  off(s.chord, 1); off(s.chord_run, 1); off(s.jam, 1); off(s.rhs, (size_t)p->S.n_unknowns); off(s.minv, NS * PIV * PIV);
+  off(s.sol, NS * PIV); off(s.sol0, NS * PIV); off(s.dx0, ns); off(s.ur, m);
+  off(s.nodes_out, n); off(s.viol_out, 1); off(s.status_out, 1); off(s.iters_out, 1);
+  s.n_active = n_active;
+  return s;
 }
 
 int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
@@ -612,70 +661,76 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
   if (!p || B < 1 || B > p->max_batch || !d_start || !d_goal || !d_nodes_out) return -1;
   int expected = 0;
   if (!p->busy.compare_exchange_strong(expected, 1)) { p->err = "the planner handle already serves a call (one call per handle at a time)"; return -5; }
-  QtosPlanner::Call &c = p->call;
-  auto fail = [&](int rc) { c.open = false; p->busy.store(0); return rc; };
+  auto fail = [&](int rc) { p->call_open = false; for (auto &L : p->lanes) L.open = false; p->busy.store(0); return rc; };
   hipStream_t st = (hipStream_t)stream_;
   if (hipSetDevice(p->device) != hipSuccess) return fail(-2);
-  c = QtosPlanner::Call();
-  c.open = true; c.B = B; c.st = st;
-  p->call_seq = p->call_seq >= 0xfffeu ? 1u : p->call_seq + 1u;   // (0xffff = the reset pattern of the slots)
-  c.seq = p->call_seq;
-  c.W = p->wk;
-  c.W.start = d_start; c.W.goal = d_goal; c.W.map_id = d_map_id; c.W.warm = d_warm;
-  c.nodes_out = d_nodes_out; c.status_out = d_status_out; c.iters_out = d_iters_out; c.viol_out = d_viol_out;
+  p->call_open = true;
+  p->call_stream = st;
+  p->seq = p->seq >= 0xfffeu ? 1u : p->seq + 1u;   // (0xffff = the reset pattern of the slots)
+  DevWork W = p->wk;
+  W.start = d_start; W.goal = d_goal; W.map_id = d_map_id; W.warm = d_warm;
   // (the kernel that finishes a problem writes its result: kernels.hpp export_problem)
-  c.W.nodes_out = d_nodes_out; c.W.status_out = d_status_out; c.W.iters_out = d_iters_out; c.W.viol_out = d_viol_out;
-  c.W.totals = (unsigned long long *)p->d_totals;
+  W.nodes_out = d_nodes_out; W.status_out = d_status_out; W.iters_out = d_iters_out; W.viol_out = d_viol_out;
+  W.totals = (unsigned long long *)p->d_totals;
   const DevPlan &D = p->dp;
 #define SUBCHK(call_) do { hipError_t e_ = (call_); if (e_ != hipSuccess) { p->err = std::string(#call_) + ": " + hipGetErrorString(e_); return fail(e_ == hipErrorOutOfMemory ? -3 : -2); } } while (0)
-  std::memset(p->h_active, 0xff, 2 * sizeof(int) * ((size_t)D.max_iter + 1));   // no counts yet (the handle's previous call is over)
-  SUBCHK(hipMemsetAsync(c.W.n_active, 0, 2 * sizeof(int), st));
-  SUBCHK(hipEventRecord(p->ev[0], st));
-  hipLaunchKernelGGL(k_start, dim3(B), dim3(ET), p->eval_lds, st, D, c.W, B);
-  // counts after k_start (slot max_iter of the pinned array), event ev_start
+  // parts: one lane up to the GPU's compute units, then as many lanes as there are (equal parts)
+  const int n_used = B <= p->lane_chunk ? 1 : std::min((int)p->lanes.size(), (B + p->lane_chunk - 1) / p->lane_chunk);
+  const int per = (B + n_used - 1) / n_used;
+  p->lanes_used = n_used;
+  if (n_used > 1) SUBCHK(hipEventRecord(p->ev_in, st));
   const int ev_start = 2 + 5 * D.max_iter;
-  if (p->counts_by_copy) SUBCHK(hipMemcpyAsync(p->h_active + 2 * D.max_iter, c.W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, p->h_active_dev + 2 * D.max_iter, c.seq);
-  SUBCHK(hipEventRecord(p->ev[ev_start], st));
+  for (int j = 0; j < n_used; ++j) {
+    QtosPlanner::Lane &c = p->lanes[j];
+    c.open = true; c.b0 = j * per; c.B = std::min(per, B - c.b0); c.spec = c.enq = c.chk = 0; c.spins = 0;
+    c.st = j == 0 ? st : c.own;
+    c.W = work_slice(p, W, c.b0, c.d_n_active);
+    if (j > 0) SUBCHK(hipStreamWaitEvent(c.st, p->ev_in, 0));
+    std::memset(c.h_active, 0xff, 2 * sizeof(int) * ((size_t)D.max_iter + 1));   // no counts yet (late stores of an earlier call carry another sequence number)
+    SUBCHK(hipMemsetAsync(c.W.n_active, 0, 2 * sizeof(int), c.st));
+    SUBCHK(hipEventRecord(c.ev[0], c.st));
+    hipLaunchKernelGGL(k_start, dim3(c.B), dim3(ET), p->eval_lds, c.st, D, c.W, c.B);
+    // counts after k_start (slot max_iter of the pinned array), event ev_start
+    if (p->counts_by_copy) SUBCHK(hipMemcpyAsync(c.h_active + 2 * D.max_iter, c.W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, c.st));
+    else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, c.st, c.W.n_active, c.h_active_dev + 2 * D.max_iter, p->seq);
+    SUBCHK(hipEventRecord(c.ev[ev_start], c.st));
+    // Blind iterations: as many as the previous call of this handle needed (its slowest problem), queued without a host
+    // round trip (qtos_set_speculation; 1 by default: the first iteration).  A batch that needs more is continued by
+    // qtos_plan_poll from the counts the iterations send back; blind launches behind the end find every problem done.
+    c.spec = std::max(0, std::min(std::min(p->spec_next, p->spec_cap), D.max_iter));
+    for (int it = 0; it < c.spec; ++it)
+      if (int rc = queue_iteration(p, c, it, false, 0, 0)) return fail(rc);
+    c.enq = c.spec;
+  }
 #undef SUBCHK
-  // Blind iterations: as many as the previous call of this handle needed (its slowest problem), queued without a host
-  // round trip (qtos_set_speculation; 1 by default: the first iteration).  A batch that needs more is continued by
-  // qtos_plan_poll from the counts the iterations send back; blind launches behind the end find every problem done.
-  c.spec = std::max(0, std::min(std::min(p->spec_next, p->spec_cap), D.max_iter));
-  for (int it = 0; it < c.spec; ++it)
-    if (int rc = queue_iteration(p, it, false, 0, 0)) return fail(rc);
-  c.enq = c.spec;
-  if (hipEventRecord(p->ev[1], st) != hipSuccess) return fail(-2);
+  if (n_used == 1 && hipEventRecord(p->lanes[0].ev[1], st) != hipSuccess) return fail(-2);
   p->last_stream = st;
   return 0;
 }
 
-int qtos_plan_poll(QtosPlanner *p, int *done) {
-  if (!p || !done) return -1;
-  QtosPlanner::Call &c = p->call;
-  *done = 0;
-  if (!c.open) { *done = 1; return 0; }
+// One lane as far as the counts that have arrived allow.  *lane_done: every problem of the part has handed its result over.
+static int advance_lane(QtosPlanner *p, QtosPlanner::Lane &c, bool *lane_done, bool *device_set) {
   const DevPlan &D = p->dp;
-  bool device_set = false;     // (only in front of launches: hipSetDevice in a spin loop of several host threads is a lock fight)
   const int ev_start = 2 + 5 * D.max_iter;
+  *lane_done = false;
   for (;;) {
     // counts in front of iteration c.chk (behind k_start / iteration c.chk - 1): the slot itself says when they are there
     // (k_post_counts stores into mapped host memory; qtos_plan_submit left -1 in every slot) -- an event query on top of
     // it is a driver call and waits for the end-of-kernel signal of the command processor
-    const int *h = p->h_active + 2 * (c.chk == 0 ? D.max_iter : c.chk - 1);
+    const int *h = c.h_active + 2 * (c.chk == 0 ? D.max_iter : c.chk - 1);
     int n, nc;
     if (p->counts_by_copy) {
-      const hipError_t q = hipEventQuery(p->ev[c.chk == 0 ? ev_start : 6 + 5 * (c.chk - 1)]);
+      const hipError_t q = hipEventQuery(c.ev[c.chk == 0 ? ev_start : 6 + 5 * (c.chk - 1)]);
       if (q == hipErrorNotReady) return 0;
-      if (q != hipSuccess) { p->err = std::string("hipEventQuery: ") + hipGetErrorString(q); c.open = false; p->busy.store(0); return -2; }
+      if (q != hipSuccess) { p->err = std::string("hipEventQuery: ") + hipGetErrorString(q); return -2; }
       n = h[0]; nc = h[1];
     } else {
       const unsigned long long v = __atomic_load_n((const unsigned long long *)h, __ATOMIC_ACQUIRE);
-      if (v == ~0ull || (unsigned)(v >> 48) != c.seq) {   // nothing yet, or the late store of a blind launch of an earlier call
+      if (v == ~0ull || (unsigned)(v >> 48) != p->seq) {   // nothing yet, or the late store of a blind launch of an earlier call
         // (a failed launch never fills the slot: look at the stream now and then)
         if ((++c.spins & 0xfffff) == 0) {
           const hipError_t q = hipStreamQuery(c.st);
-          if (q != hipSuccess && q != hipErrorNotReady) { p->err = std::string("hipStreamQuery: ") + hipGetErrorString(q); c.open = false; p->busy.store(0); return -2; }
+          if (q != hipSuccess && q != hipErrorNotReady) { p->err = std::string("hipStreamQuery: ") + hipGetErrorString(q); return -2; }
         }
         return 0;
       }
@@ -684,29 +739,58 @@ int qtos_plan_poll(QtosPlanner *p, int *done) {
     if (n <= 0 || c.chk >= D.max_iter) {
       // finished in front of iteration c.chk (every problem has handed its result over: export_problem)
       const int iters = c.chk;
-      for (int j = iters; j < c.enq; ++j) { p->was_kkt[j] = 0; p->was_chord[j] = 0; }   // blind launches behind the end: no work
-      // (the end-of-call event ev[1] sits behind the last launch already: submit and every continuation record it)
-      p->last_launches = iters;
-      p->last_iters = iters;
-      p->spec_next = std::max(1, iters);
+      for (int j = iters; j < c.enq; ++j) { c.was_kkt[j] = 0; c.was_chord[j] = 0; }   // blind launches behind the end: no work
+      c.last_launches = iters;
+      c.last_iters = iters;
       c.open = false;
-      p->busy.store(0);
-      *done = 1;
+      *lane_done = true;
       return 0;
     }
     if (c.chk < c.spec) {
       // a blind iteration that did run: which of its two solve kernels had work
-      p->was_kkt[c.chk] = n - nc > 0;
-      p->was_chord[c.chk] = nc > 0 && p->chord_fn && c.chk >= 1;
+      c.was_kkt[c.chk] = n - nc > 0;
+      c.was_chord[c.chk] = nc > 0 && p->chord_fn && c.chk >= 1;
     }
     if (c.chk == c.enq) {
-      if (!device_set) { HIPCHK(p, hipSetDevice(p->device)); device_set = true; }
-      if (int rc = queue_iteration(p, c.chk, true, n, nc)) { c.open = false; p->busy.store(0); return rc; }
+      if (!*device_set) { HIPCHK(p, hipSetDevice(p->device)); *device_set = true; }
+      if (int rc = queue_iteration(p, c, c.chk, true, n, nc)) return rc;
       c.enq++;
-      HIPCHK(p, hipEventRecord(p->ev[1], c.st));
+      if (p->lanes_used == 1) HIPCHK(p, hipEventRecord(c.ev[1], c.st));   // (the end-of-call event sits behind the last launch)
     }
     c.chk++;
   }
+}
+
+int qtos_plan_poll(QtosPlanner *p, int *done) {
+  if (!p || !done) return -1;
+  *done = 0;
+  if (!p->call_open) { *done = 1; return 0; }
+  bool device_set = false;     // (only in front of launches: hipSetDevice in a spin loop of several host threads is a lock fight)
+  auto fail = [&](int rc) { p->call_open = false; for (auto &L : p->lanes) L.open = false; p->busy.store(0); return rc; };
+  int n_open = 0;
+  for (int j = 0; j < p->lanes_used; ++j) {
+    QtosPlanner::Lane &c = p->lanes[j];
+    if (!c.open) continue;
+    bool lane_done = false;
+    if (int rc = advance_lane(p, c, &lane_done, &device_set)) return fail(rc);
+    if (!lane_done) { ++n_open; continue; }
+    if (j > 0) {   // the caller's stream waits for the part that ran beside it
+      if (!device_set) { if (hipSetDevice(p->device) != hipSuccess) return fail(-2); device_set = true; }
+      if (hipEventRecord(c.ev_done, c.st) != hipSuccess || hipStreamWaitEvent(p->call_stream, c.ev_done, 0) != hipSuccess) return fail(-2);
+    }
+  }
+  if (n_open) return 0;
+  if (p->lanes_used > 1) {   // end of the call: behind every part
+    if (!device_set && hipSetDevice(p->device) != hipSuccess) return fail(-2);
+    if (hipEventRecord(p->lanes[0].ev[1], p->call_stream) != hipSuccess) return fail(-2);
+  }
+  int iters = 0;
+  for (int j = 0; j < p->lanes_used; ++j) iters = std::max(iters, p->lanes[j].last_iters);
+  p->spec_next = std::max(1, iters);
+  p->call_open = false;
+  p->busy.store(0);
+  *done = 1;
+  return 0;
 }
 
 int qtos_plan_wait(QtosPlanner *p) {
@@ -735,8 +819,8 @@ int qtos_plan_totals(QtosPlanner *p, long long *converged, long long *iterations
   HIPCHK(p, hipSetDevice(p->device));
   long long h[2] = {0, 0};
   // on the planner's own stream, behind the end event of the last call (the caller's stream may be gone by now)
-  if (p->call.open) HIPCHK(p, qtos_plan_wait(p) ? hipErrorUnknown : hipSuccess);
-  HIPCHK(p, hipStreamWaitEvent(p->own_stream, p->ev[1], 0));
+  if (p->call_open) HIPCHK(p, qtos_plan_wait(p) ? hipErrorUnknown : hipSuccess);
+  HIPCHK(p, hipStreamWaitEvent(p->own_stream, p->lanes[0].ev[1], 0));
   HIPCHK(p, hipMemcpyAsync(h, p->d_totals, sizeof(h), hipMemcpyDeviceToHost, p->own_stream));
   if (reset) HIPCHK(p, hipMemsetAsync(p->d_totals, 0, sizeof(h), p->own_stream));
   HIPCHK(p, hipStreamSynchronize(p->own_stream));
@@ -769,40 +853,49 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
   return 0;
 }
 
+// Timing of the last call from the HIP events of its lanes: KKT (chord) launches and their seconds summed over the lanes,
+// total = first kernel of lane 0 to the end of the call, iterations = the slowest lane's.
 int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, double *total_seconds, int *iterations) {
   if (!p) return -1;
   HIPCHK(p, hipSetDevice(p->device));
-  HIPCHK(p, hipEventSynchronize(p->ev[1]));
+  HIPCHK(p, hipEventSynchronize(p->lanes[0].ev[1]));
   double kkt = 0;
-  int n_kkt = 0;
-  for (int i = 0; i < p->last_launches; ++i) {
-    if (!p->was_kkt[i]) continue;
-    float ms = 0;
-    HIPCHK(p, hipEventElapsedTime(&ms, p->ev[2 + 5 * i], p->ev[3 + 5 * i]));
-    kkt += ms * 1e-3;
-    ++n_kkt;
+  int n_kkt = 0, iters = 0;
+  for (int j = 0; j < p->lanes_used; ++j) {
+    const QtosPlanner::Lane &L = p->lanes[j];
+    iters = std::max(iters, L.last_iters);
+    for (int i = 0; i < L.last_launches; ++i) {
+      if (!L.was_kkt[i]) continue;
+      float ms = 0;
+      HIPCHK(p, hipEventElapsedTime(&ms, L.ev[2 + 5 * i], L.ev[3 + 5 * i]));
+      kkt += ms * 1e-3;
+      ++n_kkt;
+    }
   }
   float tot = 0;
-  HIPCHK(p, hipEventElapsedTime(&tot, p->ev[0], p->ev[1]));
+  HIPCHK(p, hipEventElapsedTime(&tot, p->lanes[0].ev[0], p->lanes[0].ev[1]));
   if (kkt_seconds) *kkt_seconds = kkt;
   if (kkt_launches) *kkt_launches = n_kkt;
   if (total_seconds) *total_seconds = tot * 1e-3;
-  if (iterations) *iterations = p->last_iters;
+  if (iterations) *iterations = iters;
   return 0;
 }
 
 int qtos_last_timing_chord(QtosPlanner *p, double *chord_seconds, int *chord_launches) {
   if (!p) return -1;
   HIPCHK(p, hipSetDevice(p->device));
-  HIPCHK(p, hipEventSynchronize(p->ev[1]));
+  HIPCHK(p, hipEventSynchronize(p->lanes[0].ev[1]));
   double t = 0;
   int nl = 0;
-  for (int i = 0; i < p->last_launches; ++i) {
-    if (!p->was_chord[i]) continue;
-    float ms = 0;
-    HIPCHK(p, hipEventElapsedTime(&ms, p->ev[4 + 5 * i], p->ev[5 + 5 * i]));
-    t += ms * 1e-3;
-    ++nl;
+  for (int j = 0; j < p->lanes_used; ++j) {
+    const QtosPlanner::Lane &L = p->lanes[j];
+    for (int i = 0; i < L.last_launches; ++i) {
+      if (!L.was_chord[i]) continue;
+      float ms = 0;
+      HIPCHK(p, hipEventElapsedTime(&ms, L.ev[4 + 5 * i], L.ev[5 + 5 * i]));
+      t += ms * 1e-3;
+      ++nl;
+    }
   }
   if (chord_seconds) *chord_seconds = t;
   if (chord_launches) *chord_launches = nl;

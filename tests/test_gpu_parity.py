@@ -476,6 +476,49 @@ def test_pool_of_handles_equals_one_call_after_the_other(cfg):
 
 
 @pytest.mark.gpu
+def test_call_larger_than_the_gpu_is_cut_into_lanes_with_identical_plans(cfg):
+    """A call of more problems than the GPU has compute units is served by several lanes of the handle (contiguous parts on
+    streams of the planner, each with its own host-driven Newton loop: the late iterations of one part's stragglers run beside
+    the other parts' full grids -- the reference's queue of probes, QTOS/generateHeightField.py:375-377, inside ONE call).
+    Mixed terrain, 1024 problems: plans, statuses and iteration counts bit for bit those of the same call on one lane
+    (QTOS_LANES=1) and of four calls of 256; the asynchronous form (device pointers, submit / wait on a caller's stream, no
+    synchronisation in between) gives the same."""
+    import torch
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    B = 1024
+    maps, cell = workloads.mixed_terrains()
+    start, goal, mid = workloads.mixed_goals(B, seed=31, terrains=(maps, cell))
+    res = {}
+    for lanes in ("4", "1"):
+        os.environ["QTOS_LANES"] = lanes
+        try:
+            P = Planner(cfg, max_batch=B)
+        finally:
+            del os.environ["QTOS_LANES"]
+        P.set_heightfields(maps, cell)
+        res[lanes] = P.plan(start, goal, map_id=mid)
+        if lanes == "4":
+            dev = torch.device("cuda", 0)
+            t = [torch.as_tensor(np.ascontiguousarray(x), device=dev) for x in (start, goal, mid.astype(np.int32))]
+            out = (torch.empty((B, P.n), dtype=torch.float64, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+                   torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.float64, device=dev))
+            st = torch.cuda.Stream(dev)
+            torch.cuda.synchronize()
+            for _ in range(2):     # back to back on one stream
+                P.submit(B, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), st.cuda_stream)
+                P.wait()
+            st.synchronize()
+            res["async"] = (out[0].cpu().numpy(), out[1].cpu().numpy(), out[2].cpu().numpy(), out[3].cpu().numpy())
+            parts = [P.plan(start[i:i + 256], goal[i:i + 256], map_id=mid[i:i + 256]) for i in range(0, B, 256)]
+            res["parts"] = tuple(np.concatenate([q[k] for q in parts]) for k in range(4))
+        P.close()
+    assert (res["4"][1] == 0).mean() > 0.95 and len(set(res["4"][2].tolist())) > 1      # stragglers exist
+    for other in ("1", "async", "parts"):
+        assert all(np.array_equal(a, b) for a, b in zip(res["4"], res[other])), other
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("flags", [["--workload", "mixed", "--steps", "10", "--warmup", "2"],
                                    ["--transcription", "knots200", "--workload", "mpc_random", "--steps", "6", "--warmup", "2"]])
 def test_bench_on_two_gpus_when_the_node_has_them(flags):
