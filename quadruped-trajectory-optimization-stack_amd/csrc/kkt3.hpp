@@ -145,7 +145,26 @@ __device__ __forceinline__ void assemble_eq(double *A, const int *sbuf, const do
   const double *rval = eval + n_ent;
   for (int i = t0; i < n_rhs; i += nth) A[rsl[i]] += rval[i];
 }
-template <int F>
+// targets [t_begin, t_end) of a record's gather table (kernels.hpp assemble_stage: one thread per target, fixed summation order)
+__device__ __forceinline__ void assemble_targets(double *A, const int *sbuf, const double *dbuf, int t_begin, int t_end, int t0, int nth) {
+  const int n_tgt = sbuf[5];
+  const int *tg = sbuf + sbuf[4];                     // n_tgt + 1 ints: (cell << 12) | first contribution
+  const int *cl = tg + n_tgt + 1;                     // one self-contained int per contribution
+  for (int t = t_begin + t0; t < min(t_end, n_tgt); t += nth) {
+    const int tv = tg[t], c0 = tv & 4095, c1 = tg[t + 1] & 4095;
+    const double a_old = A[tv >> 12];
+    double acc = 0;
+    for (int j = c0; j < c1; ++j) acc += gather_term(dbuf, cl[j]);
+    A[tv >> 12] = a_old + acc;
+  }
+}
+#ifndef QTOS_AB_ROUNDS
+#define QTOS_AB_ROUNDS 64
+#endif
+// MODE 0: the inequality blocks condensed by matrix instructions (records of Symbolic::iq_mfma); MODE 1: the records and the
+// gather-table assembly of k_kkt2 (assemble_stage), its first QTOS_AB_ROUNDS targets per thread moved into phase AB onto the
+// waves that have no job there (with the equality entries), the rest on every wave but the factor wave at the end of phase C.
+template <int F, int MODE>
 __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
   static_assert(F <= 128 && F % 16 == 0, "k_kkt3: fronts of up to 128 slots (waves 9 .. 15 must be free in phase AB)");
   const int b = blockIdx.x;
@@ -153,7 +172,11 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
   extern __shared__ double lds[];
   using CF = Kkt2Cfg<F>;
   using LY = Kkt2Layout<F>;
-  constexpr int NT = CF::NT, NU = CF::NU, MAXT2 = CF::MAXT, FR = CF::FR, PSZ = LY::PSZ;
+#ifndef QTOS_NU3
+#define QTOS_NU3 0
+#endif
+  // (MODE 1: the number of update waves may be overridden for experiments -- waves 4, 8, 12 join as update indices 12 .. 14)
+  constexpr int NT = CF::NT, NU = (MODE == 1 && QTOS_NU3 > 0 && F == 128) ? QTOS_NU3 : CF::NU, MAXT2 = (CF::NTILE + NU - 1) / NU, FR = CF::FR, PSZ = LY::PSZ;
   const int tid = threadIdx.x, NS = P.n_stages, n = P.n_sol;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
   double *Lib = lds + LY::LIB, *dvb = lds + LY::DVB, *dgb = lds + LY::DGB, *UF = lds + LY::UF, *xs = lds + LY::XS;
@@ -381,6 +404,10 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
       //      or retired by the tile waves here: those belong to the columns of stage k+1, and a retired cell is handed out
       //      again two stages later (Symbolic::compact_cells).  Waves 13 .. 15: the inequality blocks and static entries, one
       //      tile type each (condense_type); the others: equality entries and multiplier right-hand sides.
+      if constexpr (MODE == 1) {
+        assemble_eq(A, sbuf, dbuf, (wv - NT - 1) * 64 + lane, (15 - NT) * 64);
+        assemble_targets(A, sbuf, dbuf, 0, QTOS_AB_ROUNDS * (15 - NT) * 64, (wv - NT - 1) * 64 + lane, (15 - NT) * 64);
+      } else {
       typedef __attribute__((address_space(3))) double lds_double;
       const unsigned abase = (unsigned)(size_t)(lds_double *)A;
 #if !(defined(QTOS_IQ_ABL) && (QTOS_IQ_ABL & 4))
@@ -395,6 +422,7 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
       else
 #endif
         assemble_eq(A, sbuf, dbuf, (wv - NT - 1) * 64 + lane, (12 - NT) * 64);
+      }
     }
     KS2(0);
     lds_barrier();
@@ -482,6 +510,11 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
       }
     }
     KS2(2);
+    if constexpr (MODE == 1) {
+      // the targets phase AB left: every wave but the factor wave (the waves without Schur tiles first: low item indices)
+      const int apos = is_upd ? (15 - NU) + uw : uw - NU;
+      if (wv >= 1 && k + 2 < NS) assemble_targets(A, sbuf, dbuf, QTOS_AB_ROUNDS * (15 - NT) * 64, 1 << 30, apos * 64 + lane, 15 * 64);
+    }
     // LDS-DMA of the records of stage k+3 into the other buffer by waves 8 and 12 (1 KB per instruction, chunk c of a record
     // by wave c mod 2; wave 12 takes the chunks with the header it publishes below)
     if ((wv == 8 || wv == 12) && k + 3 < NS) {
@@ -499,7 +532,7 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gs + min(c * 1024 + lane * 16, nbs - 16)), (__attribute__((address_space(3))) void *)(ls + c * 1024), 16, 0, 0);
     }
     // the second part of the inequality blocks of record k+2, one tile type per wave (condense_type), while the records travel
-    if (!(wv & 3) && wv != 0 && k + 2 < NS) {
+    if (MODE == 0 && !(wv & 3) && wv != 0 && k + 2 < NS) {
       typedef __attribute__((address_space(3))) double lds_double;
       const unsigned abase = (unsigned)(size_t)(lds_double *)A;
 #ifdef QTOS_STAMPS

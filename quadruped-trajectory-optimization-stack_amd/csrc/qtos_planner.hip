@@ -71,6 +71,7 @@ struct QtosPlanner {
   hipEvent_t ev_in = nullptr;                // the caller's stream at submit time: the other lanes start behind it
   unsigned call_seq = 0;             // sequence number of the last call submitted
   bool use_kkt3 = false;             // k_kkt3 (kkt3.hpp) instead of k_kkt2: chosen by qtos_planner_create
+  int kkt3_mode = 0;                 // k_kkt3's MODE (QTOS_KKT=3: 0, QTOS_KKT=4: 1)
   bool counts_by_copy = false;       // the counts of unfinished problems reach the host by hipMemcpyAsync instead of k_post_counts (QTOS_COUNTS_COPY=1)
   int spec_next = 1;                 // blind iterations of the next call: the iterations the last one took
   int spec_cap = 1;                  // limit of the blind iterations (qtos_set_speculation): 1 = off, the measured optimum
@@ -117,8 +118,8 @@ static void (*kkt2_kernel(int F, bool cont))(DevPlan, DevWork, int) {
   return nullptr;
 }
 // k_kkt3 (inequality blocks condensed on the matrix core): fronts up to 128 slots
-static void (*kkt3_kernel(int F))(DevPlan, DevWork, int) {
-#define QTOS_KKT3(f) case f: return k_kkt3<f>;
+static void (*kkt3_kernel(int F, int mode))(DevPlan, DevWork, int) {
+#define QTOS_KKT3(f) case f: return mode == 0 ? k_kkt3<f, 0> : k_kkt3<f, 1>;
   switch (F) { QTOS_KKT3(16) QTOS_KKT3(32) QTOS_KKT3(48) QTOS_KKT3(64) QTOS_KKT3(80) QTOS_KKT3(96) QTOS_KKT3(112) QTOS_KKT3(128) }
 #undef QTOS_KKT3
   return nullptr;
@@ -183,26 +184,33 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   p->max_batch = max_batch;
   // model + symbolic analysis; if the stage records and cells of the result do not fit the LDS next to the panels, again with
   // smaller records (heavy stages then spill into continuation records): both are rebuilt, the analysis writes into the model
-  // QTOS_KKT=3 selects k_kkt3 (round-4 experiment, kkt3.hpp: inequality blocks condensed on the matrix core by three waves per
-  // phase; fronts of up to 128 slots, every stage's blocks in its own record, everything in LDS).  Correct -- the parity tests
-  // pass with it -- and 11 % slower than k_kkt2 on the benchmark (profiles/r04_experiments): not the default.
+  // Which factor + solve kernel (kkt2.hpp, kkt3.hpp; all give the same plans where they share the arithmetic):
+  //   k_kkt2            the default for fronts above 112 slots
+  //   k_kkt3, MODE 1    the default up to 112 slots: k_kkt2's records and arithmetic -- bit-identical plans -- with the
+  //                     assembly of the records on the waves that have no job in phase AB (-5 % per launch on the trot's
+  //                     112 slots, -6 % on reference_compat's 96; +4 % on 128 slots, where seven idle waves are too few;
+  //                     profiles/r04_experiments)
+  //   k_kkt3, MODE 0    QTOS_KKT=3 only: inequality blocks condensed by matrix instructions (correct, slower)
+  // QTOS_KKT=2 / 3 / 4 force k_kkt2 / MODE 0 / MODE 1.
   p->use_kkt3 = false;
   {
     const char *e = getenv("QTOS_KKT");
-    if (e && atoi(e) == 3) {
+    const int forced = e ? atoi(e) : 0;
+    p->kkt3_mode = forced == 3 ? 0 : 1;
+    if (forced != 2) {
       p->M = HostModel();
       p->S = Symbolic();
       if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
       p->S.cell_mode = 2;
-      p->S.iq_mfma = true;
-      bool ok = p->S.build(p->M) == 0 && p->S.front <= 128 && !(p->S.pack_src.size() & 1);
+      p->S.iq_mfma = p->kkt3_mode == 0;
+      bool ok = p->S.build(p->M) == 0 && p->S.front <= (forced ? 128 : 112) && !(p->S.pack_src.size() & 1);
       if (ok) {
         int n_cont = 0;
         for (int k = 0; k < p->S.n_stages; ++k) n_cont += p->S.srec[p->S.srec_off[k] + 6];
         ok = n_cont == 0 && kkt3_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) <= 160 * 1024 - 256;
       }
       p->use_kkt3 = ok;
-      if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: k_kkt3 %s (%s)\n", ok ? "selected" : "not applicable", p->S.err.c_str());
+      if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: k_kkt3 MODE %d %s (%s)\n", p->kkt3_mode, ok ? "selected" : "not applicable", p->S.err.c_str());
     }
   }
   for (int cap : {0, 4096, 3072, 2048}) {
@@ -407,7 +415,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     return -4;
   }
   {
-    p->kkt_fn = p->use_kkt3 ? kkt3_kernel(F) : kkt2_kernel(F, D.n_cont > 0);
+    p->kkt_fn = p->use_kkt3 ? kkt3_kernel(F, p->kkt3_mode) : kkt2_kernel(F, D.n_cont > 0);
     p->chord_fn = chord_kernel(F);
     if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
