@@ -408,7 +408,7 @@ class Planner:
     def structure(self):
         rk = np.empty(self.m, np.int32)
         vf = np.empty(self.n, np.int32)
-        order = np.empty(self.dims.n_unknowns, np.int32)
+        order = np.empty(self.dims.n_stages * self.dims.pivots, np.int32)    # by position; -1 = a dummy pivot (short stage)
         self.lib.qtos_debug_structure(self.h, _ip(rk), _ip(vf), _ip(order))
         return rk, vf, order
 

@@ -537,7 +537,7 @@ static void fill_dims(const HostModel &M, const Symbolic &S, QtosDims *d) {
       else d->n_ineq_upper++;
     }
   }
-  d->n_eq_work = S.n_eq; d->n_unknowns = S.n_unknowns; d->n_stages = S.n_stages;
+  d->n_eq_work = S.n_eq; d->n_unknowns = S.n_real_unknowns; d->n_stages = S.n_stages;   // (the unknowns of the KKT system; positions incl. the dummy pivots of short stages: n_stages x 16)
   d->pivots = PIV; d->front = S.front;
   d->n_base_nodes = M.n_base_nodes; d->n_dyn_times = (int)M.t_dyn.size(); d->n_rom_times = (int)M.t_rom.size();
   d->n_rows_csv = (int)std::llround(M.T * 1000.0) + 1;
@@ -1280,7 +1280,10 @@ int qtos_debug_structure(const QtosPlanner *p, int *row_kind, int *var_free, int
   if (row_kind) std::memcpy(row_kind, p->M.row_kind.data(), p->M.n_cons * sizeof(int));
   if (var_free)
     for (int v = 0; v < p->M.n_vars; ++v) var_free[v] = p->M.is_free(v) ? 1 : 0;
-  if (order) std::memcpy(order, p->S.order.data(), p->S.n_unknowns * sizeof(int));
+  if (order) {   // n_stages x 16 positions: the unknown eliminated there (variable, or n_vars + row), -1 = dummy pivot
+    std::memcpy(order, p->S.order.data(), p->S.n_unknowns * sizeof(int));
+    for (int i = p->S.n_unknowns; i < p->S.n_stages * PIV; ++i) order[i] = -1;
+  }
   return 0;
 }
 

@@ -30,7 +30,11 @@ constexpr int PIV = 16;
 // Which update wave holds which 16 x 16 tile of the Schur complement (k_kkt2 / k_kkt3): update index u holds the tiles
 // t = u + NU i of the lower triangle, row by row.  Shared by the kernels and by the analysis (the per-wave chunk masks of the
 // inequality blocks, Symbolic::iq_mfma).
+#ifndef QTOS_NU112
+#define QTOS_NU112 0
+#endif
 constexpr int kkt_pick_nu(int ntile) {
+  if (QTOS_NU112 > 0 && ntile == 28) return QTOS_NU112;   // (experiment: update waves of a 112-slot front)
   int best = 14, best_t = (ntile + 13) / 14;
   for (int nu = 14; nu >= 8; --nu) {
     const int t = (ntile + nu - 1) / nu;
@@ -62,6 +66,15 @@ struct IqBlock {
 
 struct Symbolic {
   int n_unknowns = 0, n_free = 0, n_eq = 0, n_stages = 0, front = 0;
+  // Short stages (round 4): stage boundaries need not fall on multiples of 16 unknowns.  Where a partition into stages of at
+  // most 16 pivots exists whose largest front is a whole 16-slot group smaller than the uniform partition's at no more stages
+  // (found by dynamic programming over the boundaries; the 100-knot walk: 112 slots instead of 128, two short stages), the
+  // (applied to fronts above 128 slots, see shorten_stages) missing pivots of a short stage are DUMMIES -- order[] entry -1, unit pivot, no entries, zero right-hand side, a slot of
+  // their own for that one stage -- and every array by position counts them: n_unknowns is then n_stages x 16 POSITIONS and
+  // n_real_unknowns the unknowns of the KKT system.
+  int n_real_unknowns = 0;
+  std::vector<int> stage_dummies;   // per stage: dummy pivots in it
+  bool short_stages = true;
   std::vector<int> order;      // position -> var index, or n_vars + row for a multiplier
   std::vector<int> var_pos;    // var -> position or -1
   std::vector<int> row_pos;    // row -> position or -1
@@ -520,6 +533,64 @@ struct Symbolic {
     return 0;
   }
 
+  // see short_stages.  first: position -> smallest coupled position (rewritten in positions that count the dummies).
+  void shorten_stages(std::vector<int> &first, std::vector<int> &block_minpos, int n_sol, int n_cons) {
+    const int N = n_unknowns, NS0 = (N + PIV - 1) / PIV;
+    std::vector<int> sf(first);
+    std::sort(sf.begin(), sf.end());
+    // unknowns alive in a stage of the positions [a, b): everyone coupled to a position below b, minus those eliminated before a
+    auto alive = [&](int a, int b) { return (int)(std::lower_bound(sf.begin(), sf.end(), b) - sf.begin()) - a; };
+    int F0 = 0;
+    for (int k = 0; k < NS0; ++k) {
+      const int a = k * PIV, b = std::min(N, a + PIV);
+      F0 = std::max(F0, alive(a, b) + (PIV - (b - a)));
+    }
+    F0 = ((F0 + PIV - 1) / PIV) * PIV;
+    // Measured (round 4, profiles/r04_short_stages.txt): fronts above 128 slots gain -- `-duration 20`: 176 -> 160 slots, 2.63 ->
+    // 1.81 ms per launch; the full system of `-duration 12`: 160 -> 144, 1.74 -> 1.69 --, the 100-knot walk does not (128 ->
+    // 112 slots: 0.643 -> 0.656 ms: twelve update waves of three tiles next to a factor wave with a SIMD of its own are the
+    // better shape than fourteen of two).  So: only above 128 slots, unless QTOS_SHORT_STAGES=1 asks for it.
+    if (F0 <= 128 && !getenv("QTOS_SHORT_STAGES")) return;
+    std::vector<int> cut;   // boundaries of the chosen partition
+    for (int target = F0 - PIV; target >= 2 * PIV; target -= PIV) {
+      const int INF = 1 << 29;
+      std::vector<int> best(N + 1, INF), prev(N + 1, -1);
+      best[0] = 0;
+      for (int a = 0; a < N; ++a) {
+        if (best[a] >= INF) continue;
+        for (int r = 1; r <= PIV && a + r <= N; ++r) {
+          if (alive(a, a + r) + (PIV - r) > target) continue;
+          // (fewest stages; among those the partition found first, i.e. the shortest stages as early as possible)
+          if (best[a] + 1 < best[a + r]) { best[a + r] = best[a] + 1; prev[a + r] = a; }
+        }
+      }
+      if (best[N] > NS0 + NS0 / 50) break;
+      cut.clear();
+      for (int b = N; b > 0; b = prev[b]) cut.push_back(b);
+      cut.push_back(0);
+      std::reverse(cut.begin(), cut.end());
+    }
+    if (cut.empty()) return;
+    const int NSv = (int)cut.size() - 1;
+    std::vector<int> vmap(N), order_v((size_t)NSv * PIV, -1), first_v((size_t)NSv * PIV);
+    stage_dummies.assign(NSv, 0);
+    for (int k = 0; k < NSv; ++k) {
+      for (int p = cut[k]; p < cut[k + 1]; ++p) vmap[p] = k * PIV + (p - cut[k]);
+      stage_dummies[k] = PIV - (cut[k + 1] - cut[k]);
+    }
+    for (size_t v = 0; v < first_v.size(); ++v) first_v[v] = (int)v;   // (a dummy is coupled to nothing)
+    for (int p = 0; p < N; ++p) {
+      order_v[vmap[p]] = order[p];
+      first_v[vmap[p]] = vmap[first[p]];
+    }
+    for (int v = 0; v < n_sol; ++v) if (var_pos[v] >= 0) var_pos[v] = vmap[var_pos[v]];
+    for (int r = 0; r < n_cons; ++r) if (row_pos[r] >= 0) row_pos[r] = vmap[row_pos[r]];
+    for (int &mp : block_minpos) if (mp >= 0 && mp < N) mp = vmap[mp];   // (position of an inequality block's earliest column)
+    order.swap(order_v);
+    first.swap(first_v);
+    n_unknowns = NSv * PIV;
+  }
+
   int build(HostModel &M) {
     // (solver variables: the model's variables, then -- QtosParams.reduce_base -- the B-spline coefficients that replace the
     //  base node values inside the solve, model.hpp)
@@ -582,7 +653,10 @@ struct Symbolic {
       const int lo = std::min(pa, pb), hi = std::max(pa, pb);
       first[hi] = std::min(first[hi], lo);
     }
+    n_real_unknowns = n_unknowns;
+    if (short_stages && !getenv("QTOS_NO_SHORT_STAGES")) shorten_stages(first, block_minpos, n, m);
     n_stages = (n_unknowns + PIV - 1) / PIV;
+    stage_dummies.resize(n_stages, 0);
     if (const char *dump = getenv("QTOS_DUMP_FIRST")) {   // diagnostic: envelope of the ordered matrix (position -> first coupled position, unknown id)
       if (FILE *f = fopen(dump, "w")) {
         for (int j = 0; j < n_unknowns; ++j) fprintf(f, "%d %d %d\n", j, first[j], order[j]);
@@ -690,7 +764,7 @@ struct Symbolic {
         if (i < hi) {
           piv_slot[q] = slot_of[i];
           piv_unknown[q] = order[i];
-          piv_diag[q] = order[i] < n ? M.sol_diag[order[i]] : -M.P.eps_dual;
+          piv_diag[q] = order[i] < 0 ? 1.0 : (order[i] < n ? M.sol_diag[order[i]] : -M.P.eps_dual);   // (a dummy pivot of a short stage: 1)
         } else {
           piv_slot[q] = dummies[i - hi];
           piv_unknown[q] = -1;
@@ -730,6 +804,7 @@ struct Symbolic {
     // (the caller found the records too large for the LDS it has left: heavy stages spill into continuation records earlier)
     if (rec_cap_ints > 0) { REC_MAX_INTS = std::min(REC_MAX_INTS, rec_cap_ints); REC_MAX_DOUBLES = std::min(REC_MAX_DOUBLES, rec_cap_ints / 3); }
     for (int j = 0; j < n_unknowns; ++j) {
+      if (order[j] < 0) continue;
       if (order[j] < n) var_slot[order[j]] = slot_of[j];
       else row_slot[order[j] - n] = slot_of[j];
     }
@@ -1084,11 +1159,12 @@ struct Symbolic {
     algorithmic_bytes = 0;
     flops = 0;
     for (int k = 0; k < n_stages; ++k) {
-      long long a = active_count[k];
+      stages[k].n_active -= stage_dummies[k];   // (the unknowns of the system: dummies of short stages are not work of the algorithm)
+      long long a = stages[k].n_active;
       algorithmic_bytes += 8LL * a * PIV;
       flops += 2LL * PIV * a * a;
     }
-    algorithmic_bytes += 8LL * 2 * n_unknowns;
+    algorithmic_bytes += 8LL * 2 * n_real_unknowns;
     return 0;
   }
 };

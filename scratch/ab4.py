@@ -23,11 +23,10 @@ libs = sys.argv[1:] or [""]
 for gait in os.environ.get("AB_GAITS", "walk").split(","):
     for rep in range(2):
         for lib in libs:
-            for kkt in ("", os.environ.get("AB_KKT", "3")):
+            for kkt in ("2", os.environ.get("AB_KKT", "3")):
                 env = dict(os.environ, AB_GAIT=gait)
                 if lib: env["QTOS_LIB"] = lib
-                if kkt: env["QTOS_KKT"] = kkt
-                else: env.pop("QTOS_KKT", None)
+                env["QTOS_KKT"] = kkt
                 subprocess.run([sys.executable, "-c", code], env=env)
     import numpy as np
     try:

@@ -1208,10 +1208,12 @@ def test_factor_panels_match_block_elimination(planner_full, oracle, gv1, cfg):
     rhs = np.concatenate([-JI.T @ w[0, Ii], -go[E]])
     pos_of_var = {v: i for i, v in enumerate(free)}
     pos_of_row = {r: nf + i for i, r in enumerate(E)}
-    perm = np.array([pos_of_var[u] if u < planner_full.n else pos_of_row[u - planner_full.n] for u in order])
-    N = len(perm); NS = (N + 15) // 16; Np = NS * 16
-    S = np.eye(Np); S[:N, :N] = K[np.ix_(perm, perm)]
-    y = np.zeros(Np); y[:N] = rhs[perm]
+    # (by position; -1 = the dummy pivots that fill a short stage: unit pivot, no entries, zero right-hand side)
+    Np = len(order); NS = Np // 16; N = Np
+    real = np.nonzero(order >= 0)[0]
+    perm = np.array([pos_of_var[u] if u < planner_full.n else pos_of_row[u - planner_full.n] for u in order[real]])
+    S = np.eye(Np); S[np.ix_(real, real)] = K[np.ix_(perm, perm)]
+    y = np.zeros(Np); y[real] = rhs[perm]
     slot_of_pos = ps.ravel()
     checked = 0
     for k in range(NS):
@@ -1342,9 +1344,10 @@ def test_other_horizons_match_oracle(kw, front, heavy, reduce_base):
     from qtos_amd.config import PlannerConfig
     cfg = PlannerConfig.reference_compat(reduce_base=reduce_base, **kw)
     d, _ = capi.analyze(cfg)
-    # fronts of the full system as listed; with the reduced base (half the base unknowns, no continuity multipliers) they are
-    # the same or smaller -- 12 s: 128 instead of 160, 20 s: 176 instead of 208
-    assert d.front == front if not reduce_base else d.front <= front
+    # fronts of the full system with stage boundaries at multiples of 16 unknowns as listed; short stages (round 4,
+    # Symbolic::shorten_stages) and the reduced base (half the base unknowns, no continuity multipliers) make them the same or
+    # smaller -- 12 s: 144 / 128 instead of 160, 20 s: 208 / 160
+    assert d.front <= front and (d.front >= front - 48)
     P = capi.Planner(cfg, max_batch=8)
     O = Oracle(oracle_dict(cfg))
     assert (P.n, P.m) == (O.n, O.m)
