@@ -13,6 +13,7 @@
 #include "kernels.hpp"
 #include "kkt2.hpp"
 #include "kkt3.hpp"
+#include "kkt4.hpp"
 
 using namespace qtos;
 
@@ -72,6 +73,7 @@ struct QtosPlanner {
   unsigned call_seq = 0;             // sequence number of the last call submitted
   bool use_kkt3 = false;             // k_kkt3 (kkt3.hpp) instead of k_kkt2: chosen by qtos_planner_create
   int kkt3_mode = 0;                 // k_kkt3's MODE (QTOS_KKT=3: 0, QTOS_KKT=4: 1)
+  bool use_kkt4 = false;             // k_kkt4 (kkt4.hpp), QTOS_KKT=5
   bool counts_by_copy = false;       // the counts of unfinished problems reach the host by hipMemcpyAsync instead of k_post_counts (QTOS_COUNTS_COPY=1)
   int spec_next = 1;                 // blind iterations of the next call: the iterations the last one took
   int spec_cap = 1;                  // limit of the blind iterations (qtos_set_speculation): 1 = off, the measured optimum
@@ -122,6 +124,13 @@ static void (*kkt3_kernel(int F, int mode))(DevPlan, DevWork, int) {
 #define QTOS_KKT3(f) case f: return mode == 0 ? k_kkt3<f, 0> : k_kkt3<f, 1>;
   switch (F) { QTOS_KKT3(16) QTOS_KKT3(32) QTOS_KKT3(48) QTOS_KKT3(64) QTOS_KKT3(80) QTOS_KKT3(96) QTOS_KKT3(112) QTOS_KKT3(128) }
 #undef QTOS_KKT3
+  return nullptr;
+}
+// k_kkt4 (panel chain and Schur updates side by side): fronts up to 128 slots
+static void (*kkt4_kernel(int F))(DevPlan, DevWork, int) {
+#define QTOS_KKT4(f) case f: return k_kkt4<f>;
+  switch (F) { QTOS_KKT4(16) QTOS_KKT4(32) QTOS_KKT4(48) QTOS_KKT4(64) QTOS_KKT4(80) QTOS_KKT4(96) QTOS_KKT4(112) QTOS_KKT4(128) }
+#undef QTOS_KKT4
   return nullptr;
 }
 static void (*chord_kernel(int F))(DevPlan, DevWork, int) {
@@ -197,6 +206,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     const char *e = getenv("QTOS_KKT");
     const int forced = e ? atoi(e) : 0;
     p->kkt3_mode = forced == 3 ? 0 : 1;
+    p->use_kkt4 = false;
     if (forced != 2) {
       p->M = HostModel();
       p->S = Symbolic();
@@ -208,6 +218,15 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
         int n_cont = 0;
         for (int k = 0; k < p->S.n_stages; ++k) n_cont += p->S.srec[p->S.srec_off[k] + 6];
         ok = n_cont == 0 && kkt3_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) <= 160 * 1024 - 256;
+      }
+      if (forced == 5) {   // k_kkt4: the standard records, its own LDS layout
+        ok = p->S.err.empty() && p->S.front <= 128 && !(p->S.pack_src.size() & 1);
+        if (ok) {
+          int n_cont = 0;
+          for (int k = 0; k < p->S.n_stages; ++k) n_cont += p->S.srec[p->S.srec_off[k] + 6];
+          ok = n_cont == 0 && kkt4_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) <= 160 * 1024 - 256;
+        }
+        p->use_kkt4 = ok;
       }
       p->use_kkt3 = ok;
       if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: k_kkt3 MODE %d %s (%s)\n", p->kkt3_mode, ok ? "selected" : "not applicable", p->S.err.c_str());
@@ -398,7 +417,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.panel_stride = (long long)S.n_stages * (S.front + 1) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  p->kkt_lds = p->use_kkt3 ? kkt3_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
+  p->kkt_lds = p->use_kkt4 ? kkt4_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : p->use_kkt3 ? kkt3_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
   p->kkt_threads = KT2;
   const int max_front = 208;
   if (S.max_drec > 2 * 2 * KT || S.max_srec > 3 * 4 * KT || F > max_front || (S.pack_src.size() & 1)) {
@@ -415,7 +434,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     return -4;
   }
   {
-    p->kkt_fn = p->use_kkt3 ? kkt3_kernel(F, p->kkt3_mode) : kkt2_kernel(F, D.n_cont > 0);
+    p->kkt_fn = p->use_kkt4 ? kkt4_kernel(F) : p->use_kkt3 ? kkt3_kernel(F, p->kkt3_mode) : kkt2_kernel(F, D.n_cont > 0);
     p->chord_fn = chord_kernel(F);
     if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);

@@ -3,13 +3,13 @@ the per-launch HBM traffic and the SQ-counter summary of the KKT kernel from the
 usage: python scratch/collect_profiles.py <tag> [r02]"""
 import csv, collections, json, os, shutil, sys
 tag = sys.argv[1]
-R = sys.argv[2] if len(sys.argv) > 2 else "r03"
+R = sys.argv[2] if len(sys.argv) > 2 else "r04"
 G = "gpurun_out/"
 names = {"default": "bench", "compat": "bench_reference_compat", "exp5": "bench_exp5", "mixed": "bench_mixed", "trot": "bench_trot",
          "tol1e-3": "bench_tol1e-3", "batch512": "bench_batch512", "batch1024": "bench_batch1024", "knots200": "bench_knots200",
          "mpc": "bench_knots200_mpc_random", "mpc_1set": "bench_knots200_mpc_random_one_set", "table": "bench_init_table", "inflight2": "bench_flat_inflight2",
          "nochord": "bench_no_chord_step", "torchrun1": "bench_torchrun_1rank", "full_system": "bench_full_system",
-         "exp5_lanes3": "bench_exp5_lanes3", "mixed_lanes3": "bench_mixed_lanes3", "lanes2": "bench_flat_lanes2", "steps500": "bench_steps500"}
+         "exp5_lanes3": "bench_exp5_lanes3", "exp5_batch1024": "bench_exp5_batch1024", "mixed_batch1024": "bench_mixed_batch1024", "mixed_lanes3": "bench_mixed_lanes3", "lanes2": "bench_flat_lanes2", "steps500": "bench_steps500"}
 for src, dst in names.items():
     f = G + "bench_%s_%s.json" % (tag, src)
     if not os.path.exists(f):

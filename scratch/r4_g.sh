@@ -1,7 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
 T=${1:-n}; shift
-AB_KKT=4 AB_GAITS=walk,trot timeout 900 python scratch/ab4.py "$@" 2>&1 | grep -v "^qtos\|amdgpu" > $O/r4_ab_$T.log
+AB_KKT=${AB_KKT:-4} AB_GAITS=walk,trot timeout 1500 python scratch/ab4.py "$@" 2>&1 | grep -v "^qtos\|amdgpu" > $O/r4_ab_$T.log
 python - <<PY
 import re, collections
 d = collections.defaultdict(list)
