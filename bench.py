@@ -89,6 +89,14 @@ def parse_args():
     return ap.parse_args()
 
 
+def kkt_kernel_name(front):
+    """The factor + solve kernel qtos_planner_create picks for a front size (csrc/qtos_planner.hip; QTOS_KKT overrides it)."""
+    forced = os.environ.get("QTOS_KKT")
+    if forced:
+        return {"2": "k_kkt2<%d>", "3": "k_kkt3<%d, 0>", "4": "k_kkt3<%d, 1>", "5": "k_kkt4<%d>"}.get(forced, "k_kkt2<%d>") % front
+    return ("k_kkt3<%d, 1>" if front <= 112 else "k_kkt2<%d>") % front
+
+
 def physical_cores():
     """Distinct (package, core) pairs among the CPUs this process may run on (SMT siblings counted once); None if unknown."""
     try:
@@ -547,7 +555,7 @@ def main():
                         "frac_if_priced_with_its_bytes": round(B * dfull.kkt_algorithmic_bytes / avg / 1e9 / HBM_PEAK_GBS, 5)}
         achieved = alg_bytes / avg / 1e9
         out["roofline"] = {
-            "kernel": "k_kkt2", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "kernel": kkt_kernel_name(d.front), "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
             "bytes_per_launch": alg_bytes, "avg_launch_ms": round(1e3 * avg, 4), "launches": kkt_n,
@@ -607,7 +615,7 @@ def main():
             "iterations_mean": round(titer / max(B * args.trot_steps, 1), 3),
             "kkt_unknowns": dt_.n_unknowns, "kkt_stages": dt_.n_stages, "front": dt_.front, "n_vars": dt_.n_vars,
             "gait": "diagonal-pair trot (config.TROT_UNNORMALISED; not pinned by any reference artefact)",
-            "roofline": {"kernel": "k_kkt2", "bound": "hbm", "achieved": round(B * dt_.kkt_algorithmic_bytes / tavg / 1e9, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": kkt_kernel_name(dt_.front), "bound": "hbm", "achieved": round(B * dt_.kkt_algorithmic_bytes / tavg / 1e9, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(B * dt_.kkt_algorithmic_bytes / tavg / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                          "bytes_per_launch": float(B) * dt_.kkt_algorithmic_bytes, "avg_launch_ms": round(1e3 * tavg, 4), "launches": tk_n,
                          "fp64_tflops": round(B * dt_.kkt_flops / tavg / 1e12, 3)},

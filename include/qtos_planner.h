@@ -157,7 +157,16 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
  * iterations (qtos_set_speculation; off by default) the host does nothing between the submit and the end.  One planner handle serves one call at a time (a second submit before the first is done returns -5);
  * handles are independent: several handles on their own streams keep several batches in flight from ONE host thread
  * (qtos_amd.pool.PlannerPool: submit to a free handle, poll the others) -- a batch that waits for its slowest problem
- * then shares the GPU with the next ones.  This is the form bench.py times. */
+ * then shares the GPU with the next ones.  This is the form bench.py times.
+ *
+ * Environment (read by qtos_planner_create; diagnostics and measured alternatives, defaults are the measured optimum):
+ *   QTOS_KKT=2 | 3 | 4 | 5   force the factor + solve kernel: k_kkt2 / k_kkt3 MODE 0 / k_kkt3 MODE 1 / k_kkt4 (default: MODE 1 for
+ *                            fronts of up to 112 slots, k_kkt2 above)
+ *   QTOS_LANES=n             a call of more problems than the GPU has compute units is cut into up to n (<= 4) contiguous parts,
+ *                            each with its own host-driven loop on a stream of the planner; bit-identical plans; default 1
+ *                            (measured slower than one lock-step loop at 1024 problems per call)
+ *   QTOS_SHORT_STAGES=1 / QTOS_NO_SHORT_STAGES=1   stage boundaries by dynamic programming for every front size / never
+ *                            (default: only where they take a 16-slot group off a front above 128 slots) */
 int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
                            const int *d_map_id, const double *d_warm, double *d_nodes_out,
                            int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream);
