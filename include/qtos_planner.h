@@ -166,7 +166,9 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
  *                            each with its own host-driven loop on a stream of the planner; bit-identical plans; default 1
  *                            (measured slower than one lock-step loop at 1024 problems per call)
  *   QTOS_SHORT_STAGES=1 / QTOS_NO_SHORT_STAGES=1   stage boundaries by dynamic programming for every front size / never
- *                            (default: only where they take a 16-slot group off a front above 128 slots) */
+ *                            (default: only where they take a 16-slot group off a front above 128 slots)
+ *   QTOS_SPEC_JAC=0          k_step evaluates the first trial point of the line search without its Jacobian and linearises in a
+ *                            second pass (default 1: one pass behind a Newton step; bit-identical plans) */
 int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
                            const int *d_map_id, const double *d_warm, double *d_nodes_out,
                            int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream);

@@ -74,6 +74,7 @@ struct DevPlan {
   int off_lin, off_ang, off_eem[NEE];   // first variable of the base / foot motion node sets
   const int *cont;             // continuation records of heavy stages: {srec offset, ints, stream offset, doubles} each
   int n_cont;                  // how many there are in the whole plan (0 for the standard transcriptions)
+  int spec_jac;                // k_step: Jacobian evaluated with the first trial point of the line search (QTOS_SPEC_JAC, default 1)
   int hold_from;               // two-phase solve: stance footholds are held once an iterate >= hold_from has violation <= hold_tol (0: never)
   double hold_weight, hold_tol;
   const unsigned *amask;       // n_stages x 8: rows of the factor panel that are stored / read back (Symbolic::amask)
@@ -1089,6 +1090,13 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   const int chord_run = W.chord_run[b];
   const int jam_prev = W.jam[b];
   const double prev_viol = W.viol[b];        // violation in front of this step
+  const int held0 = W.held[b];
+  // The first trial point of the line search is evaluated WITH its Jacobian when the solve will very likely go on from it
+  // (a Newton step is accepted whole at its fraction-to-the-boundary length nearly always, and a solve converges behind a
+  // chord step): the linearisation at the accepted point is then this evaluation instead of a second pass over the same
+  // point.  A wrong guess costs the difference of the two passes once (the problem converged: nobody reads the stream; the
+  // trial point was cut: the linearisation below runs as before).
+  const bool spec = P.spec_jac && !was_chord && it + 1 < P.max_iter;
 #ifdef QTOS_STAMPS
   unsigned long long ks[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kt0 = 0;
 #define KSTAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ks[i] += t_ - kt0; kt0 = t_; } } while (0)
@@ -1265,19 +1273,24 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   // backtracking on the l1 infeasibility of (c_E, c_I - s)
   double al = amax, th = 0;
   double rgt[KR], egt[KE];
+  bool lin_done = false;   // g and the stream hold the linearisation at the accepted point already
   for (int ls = 0; ls < 6; ++ls) {
     // the trial point goes to LDS directly (and stays there for the linearisation below if it is accepted): written to
     // memory and staged back it would cost two memory round trips
     for (int v = tid; v < n; v += blockDim.x) evl[v] = x[v] + al * dx[v];
     __syncthreads();
-    eval_all<false>(P, map, nullptr, gt, nullptr, evl, (W.trace && it == 1 && ls == 0) ? W.trace + ((size_t)b * (P.max_iter + 1) + 76) * 4 : nullptr);
+    double *gv = (spec && ls == 0) ? g : gt;   // (th0 and the thread's rows of g are in registers)
+    if (spec && ls == 0)
+      eval_all<true>(P, map, nullptr, g, W.stream + (size_t)b * P.stream_len, evl, (W.trace && it == 1) ? W.trace + ((size_t)b * (P.max_iter + 1) + 72) * 4 : nullptr, held0);
+    else
+      eval_all<false>(P, map, nullptr, gt, nullptr, evl, (W.trace && it == 1 && ls == 0) ? W.trace + ((size_t)b * (P.max_iter + 1) + 76) * 4 : nullptr);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < KR; ++k) rgt[k] = gt[rr[k]];
+    for (int k = 0; k < KR; ++k) rgt[k] = gv[rr[k]];
 #pragma unroll
-    for (int k = 0; k < KE; ++k) egt[k] = gt[er[k]];
-    th = l1_rows(rgt, egt, gt, al);
-    if (th <= (1.0 - 1e-4 * al) * th0 || th < 1e-9) break;
+    for (int k = 0; k < KE; ++k) egt[k] = gv[er[k]];
+    th = l1_rows(rgt, egt, gv, al);
+    if (th <= (1.0 - 1e-4 * al) * th0 || th < 1e-9) { lin_done = spec && ls == 0; break; }
     if (ls < 5) al *= 0.5;
   }
   KSTAMP(2);
@@ -1294,7 +1307,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     for (int k = 0; k < KE; ++k) eg[k] = egt[k];
     // (the constraint values in memory: rewritten by the linearisation below whenever the solve goes on; copied here only
     //  for the rows that are read from memory before that)
-    if (!rows_in_regs) {
+    if (!rows_in_regs && !lin_done) {
 #pragma unroll 4
       for (int r = tid; r < m; r += blockDim.x) g[r] = gt[r];
     }
@@ -1401,8 +1414,19 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   const int held = (W.held[b] || (P.hold_from > 0 && it + 1 >= P.hold_from && viol <= P.hold_tol)) ? 1 : 0;
   __syncthreads();
   if (tid == 0) W.held[b] = held;
-  eval_all<true>(P, map, reject ? x : nullptr, g, W.stream + (size_t)b * P.stream_len, evl, (W.trace && it == 1) ? W.trace + ((size_t)b * (P.max_iter + 1) + 72) * 4 : nullptr,
-                 held);
+  if (!lin_done) {
+    eval_all<true>(P, map, reject ? x : nullptr, g, W.stream + (size_t)b * P.stream_len, evl, (W.trace && it == 1) ? W.trace + ((size_t)b * (P.max_iter + 1) + 72) * 4 : nullptr,
+                   held);
+  } else if (held != held0) {
+    // the footholds are held from this iterate on: the proximal weights of the stance footholds (eval_terr), the one thing
+    // of the linearisation that depends on the latch
+    double *Gp = W.stream + (size_t)b * P.stream_len;
+    for (int ti = tid; ti < P.n_terr; ti += nt) {
+      const TerrDev TI = P.terr[ti];
+      if (TI.d0 >= 0) Gp[TI.d0] = P.hold_weight;
+      if (TI.d1 >= 0) Gp[TI.d1] = P.hold_weight;
+    }
+  }
   __syncthreads();
   KSTAMP(4);
   {

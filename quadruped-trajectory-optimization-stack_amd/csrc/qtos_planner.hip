@@ -367,6 +367,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     }
     TRY(p->upload(td, &D.terr));
     D.hold_from = M.P.hold_from;
+    { const char *e = getenv("QTOS_SPEC_JAC"); D.spec_jac = e ? atoi(e) : 1; }
     D.hold_weight = M.P.hold_weight > 0 ? M.P.hold_weight : 1e6;
     D.hold_tol = M.P.hold_tol;
   }
