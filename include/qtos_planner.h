@@ -167,6 +167,9 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
  *                            (measured slower than one lock-step loop at 1024 problems per call)
  *   QTOS_SHORT_STAGES=1 / QTOS_NO_SHORT_STAGES=1   stage boundaries by dynamic programming for every front size / never
  *                            (default: only where they take a 16-slot group off a front above 128 slots)
+ *   QTOS_SWEEP_DS=0          k_step forms the slack steps ds = Ji dx + (g - s) itself (default 1: three waves that idle in the
+ *                            backward sweep of the KKT kernels form them, block by block behind the stage that solves the
+ *                            block's earliest column; bit-identical plans)
  *   QTOS_SPEC_JAC=0          k_step evaluates the first trial point of the line search without its Jacobian and linearises in a
  *                            second pass (default 1: one pass behind a Newton step; bit-identical plans) */
 int qtos_plan_batch_device(QtosPlanner *p, int B, const double *d_start, const double *d_goal,

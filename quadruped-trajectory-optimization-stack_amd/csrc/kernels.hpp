@@ -96,6 +96,11 @@ struct DevPlan {
   const int *block_cols;
   const IqRow *iq_rows;   // rows of the inequality blocks (stream offsets)
   int n_iq_rows;
+  // the same rows as rounds of 16 for the helper waves of the backward sweep (QTOS_SWEEP_DS, default on): round i runs in
+  // step i of the chain; k_step then reads ds instead of forming it
+  const SwTask *sw_tasks;
+  const int *sw_cpos, *sw_c16;   // sw_c16: per block 20 ints = for lane q of a row's quad the positions of entries q, q + 4, ... (8 x 16 bit), then of the up to three entries behind the whole groups
+  int sw_steps, sw_on;
   // compact row lists of the working set (the row loops of k_step run over these, branch-free):
   // inequality rows with their bounds, equality rows
   const int *iq_idx, *eq_idx;
@@ -1129,8 +1134,10 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   auto row_of = [&](int i4) __attribute__((always_inline)) { return P.iq_rows[min(i4 >> 2, P.n_iq_rows - 1)]; };
   IqRow Rn[TP];
   if (P.n_rec) rec_load(tid);
+  if (!P.sw_on) {
 #pragma unroll
-  for (int t = 0; t < TP; ++t) Rn[t] = row_of(tid + t * nt);
+    for (int t = 0; t < TP; ++t) Rn[t] = row_of(tid + t * nt);
+  }
   // (c) the rows of the working set this thread owns: inequality rows tid + k nt (k < KR) and equality rows tid + k nt
   //     (k < KE) with their bounds, slacks, multipliers and values live in registers from here to the end of the kernel -- every
   //     pass below (ratio test, merit function, update, convergence test, barrier weights) read them through the row lists
@@ -1173,7 +1180,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     }
     __syncthreads();
   }
-  for (int base = 0; base < ntask; base += TP * nt) {
+  for (int base = 0; base < (P.sw_on ? 0 : ntask); base += TP * nt) {   // (sw_on: the backward sweep has left ds)
     IqRow R[TP];
 #pragma unroll
     for (int t = 0; t < TP; ++t) R[t] = Rn[t];

@@ -72,6 +72,12 @@ __host__ __device__ inline size_t kkt2_dbuf_doubles(int F, int max_drec) {
 __host__ __device__ inline size_t kkt2_sbuf_ints(int F, int max_srec) {
   return F <= 128 ? (((size_t)max_srec * 4 + 1023) & ~(size_t)1023) / 4 : (((size_t)max_srec + 3) & ~(size_t)3);
 }
+// what the backward sweep of k_kkt2 / k_kkt3 keeps in LDS in front of the helper waves' tables (sweep_ds_lds_bytes)
+inline size_t kkt2_sweep_base_bytes(int F, int NS) {
+  const int FR = (F + 63) & ~63;
+  const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 2 * (size_t)FR + 2 * 16 * PIV + 64 + 3 * PIV / 2 + 2 + FR + 8 + PIV * PLD;
+  return fixed * sizeof(double) + (size_t)NS * 12 * sizeof(int);
+}
 inline size_t kkt2_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells) {
   const int FR = (F + 63) & ~63, PSZ = (F + 1) * PLD;
   const size_t fixed = 2 * PIV * PLD + 2 * PIV + 3 * PIV + 2 * (size_t)FR + 2 * 16 * PIV + 64 + 3 * PIV / 2 + 2 + FR + 8 + PIV * PLD;
@@ -164,10 +170,70 @@ constexpr int SWD = QTOS_SWD;   // stages of factor panel in flight per wave (pr
 // doubles, nxp = LDS copy of Symbolic::nxt_pack (NS x 4 ints) followed by Symbolic::amask2 (NS x 8): they are addresses of
 // the panel loads, a copy in global memory would put a second memory round trip in front of every one of them.  The
 // caller has synchronised the workgroup.
+// The slack steps ds = Ji dx + (g - s) on the waves that idle in the sweep (P.sw_on; Symbolic-independent tables built by
+// the planner: sw_tasks, sw_cpos).  An inequality block belongs to the stage of its earliest column: once the chain has
+// solved that stage every column of the block is known.  Waves 13..15 (three SIMDs that do not hold the chain wave) take
+// the rows of the blocks in turns, one round of 16 rows per step of the chain, four lanes per row with k_step's own order
+// of summation (the same bits), G and the column positions prefetched three steps ahead; xp = the solution by position in LDS.
+struct SweepDs {
+  const double *G;     // the problem's stream
+  double *ds;
+  const double *g, *s;
+};
+constexpr int SW_W0 = 13, SW_NW = 3, SW_ROUND = 16, SW_RU = 8;
+typedef int swi4_t __attribute__((ext_vector_type(4)));
+typedef int swi2_t __attribute__((ext_vector_type(2)));
+struct SwSlot {
+  double gv[SW_RU], gr[3], g_row, s_row;
+  swi4_t c;    // positions of the lane's entries, 16 bits each (sw_c16)
+  swi2_t cr;
+};
+// LDS behind the sweep tables: the solution by position (NS x 16 doubles), then the rounds' rows (first four ints of a SwTask)
+__host__ __device__ inline size_t sweep_ds_lds_bytes(int NS, int sw_steps) {
+  return sw_steps > 0 ? 16 + (size_t)NS * PIV * sizeof(double) + (size_t)sw_steps * SW_ROUND * 16 : 0;
+}
+// T = the first four ints of a SwTask: goff, n, row, c16_off
+__device__ __forceinline__ void sw_load(const DevPlan &P, const SweepDs &sd, const swi4_t &T, SwSlot &S, int q) {
+  const double *Gr = sd.G + T[0];
+  const int n = T[1], n4 = n & ~3, row = max(T[2], 0);
+  S.g_row = sd.g[row];
+  S.s_row = sd.s[row];
+  S.c = *(const swi4_t *)(P.sw_c16 + T[3] + 4 * q);
+  S.cr = *(const swi2_t *)(P.sw_c16 + T[3] + 16);
+#pragma unroll
+  for (int u = 0; u < SW_RU; ++u) S.gv[u] = Gr[max(min(q + 4 * u, n4 - 4 + q), 0)];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) S.gr[u] = Gr[min(n4 + u, n - 1)];
+}
+__device__ __forceinline__ void sw_row(const DevPlan &P, const SweepDs &sd, const swi4_t &T, const SwSlot &S, const double *xp, int q, const SwTask *full) {
+  const int n = T[1], n4 = n & ~3;
+  double ev[SW_RU], er[3];
+#pragma unroll
+  for (int u = 0; u < SW_RU; ++u) ev[u] = xp[((unsigned)S.c[u >> 1] >> (16 * (u & 1))) & 0xffffu];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) er[u] = xp[((unsigned)S.cr[u >> 1] >> (16 * (u & 1))) & 0xffffu];
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < SW_RU; ++u) acc = q + 4 * u < n4 ? fma(S.gv[u], ev[u], acc) : acc;
+  if (n4 > 4 * SW_RU) {   // (rows of more than 35 entries: the rest of the whole groups, at memory latency)
+    const double *Gr = sd.G + T[0];
+    const int *cols = P.sw_cpos + full->cpos_off;
+    for (int a = q + 4 * SW_RU; a < n4; a += 4) acc = fma(Gr[a], xp[cols[a]], acc);
+  }
+  // (no branch around the uses of gr: behind a branch the compiler must take the loads for pending at the next turn's
+  //  address arithmetic -- their registers are recycled -- and waits for everything, the row's store included)
+#pragma unroll
+  for (int u = 0; u < 3; ++u) acc = (q == 0 && n4 + u < n) ? fma(S.gr[u], er[u], acc) : acc;
+  acc = quadsum(acc);
+  if (q == 0 && T[2] >= 0) sd.ds[T[2]] = acc + (S.g_row - S.s_row);
+}
+
 template <int F>
 __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *__restrict__ panel, double *__restrict__ dx,
-                                               double *__restrict__ sol, double *xs, double *red, const int *nxp, int wv, int lane) {
+                                               double *__restrict__ sol, double *xs, double *red, const int *nxp, int wv, int lane,
+                                               double *xp, const SweepDs &sd) {
   constexpr int NT = Kkt2Cfg<F>::NT, pstride = (F + 1) * PIV;
+  constexpr bool HELP = NT < SW_W0;   // (fronts of 208 slots and more have no idle helper waves: the planner leaves sw_on off)
   const int NS = P.n_stages, n = P.n_sol;
   const int j = lane & 15, q = lane >> 4;
   const int vcol = 4 * (j & 3) + (j >> 2);   // where column j of a V row sits
@@ -198,14 +264,46 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
     }
   };
   if (lane < PIV) { red[wv * PIV + lane] = 0.0; red[256 + wv * PIV + lane] = 0.0; }   // (the last stage has no rows besides its pivots)
+  swi4_t *swt = (swi4_t *)(xp + NS * PIV);   // (16-byte aligned: the callers' xp is)
+  if (HELP && P.sw_on)
+    for (int i = wv * 64 + lane; i < P.sw_steps * SW_ROUND; i += KT2) swt[i] = *(const swi4_t *)(P.sw_tasks + i);
   // waves NT+1 .. 15 have no rows: they only meet the barriers (a SIMD has one vector ALU: what they would execute on
   // dummies is time the working waves of their SIMD do not get)
   const bool active = wv <= NT;
   if (!active) {
-    lds_barrier();
-    for (int k0 = NS - 1; k0 >= 0; k0 -= SWD)
+    if (!HELP || wv < SW_W0 || !P.sw_on) {
+      lds_barrier();
+      for (int k0 = NS - 1; k0 >= 0; k0 -= SWD)
 #pragma unroll
-      for (int d = 0; d < SWD; ++d) lds_barrier();
+        for (int d = 0; d < SWD; ++d) lds_barrier();
+      return;
+    }
+    // round i (16 rows) runs in step i of the chain (stage NS - 1 - i); the planner's schedule puts a block's rows behind
+    // its stage.  The three waves take turns: a wave's loads have three steps to arrive, one set of prefetch registers.
+    const int hq = lane & 3, hr = lane >> 2, hw = wv - SW_W0;
+    const int nstep = ((NS + SWD - 1) / SWD) * SWD;   // (steps of the chain loop below)
+    lds_barrier();
+    // (the rows of a round come from the LDS copy of the schedule: a descriptor carried from turn to turn in registers is
+    //  copied into the carried register right behind its load -- a wait for the memory in front of the step's barrier)
+    auto task = [&](int i) __attribute__((always_inline)) { return swt[min(i, P.sw_steps - 1) * SW_ROUND + hr]; };
+    swi4_t T = task(hw);
+    SwSlot S;
+    sw_load(P, sd, T, S, hq);
+    int turn = hw;
+    for (int i = 0; i < nstep; ++i) {
+      if (i == turn) {
+        sw_row(P, sd, T, S, xp, hq, P.sw_tasks + (size_t)turn * SW_ROUND + hr);
+        turn += SW_NW;
+        T = task(turn);
+        sw_load(P, sd, T, S, hq);
+      }
+      lds_barrier();
+    }
+    for (; turn < P.sw_steps; turn += SW_NW) {   // rounds the schedule could not place earlier (x is complete)
+      sw_row(P, sd, T, S, xp, hq, P.sw_tasks + (size_t)turn * SW_ROUND + hr);
+      T = task(turn + SW_NW);
+      sw_load(P, sd, T, S, hq);
+    }
     return;
   }
 #pragma unroll
@@ -226,6 +324,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
         const double x = t >= 0 ? bw[d] - sm - corr : 0.0;
         if (lane < PIV && t >= 0) {
           xs[bps[d]] = x;
+          xp[t * PIV + lane] = x;        // by position, for the helper waves (ds = Ji dx)
           sol[t * PIV + lane] = x;       // by unknown position, multipliers included (k_residual)
           if (bun[d] >= 0 && bun[d] < n) dx[bun[d]] = x;
         }
@@ -802,7 +901,8 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     for (int i = tid; i < NS * 4; i += KT2) nxp[i] = P.nxt_pack[i];
     for (int i = tid; i < NS * 8; i += KT2) nxp[NS * 4 + i] = (int)P.amask2[i];
     __syncthreads();
-    sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane);
+    const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons};
+    sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane, lds + ((LY::PB + NS * 6 + 1) & ~1), sd);
   }
 #ifdef QTOS_STAMPS
   KS2(6);
@@ -824,7 +924,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
 //   waves 1 .. NT   u -= V_{k-1} p_{k-1} on the other rows of row tile wv - 1, one stage behind
 //   wave NT + 1     w_{k-1} = B_{k-1}^-1 p_{k-1}
 constexpr int KTC = 1024;
-inline size_t chord_lds_bytes(int NS) { return sizeof(int) * (size_t)NS * 12; }
+inline size_t chord_lds_bytes(int NS, int sw_steps) { return sizeof(int) * (size_t)NS * 12 + sweep_ds_lds_bytes(NS, sw_steps); }   // sweep tables; solution by position and rounds of the helper waves
 template <int F>
 __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
@@ -918,7 +1018,8 @@ __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
     }
   }
   __syncthreads();   // the w entries written above are read back below (same workgroup: visible after the barrier)
-  sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane);
+  const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons};
+  sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane, (double *)(nxp + ((NS * 12 + 3) & ~3)), sd);
 }
 
 // =================================================================================================

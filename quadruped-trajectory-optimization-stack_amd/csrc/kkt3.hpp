@@ -581,7 +581,8 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
     for (int i = tid; i < NS * 4; i += KT2) nxp[i] = P.nxt_pack[i];
     for (int i = tid; i < NS * 8; i += KT2) nxp[NS * 4 + i] = (int)P.amask2[i];
     __syncthreads();
-    sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane);
+    const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons};
+    sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane, lds + ((LY::PB + NS * 6 + 1) & ~1), sd);
   }
 #ifdef QTOS_STAMPS
   KS2(6);

@@ -49,6 +49,10 @@ struct Kkt4Layout {
   // backward sweep (the panels are dead): solution by slot, partial sums, sweep tables
   static constexpr int XS = PAN, RED = XS + FR, NXP = RED + 2 * 16 * PIV + 64;
 };
+inline size_t kkt4_sweep_base_bytes(int F, int NS) {
+  const int FR = (F + 63) & ~63;
+  return (PIV * PLD + PIV + 4 * PIV + FR + 64 + 4 * PIV / 2 + 4 * FR / 8 + 16 + 2 * PIV * PLD + FR + 2 * 16 * PIV + 64) * sizeof(double) + (size_t)NS * 12 * sizeof(int);
+}
 inline size_t kkt4_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells) {
   const int FR = (F + 63) & ~63, PSZ = (F + 1) * PLD;
   size_t o = PIV * PLD + PIV + 4 * PIV + FR + 64 + 4 * PIV / 2 + 4 * FR / 8 + 16 + 2 * PIV * PLD + 4 * (size_t)PSZ + 2 * (size_t)F * PIV;
@@ -457,7 +461,8 @@ __global__ __launch_bounds__(KT2) void k_kkt4(DevPlan P, DevWork W, int B) {
     for (int i = tid; i < NS * 4; i += KT2) nxp[i] = P.nxt_pack[i];
     for (int i = tid; i < NS * 8; i += KT2) nxp[NS * 4 + i] = (int)P.amask2[i];
     __syncthreads();
-    sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane);
+    const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons};
+    sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane, lds + ((LY::NXP + NS * 6 + 1) & ~1), sd);
   }
 #ifdef QTOS_STAMPS
   KS2(6);

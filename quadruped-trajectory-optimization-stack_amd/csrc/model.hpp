@@ -88,6 +88,15 @@ struct IqRow {
   int col_off;  // into block_cols
   int row;      // constraint row
 };
+// one row of an inequality block for the helper waves of the backward sweep (sweep_backward: ds = Ji dx there)
+struct SwTask {
+  int goff;      // stream offset of the row's first Jacobian entry
+  int n;         // entries
+  int row;       // constraint row; -1: an empty place of the round
+  int c16_off;   // into sw_c16: the positions of the block's columns in elimination order as 16-bit values, in the order the four lanes of a row read them
+  int cpos_off;  // into sw_cpos: the same positions as ints (rows of more than 35 entries)
+  int pad[3];
+};
 // initial guess per variable (towr SetByLinearInterpolation): x = a + frac*(b-a) or (b-a)/T
 struct InitDesc {
   int set;  // 0 base-lin, 1 base-ang, 2+e ee-motion, 6+e ee-force

@@ -185,6 +185,65 @@ void qtos_planner_destroy(QtosPlanner *p) {
   delete p;
 }
 
+// The rows of the inequality blocks for the helper waves of the backward sweep (sweep_backward): a block belongs to the stage
+// of its earliest column; rounds of SW_ROUND rows (one helper wave), round i in step i of the chain (stage NS - 1 - i): a
+// stage's rounds come behind the step that solves it, in the order the chain meets the stages.  Returns the number of
+// rounds (0: the tables cannot be built for this plan).
+static int build_sweep_tasks(const HostModel &M, const Symbolic &S, std::vector<SwTask> &tasks, std::vector<int> &cpos, std::vector<int> &c16) {
+  const int NS = S.n_stages;
+  std::vector<std::vector<SwTask>> by_stage(NS);
+  bool ok = true;
+  for (const Block &b : M.blocks) {
+    if (b.kind != 1) continue;
+    int mn = INT_MAX;
+    const int c0 = (int)cpos.size();
+    for (int a = 0; a < b.n; ++a) {
+      const int pos = S.var_pos[M.block_cols[b.col_off + a]];
+      if (pos < 0) ok = false;
+      cpos.push_back(std::max(pos, 0));
+      mn = std::min(mn, pos);
+    }
+    if (mn < 0 || mn / PIV >= NS) { ok = false; continue; }
+    const int k0 = (int)c16.size(), n4 = b.n & ~3;
+    auto at = [&](int e) { return (unsigned)cpos[c0 + e] & 0xffffu; };
+    for (int q = 0; q < 4; ++q)
+      for (int u = 0; u < SW_RU; u += 2) {
+        const int e0 = std::max(std::min(q + 4 * u, n4 - 4 + q), 0), e1 = std::max(std::min(q + 4 * (u + 1), n4 - 4 + q), 0);
+        c16.push_back((int)(at(std::min(e0, b.n - 1)) | (at(std::min(e1, b.n - 1)) << 16)));
+      }
+    {
+      const int r0 = std::min(n4, b.n - 1), r1 = std::min(n4 + 1, b.n - 1), r2 = std::min(n4 + 2, b.n - 1);
+      c16.push_back((int)(at(r0) | (at(r1) << 16)));
+      c16.push_back((int)at(r2));
+      c16.push_back(0); c16.push_back(0);
+    }
+    for (int r = 0; r < b.m; ++r) by_stage[mn / PIV].push_back({b.goff + r * b.n, b.n, b.row0 + r, k0, c0, {0, 0, 0}});
+  }
+  if ((size_t)NS * PIV > 65535) ok = false;
+  const SwTask none = {0, 4, -1, 0, 0, {0, 0, 0}};
+  int step = 0;
+  auto round_of = [&](const SwTask *t, int cnt) {
+    for (int i = 0; i < SW_ROUND; ++i) tasks.push_back(i < cnt ? t[i] : none);
+    ++step;
+  };
+  for (int u = NS - 1; u >= 0 && ok; --u) {
+    while (step < NS - u) round_of(nullptr, 0);   // (x of stage u is complete behind the barrier of step NS - 1 - u)
+    for (size_t i = 0; i < by_stage[u].size(); i += SW_ROUND) round_of(by_stage[u].data() + i, (int)std::min<size_t>(SW_ROUND, by_stage[u].size() - i));
+  }
+  const int nstep = ((NS + SWD - 1) / SWD) * SWD;
+  while (step < nstep) round_of(nullptr, 0);
+  if (cpos.empty()) cpos.push_back(0);
+  while (c16.size() < 20) c16.push_back(0);
+  if (getenv("QTOS_DEBUG_SYMBOLIC")) {
+    size_t mx = 0, tot = 0;
+    for (auto &v : by_stage) { mx = std::max(mx, v.size()); tot += v.size(); }
+    fprintf(stderr, "qtos: sweep ds: %d rounds for %d stages (chain %d steps), %zu rows, most in a stage %zu; rows by stage:", step, NS, nstep, tot, mx);
+    for (auto &v : by_stage) fprintf(stderr, " %zu", v.size());
+    fprintf(stderr, "\n");
+  }
+  return ok ? step : 0;
+}
+
 int qtos_planner_create(const QtosParams *params, int max_batch, int device, QtosPlanner **out) {
   if (!params || !out || max_batch < 1 || max_batch >= (1 << 24)) return -1;   // (the count words of k_post_counts hold 24 bits per count)
   *out = nullptr;
@@ -381,6 +440,15 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     TRY(p->upload(rows, &D.iq_rows));
   }
   {
+    std::vector<SwTask> tasks;
+    std::vector<int> cpos, c16;
+    D.sw_steps = build_sweep_tasks(M, S, tasks, cpos, c16);
+    const bool ok = D.sw_steps > 0;
+    const char *e = getenv("QTOS_SWEEP_DS");
+    D.sw_on = ok && D.n_iq_rows > 0 && S.front / PIV < SW_W0 && (e ? atoi(e) != 0 : true);
+    TRY(p->upload(tasks, &D.sw_tasks)); TRY(p->upload(cpos, &D.sw_cpos)); TRY(p->upload(c16, &D.sw_c16));
+  }
+  {
     std::vector<int> iq, eq;
     std::vector<double> lo, hi;
     for (int r = 0; r < M.n_cons; ++r) {
@@ -419,6 +487,13 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   // LDS budget of k_kkt
   const int F = S.front;
   p->kkt_lds = p->use_kkt4 ? kkt4_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : p->use_kkt3 ? kkt3_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
+  if (D.sw_on) {
+    // the helper waves' tables of the backward sweep (solution by position, rounds) behind the sweep's own: within the LDS
+    // the forward pass needs anyway, or the kernel's allocation grows up to the limit; beyond that k_step forms ds itself
+    const size_t need = (p->use_kkt4 ? kkt4_sweep_base_bytes(F, S.n_stages) : kkt2_sweep_base_bytes(F, S.n_stages)) + sweep_ds_lds_bytes(S.n_stages, D.sw_steps);
+    if (need > 160 * 1024 - 256 || chord_lds_bytes(S.n_stages, D.sw_steps) > 96 * 1024) D.sw_on = 0;
+    else p->kkt_lds = std::max(p->kkt_lds, need);
+  }
   p->kkt_threads = KT2;
   const int max_front = 208;
   if (S.max_drec > 2 * 2 * KT || S.max_srec > 3 * 4 * KT || F > max_front || (S.pack_src.size() & 1)) {
@@ -440,6 +515,10 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
     if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
+    if (p->chord_fn && D.sw_on) {
+      e = hipFuncSetAttribute((const void *)p->chord_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chord_lds_bytes(S.n_stages, D.sw_steps));
+      if (e != hipSuccess) { p->err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); fprintf(stderr, "qtos: %s\n", p->err.c_str()); qtos_planner_destroy(p); return -2; }
+    }
   }
   p->eval_lds = sizeof(double) * (((size_t)M.n_sol + 1) / 2 * 2 + std::max((size_t)DYN_LOC * D.dyn_chunk, (size_t)ROM_LOC * D.rom_chunk) +
                                   std::max((size_t)DYN_VIN * D.dyn_chunk, (size_t)ROM_VIN * D.rom_chunk));
@@ -580,6 +659,7 @@ int qtos_analyze(const QtosParams *params, QtosDims *d, int *stage_active, int m
   if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
   if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
   fill_dims(M, S, d);
+  if (getenv("QTOS_DEBUG_SYMBOLIC")) { std::vector<SwTask> t; std::vector<int> c, c2; (void)build_sweep_tasks(M, S, t, c, c2); }
   if (stage_active)
     for (int k = 0; k < S.n_stages && k < max_stages; ++k) stage_active[k] = S.stages[k].n_active;
   return 0;
@@ -651,7 +731,7 @@ static int queue_iteration(QtosPlanner *p, QtosPlanner::Lane &c, int it, bool in
   }
   if (do_chord) {
     HIPCHK(p, hipEventRecord(c.ev[4 + 5 * it], cs));
-    hipLaunchKernelGGL(p->chord_fn, dim3(c.B), dim3(KTC), chord_lds_bytes(p->S.n_stages), cs, D, c.W, c.B);
+    hipLaunchKernelGGL(p->chord_fn, dim3(c.B), dim3(KTC), chord_lds_bytes(p->S.n_stages, p->dp.sw_on ? p->dp.sw_steps : 0), cs, D, c.W, c.B);
     HIPCHK(p, hipEventRecord(c.ev[5 + 5 * it], cs));
   }
   if (fork) {
@@ -1245,7 +1325,7 @@ int qtos_debug_chord(QtosPlanner *p, int B, double *dx_out) {
   HIPCHK(p, hipSetDevice(p->device));
   DevWork W = p->wk;
   hipLaunchKernelGGL(k_debug_rhs, dim3(B), dim3(256), 0, 0, p->dp, W, B);
-  hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), chord_lds_bytes(p->S.n_stages), 0, p->dp, W, B);
+  hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), chord_lds_bytes(p->S.n_stages, p->dp.sw_on ? p->dp.sw_steps : 0), 0, p->dp, W, B);
   hipLaunchKernelGGL(k_debug_unchord, dim3((B + 63) / 64), dim3(64), 0, 0, W, B);
   HIPCHK(p, hipDeviceSynchronize());
   if (int rc = copy_dx_out(p, W, B, dx_out)) return rc;
@@ -1266,7 +1346,7 @@ int qtos_debug_residual(QtosPlanner *p, int B, int refine, double *dx_out, doubl
   if (refine) {
     hipLaunchKernelGGL(k_residual, dim3(B), dim3(512), 0, 0, p->dp, W, B, (double *)nullptr, 1);   // r -> W.rhs, x remembered
     hipLaunchKernelGGL(k_debug_flag_chord, dim3((B + 63) / 64), dim3(64), 0, 0, W, B);
-    hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), chord_lds_bytes(p->S.n_stages), 0, p->dp, W, B);
+    hipLaunchKernelGGL(p->chord_fn, dim3(B), dim3(KTC), chord_lds_bytes(p->S.n_stages, p->dp.sw_on ? p->dp.sw_steps : 0), 0, p->dp, W, B);
     hipLaunchKernelGGL(k_debug_unchord, dim3((B + 63) / 64), dim3(64), 0, 0, W, B);
     hipLaunchKernelGGL(k_refine_add, dim3(B), dim3(512), 0, 0, p->dp, W, B);
   }

@@ -16,11 +16,11 @@ else: ter = workloads.exp1_terrain(); s, g = workloads.flat_goals(256, 0)
 P = capi.Planner(cfg, max_batch=256)
 P.set_heightfields(ter[0], ter[1])
 kw = {} if mid is None else {"map_id": mid}
-tt = []
+tt, tk, tc = [], [], []
 for i in range(12):
-    nodes, status, iters, viol = P.plan(s, g, **kw); t = P.timing(); tt.append(t["total_seconds"])
-print("%-6s %s=%s whole solve ms %.4f; kkt %d chord %d; conv %d/256 iters mean %.3f max %d; sha %s" % (wl, os.environ["AB_VAR"], os.environ.get(os.environ["AB_VAR"], "-"),
-      1e3 * np.median(tt[2:]), t["kkt_launches"], t["chord_launches"], int((status == 0).sum()), iters.mean(), int(iters.max()), hashlib.sha1(nodes.tobytes()).hexdigest()[:10]))
+    nodes, status, iters, viol = P.plan(s, g, **kw); t = P.timing(); tt.append(t["total_seconds"]); tk.append(t["kkt_seconds"] / max(t["kkt_launches"], 1)); tc.append(t["chord_seconds"] / max(t["chord_launches"], 1))
+print("%-6s %s=%s whole solve ms %.4f (kkt %.4f / launch, chord %.4f); kkt %d chord %d; conv %d/256 iters mean %.3f max %d; sha %s" % (wl, os.environ["AB_VAR"], os.environ.get(os.environ["AB_VAR"], "-"),
+      1e3 * np.median(tt[2:]), 1e3 * np.median(tk[2:]), 1e3 * np.median(tc[2:]), t["kkt_launches"], t["chord_launches"], int((status == 0).sum()), iters.mean(), int(iters.max()), hashlib.sha1(nodes.tobytes()).hexdigest()[:10]))
 np.save("/tmp/ab5_%s_%s.npy" % (wl, os.environ.get(os.environ["AB_VAR"], "-")), nodes)
 '''
 var = os.environ.get("AB_VAR", "QTOS_SPEC_JAC")

@@ -476,6 +476,43 @@ def test_pool_of_handles_equals_one_call_after_the_other(cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["QTOS_SWEEP_DS", "QTOS_SPEC_JAC"])
+@pytest.mark.parametrize("workload", ["mixed", "trot", "knots200", "duration12"])
+def test_work_moved_between_kernels_leaves_the_plans_bit_for_bit(switch, workload):
+    """Round 4 moved two pieces of k_step without touching their arithmetic: the slack steps ds = Ji dx + (g - s) are formed by
+    the waves that idle in the backward sweep of the KKT kernels (QTOS_SWEEP_DS, kkt2.hpp sweep_backward: same four-lane sums
+    in the same order), and the first trial point of a Newton step's line search is evaluated together with its Jacobian
+    (QTOS_SPEC_JAC).  With either switched off the planner takes the round-3 path: plans, statuses, iteration counts and
+    violations must be the same bits -- on terrain (stragglers, chord steps, rejected chord steps), on the trot (k_kkt3),
+    on 200 knots and on a longer horizon (fronts above 128 slots, short stages)."""
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    B = 64
+    mid = None
+    if workload == "mixed":
+        c = PlannerConfig.knots100(); ter = workloads.mixed_terrains(); start, goal, mid = workloads.mixed_goals(B, seed=7, terrains=ter)
+    elif workload == "trot":
+        c = PlannerConfig.knots100(gait="trot"); ter = workloads.exp1_terrain(); start, goal = workloads.flat_goals(B, 3)
+    elif workload == "knots200":
+        c = PlannerConfig.knots200(); ter = workloads.random_terrains(); start, goal, mid = workloads.mpc_goals(B, seed=5, terrains=ter)
+    else:
+        c = PlannerConfig.reference_compat(reduce_base=True, duration=12.0); ter = workloads.exp1_terrain(); start, goal = workloads.flat_goals(B, 4)
+    res = {}
+    for v in ("0", "1"):
+        os.environ[switch] = v
+        try:
+            P = Planner(c, max_batch=B)
+        finally:
+            del os.environ[switch]
+        P.set_heightfields(ter[0], ter[1])
+        res[v] = P.plan(start, goal, map_id=mid)
+        P.close()
+    assert (res["1"][1] == 0).mean() > 0.9
+    assert all(np.array_equal(a, b) for a, b in zip(res["0"], res["1"]))
+
+
+@pytest.mark.gpu
 def test_call_larger_than_the_gpu_is_cut_into_lanes_with_identical_plans(cfg):
     """A call of more problems than the GPU has compute units is served by several lanes of the handle (contiguous parts on
     streams of the planner, each with its own host-driven Newton loop: the late iterations of one part's stragglers run beside
