@@ -172,17 +172,23 @@ constexpr int SWD = QTOS_SWD;   // stages of factor panel in flight per wave (pr
 // caller has synchronised the workgroup.
 // The slack steps ds = Ji dx + (g - s) on the waves that idle in the sweep (P.sw_on; Symbolic-independent tables built by
 // the planner: sw_tasks, sw_cpos).  An inequality block belongs to the stage of its earliest column: once the chain has
-// solved that stage every column of the block is known.  Waves 13..15 (three SIMDs that do not hold the chain wave) take
+// solved that stage every column of the block is known.  The waves without rows (all but wave 12, on the chain wave's SIMD) take
 // the rows of the blocks in turns, one round of 16 rows per step of the chain, four lanes per row with k_step's own order
 // of summation (the same bits), G and the column positions prefetched three steps ahead; xp = the solution by position in LDS.
 struct SweepDs {
   const double *G;     // the problem's stream
   double *ds;
   const double *g, *s;
+  double *dbg;         // diagnostic build: cycles of the helper waves' turns (sums, loads) and of the chain wave's step parts
 };
 constexpr int SW_W0 = 13, SW_NW = 3, SW_ROUND = 16, SW_RU = 8;
 typedef int swi4_t __attribute__((ext_vector_type(4)));
 typedef int swi2_t __attribute__((ext_vector_type(2)));
+#ifdef QTOS_STAMPS
+#define HSTAMP(v) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v = t_; } while (0)
+#else
+#define HSTAMP(v) do {} while (0)
+#endif
 struct SwSlot {
   double gv[SW_RU], gr[3], g_row, s_row;
   swi4_t c;    // positions of the lane's entries, 16 bits each (sw_c16)
@@ -200,10 +206,14 @@ __device__ __forceinline__ void sw_load(const DevPlan &P, const SweepDs &sd, con
   S.s_row = sd.s[row];
   S.c = *(const swi4_t *)(P.sw_c16 + T[3] + 4 * q);
   S.cr = *(const swi2_t *)(P.sw_c16 + T[3] + 16);
+  // (entries q + 4 u and n4 + u unclamped: one address for the eight, one for the three; what lies behind the row's end --
+  //  the stream goes on, the allocation has 64 doubles to spare -- is loaded and never used: sw_row selects by the counts)
+  const double *Gq = Gr + q, *Gt = Gr + n4;
 #pragma unroll
-  for (int u = 0; u < SW_RU; ++u) S.gv[u] = Gr[max(min(q + 4 * u, n4 - 4 + q), 0)];
+  for (int u = 0; u < SW_RU; ++u) S.gv[u] = Gq[4 * u];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) S.gr[u] = Gr[min(n4 + u, n - 1)];
+  for (int u = 0; u < 3; ++u) S.gr[u] = Gt[u];
+  (void)n;
 }
 __device__ __forceinline__ void sw_row(const DevPlan &P, const SweepDs &sd, const swi4_t &T, const SwSlot &S, const double *xp, int q, const SwTask *full) {
   const int n = T[1], n4 = n & ~3;
@@ -233,7 +243,10 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
                                                double *__restrict__ sol, double *xs, double *red, const int *nxp, int wv, int lane,
                                                double *xp, const SweepDs &sd) {
   constexpr int NT = Kkt2Cfg<F>::NT, pstride = (F + 1) * PIV;
-  constexpr bool HELP = NT < SW_W0;   // (fronts of 208 slots and more have no idle helper waves: the planner leaves sw_on off)
+  // helper waves (ds = Ji dx): the waves without rows, except wave 12 on the chain wave's SIMD; fronts of 208 slots and more
+  // have fewer than three: the planner leaves sw_on off
+  constexpr int HN = (15 - NT) - (NT < 12 ? 1 : 0);
+  constexpr bool HELP = NT < SW_W0;
   const int NS = P.n_stages, n = P.n_sol;
   const int j = lane & 15, q = lane >> 4;
   const int vcol = 4 * (j & 3) + (j >> 2);   // where column j of a V row sits
@@ -244,23 +257,37 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
   double bv[SWD][4], bw[SWD];
   int bps[SWD], bun[SWD];
   unsigned bam[SWD];
-  auto load = [&](int s, double (&v)[4], unsigned &am, double &wj, int &psj, int &unkj) __attribute__((always_inline)) {
+  // The sweep tables are addresses of the panel loads.  A stage's word (wave 0: the slots of the next stage's pivots, nxt_pack;
+  // row waves: the row mask of their tile, amask2) is read from LDS together with the step's other LDS reads and handed to
+  // fetch(): read inside it, behind the step's barrier, every word was a round trip of its own in front of the chain's reads
+  // of the partial sums (round 4: 1.74 k -> cycles per stage).  am: row waves the tile's row mask, wave 0 the rows of the
+  // chain block that exist (bit m: pivot q + 4 m of the next stage has a slot at this stage).
+  auto word_of = [&](int s) __attribute__((always_inline)) {
+    const int kk = max(s, 0);
+    return (unsigned)(wv == 0 ? nxp[kk * 4 + q] : nxp[NS * 4 + kk * 8 + (R >> 1)]);
+  };
+  auto fetch = [&](int s, unsigned word, double (&v)[4], unsigned &am, double &wj, int &psj, int &unkj) __attribute__((always_inline)) {
     const int kk = max(s, 0);
     const double *pk = panel + (size_t)kk * pstride;
-    // (the masks and slots below are addresses of the loads: from LDS)
-    am = owner ? ((unsigned)nxp[NS * 4 + kk * 8 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu : 0u;
-    const unsigned np = (unsigned)nxp[kk * 4 + q];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = q + 4 * i;
-      const unsigned nr = (np >> (8 * i)) & 255u;
-      const int off = wv == 0 ? (nr != 255u ? PIV + (int)nr * PIV + vcol : j) : (((am >> row) & 1u) ? PIV + (16 * R + row) * PIV + vcol : j);
-      v[i] = pk[off];
-    }
     if (wv == 0) {
+      unsigned present = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned nr = (word >> (8 * i)) & 255u;
+        present |= (nr != 255u ? 1u : 0u) << i;
+        v[i] = pk[nr != 255u ? PIV + (int)nr * PIV + vcol : j];
+      }
+      am = present;
       wj = pk[j];
       psj = P.piv_slot[kk * PIV + j];
       unkj = P.piv_unknown[kk * PIV + j];
+    } else {
+      am = (word >> ((R & 1) * 16)) & 0xffffu;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = q + 4 * i;
+        v[i] = pk[((am >> row) & 1u) ? PIV + (16 * R + row) * PIV + vcol : j];
+      }
     }
   };
   if (lane < PIV) { red[wv * PIV + lane] = 0.0; red[256 + wv * PIV + lane] = 0.0; }   // (the last stage has no rows besides its pivots)
@@ -271,7 +298,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
   // dummies is time the working waves of their SIMD do not get)
   const bool active = wv <= NT;
   if (!active) {
-    if (!HELP || wv < SW_W0 || !P.sw_on) {
+    if (!HELP || wv == 12 || !P.sw_on) {
       lds_barrier();
       for (int k0 = NS - 1; k0 >= 0; k0 -= SWD)
 #pragma unroll
@@ -279,41 +306,77 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
       return;
     }
     // round i (16 rows) runs in step i of the chain (stage NS - 1 - i); the planner's schedule puts a block's rows behind
-    // its stage.  The three waves take turns: a wave's loads have three steps to arrive, one set of prefetch registers.
-    const int hq = lane & 3, hr = lane >> 2, hw = wv - SW_W0;
+    // its stage.  The helper waves take turns: a wave's loads have HN steps to arrive (a load from the stream takes longer
+    // than two steps of the chain: with three waves the sweep waited for them), one set of prefetch registers.
+    const int hq = lane & 3, hr = lane >> 2, hw = wv - (NT + 1) - (wv > 12 && NT < 12 ? 1 : 0);
     const int nstep = ((NS + SWD - 1) / SWD) * SWD;   // (steps of the chain loop below)
     lds_barrier();
     // (the rows of a round come from the LDS copy of the schedule: a descriptor carried from turn to turn in registers is
     //  copied into the carried register right behind its load -- a wait for the memory in front of the step's barrier)
     auto task = [&](int i) __attribute__((always_inline)) { return swt[min(i, P.sw_steps - 1) * SW_ROUND + hr]; };
+    // (sums and loads of a turn in ONE step: split over two steps the compiler puts a wait for the row's store in front of
+    //  the loads -- it cannot know that the sums' branch has waited for the registers they recycle; the next round's rows are
+    //  read from LDS ahead of the sums, their latency under the sums' chain)
     swi4_t T = task(hw);
     SwSlot S;
     sw_load(P, sd, T, S, hq);
     int turn = hw;
+#ifdef QTOS_STAMPS
+    unsigned long long hs0 = 0, hs1 = 0, hs2 = 0, hn = 0;
+#endif
     for (int i = 0; i < nstep; ++i) {
       if (i == turn) {
+#ifdef QTOS_STAMPS
+        unsigned long long a0, a1, a2;
+#endif
+        HSTAMP(a0);
+        const swi4_t Tn = task(turn + HN);
         sw_row(P, sd, T, S, xp, hq, P.sw_tasks + (size_t)turn * SW_ROUND + hr);
-        turn += SW_NW;
-        T = task(turn);
+        HSTAMP(a1);
+        turn += HN;
+        T = Tn;
         sw_load(P, sd, T, S, hq);
+        HSTAMP(a2);
+#ifdef QTOS_STAMPS
+        hs0 += a1 - a0; hs1 += a2 - a1; hn += 1;
+#endif
       }
+#ifdef QTOS_STAMPS
+      unsigned long long b0, b1;
+      HSTAMP(b0);
+#endif
       lds_barrier();
+#ifdef QTOS_STAMPS
+      HSTAMP(b1);
+      if (i + 1 == turn || true) hs2 += b1 - b0;
+#endif
     }
-    for (; turn < P.sw_steps; turn += SW_NW) {   // rounds the schedule could not place earlier (x is complete)
+#ifdef QTOS_STAMPS
+    if (sd.dbg && wv == 13 && lane == 0) { sd.dbg[0] = (double)hs0 / (double)hn; sd.dbg[1] = (double)hs1 / (double)hn; sd.dbg[2] = (double)hs2 / (double)nstep; sd.dbg[3] = (double)hn; }
+#endif
+    for (; turn < P.sw_steps; turn += HN) {   // rounds the schedule could not place earlier (x is complete)
       sw_row(P, sd, T, S, xp, hq, P.sw_tasks + (size_t)turn * SW_ROUND + hr);
-      T = task(turn + SW_NW);
+      T = task(turn + HN);
       sw_load(P, sd, T, S, hq);
     }
     return;
   }
 #pragma unroll
-  for (int d = 0; d < SWD; ++d) load(NS - 1 - d, bv[d], bam[d], bw[d], bps[d], bun[d]);
+  for (int d = 0; d < SWD; ++d) fetch(NS - 1 - d, word_of(NS - 1 - d), bv[d], bam[d], bw[d], bps[d], bun[d]);
   double corr = 0.0;
+#ifdef QTOS_STAMPS
+  unsigned long long cs[4] = {0, 0, 0, 0};
+#endif
   lds_barrier();
   for (int k0 = NS - 1; k0 >= 0; k0 -= SWD) {
 #pragma unroll
     for (int d = 0; d < SWD; ++d) {
       const int t = k0 - d, dn = (d + 1) % SWD;   // stage of the chain; ring slot of stage t - 1
+#ifdef QTOS_STAMPS
+      unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+      if (wv == 0) HSTAMP(c0);
+#endif
+      const unsigned wnext = word_of(t - SWD);    // (for the prefetch at the end of the step)
       if (wv == 0) {
         double r16[NT];                           // (the partial sums of waves 1 .. NT)
 #pragma unroll
@@ -322,6 +385,9 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
 #pragma unroll
         for (int w2 = 0; w2 < NT; ++w2) sm += r16[w2];
         const double x = t >= 0 ? bw[d] - sm - corr : 0.0;
+#ifdef QTOS_STAMPS
+        HSTAMP(c1);
+#endif
         if (lane < PIV && t >= 0) {
           xs[bps[d]] = x;
           xp[t * PIV + lane] = x;        // by position, for the helper waves (ds = Ji dx)
@@ -329,11 +395,13 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
           if (bun[d] >= 0 && bun[d] < n) dx[bun[d]] = x;
         }
         // the block of stage t - 1 against the entries just found
-        const unsigned np = (unsigned)nxp[max(t - 1, 0) * 4 + q];
         double c[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) c[m] = ((np >> (8 * m)) & 255u) != 255u && t >= 1 ? bv[dn][m] : 0.0;
+        for (int m = 0; m < 4; ++m) c[m] = ((bam[dn] >> m) & 1u) && t >= 1 ? bv[dn][m] : 0.0;
         corr = rowsum4(dot4_by_row(x, c));
+#ifdef QTOS_STAMPS
+        HSTAMP(c2);
+#endif
       }
       // the other rows of stage t - 1 (they meet entries that are at least one barrier old)
       if (wv >= 1) {
@@ -348,10 +416,20 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
         pp = rowsum4(pp);
         if (lane < PIV) red[((t - 1) & 1) * 256 + wv * PIV + j] = t >= 1 ? pp : 0.0;
       }
+      // ring slot d is free: wave 0 has used the stage's w, slots and unknowns above, the row waves its rows a step ago
+      fetch(t - SWD, wnext, bv[d], bam[d], bw[d], bps[d], bun[d]);
+#ifdef QTOS_STAMPS
+      if (wv == 0) HSTAMP(c3);
+#endif
       lds_barrier();
-      load(t - SWD, bv[d], bam[d], bw[d], bps[d], bun[d]);
+#ifdef QTOS_STAMPS
+      if (wv == 0) { HSTAMP(c4); cs[0] += c1 - c0; cs[1] += c2 - c1; cs[2] += c3 - c2; cs[3] += c4 - c3; }
+#endif
     }
   }
+#ifdef QTOS_STAMPS
+  if (sd.dbg && wv == 0 && lane == 0) for (int i = 0; i < 4; ++i) sd.dbg[4 + i] = (double)cs[i] / (double)NS;
+#endif
 }
 
 
@@ -901,7 +979,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     for (int i = tid; i < NS * 4; i += KT2) nxp[i] = P.nxt_pack[i];
     for (int i = tid; i < NS * 8; i += KT2) nxp[NS * 4 + i] = (int)P.amask2[i];
     __syncthreads();
-    const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons};
+    const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons, W.trace ? W.trace + ((size_t)b * (P.max_iter + 1) + 66) * 4 : nullptr};
     sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane, lds + ((LY::PB + NS * 6 + 1) & ~1), sd);
   }
 #ifdef QTOS_STAMPS
@@ -1018,7 +1096,7 @@ __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
     }
   }
   __syncthreads();   // the w entries written above are read back below (same workgroup: visible after the barrier)
-  const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons};
+  const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons, W.trace ? W.trace + ((size_t)b * (P.max_iter + 1) + 66) * 4 : nullptr};
   sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane, (double *)(nxp + ((NS * 12 + 3) & ~3)), sd);
 }
 

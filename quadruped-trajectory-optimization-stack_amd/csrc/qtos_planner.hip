@@ -445,7 +445,9 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     D.sw_steps = build_sweep_tasks(M, S, tasks, cpos, c16);
     const bool ok = D.sw_steps > 0;
     const char *e = getenv("QTOS_SWEEP_DS");
-    D.sw_on = ok && D.n_iq_rows > 0 && S.front / PIV < SW_W0 && (e ? atoi(e) != 0 : true);
+    // (five helper waves at least -- fronts of up to 144 slots --: a helper's loads then have four steps of the chain to arrive)
+    const int nt = S.front / PIV, helpers = (15 - nt) - (nt < 12 ? 1 : 0);
+    D.sw_on = ok && D.n_iq_rows > 0 && helpers >= 5 && (e ? atoi(e) != 0 : true);
     TRY(p->upload(tasks, &D.sw_tasks)); TRY(p->upload(cpos, &D.sw_cpos)); TRY(p->upload(c16, &D.sw_c16));
   }
   {
@@ -557,7 +559,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->alloc(&W.dzl, Bm * m)); TRY(p->alloc(&W.dzu, Bm * m)); TRY(p->alloc(&W.sig, Bm * m));
   TRY(p->alloc(&W.w, Bm * m));
   TRY(p->alloc(&W.panel, Bm * (size_t)D.panel_stride));
-  TRY(p->alloc(&W.stream, Bm * (size_t)S.pack_src.size()));
+  TRY(p->alloc(&W.stream, Bm * (size_t)S.pack_src.size() + 64));   // (+ 64: the helper waves of the sweep read whole groups of a row's entries, sw_load)
   {  // constants of the stream (static Jacobian values, pivot diagonals): written once per problem
     std::vector<double> one(S.pack_src.size(), 0.0);
     for (size_t i = 0; i < S.const_pos.size(); ++i) one[S.const_pos[i]] = S.const_val[i];

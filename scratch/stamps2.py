@@ -33,3 +33,11 @@ for b in (0, 5, NB - 1):
     es += t[72:76].reshape(16); el += t[76:80].reshape(16)
 print("eval_all<true> stamps:", (es / 3).round(0))
 print("eval_all<false> stamps:", (el / 3).round(0))
+
+hd = np.zeros(4); hc = np.zeros(4)
+for b in (0, 5, NB - 1):
+    t = np.zeros((cfg.max_iter + 1, 4))
+    P.lib.qtos_debug_trace(P.h, b, t.ctypes.data_as(C.POINTER(C.c_double)))
+    hd += t[66]; hc += t[67]
+print("helper turn of wave 13 (last sweep): sums | loads | barrier wait per step | turns:", (hd / 3).round(0))
+print("chain wave per step (last sweep): partial sums -> x | stores + block product | prefetch | barrier:", (hc / 3).round(0))
