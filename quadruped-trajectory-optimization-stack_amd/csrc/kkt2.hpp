@@ -172,14 +172,14 @@ constexpr int SWD = QTOS_SWD;   // stages of factor panel in flight per wave (pr
 // caller has synchronised the workgroup.
 // The slack steps ds = Ji dx + (g - s) on the waves that idle in the sweep (P.sw_on; Symbolic-independent tables built by
 // the planner: sw_tasks, sw_cpos).  An inequality block belongs to the stage of its earliest column: once the chain has
-// solved that stage every column of the block is known.  The waves without rows (all but wave 12, on the chain wave's SIMD) take
+// solved that stage every column of the block is known.  Waves 13..15 (three SIMDs that do not hold the chain wave) take
 // the rows of the blocks in turns, one round of 16 rows per step of the chain, four lanes per row with k_step's own order
 // of summation (the same bits), G and the column positions prefetched three steps ahead; xp = the solution by position in LDS.
 struct SweepDs {
   const double *G;     // the problem's stream
   double *ds;
   const double *g, *s;
-  double *dbg;         // diagnostic build: cycles of the helper waves' turns (sums, loads) and of the chain wave's step parts
+  double *dbg;         // diagnostic build: cycles of the helper waves' turns and of the chain wave's step parts (sweep_backward_early)
 };
 constexpr int SW_W0 = 13, SW_NW = 3, SW_ROUND = 16, SW_RU = 8;
 typedef int swi4_t __attribute__((ext_vector_type(4)));
@@ -200,6 +200,19 @@ __host__ __device__ inline size_t sweep_ds_lds_bytes(int NS, int sw_steps) {
 }
 // T = the first four ints of a SwTask: goff, n, row, c16_off
 __device__ __forceinline__ void sw_load(const DevPlan &P, const SweepDs &sd, const swi4_t &T, SwSlot &S, int q) {
+  const double *Gr = sd.G + T[0];
+  const int n = T[1], n4 = n & ~3, row = max(T[2], 0);
+  S.g_row = sd.g[row];
+  S.s_row = sd.s[row];
+  S.c = *(const swi4_t *)(P.sw_c16 + T[3] + 4 * q);
+  S.cr = *(const swi2_t *)(P.sw_c16 + T[3] + 16);
+#pragma unroll
+  for (int u = 0; u < SW_RU; ++u) S.gv[u] = Gr[max(min(q + 4 * u, n4 - 4 + q), 0)];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) S.gr[u] = Gr[min(n4 + u, n - 1)];
+}
+// sw_load with the row's entries unclamped (sweep_backward_early)
+__device__ __forceinline__ void sw_load2(const DevPlan &P, const SweepDs &sd, const swi4_t &T, SwSlot &S, int q) {
   const double *Gr = sd.G + T[0];
   const int n = T[1], n4 = n & ~3, row = max(T[2], 0);
   S.g_row = sd.g[row];
@@ -240,6 +253,137 @@ __device__ __forceinline__ void sw_row(const DevPlan &P, const SweepDs &sd, cons
 
 template <int F>
 __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *__restrict__ panel, double *__restrict__ dx,
+                                               double *__restrict__ sol, double *xs, double *red, const int *nxp, int wv, int lane,
+                                               double *xp, const SweepDs &sd) {
+  constexpr int NT = Kkt2Cfg<F>::NT, pstride = (F + 1) * PIV;
+  constexpr bool HELP = NT < SW_W0;   // (fronts of 208 slots and more have no idle helper waves: the planner leaves sw_on off)
+  const int NS = P.n_stages, n = P.n_sol;
+  const int j = lane & 15, q = lane >> 4;
+  const int vcol = 4 * (j & 3) + (j >> 2);   // where column j of a V row sits
+  const bool owner = wv >= 1 && wv <= NT;
+  const int R = owner ? wv - 1 : 0;
+  // ring slot of a stage: four doubles -- the chain block on wave 0, the rows of the wave's tile on waves 1..NT --, and on
+  // wave 0 the stage's w, pivot slots and unknowns
+  double bv[SWD][4], bw[SWD];
+  int bps[SWD], bun[SWD];
+  unsigned bam[SWD];
+  auto load = [&](int s, double (&v)[4], unsigned &am, double &wj, int &psj, int &unkj) __attribute__((always_inline)) {
+    const int kk = max(s, 0);
+    const double *pk = panel + (size_t)kk * pstride;
+    // (the masks and slots below are addresses of the loads: from LDS)
+    am = owner ? ((unsigned)nxp[NS * 4 + kk * 8 + (R >> 1)] >> ((R & 1) * 16)) & 0xffffu : 0u;
+    const unsigned np = (unsigned)nxp[kk * 4 + q];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = q + 4 * i;
+      const unsigned nr = (np >> (8 * i)) & 255u;
+      const int off = wv == 0 ? (nr != 255u ? PIV + (int)nr * PIV + vcol : j) : (((am >> row) & 1u) ? PIV + (16 * R + row) * PIV + vcol : j);
+      v[i] = pk[off];
+    }
+    if (wv == 0) {
+      wj = pk[j];
+      psj = P.piv_slot[kk * PIV + j];
+      unkj = P.piv_unknown[kk * PIV + j];
+    }
+  };
+  if (lane < PIV) { red[wv * PIV + lane] = 0.0; red[256 + wv * PIV + lane] = 0.0; }   // (the last stage has no rows besides its pivots)
+  swi4_t *swt = (swi4_t *)(xp + NS * PIV);   // (16-byte aligned: the callers' xp is)
+  if (HELP && P.sw_on)
+    for (int i = wv * 64 + lane; i < P.sw_steps * SW_ROUND; i += KT2) swt[i] = *(const swi4_t *)(P.sw_tasks + i);
+  // waves NT+1 .. 15 have no rows: they only meet the barriers (a SIMD has one vector ALU: what they would execute on
+  // dummies is time the working waves of their SIMD do not get)
+  const bool active = wv <= NT;
+  if (!active) {
+    if (!HELP || wv < SW_W0 || !P.sw_on) {
+      lds_barrier();
+      for (int k0 = NS - 1; k0 >= 0; k0 -= SWD)
+#pragma unroll
+        for (int d = 0; d < SWD; ++d) lds_barrier();
+      return;
+    }
+    // round i (16 rows) runs in step i of the chain (stage NS - 1 - i); the planner's schedule puts a block's rows behind
+    // its stage.  The three waves take turns: a wave's loads have three steps to arrive, one set of prefetch registers.
+    const int hq = lane & 3, hr = lane >> 2, hw = wv - SW_W0;
+    const int nstep = ((NS + SWD - 1) / SWD) * SWD;   // (steps of the chain loop below)
+    lds_barrier();
+    // (the rows of a round come from the LDS copy of the schedule: a descriptor carried from turn to turn in registers is
+    //  copied into the carried register right behind its load -- a wait for the memory in front of the step's barrier)
+    auto task = [&](int i) __attribute__((always_inline)) { return swt[min(i, P.sw_steps - 1) * SW_ROUND + hr]; };
+    swi4_t T = task(hw);
+    SwSlot S;
+    sw_load(P, sd, T, S, hq);
+    int turn = hw;
+    for (int i = 0; i < nstep; ++i) {
+      if (i == turn) {
+        sw_row(P, sd, T, S, xp, hq, P.sw_tasks + (size_t)turn * SW_ROUND + hr);
+        turn += SW_NW;
+        T = task(turn);
+        sw_load(P, sd, T, S, hq);
+      }
+      lds_barrier();
+    }
+    for (; turn < P.sw_steps; turn += SW_NW) {   // rounds the schedule could not place earlier (x is complete)
+      sw_row(P, sd, T, S, xp, hq, P.sw_tasks + (size_t)turn * SW_ROUND + hr);
+      T = task(turn + SW_NW);
+      sw_load(P, sd, T, S, hq);
+    }
+    return;
+  }
+#pragma unroll
+  for (int d = 0; d < SWD; ++d) load(NS - 1 - d, bv[d], bam[d], bw[d], bps[d], bun[d]);
+  double corr = 0.0;
+  lds_barrier();
+  for (int k0 = NS - 1; k0 >= 0; k0 -= SWD) {
+#pragma unroll
+    for (int d = 0; d < SWD; ++d) {
+      const int t = k0 - d, dn = (d + 1) % SWD;   // stage of the chain; ring slot of stage t - 1
+      if (wv == 0) {
+        double r16[NT];                           // (the partial sums of waves 1 .. NT)
+#pragma unroll
+        for (int w2 = 0; w2 < NT; ++w2) r16[w2] = red[(t & 1) * 256 + (w2 + 1) * PIV + j];
+        double sm = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < NT; ++w2) sm += r16[w2];
+        const double x = t >= 0 ? bw[d] - sm - corr : 0.0;
+        if (lane < PIV && t >= 0) {
+          xs[bps[d]] = x;
+          xp[t * PIV + lane] = x;        // by position, for the helper waves (ds = Ji dx)
+          sol[t * PIV + lane] = x;       // by unknown position, multipliers included (k_residual)
+          if (bun[d] >= 0 && bun[d] < n) dx[bun[d]] = x;
+        }
+        // the block of stage t - 1 against the entries just found
+        const unsigned np = (unsigned)nxp[max(t - 1, 0) * 4 + q];
+        double c[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) c[m] = ((np >> (8 * m)) & 255u) != 255u && t >= 1 ? bv[dn][m] : 0.0;
+        corr = rowsum4(dot4_by_row(x, c));
+      }
+      // the other rows of stage t - 1 (they meet entries that are at least one barrier old)
+      if (wv >= 1) {
+        double pp = 0.0;
+        const unsigned am = bam[dn];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = q + 4 * i;
+          const double xv = xs[16 * R + row];
+          pp = ((am >> row) & 1u) ? fma(bv[dn][i], xv, pp) : pp;
+        }
+        pp = rowsum4(pp);
+        if (lane < PIV) red[((t - 1) & 1) * 256 + wv * PIV + j] = t >= 1 ? pp : 0.0;
+      }
+      lds_barrier();
+      load(t - SWD, bv[d], bam[d], bw[d], bps[d], bun[d]);
+    }
+  }
+}
+
+
+// sweep_backward with the prefetch of a ring slot IN FRONT of the step's barrier and its table word read with the step's
+// other LDS reads (round 4).  k_chord's backward sweep: 1.74 k -> 1.51 k cycles per stage (0.156 -> 0.145 ms per launch); inside
+// k_kkt2 / k_kkt3 the same text measured 5 - 10 us per launch SLOWER than sweep_backward above (A/B of two libraries on one
+// box, profiles/r04_experiments/sweep_variants.log), so they keep that one.  Helper waves: every wave without rows but wave 12.
+template <int F, bool EARLY>
+__device__ __forceinline__ void sweep_backward_early(const DevPlan &P, const double *__restrict__ panel, double *__restrict__ dx,
                                                double *__restrict__ sol, double *xs, double *red, const int *nxp, int wv, int lane,
                                                double *xp, const SweepDs &sd) {
   constexpr int NT = Kkt2Cfg<F>::NT, pstride = (F + 1) * PIV;
@@ -319,7 +463,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
     //  read from LDS ahead of the sums, their latency under the sums' chain)
     swi4_t T = task(hw);
     SwSlot S;
-    sw_load(P, sd, T, S, hq);
+    sw_load2(P, sd, T, S, hq);
     int turn = hw;
 #ifdef QTOS_STAMPS
     unsigned long long hs0 = 0, hs1 = 0, hs2 = 0, hn = 0;
@@ -335,7 +479,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
         HSTAMP(a1);
         turn += HN;
         T = Tn;
-        sw_load(P, sd, T, S, hq);
+        sw_load2(P, sd, T, S, hq);
         HSTAMP(a2);
 #ifdef QTOS_STAMPS
         hs0 += a1 - a0; hs1 += a2 - a1; hn += 1;
@@ -357,7 +501,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
     for (; turn < P.sw_steps; turn += HN) {   // rounds the schedule could not place earlier (x is complete)
       sw_row(P, sd, T, S, xp, hq, P.sw_tasks + (size_t)turn * SW_ROUND + hr);
       T = task(turn + HN);
-      sw_load(P, sd, T, S, hq);
+      sw_load2(P, sd, T, S, hq);
     }
     return;
   }
@@ -365,7 +509,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
   for (int d = 0; d < SWD; ++d) fetch(NS - 1 - d, word_of(NS - 1 - d), bv[d], bam[d], bw[d], bps[d], bun[d]);
   double corr = 0.0;
 #ifdef QTOS_STAMPS
-  unsigned long long cs[4] = {0, 0, 0, 0};
+  unsigned long long cs[4] = {0, 0, 0, 0}, wk = 0;
 #endif
   lds_barrier();
   for (int k0 = NS - 1; k0 >= 0; k0 -= SWD) {
@@ -374,9 +518,9 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
       const int t = k0 - d, dn = (d + 1) % SWD;   // stage of the chain; ring slot of stage t - 1
 #ifdef QTOS_STAMPS
       unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-      if (wv == 0) HSTAMP(c0);
+      HSTAMP(c0);
 #endif
-      const unsigned wnext = word_of(t - SWD);    // (for the prefetch at the end of the step)
+      const unsigned wnext = EARLY ? word_of(t - SWD) : 0u;    // (for the prefetch at the end of the step)
       if (wv == 0) {
         double r16[NT];                           // (the partial sums of waves 1 .. NT)
 #pragma unroll
@@ -391,8 +535,10 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
         if (lane < PIV && t >= 0) {
           xs[bps[d]] = x;
           xp[t * PIV + lane] = x;        // by position, for the helper waves (ds = Ji dx)
+#ifndef QTOS_EXP_CHAIN
           sol[t * PIV + lane] = x;       // by unknown position, multipliers included (k_residual)
           if (bun[d] >= 0 && bun[d] < n) dx[bun[d]] = x;
+#endif
         }
         // the block of stage t - 1 against the entries just found
         double c[4];
@@ -417,11 +563,16 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
         if (lane < PIV) red[((t - 1) & 1) * 256 + wv * PIV + j] = t >= 1 ? pp : 0.0;
       }
       // ring slot d is free: wave 0 has used the stage's w, slots and unknowns above, the row waves its rows a step ago
-      fetch(t - SWD, wnext, bv[d], bam[d], bw[d], bps[d], bun[d]);
+#ifdef QTOS_EXP_CHAIN
+      if (wv != 0)
+#endif
+      if (EARLY) fetch(t - SWD, wnext, bv[d], bam[d], bw[d], bps[d], bun[d]);
 #ifdef QTOS_STAMPS
-      if (wv == 0) HSTAMP(c3);
+      HSTAMP(c3);
+      wk += c3 - c0;
 #endif
       lds_barrier();
+      if (!EARLY) fetch(t - SWD, word_of(t - SWD), bv[d], bam[d], bw[d], bps[d], bun[d]);
 #ifdef QTOS_STAMPS
       if (wv == 0) { HSTAMP(c4); cs[0] += c1 - c0; cs[1] += c2 - c1; cs[2] += c3 - c2; cs[3] += c4 - c3; }
 #endif
@@ -429,8 +580,10 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
   }
 #ifdef QTOS_STAMPS
   if (sd.dbg && wv == 0 && lane == 0) for (int i = 0; i < 4; ++i) sd.dbg[4 + i] = (double)cs[i] / (double)NS;
+  if (sd.dbg && lane == 0) sd.dbg[8 + wv] = (double)wk / (double)NS;
 #endif
 }
+
 
 
 template <int F, bool CONT>
@@ -979,7 +1132,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     for (int i = tid; i < NS * 4; i += KT2) nxp[i] = P.nxt_pack[i];
     for (int i = tid; i < NS * 8; i += KT2) nxp[NS * 4 + i] = (int)P.amask2[i];
     __syncthreads();
-    const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons, W.trace ? W.trace + ((size_t)b * (P.max_iter + 1) + 66) * 4 : nullptr};
+    const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons, W.trace ? W.trace + ((size_t)b * (P.max_iter + 1) + 64) * 4 : nullptr};
     sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane, lds + ((LY::PB + NS * 6 + 1) & ~1), sd);
   }
 #ifdef QTOS_STAMPS
@@ -1096,8 +1249,8 @@ __global__ __launch_bounds__(KTC) void k_chord(DevPlan P, DevWork W, int B) {
     }
   }
   __syncthreads();   // the w entries written above are read back below (same workgroup: visible after the barrier)
-  const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons, W.trace ? W.trace + ((size_t)b * (P.max_iter + 1) + 66) * 4 : nullptr};
-  sweep_backward<F>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane, (double *)(nxp + ((NS * 12 + 3) & ~3)), sd);
+  const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons, W.trace ? W.trace + ((size_t)b * (P.max_iter + 1) + 64) * 4 : nullptr};
+  sweep_backward_early<F, true>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane, (double *)(nxp + ((NS * 12 + 3) & ~3)), sd);
 }
 
 // =================================================================================================

@@ -445,9 +445,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     D.sw_steps = build_sweep_tasks(M, S, tasks, cpos, c16);
     const bool ok = D.sw_steps > 0;
     const char *e = getenv("QTOS_SWEEP_DS");
-    // (five helper waves at least -- fronts of up to 144 slots --: a helper's loads then have four steps of the chain to arrive)
-    const int nt = S.front / PIV, helpers = (15 - nt) - (nt < 12 ? 1 : 0);
-    D.sw_on = ok && D.n_iq_rows > 0 && helpers >= 5 && (e ? atoi(e) != 0 : true);
+    D.sw_on = ok && D.n_iq_rows > 0 && S.front / PIV < SW_W0 && (e ? atoi(e) != 0 : true);   // (waves 13 .. 15 must be without rows)
     TRY(p->upload(tasks, &D.sw_tasks)); TRY(p->upload(cpos, &D.sw_cpos)); TRY(p->upload(c16, &D.sw_c16));
   }
   {

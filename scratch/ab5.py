@@ -5,6 +5,7 @@ code = r'''
 import sys; sys.path.insert(0, '.')
 import numpy as np, os, hashlib
 from qtos_amd import capi, workloads
+if os.environ.get("QTOS_LIB"): capi.LIB_PATH = capi.LIB_PATH.replace("libqtos_planner.so", os.environ["QTOS_LIB"])
 from qtos_amd.config import PlannerConfig
 wl = os.environ["AB_WL"]
 gait = "trot" if wl == "trot" else "walk"

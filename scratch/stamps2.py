@@ -34,10 +34,11 @@ for b in (0, 5, NB - 1):
 print("eval_all<true> stamps:", (es / 3).round(0))
 print("eval_all<false> stamps:", (el / 3).round(0))
 
-hd = np.zeros(4); hc = np.zeros(4)
+hd = np.zeros(4); hc = np.zeros(4); hw_ = np.zeros(16)
 for b in (0, 5, NB - 1):
     t = np.zeros((cfg.max_iter + 1, 4))
     P.lib.qtos_debug_trace(P.h, b, t.ctypes.data_as(C.POINTER(C.c_double)))
-    hd += t[66]; hc += t[67]
+    hd += t[64]; hc += t[65]; hw_ += t[66:70].reshape(16)
 print("helper turn of wave 13 (last sweep): sums | loads | barrier wait per step | turns:", (hd / 3).round(0))
 print("chain wave per step (last sweep): partial sums -> x | stores + block product | prefetch | barrier:", (hc / 3).round(0))
+print("work before the barrier per step, waves 0..15 (chain, row waves):", (hw_ / 3).round(0))
