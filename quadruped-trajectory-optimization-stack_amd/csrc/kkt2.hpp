@@ -251,6 +251,21 @@ __device__ __forceinline__ void sw_row(const DevPlan &P, const SweepDs &sd, cons
   if (q == 0 && T[2] >= 0) sd.ds[T[2]] = acc + (S.g_row - S.s_row);
 }
 
+// The rounds the schedule could not place inside the sweep (a transcription with more rows than 16 per stage): the solution
+// is complete, every wave of the workgroup takes rounds (the helper waves alone go through them one memory latency at a time).
+// k_chord only (sweep_backward_early): any change to the text of sweep_backward has moved k_kkt2 / k_kkt3 by +1 % per launch
+// in the A/B of libraries (profiles/r04_experiments/sweep_variants.log), this one included.
+template <bool UNCLAMPED>
+__device__ __forceinline__ void sw_tail(const DevPlan &P, const SweepDs &sd, const swi4_t *swt, const double *xp, int nstep, int wv, int lane) {
+  const int hq = lane & 3, hr = lane >> 2;
+  for (int r = nstep + wv; r < P.sw_steps; r += 16) {
+    const swi4_t T = swt[r * SW_ROUND + hr];
+    SwSlot S;
+    if (UNCLAMPED) sw_load2(P, sd, T, S, hq); else sw_load(P, sd, T, S, hq);
+    sw_row(P, sd, T, S, xp, hq, P.sw_tasks + (size_t)r * SW_ROUND + hr);
+  }
+}
+
 template <int F>
 __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *__restrict__ panel, double *__restrict__ dx,
                                                double *__restrict__ sol, double *xs, double *red, const int *nxp, int wv, int lane,
@@ -447,6 +462,7 @@ __device__ __forceinline__ void sweep_backward_early(const DevPlan &P, const dou
       for (int k0 = NS - 1; k0 >= 0; k0 -= SWD)
 #pragma unroll
         for (int d = 0; d < SWD; ++d) lds_barrier();
+      if (HELP && P.sw_on) sw_tail<true>(P, sd, swt, xp, ((NS + SWD - 1) / SWD) * SWD, wv, lane);
       return;
     }
     // round i (16 rows) runs in step i of the chain (stage NS - 1 - i); the planner's schedule puts a block's rows behind
@@ -498,11 +514,7 @@ __device__ __forceinline__ void sweep_backward_early(const DevPlan &P, const dou
 #ifdef QTOS_STAMPS
     if (sd.dbg && wv == 13 && lane == 0) { sd.dbg[0] = (double)hs0 / (double)hn; sd.dbg[1] = (double)hs1 / (double)hn; sd.dbg[2] = (double)hs2 / (double)nstep; sd.dbg[3] = (double)hn; }
 #endif
-    for (; turn < P.sw_steps; turn += HN) {   // rounds the schedule could not place earlier (x is complete)
-      sw_row(P, sd, T, S, xp, hq, P.sw_tasks + (size_t)turn * SW_ROUND + hr);
-      T = task(turn + HN);
-      sw_load2(P, sd, T, S, hq);
-    }
+    sw_tail<true>(P, sd, swt, xp, nstep, wv, lane);
     return;
   }
 #pragma unroll
@@ -582,6 +594,7 @@ __device__ __forceinline__ void sweep_backward_early(const DevPlan &P, const dou
   if (sd.dbg && wv == 0 && lane == 0) for (int i = 0; i < 4; ++i) sd.dbg[4 + i] = (double)cs[i] / (double)NS;
   if (sd.dbg && lane == 0) sd.dbg[8 + wv] = (double)wk / (double)NS;
 #endif
+  if (HELP && P.sw_on) sw_tail<true>(P, sd, swt, xp, ((NS + SWD - 1) / SWD) * SWD, wv, lane);
 }
 
 

@@ -9,7 +9,8 @@ if os.environ.get("QTOS_LIB"): capi.LIB_PATH = capi.LIB_PATH.replace("libqtos_pl
 from qtos_amd.config import PlannerConfig
 wl = os.environ["AB_WL"]
 gait = "trot" if wl == "trot" else "walk"
-cfg = PlannerConfig.knots100(gait=gait) if gait != "walk" else PlannerConfig.knots100()
+mk = getattr(PlannerConfig, os.environ.get("AB_CFG", "knots100"))
+cfg = mk(gait=gait) if gait != "walk" else mk()
 mid = None
 if wl == "exp5": ter = workloads.exp5_terrain(); s, g = workloads.step_goals(256, 1, ter)
 elif wl == "mixed": ter = workloads.mixed_terrains(); s, g, mid = workloads.mixed_goals(256, 2, ter)
