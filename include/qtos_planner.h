@@ -98,6 +98,12 @@ const char *qtos_last_error(const QtosPlanner *p);
 /* Host-only structure analysis (no GPU needed): the dimensions a planner built from `params`
  * would have; stage_active (may be NULL) receives the populated front size of each stage. */
 int qtos_analyze(const QtosParams *params, QtosDims *dims, int *stage_active, int max_stages);
+/* Host-only: the schedule by which the idle waves of the KKT kernels' backward sweep form the slack steps ds = Ji dx
+ * (round 4; replaces a pass of the line-search kernel).  Per place of a round (16 places per round; round i runs while
+ * the sweep solves stage n_stages - 1 - i): constraint row (-1: empty), entries of the row, smallest / largest position
+ * of its columns in elimination order.  Arrays may be NULL.  0, or -4: no schedule for this transcription, -5: the packed
+ * copy of the column positions disagrees with the list. */
+int qtos_analyze_sweep(const QtosParams *params, int *n_rounds, int *rows, int *entries, int *pos_min, int *pos_max, int max_places);
 
 /* Terrain side channel.  Replaces `docker cp towr_heightfield.txt <id>:...`
  * (QTOS/utils.py:21-22; scripts/main.py:77-78; QTOS/generateHeightField.py:276-279).

@@ -665,6 +665,39 @@ int qtos_analyze(const QtosParams *params, QtosDims *d, int *stage_active, int m
   return 0;
 }
 
+// Host-only: the schedule the helper waves of the backward sweep follow (build_sweep_tasks).  Per place of a round (16 per
+// round, round i runs in step i of the chain, i.e. while it solves stage n_stages - 1 - i): the constraint row (-1: empty),
+// the row's entries, and the smallest and largest position (elimination order) of the row's columns.
+int qtos_analyze_sweep(const QtosParams *params, int *n_rounds, int *rows, int *entries, int *pos_min, int *pos_max, int max_places) {
+  if (!params || !n_rounds) return -1;
+  HostModel M;
+  Symbolic S;
+  if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
+  if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
+  std::vector<SwTask> tasks;
+  std::vector<int> cpos, c16;
+  *n_rounds = build_sweep_tasks(M, S, tasks, cpos, c16);
+  if (*n_rounds <= 0) return -4;
+  for (int i = 0; i < *n_rounds * SW_ROUND && i < max_places; ++i) {
+    const SwTask &t = tasks[i];
+    int lo = INT_MAX, hi = -1;
+    for (int a = 0; a < t.n && t.row >= 0; ++a) { lo = std::min(lo, cpos[t.cpos_off + a]); hi = std::max(hi, cpos[t.cpos_off + a]); }
+    if (rows) rows[i] = t.row;
+    if (entries) entries[i] = t.row >= 0 ? t.n : 0;
+    if (pos_min) pos_min[i] = t.row >= 0 ? lo : -1;
+    if (pos_max) pos_max[i] = hi;
+    // the 16-bit copy of the positions the lanes read must say the same as the list
+    if (t.row >= 0)
+      for (int q = 0; q < 4; ++q)
+        for (int u = 0; u < SW_RU; ++u) {
+          const int n4 = t.n & ~3, e = std::max(std::min(q + 4 * u, n4 - 4 + q), 0);
+          const unsigned w = (unsigned)c16[t.c16_off + 4 * q + (u >> 1)];
+          if ((int)((w >> (16 * (u & 1))) & 0xffffu) != cpos[t.cpos_off + std::min(e, t.n - 1)]) return -5;
+        }
+  }
+  return 0;
+}
+
 int qtos_set_heightfields(QtosPlanner *p, int n_maps, const double *height, int hnx, int hny,
                           double cell, double x0, double y0) {
   if (!p) return -1;

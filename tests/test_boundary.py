@@ -7,6 +7,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN, ROOT
 
@@ -124,6 +125,36 @@ def test_knots200_structure(hip_lib):
     assert (dr.n_vars, dr.n_cons) == (3160, 4558) and actr.max() <= dr.front == 128 and dr.n_stages == 208
     d2, _ = capi.analyze(PlannerConfig.knots100(duration=10.0, reduce_base=False))
     assert d2.front > 128
+
+
+@pytest.mark.parametrize("which", ["knots100", "trot", "knots200", "reference_compat", "duration12", "full_system"])
+def test_sweep_schedule_of_the_slack_steps(which):
+    """The schedule by which the idle waves of the backward sweep form ds = Ji dx (qtos_planner.hip build_sweep_tasks; the
+    reference has no counterpart: Ipopt forms J d inside its line search).  Host-only invariants: every inequality row of
+    the working set exactly once; a row runs no earlier than the step behind the one that solves the stage of its earliest
+    column -- every column of the row is then known, positions never decrease along the sweep --; the 16-bit copy of the
+    column positions agrees with the list (checked inside the call)."""
+    import dataclasses
+    from qtos_amd import capi
+    from qtos_amd.config import PlannerConfig
+    cfg = {"knots100": PlannerConfig.knots100(), "trot": PlannerConfig.knots100(gait="trot"), "knots200": PlannerConfig.knots200(),
+           "reference_compat": PlannerConfig.reference_compat(), "duration12": PlannerConfig.reference_compat(reduce_base=True, duration=12.0),
+           "full_system": dataclasses.replace(PlannerConfig.knots100(), reduce_base=False)}[which]
+    d, _ = capi.analyze(cfg)
+    rows, entries, pos_min, pos_max = capi.analyze_sweep(cfg)
+    live = rows >= 0
+    assert live.sum() > 0 and len(np.unique(rows[live])) == live.sum()          # each row once
+    assert rows.shape[0] >= d.n_stages                                        # a round per step of the chain at least
+    step = np.repeat(np.arange(rows.shape[0])[:, None], 16, axis=1)
+    stage_of_first_col = pos_min // 16
+    assert (step[live] >= d.n_stages - stage_of_first_col[live]).all()        # behind the step that solves that stage
+    assert (pos_max[live] < 16 * d.n_stages).all() and (entries[live] >= 1).all()
+    assert not live[0].any()                                                  # nothing is known in the first step
+    # rows of one round belong to one stage, and the stages come in the order the sweep meets them
+    st = np.where(live, stage_of_first_col, -1).max(axis=1)
+    assert all((stage_of_first_col[i][live[i]] == st[i]).all() for i in range(rows.shape[0]))
+    seq = st[st >= 0]
+    assert (np.diff(seq) <= 0).all()
 
 
 def test_bad_parameters_are_rejected(hip_lib, cfg):
