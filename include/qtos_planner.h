@@ -173,6 +173,9 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
  *                            (measured slower than one lock-step loop at 1024 problems per call)
  *   QTOS_SHORT_STAGES=1 / QTOS_NO_SHORT_STAGES=1   stage boundaries by dynamic programming for every front size / never
  *                            (default: only where they take a 16-slot group off a front above 128 slots)
+ *   QTOS_KRON=1              experiment (128-slot fronts, k_kkt2 only): the range-of-motion blocks are assembled through their
+ *                            Kronecker structure -- 33 sums per block and one product of static weights per entry instead of a
+ *                            three-term sum per entry; plans equal to rounding (1e-8), -0.4 % per launch: off by default
  *   QTOS_SWEEP_DS=0          k_step forms the slack steps ds = Ji dx + (g - s) itself (default 1: three waves that idle in the
  *                            backward sweep of the KKT kernels form them, block by block behind the stage that solves the
  *                            block's earliest column; bit-identical plans)

@@ -131,6 +131,7 @@ struct DevPlan {
   int n_maps, hnx, hny, terrain_mode;
   double hcell, hx0, hy0;
   long long g_doubles, panel_stride;  // per problem
+  int kron_lds_off;            // k_kkt2<F, CONT, true>: byte offset of the Kronecker scratch (33 doubles per block of a record) in its LDS
 };
 
 struct DevWork {
@@ -1037,6 +1038,71 @@ __device__ __forceinline__ double gather_term(const double *dbuf, int code) {
     }
   }
   return acc;
+}
+// ---- Kronecker blocks (Symbolic::kron, k_kkt2<F, CONT, true>) -----------------------------------------------------
+// The 33 sums of every Kronecker block of a record: lane t < 33 of a wave forms entry t of the blocks widx, widx + nw, ...
+// (entries 0..26: T'[mu nu][d][e] = sum_i sig_i G[i][rep(mu, d)] G[i][rep(nu, e)]; 27..32: V'[mu][d] = sum_i G[i][rep(mu, d)] w_i)
+__device__ __forceinline__ void kron_sums(const int *sbuf, const double *dbuf, double *ksm, int widx, int nw, int lane) {
+  const int koff = sbuf[2] >> 9, nk = (sbuf[2] >> 5) & 15;
+  if (nk == 0 || lane >= 33) return;
+  const int *ks = sbuf + koff;
+  const int t = lane;
+  int mu, nu, d, e;
+  if (t < 9) { mu = nu = 0; d = t / 3; e = t % 3; }
+  else if (t < 18) { mu = 0; nu = 1; d = (t - 9) / 3; e = (t - 9) % 3; }
+  else if (t < 27) { mu = nu = 1; d = (t - 18) / 3; e = (t - 18) % 3; }
+  else { mu = nu = (t - 27) / 3; d = e = (t - 27) % 3; }
+  const int sh1 = 5 * (3 * mu + d), sh2 = 5 * (3 * nu + e);
+  for (int kb = widx; kb < nk; kb += nw) {
+    const int *bd = ks + kb * 22;
+    const int goff = bd[0] & 4095, n = ((bd[0] >> 12) & 31) + 1, reps = bd[1];
+    const int c1 = (reps >> sh1) & 31, c2 = (reps >> sh2) & 31;
+    const double *Gb = dbuf + goff, *sg = Gb + 3 * n, *wq = sg + 3;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double g1 = Gb[i * n + c1], g2 = Gb[i * n + c2], sv = sg[i], wv = wq[i];
+      acc += t < 27 ? sv * g1 * g2 : g1 * wv;
+    }
+    ksm[kb * 33 + t] = acc;
+  }
+}
+// one Kronecker contribution: rho_a rho_c T' (an entry of G' S G) or -rho_a V' (of the right-hand side -G' w)
+__device__ __forceinline__ double kron_term(const int *ks, const double *ksm, int code) {
+  const int t = code & 63, kb = (code >> 6) & 15, ga = (code >> 12) & 15, gc = (code >> 24) & 15;
+  const double *rho = (const double *)(ks + kb * 22 + 2);
+  const double v = ksm[kb * 33 + t], ra = ga == 15 ? 1.0 : rho[min(ga, 9)], rc = gc == 15 ? 1.0 : rho[min(gc, 9)];
+  return t >= 27 ? -(ra * v) : ra * rc * v;
+}
+__device__ __forceinline__ void assemble_stage_kron(double *A, int F, const int *sbuf, const double *dbuf, const double *ksm, int t0, int nth) {
+  const int n_ent = sbuf[0], n_rhs = sbuf[1];
+  const int *eidx = sbuf + SHDR + PIV;
+  const double *eval = dbuf + PIV;
+  for (int i = t0; i < n_ent; i += nth) A[eidx[i]] += eval[i];
+  const int *rsl = eidx + n_ent;
+  const double *rval = eval + n_ent;
+  for (int i = t0; i < n_rhs; i += nth) A[rsl[i]] += rval[i];
+  const int n_tgt = sbuf[5];
+  if (n_tgt == 0) return;
+  const int *tg = sbuf + sbuf[4];
+  const int *cl = tg + n_tgt + 1;
+  const int *ks = sbuf + (sbuf[2] >> 9);
+  for (int t = t0; t < n_tgt; t += nth) {
+    const int tv = tg[t], c0 = tv & 4095, c1 = tg[t + 1] & 4095;
+    const double a_old = A[tv >> 12];
+    double acc = 0;
+    int j = c0;
+    // a target's Kronecker contributions come first in its list: a loop of their own (a wave runs both kinds of a mixed
+    // round one after the other)
+    for (;;) {
+      const int code = cl[min(j, c1 - 1)];
+      const bool kk = j < c1 && ((code >> 18) & 63) == 61;
+      if (__builtin_amdgcn_ballot_w64(kk) == 0ull) break;
+      if (kk) { acc += kron_term(ks, ksm, code); ++j; }
+    }
+    for (; j < c1; ++j) acc += gather_term(dbuf, cl[j]);
+    A[tv >> 12] = a_old + acc;
+  }
 }
 __device__ __forceinline__ void assemble_stage(double *A, int F, const int *sbuf, const double *dbuf, int t0, int nth) {
   const int n_ent = sbuf[0], n_rhs = sbuf[1], n_iq = sbuf[2];

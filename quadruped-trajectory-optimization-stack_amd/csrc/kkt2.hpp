@@ -599,7 +599,7 @@ __device__ __forceinline__ void sweep_backward_early(const DevPlan &P, const dou
 
 
 
-template <int F, bool CONT>
+template <int F, bool CONT, bool KRON = false>
 __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   const int b = blockIdx.x;
   if (b >= B || W.done[b] || W.chord[b] == 1) return;   // (a problem flagged for a chord step is k_chord's)
@@ -617,6 +617,7 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   // one 32-bit read gives a lane the four rows of a tile it holds
   unsigned char *jmb = (unsigned char *)jm;
   double *Minv = lds + LY::MIV;
+  double *ksm = (double *)((char *)lds + (KRON ? P.kron_lds_off : 0));   // KRON: the 33 sums of the Kronecker blocks of the record about to be assembled
   // record buffers: [dbuf 0][dbuf 1][sbuf 0][sbuf 1] with DMA (record s lives in buffer s & 1), one of each without
   constexpr bool DMA = F <= 128;
   constexpr int NBUF = DMA ? 2 : 1;
@@ -735,7 +736,9 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
   load_records(0);
   __syncthreads();
   header_from_lds(0);
+  if constexpr (KRON) kron_sums(sbuf, dbuf, ksm, wv, 16, lane);
   __syncthreads();
+  if constexpr (KRON) assemble_stage_kron(A, F, sbuf, dbuf, ksm, tid, KT2); else
   assemble_stage(A, F, sbuf, dbuf, tid, KT2);
   assemble_continuations(tid, KT2);
   __syncthreads();
@@ -762,8 +765,13 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     load_records(s);
     __syncthreads();
     header_from_lds(s);
+    if constexpr (KRON) { if (s == 1) kron_sums(sbuf, dbuf, ksm, wv, 16, lane); }
     __syncthreads();
-    if (s == 1) { assemble_stage(A, F, sbuf, dbuf, tid, KT2); assemble_continuations(tid, KT2); }
+    if (s == 1) {
+      if constexpr (KRON) assemble_stage_kron(A, F, sbuf, dbuf, ksm, tid, KT2); else
+      assemble_stage(A, F, sbuf, dbuf, tid, KT2);
+      assemble_continuations(tid, KT2);
+    }
     __syncthreads();
   }
 
@@ -922,6 +930,10 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
           }
         }
       }
+      else if (KRON && LY::VP) {
+        // the waves that idle in this phase: the 33 sums of the Kronecker blocks of the records of stage k+2 (assembled in C(k))
+        if (k + 2 < NS) kron_sums(sbuf, dbuf, ksm, sv - 1, NSV - 1, lane);
+      }
       else if (!LY::VP && sv < NT) {
         // Y = P L^-T of row tile R = sv for its tile wave
         const int R = sv;
@@ -1067,6 +1079,12 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
     // take FREEW shares each
     constexpr int FREEW = NU == 12 ? QTOS_ASM_FREEW : 1, NFREE = 15 - NU, NVIRT = NASM + NFREE * (FREEW - 1);
     if (wv >= 1 && k + 2 < NS && apos < NASM) {
+      if constexpr (KRON) {
+        if (apos < NFREE) {
+#pragma unroll
+          for (int f = 0; f < FREEW; ++f) assemble_stage_kron(A, F, sbuf, dbuf, ksm, (apos * FREEW + f) * 64 + lane, NVIRT * 64);
+        } else assemble_stage_kron(A, F, sbuf, dbuf, ksm, (apos + NFREE * (FREEW - 1)) * 64 + lane, NVIRT * 64);
+      } else
       if (apos < NFREE) {
 #pragma unroll
         for (int f = 0; f < FREEW; ++f) assemble_stage(A, F, sbuf, dbuf, (apos * FREEW + f) * 64 + lane, NVIRT * 64);

@@ -108,7 +108,8 @@ struct QtosPlanner {
 // k_kkt is compiled once per front size (multiples of 16 up to 128): the LDS layout and every tile
 // loop bound are compile-time constants
 // k_kkt2 (16 waves per problem): fronts up to 208 slots
-static void (*kkt2_kernel(int F, bool cont))(DevPlan, DevWork, int) {
+static void (*kkt2_kernel(int F, bool cont, bool kron = false))(DevPlan, DevWork, int) {
+  if (kron && !cont && F == 128) return k_kkt2<128, false, true>;   // (the Kronecker assembly: the benchmark's front only)
 #define QTOS_KKT2(f) case f: return cont ? k_kkt2<f, true> : k_kkt2<f, false>;
   switch (F) {
     QTOS_KKT2(16) QTOS_KKT2(32) QTOS_KKT2(48) QTOS_KKT2(64) QTOS_KKT2(80) QTOS_KKT2(96) QTOS_KKT2(112) QTOS_KKT2(128)
@@ -291,6 +292,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
       if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: k_kkt3 MODE %d %s (%s)\n", p->kkt3_mode, ok ? "selected" : "not applicable", p->S.err.c_str());
     }
   }
+  bool want_kron = getenv("QTOS_KRON") && atoi(getenv("QTOS_KRON")) != 0;   // (experiment: Kronecker assembly of the range-of-motion blocks, k_kkt2<128> only)
   for (int cap : {0, 4096, 3072, 2048}) {
     if (p->use_kkt3) break;
     p->M = HostModel();
@@ -298,7 +300,22 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
     p->S.cell_mode = 2;
     p->S.rec_cap_ints = cap;
+    p->S.kron = want_kron;
     if (p->S.build(p->M)) { fprintf(stderr, "qtos: %s\n", p->S.err.c_str()); delete p; return -1; }
+    if (p->S.kron) {
+      // the Kronecker assembly needs the benchmark's shape: a 128-slot front, no continuation records, its scratch within the LDS
+      int n_cont = 0;
+      for (int k = 0; k < p->S.n_stages; ++k) n_cont += p->S.srec[p->S.srec_off[k] + 6];
+      const size_t need = kkt2_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) + 16 + sizeof(double) * Symbolic::KRON_SM * (size_t)p->S.max_kblocks;
+      if (p->S.front != 128 || n_cont != 0 || p->S.max_kblocks == 0 || need > 160 * 1024 - 256) {
+        if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: Kronecker assembly not applicable (front %d, %d continuation records, %zu B of LDS)\n", p->S.front, n_cont, need);
+        want_kron = false;
+        p->M = HostModel(); p->S = Symbolic();
+        if (p->M.build(*params)) { delete p; return -1; }
+        p->S.cell_mode = 2; p->S.rec_cap_ints = cap;
+        if (p->S.build(p->M)) { delete p; return -1; }
+      }
+    }
     if (kkt2_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) <= 160 * 1024 - 256) break;
   }
   const HostModel &M = p->M;
@@ -487,6 +504,12 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   // LDS budget of k_kkt
   const int F = S.front;
   p->kkt_lds = p->use_kkt4 ? kkt4_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : p->use_kkt3 ? kkt3_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
+  D.kron_lds_off = 0;
+  if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: Kronecker assembly %s (kkt3 %d, most blocks in a record %d)\n", S.kron ? "on" : "off", (int)p->use_kkt3, S.max_kblocks);
+  if (S.kron && !p->use_kkt3 && !p->use_kkt4) {
+    D.kron_lds_off = (int)((p->kkt_lds + 15) & ~(size_t)15);
+    p->kkt_lds = (size_t)D.kron_lds_off + sizeof(double) * Symbolic::KRON_SM * (size_t)S.max_kblocks;
+  }
   if (D.sw_on) {
     // the helper waves' tables of the backward sweep (solution by position, rounds) behind the sweep's own: within the LDS
     // the forward pass needs anyway, or the kernel's allocation grows up to the limit; beyond that k_step forms ds itself
@@ -510,7 +533,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     return -4;
   }
   {
-    p->kkt_fn = p->use_kkt4 ? kkt4_kernel(F) : p->use_kkt3 ? kkt3_kernel(F, p->kkt3_mode) : kkt2_kernel(F, D.n_cont > 0);
+    p->kkt_fn = p->use_kkt4 ? kkt4_kernel(F) : p->use_kkt3 ? kkt3_kernel(F, p->kkt3_mode) : kkt2_kernel(F, D.n_cont > 0, S.kron);
     p->chord_fn = chord_kernel(F);
     if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
@@ -657,7 +680,15 @@ int qtos_analyze(const QtosParams *params, QtosDims *d, int *stage_active, int m
   HostModel M;
   Symbolic S;
   if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
+  if (getenv("QTOS_DEBUG_KRON")) S.kron = true;
   if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
+  if (getenv("QTOS_DEBUG_KRON")) {
+    int nb = 0;
+    const double worst = S.check_kron(&nb);
+    size_t tot = 0;
+    for (const Block &b : M.blocks) tot += b.kind == 1;
+    fprintf(stderr, "qtos: Kronecker blocks %d of %zu inequality blocks, most in a record %d, worst relative difference %.2e, max record %d ints / %d doubles\n", nb, tot, S.max_kblocks, worst, S.max_srec, S.max_drec);
+  }
   fill_dims(M, S, d);
   if (getenv("QTOS_DEBUG_SYMBOLIC")) { std::vector<SwTask> t; std::vector<int> c, c2; (void)build_sweep_tasks(M, S, t, c, c2); }
   if (stage_active)

@@ -16,6 +16,8 @@
 #include <array>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
+#include <cstring>
 #include <map>
 #include <set>
 #include <numeric>
@@ -64,8 +66,26 @@ struct IqBlock {
   int m, n, row0, gloc /* offset inside the stage's G slice */, slot_off, pad0, pad1, pad2;
 };
 
+// Kronecker structure of a range-of-motion block (Symbolic::kron): every column of G is a static multiple of a column of
+// one of two 3 x 3 matrices -- G[i][col] = alpha_col M_mu[i][d], M_0 = R^T (base position and foot columns), M_1 = d(R^T (p - r))/d theta
+// (kernels.hpp eval_rom, Symbolic::build_linear_terms) --, so G' S G [a][c] = rho_a rho_c T'[mu_a mu_c][d_a][d_c] with the 27
+// entries T' = (three-term sums over a representative column per (mu, d)) and rho = alpha / alpha of the representative,
+// and the right-hand side -G' w [a] = -rho_a V'[mu_a][d_a].  33 sums per block instead of 405 per block.
+struct KMeta {
+  bool ok = false;
+  unsigned char mu[32], d[32], grp[32];   // per local column
+  int rep[6];                             // representative column of (mu, d): index 3 mu + d
+  double rho[12];                         // per group
+  double alpha[32];                       // per local column (host-side checks)
+  int n_grp = 0;
+};
+
 struct Symbolic {
   int n_unknowns = 0, n_free = 0, n_eq = 0, n_stages = 0, front = 0;
+  bool kron = false;                 // range-of-motion blocks of the main records assembled through their Kronecker structure (QTOS_KRON)
+  std::vector<KMeta> iq_kron;        // parallel to iq_blocks
+  int max_kblocks = 0;               // most Kronecker blocks in one record (LDS scratch of the kernel: 33 doubles each)
+  static constexpr int KRON_SM = 33, KRON_STRIDE = 22, KRON_MAXB = 15;
   // Short stages (round 4): stage boundaries need not fall on multiples of 16 unknowns.  Where a partition into stages of at
   // most 16 pivots exists whose largest front is a whole 16-slot group smaller than the uniform partition's at no more stages
   // (found by dynamic programming over the boundaries; the 100-knot walk: 112 slots instead of 128, two short stages), the
@@ -222,6 +242,130 @@ struct Symbolic {
   int REC_MAX_DOUBLES = 2048, REC_MAX_INTS = 6144;
   int rec_cap_ints = 0;   // optional upper limit of a record's ints (qtos_planner_create retries with smaller records if the LDS budget is exceeded)
   std::vector<int> cont;   // continuation records: {srec offset, ints, stream offset, doubles} each
+  // Kronecker structure of block bi if it belongs to a range-of-motion instance (the instances hold their block id in .goff
+  // until HostModel::finalize_goff)
+  KMeta kron_meta(const HostModel &M, int bi) const {
+    KMeta K;
+    const Block &b = M.blocks[bi];
+    if (b.kind != 1 || b.m != 3 || b.n > 32) return K;
+    int inst = -1;
+    for (size_t k = 0; k < M.rom.size(); ++k)
+      if (M.rom[k].goff == bi) { inst = (int)k; break; }
+    if (inst < 0) return K;
+    const RomInst &I = M.rom[inst];
+    const HostModel::BaseIn &Bi = M.rom_sol[inst];
+    double alpha[32];
+    int kind[32];
+    for (int c = 0; c < b.n; ++c) { alpha[c] = 0.0; kind[c] = -1; K.d[c] = 0; K.mu[c] = 0; K.grp[c] = 0; }
+    auto add = [&](const short cmap[12], const VecIn &in, int kd, double sgn) {
+      for (int sidx = 0; sidx < 4; ++sidx)
+        for (int d = 0; d < 3; ++d) {
+          const int c = cmap[3 * sidx + d];
+          if (c < 0 || c >= b.n) continue;
+          if (kind[c] >= 0 && (kind[c] != kd || K.d[c] != d)) { kind[c] = 99; continue; }   // a column with two roles: no structure
+          kind[c] = kd; K.d[c] = (unsigned char)d; K.mu[c] = kd == 1 ? 1 : 0;
+          alpha[c] += sgn * in.w[sidx];
+        }
+    };
+    add(I.c_lin, Bi.r, 0, -1.0);
+    add(I.c_ang, Bi.th, 1, 1.0);
+    add(I.c_p, I.p, 2, 1.0);
+    for (int c = 0; c < b.n; ++c)
+      if (kind[c] < 0 || kind[c] == 99 || alpha[c] == 0.0) return K;
+    // groups: columns of one kind with one weight
+    double galpha[12];
+    int gkind[12];
+    for (int c = 0; c < b.n; ++c) {
+      int g = -1;
+      for (int j = 0; j < K.n_grp; ++j)
+        if (gkind[j] == kind[c] && galpha[j] == alpha[c]) { g = j; break; }
+      if (g < 0) {
+        if (K.n_grp == 12) return K;
+        g = K.n_grp++;
+        gkind[g] = kind[c]; galpha[g] = alpha[c];
+      }
+      K.grp[c] = (unsigned char)g;
+    }
+    // representatives: per mu the group of largest |alpha| with all three dimensions among the block's columns
+    double ralpha[2] = {0.0, 0.0};
+    for (int i = 0; i < 6; ++i) K.rep[i] = -1;
+    for (int mu = 0; mu < 2; ++mu) {
+      int best = -1;
+      for (int g = 0; g < K.n_grp; ++g) {
+        if ((gkind[g] == 1 ? 1 : 0) != mu) continue;
+        bool have[3] = {false, false, false};
+        for (int c = 0; c < b.n; ++c)
+          if (K.grp[c] == g) have[K.d[c]] = true;
+        if (have[0] && have[1] && have[2] && (best < 0 || std::fabs(galpha[g]) > std::fabs(galpha[best]))) best = g;
+      }
+      bool any = false;
+      for (int g = 0; g < K.n_grp; ++g) any |= (gkind[g] == 1 ? 1 : 0) == mu;
+      if (best < 0) { if (any) return K; continue; }   // (columns of this mu without a full representative: old path)
+      ralpha[mu] = galpha[best];
+      for (int c = 0; c < b.n; ++c)
+        if (K.grp[c] == best) K.rep[3 * mu + K.d[c]] = c;
+    }
+    // the representatives' groups have rho = 1 and no table entry (index 15); the others are renumbered 0 .. 9
+    int repg[2] = {-1, -1};
+    for (int mu = 0; mu < 2; ++mu)
+      if (K.rep[3 * mu] >= 0) repg[mu] = K.grp[K.rep[3 * mu]];
+    int renum[12], n_tab = 0;
+    for (int g = 0; g < K.n_grp; ++g) renum[g] = (g == repg[0] || g == repg[1]) ? 15 : n_tab++;
+    if (n_tab > 10) return K;
+    for (int g = 0; g < 12; ++g) K.rho[g] = 0.0;
+    for (int g = 0; g < K.n_grp; ++g)
+      if (renum[g] != 15) K.rho[renum[g]] = galpha[g] / ralpha[gkind[g] == 1 ? 1 : 0];
+    for (int c = 0; c < b.n; ++c) K.grp[c] = (unsigned char)renum[K.grp[c]];
+    K.n_grp = n_tab;
+    for (int c = 0; c < 32; ++c) K.alpha[c] = c < b.n ? alpha[c] : 0.0;
+    K.ok = true;
+    return K;
+  }
+  // host-side check of the structure (QTOS_DEBUG_KRON): random matrices and weights, every entry of G' S G and of G' w through
+  // the 33 sums against the direct three-term sums; returns the largest relative difference
+  double check_kron(int *n_blocks) const {
+    double worst = 0.0;
+    unsigned rng = 12345u;
+    auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) & 0xffff) / 65536.0 - 0.5; };
+    *n_blocks = 0;
+    for (size_t q = 0; q < iq_blocks.size(); ++q) {
+      const KMeta &K = iq_kron[q];
+      if (!K.ok) continue;
+      ++*n_blocks;
+      const int n = iq_blocks[q].n;
+      double Mm[2][3][3], sg[3], w[3], G[3][32];
+      for (auto &m2 : Mm) for (auto &r : m2) for (double &v : r) v = rnd();
+      for (int i = 0; i < 3; ++i) { sg[i] = 1.0 + rnd(); w[i] = rnd(); }
+      for (int i = 0; i < 3; ++i) for (int c = 0; c < n; ++c) G[i][c] = K.alpha[c] * Mm[K.mu[c]][i][K.d[c]];
+      double T[33];
+      for (int t = 0; t < 33; ++t) {
+        int mu, nu, d, e;
+        if (t < 9) { mu = nu = 0; d = t / 3; e = t % 3; } else if (t < 18) { mu = 0; nu = 1; d = (t - 9) / 3; e = (t - 9) % 3; }
+        else if (t < 27) { mu = nu = 1; d = (t - 18) / 3; e = (t - 18) % 3; } else { mu = nu = (t - 27) / 3; d = e = (t - 27) % 3; }
+        const int c1 = K.rep[3 * mu + d], c2 = K.rep[3 * nu + e];
+        double acc = 0.0;
+        for (int i = 0; i < 3; ++i) acc += t < 27 ? (c1 >= 0 && c2 >= 0 ? sg[i] * G[i][c1] * G[i][c2] : 0.0) : (c1 >= 0 ? G[i][c1] * w[i] : 0.0);
+        T[t] = acc;
+      }
+      for (int a = 0; a < n; ++a)
+        for (int c = 0; c <= a; ++c) {
+          double direct = 0.0;
+          for (int i = 0; i < 3; ++i) direct += sg[i] * G[i][a] * G[i][c];
+          int t;
+          if (K.mu[a] == K.mu[c]) t = (K.mu[a] ? 18 : 0) + 3 * K.d[a] + K.d[c];
+          else t = 9 + (K.mu[a] == 0 ? 3 * K.d[a] + K.d[c] : 3 * K.d[c] + K.d[a]);
+          const double viaK = (K.grp[a] == 15 ? 1.0 : K.rho[K.grp[a]]) * (K.grp[c] == 15 ? 1.0 : K.rho[K.grp[c]]) * T[t];
+          worst = std::max(worst, std::fabs(viaK - direct) / (std::fabs(direct) + 1e-30));
+        }
+      for (int a = 0; a < n; ++a) {
+        double direct = 0.0;
+        for (int i = 0; i < 3; ++i) direct += G[i][a] * w[i];
+        const double viaK = (K.grp[a] == 15 ? 1.0 : K.rho[K.grp[a]]) * T[27 + 3 * K.mu[a] + K.d[a]];
+        worst = std::max(worst, std::fabs(viaK - direct) / (std::fabs(direct) + 1e-30));
+      }
+    }
+    return worst;
+  }
   // dynamic part (per block G, sig, w) and gather table of the blocks `blks` of stage k, appended to the
   // record that starts at srec[s0] / pack_src[d0]; patches the record's header ints [4], [5]
   // the longest prefix of `blks` that fits a record which already holds `dyn` doubles and `fixed` ints
@@ -243,8 +387,9 @@ struct Symbolic {
         for (int cc = 0; cc <= a; ++cc) t2.insert(trs(sa, iq_slots[Q.slot_off + cc]));
         t2.insert(front * (front + 1) / 2 + sa);
       }
+      const int kints = kron ? 2 + KRON_STRIDE * ((int)mine.size() + 1) : 0;   // (the Kronecker section, if every block had one)
       bool fits = rest.empty() && dyn < 4096 && dyn + d <= REC_MAX_DOUBLES - 2 && contrib + c < 4096 &&
-                  fixed + (int)t2.size() + 1 + contrib + c <= REC_MAX_INTS - 8;
+                  fixed + (int)t2.size() + 1 + contrib + c + kints <= REC_MAX_INTS - 8;
       if (iq_mfma) {   // (no gather table: a block costs its tables, 4 + 128 per tile + 16 ints)
         int ints = fixed + 8 + 8 + 4 * 16;
         for (int q2 : mine) ints += 32 + (iq_blocks[S.iq_begin + q2].n > 16 ? 384 : 256);
@@ -305,22 +450,67 @@ struct Symbolic {
     // launch, descending 1.130, ascending 1.110).  The order of the sums of a target does not change.
     std::vector<std::pair<int, std::vector<int>>> tlist(tmap.begin(), tmap.end());
     std::stable_sort(tlist.begin(), tlist.end(), [](const auto &a, const auto &b) { return a.second.size() < b.second.size(); });
+    // Kronecker blocks of this record (main records only): index among them, or -1
+    std::vector<int> kidx(blks.size(), -1);
+    int n_k = 0;
+    if (kron && syms)
+      for (size_t bi = 0; bi < blks.size(); ++bi)
+        if (iq_kron[S.iq_begin + blks[bi]].ok && n_k < KRON_MAXB) kidx[bi] = n_k++;
     for (auto &kv : tlist) {
       srec.push_back((kv.first << 12) | cpos);
       cpos += (int)kv.second.size();
+      std::vector<int> kc, oc;   // a target's Kronecker contributions come first (the kernel runs them as a loop of their own)
       for (int code : kv.second) {
-        if (code < 0) { codes.push_back((-code - 1) | (62 << 18)); continue; }   // static contribution
+        if (code < 0) { oc.push_back((-code - 1) | (62 << 18)); continue; }   // static contribution
         const int bi = code >> 16, a = (code >> 8) & 255, c = code & 255;
         const IqBlock &Q = iq_blocks[S.iq_begin + blks[bi]];
-        codes.push_back(blk_goff[bi] | (a << 12) | ((c == 255 ? 63 : c) << 18) | ((Q.n - 1) << 24) | (int)((unsigned)(Q.m - 1) << 29));
+        if (kidx[bi] >= 0) {
+          // [0:6) entry of the block's 33 sums | [6:10) block | [12:18) group of a | 61 << 18 | [24:28) group of c
+          const KMeta &K = iq_kron[S.iq_begin + blks[bi]];
+          int tidx, gc = 0;
+          if (c == 255) tidx = 27 + 3 * K.mu[a] + K.d[a];
+          else {
+            gc = K.grp[c];
+            if (K.mu[a] == K.mu[c]) tidx = (K.mu[a] ? 18 : 0) + 3 * K.d[a] + K.d[c];
+            else tidx = 9 + (K.mu[a] == 0 ? 3 * K.d[a] + K.d[c] : 3 * K.d[c] + K.d[a]);
+          }
+          kc.push_back(tidx | (kidx[bi] << 6) | ((int)K.grp[a] << 12) | (61 << 18) | (gc << 24));
+          continue;
+        }
+        oc.push_back(blk_goff[bi] | (a << 12) | ((c == 255 ? 63 : c) << 18) | ((Q.n - 1) << 24) | (int)((unsigned)(Q.m - 1) << 29));
       }
+      codes.insert(codes.end(), kc.begin(), kc.end());
+      codes.insert(codes.end(), oc.begin(), oc.end());
     }
     if (cpos >= 4096) { err = "gather table overflow"; return -1; }
     srec.push_back(cpos);   // sentinel: end of the last target's contributions
     srec.insert(srec.end(), codes.begin(), codes.end());
+    if (n_k > 0) {
+      // Kronecker section: per block KRON_STRIDE ints: offset of G in the dynamic record | (n - 1) << 12, the six representative
+      // columns (5 bits each), ten doubles rho (group 15 = a representative's: 1).
+      if ((srec.size() - s0) & 1) srec.push_back(0);
+      const int koff = (int)srec.size() - s0;
+      for (size_t bi = 0; bi < blks.size(); ++bi) {
+        if (kidx[bi] < 0) continue;
+        const KMeta &K = iq_kron[S.iq_begin + blks[bi]];
+        const IqBlock &Q = iq_blocks[S.iq_begin + blks[bi]];
+        srec.push_back(blk_goff[bi] | ((Q.n - 1) << 12));
+        int reps = 0;
+        for (int i = 0; i < 6; ++i) reps |= (K.rep[i] < 0 ? 0 : K.rep[i]) << (5 * i);
+        srec.push_back(reps);
+        for (int g = 0; g < 10; ++g) {
+          int w[2];
+          std::memcpy(w, &K.rho[g], 8);
+          srec.push_back(w[0]); srec.push_back(w[1]);
+        }
+      }
+      kron_off_of_record[s0] = (n_k << 5) | (koff << 9);   // (header int [2]: blocks of the record | Kronecker blocks << 5 | offset of their section << 9)
+      max_kblocks = std::max(max_kblocks, n_k);
+    }
     if (iq_mfma && emit_iq_section(S, blks, blk_goff, s0, static_list)) return -1;
     return 0;
   }
+  std::map<int, int> kron_off_of_record;   // record start -> offset of its Kronecker section (the header int [2] is set by the caller)
   // Inequality section of a record (iq_mfma), ints relative to its start:
   //   [0] number of blocks (at most 16); [1..3] number of static entries of tile type 0 / 1 / 2; [4..6] their offsets
   //   [8 .. 72)  per block {offset of G in the dynamic record, m | n << 8 | tile types present << 16, offset of its data, 0}
@@ -834,6 +1024,7 @@ struct Symbolic {
           iq_class.push_back(iq_mfma ? var_class[M.block_cols[b.col_off + a]] : 0);
         }
         iq_blocks.push_back(q);
+        iq_kron.push_back(kron ? kron_meta(M, bi) : KMeta());
         g_doubles += (long long)b.m * b.n;
       }
       S.g_len = (int)(g_doubles - S.g_begin);
@@ -964,7 +1155,7 @@ struct Symbolic {
         if (split_blocks(S, all, (int)pack_src.size() - drec_off[k], (int)srec.size() - srec_off[k], trs, mine, rest, (int)sym_of[k].size())) return -1;
       }
       if (emit_blocks(k, S, mine, srec_off[k], drec_off[k], trs, &sym_of[k])) return -1;
-      if (!iq_mfma) srec[srec_off[k] + 2] = (int)mine.size();
+      if (!iq_mfma) srec[srec_off[k] + 2] = (int)mine.size() | (kron_off_of_record.count(srec_off[k]) ? kron_off_of_record[srec_off[k]] : 0);
       pending.push_back(rest);
       max_srec = std::max(max_srec, (int)srec.size() - srec_off[k]);
       max_drec = std::max(max_drec, (int)pack_src.size() - drec_off[k]);

@@ -513,6 +513,46 @@ def test_work_moved_between_kernels_leaves_the_plans_bit_for_bit(switch, workloa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["flat", "mixed"])
+def test_kronecker_assembly_of_the_range_of_motion_blocks(workload):
+    """QTOS_KRON=1 (experiment of round 4, k_kkt2<128, false, true>): every column of a range-of-motion block's Jacobian is
+    a static multiple of a column of one of two 3 x 3 matrices (towr range_of_motion_constraint.cc: R(theta)^T (p - r)), so
+    the entries of G' S G are products of two static weights with one of 33 sums per block (Symbolic::kron_meta, kernels.hpp
+    kron_sums / kron_term) instead of three-term sums of their own.  Same iterates as the default assembly up to rounding
+    (a few 1e-8 on the nodes), same iteration counts, and the oracle's plans within the usual tolerance."""
+    from oracle.oracle import Oracle, oracle_dict
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    cfg = PlannerConfig.knots100()      # (the 128-slot front of the benchmark: the experiment's only kernel)
+    B = 64
+    mid = None
+    if workload == "flat":
+        ter = workloads.exp1_terrain(); start, goal = workloads.flat_goals(B, 5)
+    else:
+        ter = workloads.mixed_terrains(); start, goal, mid = workloads.mixed_goals(B, seed=9, terrains=ter)
+    res = {}
+    for v in ("0", "1"):
+        os.environ["QTOS_KRON"] = v
+        try:
+            P = Planner(cfg, max_batch=B)
+        finally:
+            del os.environ["QTOS_KRON"]
+        P.set_heightfields(ter[0], ter[1])
+        res[v] = P.plan(start, goal, map_id=mid)
+        P.close()
+    assert (res["1"][1] == res["0"][1]).all() and (res["1"][2] == res["0"][2]).all()
+    ok = res["0"][1] == 0
+    d = np.abs(res["1"][0][ok] - res["0"][0][ok]).max()
+    assert 0.0 < d < 1e-6, d      # (> 0: the other path did run)
+    if workload == "flat":
+        O = Oracle(oracle_dict(cfg))
+        xo, infos = _oracle_solve(O, start[:4], goal[:4])
+        assert [int(i) for i in res["1"][2][:4]] == [i[1] for i in infos]
+        assert np.abs(res["1"][0][:4] - xo).max() < 1e-6
+
+
+@pytest.mark.gpu
 def test_call_larger_than_the_gpu_is_cut_into_lanes_with_identical_plans(cfg):
     """A call of more problems than the GPU has compute units is served by several lanes of the handle (contiguous parts on
     streams of the planner, each with its own host-driven Newton loop: the late iterations of one part's stragglers run beside
