@@ -777,12 +777,14 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
 
 #ifdef QTOS_STAMPS
   // diagnostic build: per wave, cycles spent in each part of a stage (accumulated in LDS by lane 0)
-  __shared__ unsigned long long st2[16][12];
+  // (the counters live in the trace rows themselves -- fire-and-forget atomics of lane 0 --: no LDS, so that the diagnostic
+  //  build has the product's LDS layout and fits the variants that fill it)
+  unsigned long long *st2g = (unsigned long long *)(W.trace + ((size_t)b * (P.max_iter + 1) + 16) * 4);
   unsigned long long ts_ = 0;
-  if (tid < 192) st2[tid / 12][tid % 12] = 0;
+  if (tid < 192) st2g[tid] = 0ull;
   __syncthreads();
 #define KS2_START() do { if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) :: "memory"); } while (0)
-#define KS2(i) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st2[wv][i] += t_ - ts_; ts_ = t_; } } while (0)
+#define KS2(i) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); atomicAdd(st2g + wv * 12 + (i), t_ - ts_); ts_ = t_; } } while (0)
   KS2_START();
 #else
 #define KS2_START() do {} while (0)
@@ -1169,9 +1171,14 @@ __global__ __launch_bounds__(KT2) void k_kkt2(DevPlan P, DevWork W, int B) {
 #ifdef QTOS_STAMPS
   KS2(6);
   __syncthreads();
-  if (tid < 192 && W.trace) W.trace[((size_t)b * (P.max_iter + 1) + 16) * 4 + tid] = (double)st2[tid / 12][tid % 12];
+  // (stamps2.py reads the 192 counters as 64-bit integers)
 #endif
 }
+#ifdef QTOS_STAMPS
+// (k_kkt3 / k_kkt4 keep their counters in LDS)
+#undef KS2
+#define KS2(i) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st2[wv][i] += t_ - ts_; ts_ = t_; } } while (0)
+#endif
 
 
 

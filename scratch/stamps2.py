@@ -14,7 +14,7 @@ acc = np.zeros((16, 12))
 for b in (0, 5, NB - 1):
     t = np.zeros((cfg.max_iter + 1, 4))
     P.lib.qtos_debug_trace(P.h, b, t.ctypes.data_as(C.POINTER(C.c_double)))
-    acc += t[16:64].reshape(16, 12)
+    acc += (t[16:64].reshape(16, 12).view(np.uint64).astype(np.float64) if os.environ.get("QTOS_KKT", "2") == "2" else t[16:64].reshape(16, 12))   # (k_kkt2: integer counters)
 acc /= 3 * NS
 print("cycles per stage by wave: 0 AB work | 1 AB wait | 2 C role work (after prefetch issue; update waves: extraction only) | 3 assembly | 4 C wait | 5 update MFMA loop | 6 backward/NS | 7 top | 8 prefetch issue | 9 inequality products (k_kkt3)")
 for w in range(16):
