@@ -1054,7 +1054,7 @@ __device__ __forceinline__ void kron_sums(const int *sbuf, const double *dbuf, d
   else { mu = nu = (t - 27) / 3; d = e = (t - 27) % 3; }
   const int sh1 = 5 * (3 * mu + d), sh2 = 5 * (3 * nu + e);
   for (int kb = widx; kb < nk; kb += nw) {
-    const int *bd = ks + kb * 22;
+    const int *bd = ks + kb * 2;
     const int goff = bd[0] & 4095, n = ((bd[0] >> 12) & 31) + 1, reps = bd[1];
     const int c1 = (reps >> sh1) & 31, c2 = (reps >> sh2) & 31;
     const double *Gb = dbuf + goff, *sg = Gb + 3 * n, *wq = sg + 3;
@@ -1067,12 +1067,10 @@ __device__ __forceinline__ void kron_sums(const int *sbuf, const double *dbuf, d
     ksm[kb * 33 + t] = acc;
   }
 }
-// one Kronecker contribution: rho_a rho_c T' (an entry of G' S G) or -rho_a V' (of the right-hand side -G' w)
-__device__ __forceinline__ double kron_term(const int *ks, const double *ksm, int code) {
-  const int t = code & 63, kb = (code >> 6) & 15, ga = (code >> 12) & 15, gc = (code >> 24) & 15;
-  const double *rho = (const double *)(ks + kb * 22 + 2);
-  const double v = ksm[kb * 33 + t], ra = ga == 15 ? 1.0 : rho[min(ga, 9)], rc = gc == 15 ? 1.0 : rho[min(gc, 9)];
-  return t >= 27 ? -(ra * v) : ra * rc * v;
+// one Kronecker contribution: rho_a rho_c T' (an entry of G' S G) or rho_a (-1) V' (of the right-hand side -G' w); rho = the
+// record's weights (behind the blocks' two ints each)
+__device__ __forceinline__ double kron_term(const double *rho, const double *ksm, int code) {
+  return rho[(code >> 9) & 255] * rho[(unsigned)code >> 24] * ksm[code & 511];
 }
 __device__ __forceinline__ void assemble_stage_kron(double *A, int F, const int *sbuf, const double *dbuf, const double *ksm, int t0, int nth) {
   const int n_ent = sbuf[0], n_rhs = sbuf[1];
@@ -1086,7 +1084,7 @@ __device__ __forceinline__ void assemble_stage_kron(double *A, int F, const int 
   if (n_tgt == 0) return;
   const int *tg = sbuf + sbuf[4];
   const int *cl = tg + n_tgt + 1;
-  const int *ks = sbuf + (sbuf[2] >> 9);
+  const double *ks = (const double *)(sbuf + (sbuf[2] >> 9) + 2 * ((sbuf[2] >> 5) & 15));   // the record's weights
   for (int t = t0; t < n_tgt; t += nth) {
     const int tv = tg[t], c0 = tv & 4095, c1 = tg[t + 1] & 4095;
     const double a_old = A[tv >> 12];

@@ -85,7 +85,7 @@ struct Symbolic {
   bool kron = false;                 // range-of-motion blocks of the main records assembled through their Kronecker structure (QTOS_KRON)
   std::vector<KMeta> iq_kron;        // parallel to iq_blocks
   int max_kblocks = 0;               // most Kronecker blocks in one record (LDS scratch of the kernel: 33 doubles each)
-  static constexpr int KRON_SM = 33, KRON_STRIDE = 22, KRON_MAXB = 15;
+  static constexpr int KRON_SM = 33, KRON_STRIDE = 22, KRON_MAXB = 15;   // (stride: two ints + ten doubles per block; + 4 ints for the two constants)
   // Short stages (round 4): stage boundaries need not fall on multiples of 16 unknowns.  Where a partition into stages of at
   // most 16 pivots exists whose largest front is a whole 16-slot group smaller than the uniform partition's at no more stages
   // (found by dynamic programming over the boundaries; the 100-knot walk: 112 slots instead of 128, two short stages), the
@@ -387,7 +387,7 @@ struct Symbolic {
         for (int cc = 0; cc <= a; ++cc) t2.insert(trs(sa, iq_slots[Q.slot_off + cc]));
         t2.insert(front * (front + 1) / 2 + sa);
       }
-      const int kints = kron ? 2 + KRON_STRIDE * ((int)mine.size() + 1) : 0;   // (the Kronecker section, if every block had one)
+      const int kints = kron ? 6 + KRON_STRIDE * ((int)mine.size() + 1) : 0;   // (the Kronecker section, if every block had one)
       bool fits = rest.empty() && dyn < 4096 && dyn + d <= REC_MAX_DOUBLES - 2 && contrib + c < 4096 &&
                   fixed + (int)t2.size() + 1 + contrib + c + kints <= REC_MAX_INTS - 8;
       if (iq_mfma) {   // (no gather table: a block costs its tables, 4 + 128 per tile + 16 ints)
@@ -474,7 +474,11 @@ struct Symbolic {
             if (K.mu[a] == K.mu[c]) tidx = (K.mu[a] ? 18 : 0) + 3 * K.d[a] + K.d[c];
             else tidx = 9 + (K.mu[a] == 0 ? 3 * K.d[a] + K.d[c] : 3 * K.d[c] + K.d[a]);
           }
-          kc.push_back(tidx | (kidx[bi] << 6) | ((int)K.grp[a] << 12) | (61 << 18) | (gc << 24));
+          // [0:9) the sum | [9:17) rho of a | 61 << 18 | [24:32) rho of c -- indices into the record's array of weights: block
+          // kb's ten at 10 kb, then +1 (a representative's weight) and -1 (as "rho of c" of a right-hand-side entry: -rho_a V')
+          const int one = 10 * n_k, ra = K.grp[a] == 15 ? one : 10 * kidx[bi] + K.grp[a];
+          const int rc = c == 255 ? one + 1 : (gc == 15 ? one : 10 * kidx[bi] + gc);
+          kc.push_back((KRON_SM * kidx[bi] + tidx) | (ra << 9) | (61 << 18) | (int)((unsigned)rc << 24));
           continue;
         }
         oc.push_back(blk_goff[bi] | (a << 12) | ((c == 255 ? 63 : c) << 18) | ((Q.n - 1) << 24) | (int)((unsigned)(Q.m - 1) << 29));
@@ -490,6 +494,8 @@ struct Symbolic {
       // columns (5 bits each), ten doubles rho (group 15 = a representative's: 1).
       if ((srec.size() - s0) & 1) srec.push_back(0);
       const int koff = (int)srec.size() - s0;
+      // two ints per block (offset of G in the dynamic record | (n - 1) << 12; the six representative columns, 5 bits each),
+      // then the record's weights: ten doubles per block, +1, -1
       for (size_t bi = 0; bi < blks.size(); ++bi) {
         if (kidx[bi] < 0) continue;
         const KMeta &K = iq_kron[S.iq_begin + blks[bi]];
@@ -498,12 +504,14 @@ struct Symbolic {
         int reps = 0;
         for (int i = 0; i < 6; ++i) reps |= (K.rep[i] < 0 ? 0 : K.rep[i]) << (5 * i);
         srec.push_back(reps);
-        for (int g = 0; g < 10; ++g) {
-          int w[2];
-          std::memcpy(w, &K.rho[g], 8);
-          srec.push_back(w[0]); srec.push_back(w[1]);
-        }
       }
+      auto push_double = [&](double v) { int w[2]; std::memcpy(w, &v, 8); srec.push_back(w[0]); srec.push_back(w[1]); };
+      for (size_t bi = 0; bi < blks.size(); ++bi) {
+        if (kidx[bi] < 0) continue;
+        const KMeta &K = iq_kron[S.iq_begin + blks[bi]];
+        for (int g = 0; g < 10; ++g) push_double(K.rho[g]);
+      }
+      push_double(1.0); push_double(-1.0);
       kron_off_of_record[s0] = (n_k << 5) | (koff << 9);   // (header int [2]: blocks of the record | Kronecker blocks << 5 | offset of their section << 9)
       max_kblocks = std::max(max_kblocks, n_k);
     }
