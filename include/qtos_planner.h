@@ -104,6 +104,10 @@ int qtos_analyze(const QtosParams *params, QtosDims *dims, int *stage_active, in
  * of its columns in elimination order.  Arrays may be NULL.  0, or -4: no schedule for this transcription, -5: the packed
  * copy of the column positions disagrees with the list. */
 int qtos_analyze_sweep(const QtosParams *params, int *n_rounds, int *rows, int *entries, int *pos_min, int *pos_max, int max_places);
+/* Host-only: the Kronecker structure of the range-of-motion blocks (experiment QTOS_KRON of round 4): inequality blocks in all,
+ * blocks with the structure, the most of them in one stage record, and the largest relative difference between an entry formed
+ * through a block's 33 sums and the direct three-term sum on random data. */
+int qtos_analyze_kron(const QtosParams *params, int *n_blocks, int *n_kron, int *max_in_record, double *worst);
 
 /* Terrain side channel.  Replaces `docker cp towr_heightfield.txt <id>:...`
  * (QTOS/utils.py:21-22; scripts/main.py:77-78; QTOS/generateHeightField.py:276-279).

@@ -55,7 +55,7 @@ EXPORTS = [
     "qtos_planner_create", "qtos_planner_destroy", "qtos_planner_dims", "qtos_last_error",
     "qtos_set_heightfields", "qtos_plan_batch", "qtos_plan_batch_device", "qtos_sample_csv",
     "qtos_sample_csv_device", "qtos_last_timing", "qtos_debug_eval", "qtos_debug_newton",
-    "qtos_debug_structure", "qtos_debug_trace", "qtos_debug_factor", "qtos_analyze", "qtos_analyze_sweep",
+    "qtos_debug_structure", "qtos_debug_trace", "qtos_debug_factor", "qtos_analyze", "qtos_analyze_sweep", "qtos_analyze_kron",
     "qtos_set_init_table", "qtos_debug_initial_guess", "qtos_shift_warm", "qtos_shift_warm_device",
     "qtos_last_timing_chord", "qtos_debug_chord", "qtos_plan_totals",
     "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation", "qtos_debug_residual", "qtos_project_nodes",
@@ -109,6 +109,7 @@ def load():
     lib.qtos_debug_factor.argtypes = [vp, C.c_int, dp, ip]
     lib.qtos_analyze.argtypes = [C.POINTER(QtosParams), C.POINTER(QtosDims), ip, C.c_int]
     lib.qtos_analyze_sweep.argtypes = [C.POINTER(QtosParams), ip, ip, ip, ip, ip, C.c_int]
+    lib.qtos_analyze_kron.argtypes = [C.POINTER(QtosParams), ip, ip, ip, dp]
     lib.qtos_set_init_table.argtypes = [vp, C.c_int, dp, C.c_int, dp, dp]
     lib.qtos_debug_initial_guess.argtypes = [vp, C.c_int, dp, dp, ip, dp]
     if hasattr(lib, "qtos_last_timing_chord"):
@@ -199,6 +200,18 @@ def analyze(cfg):
     if rc != 0:
         raise ValueError("qtos_analyze failed (%d)" % rc)
     return d, act[:d.n_stages].copy()
+
+
+def analyze_kron(cfg):
+    """Host-only: (inequality blocks, blocks with the Kronecker structure, most in a record, worst relative difference)."""
+    lib = load()
+    p = params_from_config(cfg)
+    a = [np.zeros(1, np.int32) for _ in range(3)]
+    w = np.zeros(1)
+    rc = lib.qtos_analyze_kron(C.byref(p), _ip(a[0]), _ip(a[1]), _ip(a[2]), _dp(w))
+    if rc != 0:
+        raise ValueError("qtos_analyze_kron failed (%d)" % rc)
+    return int(a[0][0]), int(a[1][0]), int(a[2][0]), float(w[0])
 
 
 def analyze_sweep(cfg, max_places=1 << 16):

@@ -696,6 +696,23 @@ int qtos_analyze(const QtosParams *params, QtosDims *d, int *stage_active, int m
   return 0;
 }
 
+// Host-only: the Kronecker structure of the range-of-motion blocks (Symbolic::kron_meta, QTOS_KRON): how many inequality
+// blocks have it, the most in one stage record, and the largest relative difference between an entry of G' S G / G' w formed
+// through the 33 sums of a block and the direct three-term sum, on random matrices and weights (Symbolic::check_kron).
+int qtos_analyze_kron(const QtosParams *params, int *n_blocks, int *n_kron, int *max_in_record, double *worst) {
+  if (!params || !n_blocks || !n_kron || !max_in_record || !worst) return -1;
+  HostModel M;
+  Symbolic S;
+  if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
+  S.kron = true;
+  if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
+  *n_blocks = 0;
+  for (const Block &b : M.blocks) *n_blocks += b.kind == 1;
+  *worst = S.check_kron(n_kron);
+  *max_in_record = S.max_kblocks;
+  return 0;
+}
+
 // Host-only: the schedule the helper waves of the backward sweep follow (build_sweep_tasks).  Per place of a round (16 per
 // round, round i runs in step i of the chain, i.e. while it solves stage n_stages - 1 - i): the constraint row (-1: empty),
 // the row's entries, and the smallest and largest position (elimination order) of the row's columns.

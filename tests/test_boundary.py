@@ -157,6 +157,19 @@ def test_sweep_schedule_of_the_slack_steps(which):
     assert (np.diff(seq) <= 0).all()
 
 
+def test_kronecker_structure_of_the_range_of_motion_blocks():
+    """Every column of a range-of-motion block's Jacobian is a static multiple of a column of R(theta)^T or of
+    d(R^T (p - r))/d theta (towr range_of_motion_constraint.cc; Symbolic::kron_meta): on the 100-knot walk 252 of the 320
+    inequality blocks (the others are the friction pyramids and terrain rows), at most 8 in a stage record; every entry of
+    G' S G and G' w through the 33 sums of a block equals the direct three-term sum to rounding (random matrices and weights)."""
+    from qtos_amd import capi
+    from qtos_amd.config import PlannerConfig
+    n_blocks, n_kron, most, worst = capi.analyze_kron(PlannerConfig.knots100())
+    assert (n_blocks, n_kron, most) == (320, 252, 8) and worst < 1e-11
+    n_blocks, n_kron, most, worst = capi.analyze_kron(PlannerConfig.knots100(gait="trot"))
+    assert 0 < n_kron < n_blocks and worst < 1e-11
+
+
 def test_bad_parameters_are_rejected(hip_lib, cfg):
     from qtos_amd import capi
     p = capi.params_from_config(cfg)
