@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 5: the trot (the gait the metric names) on the same evidence footing as the walk: rocprofv3 kernel stats + the PMC passes
+# usage: scratch/r5_trot_prof.sh <tag> [extra bench flags]
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; T=${1:-r5trot}; shift
+mkdir -p $O
+F="--gait trot --cpu-sample 0 --no-parity --no-trot $*"
+cd $R
+timeout 600 python3 bench.py $F --steps 100 > $O/bench_${T}.json 2> $O/bench_${T}.err
+tail -c 600 $O/bench_${T}.json
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o runc -- python3 $R/bench.py $F > $O/prof_$T.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$T -o runc -- python3 $R/bench.py --steps 3 --warmup 1 $F > $O/pmc_fetch_$T.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$T -o runc -- python3 $R/bench.py --steps 3 --warmup 1 $F > $O/pmc_write_$T.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d $O/pmc_sq_$T -o runc -- python3 $R/bench.py --steps 3 --warmup 1 $F > $O/pmc_sq_$T.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2_$T -o runc -- python3 $R/bench.py --steps 3 --warmup 1 $F > $O/pmc_sq2_$T.log 2>&1
+f=$(find $O/prof_$T -name "*kernel_stats.csv" | head -1); head -8 $f | cut -c1-200
