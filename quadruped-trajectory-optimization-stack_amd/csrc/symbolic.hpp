@@ -93,6 +93,18 @@ struct Symbolic {
   // their own for that one stage -- and every array by position counts them: n_unknowns is then n_stages x 16 POSITIONS and
   // n_real_unknowns the unknowns of the KKT system.
   int n_real_unknowns = 0;
+  // Pair mode (round 5, k_kkt5): two consecutive stages -- a PAIR (a, b) -- are eliminated behind one set of barriers.  Both
+  // stages' pivots must hold slots for the whole pair: an unknown enters the front at the even stage of the pair of its first
+  // coupling, the slots of a pair's pivots are released together at its end, the number of stages is even (an all-dummy stage
+  // is appended if need be), and a pair has ONE record (32 pivot slots / diagonals, the entries, right-hand sides and
+  // inequality blocks of both stages, one gather table whose targets are unique within the pair: two records assembled side
+  // by side would race on the cells they share).  Panels, pivot-block inverses, masks and every per-position array keep the
+  // 16-pivot stage as their unit: k_chord, the sweeps and k_residual do not change.
+  bool pair_mode = false;
+  int n_records = 0;                // records: one per stage, or one per pair (srec_off / drec_off have n_records + 1 entries)
+  int rec_stages = 1;               // stages per record
+  int tgt_shift = 12;               // a gather-table target word = (cell << tgt_shift) | first contribution
+  std::vector<int> diag_pos;        // per position: stream position of its pivot diagonal (k_residual)
   std::vector<int> stage_dummies;   // per stage: dummy pivots in it
   bool short_stages = true;
   std::vector<int> order;      // position -> var index, or n_vars + row for a multiplier
@@ -388,7 +400,7 @@ struct Symbolic {
         t2.insert(front * (front + 1) / 2 + sa);
       }
       const int kints = kron ? 6 + KRON_STRIDE * ((int)mine.size() + 1) : 0;   // (the Kronecker section, if every block had one)
-      bool fits = rest.empty() && dyn < 4096 && dyn + d <= REC_MAX_DOUBLES - 2 && contrib + c < 4096 &&
+      bool fits = rest.empty() && dyn < 4096 && dyn + d <= REC_MAX_DOUBLES - 2 && contrib + c < (1 << tgt_shift) &&
                   fixed + (int)t2.size() + 1 + contrib + c + kints <= REC_MAX_INTS - 8;
       if (iq_mfma) {   // (no gather table: a block costs its tables, 4 + 128 per tile + 16 ints)
         int ints = fixed + 8 + 8 + 4 * 16;
@@ -457,7 +469,7 @@ struct Symbolic {
       for (size_t bi = 0; bi < blks.size(); ++bi)
         if (iq_kron[S.iq_begin + blks[bi]].ok && n_k < KRON_MAXB) kidx[bi] = n_k++;
     for (auto &kv : tlist) {
-      srec.push_back((kv.first << 12) | cpos);
+      srec.push_back((kv.first << tgt_shift) | cpos);
       cpos += (int)kv.second.size();
       std::vector<int> kc, oc;   // a target's Kronecker contributions come first (the kernel runs them as a loop of their own)
       for (int code : kv.second) {
@@ -486,7 +498,7 @@ struct Symbolic {
       codes.insert(codes.end(), kc.begin(), kc.end());
       codes.insert(codes.end(), oc.begin(), oc.end());
     }
-    if (cpos >= 4096) { err = "gather table overflow"; return -1; }
+    if (cpos >= (1 << tgt_shift)) { err = "gather table overflow"; return -1; }
     srec.push_back(cpos);   // sentinel: end of the last target's contributions
     srec.insert(srec.end(), codes.begin(), codes.end());
     if (n_k > 0) {
@@ -592,8 +604,11 @@ struct Symbolic {
   int compact_cells(const std::vector<int> &first, const std::vector<int> &slot_of) {
     const int F = front, ntri_rhs = F * (F + 1) / 2;
     std::vector<int> occ((size_t)n_stages * F, -1);
-    for (int j = 0; j < n_unknowns; ++j)
-      for (int k = first[j] / PIV; k <= j / PIV; ++k) occ[(size_t)k * F + slot_of[j]] = j;
+    for (int j = 0; j < n_unknowns; ++j) {
+      // (pair mode: a slot is held from the even stage of the pair of the first coupling to the end of the pivot's pair)
+      const int k0 = pair_mode ? (first[j] / PIV) & ~1 : first[j] / PIV, k1 = pair_mode ? (j / PIV) | 1 : j / PIV;
+      for (int k = k0; k <= k1; ++k) occ[(size_t)k * F + slot_of[j]] = j;
+    }
     std::map<std::pair<int, int>, int> cell;
     std::vector<std::vector<int>> retire(n_stages);
     std::vector<int> free_cells;
@@ -631,14 +646,15 @@ struct Symbolic {
     };
     auto rewrite = [&](int k, int s0) -> int {
       const int n_ent = srec[s0], n_rhs = srec[s0 + 1];
-      int *e = &srec[s0 + SHDR_INTS + PIV];
+      int *e = &srec[s0 + SHDR_INTS + PIV * rec_stages];
       for (int i = 0; i < n_ent; ++i) if ((e[i] = target(k, e[i])) < 0) return -1;
       for (int i = 0; i < n_rhs; ++i) if ((e[n_ent + i] = target(k, ntri_rhs + e[n_ent + i])) < 0) return -1;
       int *tg = &srec[s0 + srec[s0 + 4]];
+      const int tmask = (1 << tgt_shift) - 1;
       for (int t = 0; t < srec[s0 + 5]; ++t) {
-        const int c = target(k, tg[t] >> 12);
+        const int c = target(k, tg[t] >> tgt_shift);
         if (c < 0) return -1;
-        tg[t] = (c << 12) | (tg[t] & 4095);
+        tg[t] = (c << tgt_shift) | (tg[t] & tmask);
       }
       if (iq_mfma) {   // inequality section: triangle indices -> cells (static lists: 20 bits, tables: 16 bits)
         int *q = &srec[s0 + srec[s0 + 2]];
@@ -678,12 +694,18 @@ struct Symbolic {
       return 0;
     };
     ctab.assign((size_t)n_stages * F * PIV, 0);
-    for (int k = 0; k < n_stages; ++k) {
+    for (int rec = 0; rec < n_records; ++rec) {
+      const int k = rec * rec_stages;
       const int lag = cell_mode == 2 ? 2 : 1;
+      if (pair_mode) {
+        // k_kkt5 assembles the record of pair q in the second half of pair q - 2; the columns of pair r were gathered -- their
+        // cells retired -- in the first phase of pair r - 1: the record may re-use the cells of every pair before its own
+        if (k >= 2) { for (int s = k - 2; s < k; ++s) for (int id : retire[s]) free_cells.push_back(id); }
+      } else
       if (k >= lag) { for (int id : retire[k - lag]) free_cells.push_back(id); }
       std::sort(free_cells.begin(), free_cells.end(), std::greater<int>());   // lowest cell first
-      if (rewrite(k, srec_off[k])) return -1;
-      const int n_cont = srec[srec_off[k] + 6], c_first = srec[srec_off[k] + 7];
+      if (rewrite(k, srec_off[rec])) return -1;
+      const int n_cont = srec[srec_off[rec] + 6], c_first = srec[srec_off[rec] + 7];
       for (int c = 0; c < n_cont; ++c)
         if (rewrite(k, cont[4 * (c_first + c)])) return -1;
     }
@@ -854,7 +876,23 @@ struct Symbolic {
     n_real_unknowns = n_unknowns;
     if (short_stages && !getenv("QTOS_NO_SHORT_STAGES")) shorten_stages(first, block_minpos, n, m);
     n_stages = (n_unknowns + PIV - 1) / PIV;
+    if (pair_mode) {
+      // whole pairs: dummy positions fill the last stage and, if the number of stages is odd, one more stage
+      const int want = ((n_stages + 1) & ~1) * PIV, have = n_unknowns;
+      for (int v = n_unknowns; v < want; ++v) { order.push_back(-1); first.push_back(v); }
+      n_unknowns = want;
+      n_stages = n_unknowns / PIV;
+      stage_dummies.resize(n_stages, 0);
+      // (the fill of the last real stage counts as before -- active, like the dummies that filled it without pair mode --, an
+      //  appended all-dummy stage is no work of the algorithm)
+      for (int v = have; v < want; ++v) if (v / PIV > (have - 1) / PIV) stage_dummies[v / PIV]++;
+      rec_stages = 2;
+      tgt_shift = 13;
+    }
+    n_records = n_stages / rec_stages;
     stage_dummies.resize(n_stages, 0);
+    // the stage at which an unknown enters the front
+    auto enter_stage = [&](int j) { const int e = first[j] / PIV; return pair_mode ? (e & ~1) : e; };
     if (const char *dump = getenv("QTOS_DUMP_FIRST")) {   // diagnostic: envelope of the ordered matrix (position -> first coupled position, unknown id)
       if (FILE *f = fopen(dump, "w")) {
         for (int j = 0; j < n_unknowns; ++j) fprintf(f, "%d %d %d\n", j, first[j], order[j]);
@@ -871,7 +909,7 @@ struct Symbolic {
     stages.resize(n_stages);
     // unknowns sorted by entry stage: an unknown enters the front at stage first[j] / PIV
     std::vector<std::vector<int>> enter(n_stages);
-    for (int j = 0; j < n_unknowns; ++j) enter[first[j] / PIV].push_back(j);
+    for (int j = 0; j < n_unknowns; ++j) enter[enter_stage(j)].push_back(j);
     std::vector<int> free_slots;  // kept sorted descending so pop_back gives the smallest
     std::vector<char> in_use;
     std::vector<int> slot_stage;   // pivot stage of the unknown occupying a slot, -1 if free
@@ -887,12 +925,13 @@ struct Symbolic {
     // (a free slot is always reused), so it is known up front and ALL its slots are on offer from the
     // first stage on: that lets the rule below keep the pivots of a stage together.
     {
-      int live = 0, peak = 0;
+      int live = 0, peak = 0, held = 0;
       for (int k = 0; k < n_stages; ++k) {
         live += (int)enter[k].size();
         const int members = std::min(n_unknowns, (k + 1) * PIV) - k * PIV;
         peak = std::max(peak, live + (PIV - members));   // + the dummy pivots of a short last stage
-        live -= members;
+        // (pair mode: the pivots of the even stage keep their slots until the pair is over)
+        if (pair_mode && !(k & 1)) held = members; else { live -= members + held; held = 0; }
       }
       n_slots = ((peak + PIV - 1) / PIV) * PIV;
       for (int t = n_slots - 1; t >= 0; --t) free_slots.push_back(t);
@@ -909,7 +948,7 @@ struct Symbolic {
         // the 100-knot problem; lowest-free-slot placement gives 3.7, same-stage preference alone 2.6.)
         int s = -1;
         if (!free_slots.empty()) {
-          const int stage_j = j / PIV, n_grp = (n_slots + 15) / 16;
+          const int stage_j = pair_mode ? j / (2 * PIV) : j / PIV, n_grp = (n_slots + 15) / 16;   // (pair mode: the pair's 32 pivots together)
           int best_grp = -1, best_score = -1;
           for (int grp = 0; grp < n_grp; ++grp) {
             int same = 0, used = 0, nfree = 0;
@@ -935,7 +974,7 @@ struct Symbolic {
         if ((int)in_use.size() <= s) in_use.resize(s + 1, 0);
         if ((int)slot_stage.size() <= s) slot_stage.resize(s + 1, -1);
         in_use[s] = 1;
-        slot_stage[s] = j / PIV;
+        slot_stage[s] = pair_mode ? j / (2 * PIV) : j / PIV;
         active++;
       }
       // dummy pivots of the (short) last stage need distinct unused slots
@@ -976,14 +1015,33 @@ struct Symbolic {
         const int t = piv_slot[(size_t)k * PIV + i];
         if (t < 256) amask[(size_t)k * 8 + (t >> 5)] &= ~(1u << (t & 31));
       }
-      // release pivots and dummies
-      for (int i = lo; i < lo + PIV; ++i) {
-        free_slots.push_back(piv_slot[(size_t)k * PIV + (i - lo)]);
-        in_use[piv_slot[(size_t)k * PIV + (i - lo)]] = 0;
-        if ((int)slot_stage.size() > piv_slot[(size_t)k * PIV + (i - lo)]) slot_stage[piv_slot[(size_t)k * PIV + (i - lo)]] = -1;
+      if (pair_mode && (k & 1)) {   // (the even stage's pivots still hold their slots: not rows of this stage's panel)
+        for (int i = 0; i < PIV; ++i) {
+          const int t = piv_slot[(size_t)(k - 1) * PIV + i];
+          if (t < 256) amask[(size_t)k * 8 + (t >> 5)] &= ~(1u << (t & 31));
+        }
       }
-      std::sort(free_slots.begin(), free_slots.end(), std::greater<int>());
+      // release pivots and dummies (pair mode: both stages' at the end of the pair)
+      if (!pair_mode || (k & 1)) {
+        for (int kk = pair_mode ? k - 1 : k; kk <= k; ++kk)
+          for (int i = 0; i < PIV; ++i) {
+            const int t = piv_slot[(size_t)kk * PIV + i];
+            free_slots.push_back(t);
+            in_use[t] = 0;
+            if ((int)slot_stage.size() > t) slot_stage[t] = -1;
+          }
+        std::sort(free_slots.begin(), free_slots.end(), std::greater<int>());
+      }
       active -= (hi - lo);
+    }
+    if (pair_mode) {
+      // the populated front of a stage as the algorithm counts it: its pivots and the later unknowns coupled to
+      // an eliminated one -- not the slots the pair holds
+      std::vector<int> fs(first.begin(), first.end());
+      for (int &v : fs) v /= PIV;
+      std::sort(fs.begin(), fs.end());
+      for (int k = 0; k < n_stages; ++k)
+        active_count[k] = (int)(std::upper_bound(fs.begin(), fs.end(), k) - fs.begin()) - k * PIV;
     }
     amask2 = amask;
     nxt_pack.assign((size_t)n_stages * 4, -1);
@@ -1024,7 +1082,7 @@ struct Symbolic {
         Block &b = M.blocks[bi];
         b.goff = (int)g_doubles;
         IqBlock q;
-        q.m = b.m; q.n = b.n; q.row0 = b.row0; q.gloc = (int)(g_doubles - S.g_begin);
+        q.m = b.m; q.n = b.n; q.row0 = b.row0; q.gloc = (int)(g_doubles - (pair_mode ? stages[k & ~1].g_begin : S.g_begin));   // (relative to the record's first stage)
         q.slot_off = (int)iq_slots.size();
         q.pad0 = q.pad1 = q.pad2 = 0;
         for (int a = 0; a < b.n; ++a) {
@@ -1127,56 +1185,73 @@ struct Symbolic {
     M.g_doubles = g_doubles;
     // ---- packed records ----
     auto trs = [](int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
-    srec_off.assign(n_stages + 1, 0);
-    drec_off.assign(n_stages + 1, 0);
-    std::vector<std::vector<int>> pending;   // per stage: inequality blocks left for continuation records
-    for (int k = 0; k < n_stages; ++k) {
-      const StageDesc &S = stages[k];
+    srec_off.assign(n_records + 1, 0);
+    drec_off.assign(n_records + 1, 0);
+    diag_pos.assign((size_t)n_stages * PIV, -1);
+    std::vector<std::vector<int>> ent_spos(n_stages);   // stream position of every equality entry of a stage
+    std::vector<std::vector<int>> pending;   // per record: inequality blocks left for continuation records
+    std::vector<StageDesc> rec_desc(n_records);
+    if (pair_mode) { REC_MAX_INTS = std::max(REC_MAX_INTS, 12288); REC_MAX_DOUBLES = 4094; if (rec_cap_ints > 0) { REC_MAX_INTS = std::min(REC_MAX_INTS, rec_cap_ints); REC_MAX_DOUBLES = std::min(REC_MAX_DOUBLES, rec_cap_ints / 3); } }
+    for (int rec = 0; rec < n_records; ++rec) {
+      const int k0 = rec * rec_stages, k1 = k0 + rec_stages;   // the record's stages
+      // (the entries, right-hand sides and inequality blocks of consecutive stages are consecutive in their lists)
+      StageDesc S = stages[k0];
+      S.ent_end = stages[k1 - 1].ent_end; S.rhs_end = stages[k1 - 1].rhs_end; S.iq_end = stages[k1 - 1].iq_end;
+      rec_desc[rec] = S;
       // 16-byte aligned records: k_kkt moves them with 128-bit loads
       while (srec.size() & 3) srec.push_back(0);
       while (pack_src.size() & 1) pack_src.push_back(6 << 28);
-      srec_off[k] = (int)srec.size();
-      drec_off[k] = (int)pack_src.size();
+      srec_off[rec] = (int)srec.size();
+      drec_off[rec] = (int)pack_src.size();
       const int n_ent = S.ent_end - S.ent_begin, n_rhs = S.rhs_end - S.rhs_begin, n_iq = S.iq_end - S.iq_begin;
-      srec.push_back(n_ent); srec.push_back(n_rhs); srec.push_back(n_iq); srec.push_back(stage_hi[k]);
+      int hi_rec = 0;
+      for (int k = k0; k < k1; ++k) hi_rec = std::max(hi_rec, stage_hi[k]);
+      srec.push_back(n_ent); srec.push_back(n_rhs); srec.push_back(n_iq); srec.push_back(hi_rec);
       srec.push_back(0); srec.push_back(0); srec.push_back(0); srec.push_back(0);   // [4] gather table offset, [5] n_tgt
-      for (int i = 0; i < PIV; ++i) {
-        srec.push_back(piv_slot[(size_t)k * PIV + i]);
-        pack_src.push_back((5 << 28) | (k * PIV + i));
-      }
-      for (int i = S.ent_begin; i < S.ent_end; ++i) {
-        const EqEntry &e = eq_entries[i];
-        srec.push_back(trs(e.slot_r, e.slot_c));
-        pack_src.push_back(e.src >= 0 ? e.src : ((1 << 28) | (-e.src - 1)));
-      }
+      for (int k = k0; k < k1; ++k)
+        for (int i = 0; i < PIV; ++i) {
+          srec.push_back(piv_slot[(size_t)k * PIV + i]);
+          diag_pos[(size_t)k * PIV + i] = (int)pack_src.size();
+          pack_src.push_back((5 << 28) | (k * PIV + i));
+        }
+      for (int k = k0; k < k1; ++k)
+        for (int i = stages[k].ent_begin; i < stages[k].ent_end; ++i) {
+          const EqEntry &e = eq_entries[i];
+          srec.push_back(trs(e.slot_r, e.slot_c));
+          ent_spos[k].push_back((int)pack_src.size());
+          pack_src.push_back(e.src >= 0 ? e.src : ((1 << 28) | (-e.src - 1)));
+        }
       for (int i = S.rhs_begin; i < S.rhs_end; ++i) {
         srec.push_back(eq_rhs[i].slot);
         pack_src.push_back((2 << 28) | eq_rhs[i].row);
       }
-      // inequality blocks of the stage: as many as the record limits allow go into the stage's own
-      // record, the rest into continuation records (same layout, no equality part) that the kernel
+      // inequality blocks of the record: as many as the record limits allow go into the record itself,
+      // the rest into continuation records (same layout, no equality part) that the kernel
       // fetches and assembles one after the other; they are emitted behind all stage records
+      std::vector<std::array<int, 6>> syms;
+      for (int k = k0; k < k1; ++k) syms.insert(syms.end(), sym_of[k].begin(), sym_of[k].end());
       std::vector<int> mine, rest;
       {
         std::vector<int> all(n_iq);
         std::iota(all.begin(), all.end(), 0);
-        if (split_blocks(S, all, (int)pack_src.size() - drec_off[k], (int)srec.size() - srec_off[k], trs, mine, rest, (int)sym_of[k].size())) return -1;
+        if (split_blocks(S, all, (int)pack_src.size() - drec_off[rec], (int)srec.size() - srec_off[rec], trs, mine, rest, (int)syms.size())) return -1;
       }
-      if (emit_blocks(k, S, mine, srec_off[k], drec_off[k], trs, &sym_of[k])) return -1;
-      if (!iq_mfma) srec[srec_off[k] + 2] = (int)mine.size() | (kron_off_of_record.count(srec_off[k]) ? kron_off_of_record[srec_off[k]] : 0);
+      if (emit_blocks(k0, S, mine, srec_off[rec], drec_off[rec], trs, &syms)) return -1;
+      if (!iq_mfma) srec[srec_off[rec] + 2] = (int)mine.size() | (kron_off_of_record.count(srec_off[rec]) ? kron_off_of_record[srec_off[rec]] : 0);
       pending.push_back(rest);
-      max_srec = std::max(max_srec, (int)srec.size() - srec_off[k]);
-      max_drec = std::max(max_drec, (int)pack_src.size() - drec_off[k]);
+      max_srec = std::max(max_srec, (int)srec.size() - srec_off[rec]);
+      max_drec = std::max(max_drec, (int)pack_src.size() - drec_off[rec]);
     }
     while (srec.size() & 3) srec.push_back(0);
     while (pack_src.size() & 1) pack_src.push_back(6 << 28);
-    srec_off[n_stages] = (int)srec.size();
-    drec_off[n_stages] = (int)pack_src.size();
+    srec_off[n_records] = (int)srec.size();
+    drec_off[n_records] = (int)pack_src.size();
     // continuation records
     cont.clear();
-    for (int k = 0; k < n_stages; ++k) {
-      const StageDesc &S = stages[k];
-      std::vector<int> rest = pending[k];
+    for (int rec = 0; rec < n_records; ++rec) {
+      const StageDesc &S = rec_desc[rec];
+      const int k = rec * rec_stages;
+      std::vector<int> rest = pending[rec];
       int first_cont = (int)cont.size() / 4, n_cont = 0;
       while (!rest.empty()) {
         while (srec.size() & 3) srec.push_back(0);
@@ -1184,9 +1259,9 @@ struct Symbolic {
         const int s0 = (int)srec.size(), d0 = (int)pack_src.size();
         srec.push_back(0); srec.push_back(0); srec.push_back(0); srec.push_back(stage_hi[k]);
         srec.push_back(0); srec.push_back(0); srec.push_back(0); srec.push_back(0);
-        for (int i = 0; i < PIV; ++i) { srec.push_back(0); pack_src.push_back(6 << 28); }
+        for (int i = 0; i < PIV * rec_stages; ++i) { srec.push_back(0); pack_src.push_back(6 << 28); }
         std::vector<int> mine, later;
-        if (split_blocks(S, rest, PIV, SHDR_INTS + PIV, trs, mine, later)) return -1;
+        if (split_blocks(S, rest, PIV * rec_stages, SHDR_INTS + PIV * rec_stages, trs, mine, later)) return -1;
         if (mine.empty()) { err = "inequality block does not fit a record"; return -1; }
         if (emit_blocks(k, S, mine, s0, d0, trs)) return -1;
         srec[s0 + 2] = (int)mine.size();
@@ -1198,8 +1273,8 @@ struct Symbolic {
         rest = later;
         ++n_cont;
       }
-      srec[srec_off[k] + 6] = n_cont;
-      srec[srec_off[k] + 7] = first_cont;
+      srec[srec_off[rec] + 6] = n_cont;
+      srec[srec_off[rec] + 7] = first_cont;
     }
     if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: %d stages, %d continuation records, max record %d ints / %d doubles\n", n_stages, (int)cont.size() / 4, max_srec, max_drec);
     if (getenv("QTOS_DEBUG_SYMBOLIC2")) {
@@ -1213,7 +1288,7 @@ struct Symbolic {
       // an entry (r,c) is assembled at stage s_a (record of that stage) and retired when min(pivot stage of slot r, of slot c)
       // here: count distinct targets per record and total
       long long tot_t = 0; int max_t = 0;
-      for (int k = 0; k < n_stages; ++k) { int nt = srec[srec_off[k] + 5] + srec[srec_off[k]] ; tot_t += nt; max_t = std::max(max_t, nt); }
+      for (int k = 0; k < n_records; ++k) { int nt = srec[srec_off[k] + 5] + srec[srec_off[k]] ; tot_t += nt; max_t = std::max(max_t, nt); }
       fprintf(stderr, "targets total %lld max/stage %d ; srec ints %zu, stream doubles %zu\n", tot_t, max_t, srec.size(), pack_src.size());
       fprintf(stderr, "active per stage:");
       for (int k = 0; k < n_stages; ++k) fprintf(stderr, " %d", active_count[k]);
@@ -1339,7 +1414,7 @@ struct Symbolic {
       std::vector<std::vector<std::pair<int, int>>> rows(n_unknowns);
       for (int k = 0; k < n_stages; ++k)
         for (size_t i = 0; i < ent_pp[k].size(); ++i) {
-          const int pr = ent_pp[k][i].first, pv = ent_pp[k][i].second, spos = drec_off[k] + PIV + (int)i;
+          const int pr = ent_pp[k][i].first, pv = ent_pp[k][i].second, spos = ent_spos[k][i];
           rows[pr].push_back({pv, spos});
           rows[pv].push_back({pr, spos});
         }

@@ -1,0 +1,319 @@
+// pair_emul.cpp -- TEST INFRASTRUCTURE, not product code (built and loaded by tests/test_pair_symbolic.py only).
+//
+// Host emulation of the DATA FLOW of k_kkt5 (csrc/kkt5.hpp): two 16-pivot stages -- a pair (a, b) -- eliminated behind one
+// set of barriers, on the tables Symbolic::build emits in pair mode (pair records and their gather table, cells, ctab / rtab,
+// row masks, pivot slots).  Everything is done at the level of matrices by slot: no lanes, no matrix instructions.  The
+// factor panels it produces (per stage w = B^-1 p_F and V = P B^-1, the layout k_chord and the sweeps read) are compared,
+// stage by stage, with a plain dense block elimination of the same KKT matrix in position order.  What this pins on the CPU:
+// the pair-mode slot allocation, the records, the cell lifetimes, the masks, and the algebra of the pair step
+//     V1 = P1 A11^-1;  P2' = P2 - V1 A21';  V2 = P2' S22^-1;  W1 = V1 - V2 L21,  W2 = V2;  U -= W1 P1' + W2 P2'
+// (P1, P2: the pair's pivot columns as they stand before the pair; A21 = rows of P1 at b's pivots; L21 = A21 A11^-1;
+// S22 = A22 - L21 A21') with the blanking rules the kernel applies.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "../../quadruped-trajectory-optimization-stack_amd/csrc/symbolic.hpp"
+
+using namespace qtos;
+
+namespace {
+struct Rng {
+  unsigned long long s;
+  double uni() { s = s * 6364136223846793005ull + 1442695040888963407ull; return ((s >> 11) & ((1ull << 53) - 1)) / (double)(1ull << 53); }
+};
+
+// unpivoted LDL^T inverse of a symmetric 16 x 16 block given by its lower triangle
+void inv16(const double (&A)[PIV][PIV], double (&Mi)[PIV][PIV]) {
+  double L[PIV][PIV] = {}, d[PIV], W[PIV][PIV];
+  for (int i = 0; i < PIV; ++i) for (int j = 0; j < PIV; ++j) W[i][j] = j <= i ? A[i][j] : A[j][i];
+  for (int i = 0; i < PIV; ++i) L[i][i] = 1.0;
+  for (int k = 0; k < PIV; ++k) {
+    d[k] = W[k][k];
+    for (int i = k + 1; i < PIV; ++i) L[i][k] = W[i][k] / d[k];
+    for (int i = k + 1; i < PIV; ++i) for (int j = k + 1; j < PIV; ++j) W[i][j] -= L[i][k] * W[k][j];
+  }
+  // Li = L^-1 (unit lower)
+  double Li[PIV][PIV] = {};
+  for (int i = 0; i < PIV; ++i) {
+    Li[i][i] = 1.0;
+    for (int j = 0; j < i; ++j) {
+      double s = 0;
+      for (int k = j; k < i; ++k) s += L[i][k] * Li[k][j];
+      Li[i][j] = -s;
+    }
+  }
+  for (int i = 0; i < PIV; ++i) for (int j = 0; j < PIV; ++j) {
+    double s = 0;
+    for (int k = 0; k < PIV; ++k) s += Li[k][i] * Li[k][j] / d[k];
+    Mi[i][j] = s;
+  }
+}
+}  // namespace
+
+// out[0] worst relative panel error (V), out[1] worst relative error of w, out[2] largest entry of a reference panel row that the
+// stage's row mask does not store (must be 0), out[3] worst stage index;  info: n_stages, front, n_records, max_srec, max_drec,
+// n_cells, continuation records, n_unknowns (positions)
+extern "C" int qtos_pair_emul(const QtosParams *prm, int pair_mode, double *out, int *info) {
+  HostModel M;
+  Symbolic S;
+  if (M.build(*prm)) { fprintf(stderr, "pair_emul: %s\n", M.err.c_str()); return -1; }
+  S.cell_mode = 2;
+  S.pair_mode = pair_mode != 0;
+  if (S.build(M)) { fprintf(stderr, "pair_emul: %s\n", S.err.c_str()); return -2; }
+  const int N = S.n_unknowns, NS = S.n_stages, F = S.front, n = M.n_sol;
+  int n_cont = 0;
+  for (int r = 0; r < S.n_records; ++r) n_cont += S.srec[S.srec_off[r] + 6];
+  info[0] = NS; info[1] = F; info[2] = S.n_records; info[3] = S.max_srec; info[4] = S.max_drec; info[5] = S.n_cells; info[6] = n_cont; info[7] = N;
+  if (!pair_mode) return 0;
+  if (n_cont) return -3;
+  // ---- a stream of values --------------------------------------------------------------------------------------
+  Rng rng{12345};
+  std::vector<double> st(S.pack_src.size(), 0.0);
+  for (size_t i = 0; i < st.size(); ++i) {
+    const int kind = S.pack_src[i] >> 28, idx = S.pack_src[i] & 0x0fffffff;
+    switch (kind) {
+      case 0: st[i] = 2 * rng.uni() - 1; break;
+      case 1: st[i] = M.g_static[idx]; break;
+      case 2: st[i] = 2 * rng.uni() - 1; break;
+      case 3: st[i] = std::pow(10.0, 4 * rng.uni() - 2); break;
+      case 4: st[i] = 2 * rng.uni() - 1; break;
+      case 5: { const double d = S.piv_diag[idx]; st[i] = std::fabs(d) < 1e-3 ? (d < 0 ? -1e-3 : 1e-3) : d; } break;   // (a milder regularisation than 1e-8: the comparison is about structure)
+      default: st[i] = 0.0;
+    }
+  }
+  // ---- dense K and right-hand side by position (k_residual's reading of the stream; inequality blocks from the model) ----
+  std::vector<double> K((size_t)N * N, 0.0), y(N, 0.0);
+  for (int p = 0; p < N; ++p) {
+    K[(size_t)p * N + p] += st[S.diag_pos[p]];
+    for (int e = S.kx_ptr[p]; e < S.kx_ptr[p + 1]; ++e) K[(size_t)p * N + S.kx_col[e]] += st[S.kx_pos[e]];
+  }
+  for (const Block &b : M.blocks) {
+    if (b.kind != 1) continue;
+    for (int a = 0; a < b.n; ++a) {
+      const int pa = S.var_pos[M.block_cols[b.col_off + a]];
+      for (int r = 0; r < b.m; ++r) y[pa] -= st[b.goff + r * b.n + a] * st[S.w_pos[b.row0 + r]];
+      for (int c = 0; c < b.n; ++c) {
+        const int pc = S.var_pos[M.block_cols[b.col_off + c]];
+        double s = 0;
+        for (int r = 0; r < b.m; ++r) s += st[S.sig_pos[b.row0 + r]] * st[b.goff + r * b.n + a] * st[b.goff + r * b.n + c];
+        K[(size_t)pa * N + pc] += s;
+      }
+    }
+  }
+  for (int r = 0; r < M.n_cons; ++r)
+    if (S.row_pos[r] >= 0) y[S.row_pos[r]] = st[S.rhs_pos[r]];
+  for (int p = 0; p < N; ++p)
+    for (int q = 0; q < p; ++q)
+      if (std::fabs(K[(size_t)p * N + q] - K[(size_t)q * N + p]) > 1e-12 * (1 + std::fabs(K[(size_t)p * N + q]))) { fprintf(stderr, "pair_emul: K not symmetric at %d %d\n", p, q); return -4; }
+  // ---- reference: block elimination in position order ----------------------------------------------------------
+  std::vector<std::vector<double>> Vref(NS), wref(NS);   // Vref[k][(pos - 16 (k + 1)) * 16 + j]
+  {
+    std::vector<double> Sx(K), yy(y);
+    for (int k = 0; k < NS; ++k) {
+      const int p0 = k * PIV, r0 = p0 + PIV, nr = N - r0;
+      double A[PIV][PIV], Mi[PIV][PIV];
+      for (int i = 0; i < PIV; ++i) for (int j = 0; j < PIV; ++j) A[i][j] = Sx[(size_t)(p0 + i) * N + p0 + j];
+      inv16(A, Mi);
+      Vref[k].assign((size_t)nr * PIV, 0.0);
+      wref[k].assign(PIV, 0.0);
+      for (int i = 0; i < PIV; ++i) for (int j = 0; j < PIV; ++j) wref[k][i] += Mi[i][j] * yy[p0 + j];
+      for (int r = 0; r < nr; ++r)
+        for (int j = 0; j < PIV; ++j) {
+          double s = 0;
+          for (int q = 0; q < PIV; ++q) s += Sx[(size_t)(r0 + r) * N + p0 + q] * Mi[q][j];
+          Vref[k][(size_t)r * PIV + j] = s;
+        }
+      for (int r = 0; r < nr; ++r) {
+        bool any = false;
+        for (int j = 0; j < PIV; ++j) any |= Vref[k][(size_t)r * PIV + j] != 0.0;
+        double s = 0;
+        for (int q = 0; q < PIV; ++q) s += Sx[(size_t)(r0 + r) * N + p0 + q] * wref[k][q];
+        yy[r0 + r] -= s;
+        if (!any) continue;
+        for (int c = 0; c < nr; ++c) {
+          double t = 0;
+          for (int q = 0; q < PIV; ++q) t += Vref[k][(size_t)r * PIV + q] * Sx[(size_t)(r0 + c) * N + p0 + q];
+          Sx[(size_t)(r0 + r) * N + r0 + c] -= t;
+        }
+      }
+    }
+  }
+  // ---- emulation of the pair kernel ---------------------------------------------------------------------------------
+  const int NP = NS / 2, NT = F / PIV, FR = F + 2;   // panel rows: F slots, the right-hand side, a row of zeros
+  std::vector<double> A(S.n_cells, 0.0), U((size_t)F * F, 0.0), UF(F, 0.0);
+  // panels: buffer [pair parity][stage of the pair][row][16]
+  std::vector<double> PB((size_t)2 * 2 * FR * PIV, 0.0);
+  auto panel = [&](int pair, int t) { return PB.data() + ((size_t)((pair & 1) * 2 + t)) * FR * PIV; };
+  std::vector<std::vector<double>> Vem(NS, std::vector<double>((size_t)F * PIV, 0.0)), wem(NS, std::vector<double>(PIV, 0.0));
+  double Minv[2][PIV][PIV] = {}, L21[PIV][PIV] = {};
+  auto slot = [&](int stage, int i) { return S.piv_slot[(size_t)stage * PIV + i]; };
+  auto in_pair = [&](int pair, int s) {   // is slot s a pivot slot of that pair
+    if (pair < 0 || pair >= NP) return false;
+    for (int i = 0; i < 2 * PIV; ++i) if (S.piv_slot[(size_t)pair * 2 * PIV + i] == s) return true;
+    return false;
+  };
+  auto ureads = [&](int r, int c) { return (r >> 4) > (c >> 4) || ((r >> 4) == (c >> 4) && r >= c) ? U[(size_t)r * F + c] : U[(size_t)c * F + r]; };
+  auto assemble = [&](int rec) {
+    const int *sb = &S.srec[S.srec_off[rec]];
+    const double *db = &st[S.drec_off[rec]];
+    const int n_ent = sb[0], n_rhs = sb[1], NPV = PIV * S.rec_stages;
+    const int *eidx = sb + Symbolic::SHDR_INTS + NPV;
+    const double *eval = db + NPV;
+    for (int i = 0; i < n_ent; ++i) A[eidx[i]] += eval[i];
+    for (int i = 0; i < n_rhs; ++i) A[eidx[n_ent + i]] += eval[n_ent + i];
+    const int n_tgt = sb[5];
+    const int *tg = sb + sb[4], *cl = tg + n_tgt + 1;
+    const int tmask = (1 << S.tgt_shift) - 1;
+    for (int t = 0; t < n_tgt; ++t) {
+      const int c0 = tg[t] & tmask, c1 = tg[t + 1] & tmask;
+      double acc = 0;
+      for (int j = c0; j < c1; ++j) {
+        const int code = cl[j];
+        const int a = (code >> 12) & 63, c = (code >> 18) & 63, qn = ((code >> 24) & 31) + 1, qm = (int)((unsigned)code >> 29) + 1;
+        const double *Gb = db + (code & 4095), *sg = Gb + qm * qn, *wq = sg + qm;
+        if (c == 62) { acc += Gb[a]; continue; }
+        double t3 = 0;
+        for (int r = 0; r < qm; ++r) t3 += c == 63 ? -(Gb[r * qn + a] * wq[r]) : sg[r] * Gb[r * qn + a] * Gb[r * qn + c];
+        acc += t3;
+      }
+      A[tg[t] >> S.tgt_shift] += acc;
+    }
+  };
+  auto cell_of = [&](int stage, int r, int col) { return (int)S.ctab[((((size_t)stage * NT + (r >> 4)) * 64) + (r & 3) * 16 + col) * 4 + ((r & 15) >> 2)]; };
+  for (int j = -2; j < NP; ++j) {
+    // ---- phase 1: the pair's factor panels and the next pair's columns ---------------------------------------------
+    std::vector<double> W1((size_t)(F + 1) * PIV, 0.0), W2((size_t)(F + 1) * PIV, 0.0);
+    double *P1 = panel(j, 0), *P2 = panel(j, 1);
+    if (j >= 0) {
+      const int a = 2 * j, b = a + 1;
+      double A21[PIV][PIV];
+      for (int m = 0; m < PIV; ++m) for (int k = 0; k < PIV; ++k) A21[m][k] = P1[(size_t)slot(b, m) * PIV + k];
+      for (int r = 0; r <= F; ++r) {   // (row F: the right-hand side)
+        double v1[PIV], p2[PIV], v2[PIV];
+        for (int k = 0; k < PIV; ++k) { double s = 0; for (int q = 0; q < PIV; ++q) s += P1[(size_t)r * PIV + q] * Minv[0][q][k]; v1[k] = s; }
+        for (int m = 0; m < PIV; ++m) { double s = P2[(size_t)r * PIV + m]; for (int k = 0; k < PIV; ++k) s -= v1[k] * A21[m][k]; p2[m] = s; }
+        bool is_b = false;
+        for (int i = 0; i < PIV; ++i) is_b |= slot(b, i) == r;
+        if (is_b) for (int m = 0; m < PIV; ++m) p2[m] = 0.0;   // b's own pivot rows leave the panel
+        for (int k = 0; k < PIV; ++k) { double s = 0; for (int q = 0; q < PIV; ++q) s += p2[q] * Minv[1][q][k]; v2[k] = s; }
+        if (r < F) {
+          const bool sa = (S.amask[(size_t)a * 8 + (r >> 5)] >> (r & 31)) & 1u, sb2 = (S.amask[(size_t)b * 8 + (r >> 5)] >> (r & 31)) & 1u;
+          for (int k = 0; k < PIV; ++k) { Vem[a][(size_t)r * PIV + k] = sa ? v1[k] : 0.0; Vem[b][(size_t)r * PIV + k] = sb2 ? v2[k] : 0.0; }
+        } else {
+          for (int k = 0; k < PIV; ++k) { wem[a][k] = v1[k]; wem[b][k] = v2[k]; }
+        }
+        const bool retiring = r < F && in_pair(j, r);
+        for (int k = 0; k < PIV; ++k) {
+          double s = v1[k];
+          for (int m = 0; m < PIV; ++m) s -= v2[m] * L21[m][k];
+          W1[(size_t)r * PIV + k] = retiring ? 0.0 : s;
+          W2[(size_t)r * PIV + k] = retiring ? 0.0 : v2[k];
+        }
+      }
+      // right-hand sides of the live slots
+      for (int r = 0; r < F; ++r) {
+        double s = 0;
+        for (int k = 0; k < PIV; ++k) s += W1[(size_t)F * PIV + k] * P1[(size_t)r * PIV + k] + W2[(size_t)F * PIV + k] * P2[(size_t)r * PIV + k];
+        UF[r] = in_pair(j, r) ? 0.0 : UF[r] - s;
+      }
+    }
+    if (j >= -1 && j + 1 < NP) {
+      for (int t = 0; t < 2; ++t) {
+        const int stage = 2 * (j + 1) + t;
+        double *Pn = panel(j + 1, t);
+        for (int m = 0; m < PIV; ++m) {
+          const int sm = slot(stage, m);
+          const bool fresh = in_pair(j, sm);   // the slot of a pivot that enters with its pair: its rows in this pair's panels are the previous occupant's
+          for (int r = 0; r < F; ++r) {
+            const int cell = cell_of(stage, r, m);
+            double acc = Pn[(size_t)r * PIV + m] + A[cell] + (r == sm ? st[S.diag_pos[(size_t)stage * PIV + m]] : 0.0);
+            if (cell) A[cell] = 0.0;
+            if (j >= 0 && !fresh)
+              for (int k = 0; k < PIV; ++k) acc -= W1[(size_t)r * PIV + k] * P1[(size_t)sm * PIV + k] + W2[(size_t)r * PIV + k] * P2[(size_t)sm * PIV + k];
+            Pn[(size_t)r * PIV + m] = acc;
+          }
+          const int rc = S.rtab[(size_t)stage * PIV + m];
+          Pn[(size_t)F * PIV + m] = A[rc] + UF[sm];
+          if (rc) A[rc] = 0.0;
+          UF[sm] = 0.0;
+        }
+      }
+    }
+    // ---- phases 2 and 3 --------------------------------------------------------------------------------------------
+    if (j >= 0) {
+      // Schur update with the rows of this pair's and the next pair's pivots blanked in both operands
+      std::vector<char> blank(F, 0);
+      for (int r = 0; r < F; ++r) blank[r] = in_pair(j, r) || in_pair(j + 1, r);
+      for (int r = 0; r < F; ++r) {
+        if (blank[r]) continue;
+        for (int c = 0; c < F; ++c) {
+          if (blank[c]) continue;
+          if (!((r >> 4) > (c >> 4) || ((r >> 4) == (c >> 4)))) continue;   // tiles of the lower triangle (diagonal tiles whole)
+          double s = 0;
+          for (int k = 0; k < PIV; ++k) s += W1[(size_t)r * PIV + k] * P1[(size_t)c * PIV + k] + W2[(size_t)r * PIV + k] * P2[(size_t)c * PIV + k];
+          U[(size_t)r * F + c] -= s;
+        }
+      }
+    }
+    if (j + 1 >= 0 && j + 1 < NP) {
+      // the pivot blocks of pair j + 1
+      const int c = 2 * (j + 1), d = c + 1;
+      double *Pc = panel(j + 1, 0), *Pd = panel(j + 1, 1);
+      double A11[PIV][PIV], A21[PIV][PIV], A22[PIV][PIV], S22[PIV][PIV];
+      for (int i = 0; i < PIV; ++i) for (int q = 0; q < PIV; ++q) {
+        A11[i][q] = q <= i ? Pc[(size_t)slot(c, i) * PIV + q] : Pc[(size_t)slot(c, q) * PIV + i];
+        A21[i][q] = Pc[(size_t)slot(d, i) * PIV + q];
+        A22[i][q] = q <= i ? Pd[(size_t)slot(d, i) * PIV + q] : Pd[(size_t)slot(d, q) * PIV + i];
+      }
+      inv16(A11, Minv[0]);
+      for (int i = 0; i < PIV; ++i) for (int k = 0; k < PIV; ++k) { double s = 0; for (int q = 0; q < PIV; ++q) s += A21[i][q] * Minv[0][q][k]; L21[i][k] = s; }
+      for (int i = 0; i < PIV; ++i) for (int q = 0; q < PIV; ++q) { double s = A22[i][q]; for (int k = 0; k < PIV; ++k) s -= L21[i][k] * A21[q][k]; S22[i][q] = s; }
+      inv16(S22, Minv[1]);
+      for (int i = 0; i < PIV; ++i) for (int q = 0; q < PIV; ++q) { Pc[(size_t)slot(c, i) * PIV + q] = 0.0; Pd[(size_t)slot(c, i) * PIV + q] = 0.0; Pd[(size_t)slot(d, i) * PIV + q] = 0.0; }
+    }
+    if (j >= 0 && j + 2 < NP) {
+      // columns of pair j + 2 out of the Schur complement, into the panels of pair j
+      for (int t = 0; t < 2; ++t) {
+        const int stage = 2 * (j + 2) + t;
+        double *X = panel(j, t);
+        for (int m = 0; m < PIV; ++m) {
+          const int sm = slot(stage, m);
+          for (int r = 0; r < F; ++r) X[(size_t)r * PIV + m] = ureads(r, sm);
+        }
+      }
+      for (int i = 0; i < 2 * PIV; ++i) {
+        const int sm = S.piv_slot[(size_t)(j + 2) * 2 * PIV + i];
+        for (int r = 0; r < F; ++r) { U[(size_t)r * F + sm] = 0.0; U[(size_t)sm * F + r] = 0.0; }
+      }
+    } else if (j < 0 && j + 2 < NP) {
+      for (int t = 0; t < 2; ++t) { double *X = panel(j, t); for (int i = 0; i < FR * PIV; ++i) X[i] = 0.0; }
+    }
+    if (j + 2 >= 0 && j + 2 < NP) assemble(j + 2);
+  }
+  // ---- compare --------------------------------------------------------------------------------------------------
+  double worst_v = 0, worst_w = 0, unstored = 0;
+  int worst_k = -1;
+  for (int k = 0; k < NS; ++k) {
+    double scale = 1.0;
+    for (double v : Vref[k]) scale = std::max(scale, std::fabs(v));
+    for (double v : wref[k]) scale = std::max(scale, std::fabs(v));
+    std::vector<int> next_occ(F, -1);
+    for (int pp = N - 1; pp >= PIV * (k + 1); --pp) next_occ[S.piv_slot[pp]] = pp;
+    for (int s = 0; s < F; ++s) {
+      const int pp = next_occ[s];
+      if (pp < 0) continue;
+      const bool stored = (S.amask[(size_t)k * 8 + (s >> 5)] >> (s & 31)) & 1u;
+      for (int q = 0; q < PIV; ++q) {
+        const double ref = Vref[k][(size_t)(pp - PIV * (k + 1)) * PIV + q];
+        if (!stored) { unstored = std::max(unstored, std::fabs(ref)); continue; }
+        const double e = std::fabs(ref - Vem[k][(size_t)s * PIV + q]) / scale;
+        if (e > worst_v) { worst_v = e; worst_k = k; }
+      }
+    }
+    for (int q = 0; q < PIV; ++q) worst_w = std::max(worst_w, std::fabs(wref[k][q] - wem[k][q]) / scale);
+  }
+  out[0] = worst_v; out[1] = worst_w; out[2] = unstored; out[3] = worst_k;
+  (void)n;
+  return 0;
+}
