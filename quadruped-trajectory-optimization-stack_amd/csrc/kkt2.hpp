@@ -266,12 +266,13 @@ __device__ __forceinline__ void sw_tail(const DevPlan &P, const SweepDs &sd, con
   }
 }
 
-template <int F>
+// NTHR / HW0: threads of the workgroup and the first of the three helper waves (k_kkt5 runs twelve waves: helpers 9 .. 11)
+template <int F, int NTHR = KT2, int HW0 = SW_W0>
 __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *__restrict__ panel, double *__restrict__ dx,
                                                double *__restrict__ sol, double *xs, double *red, const int *nxp, int wv, int lane,
                                                double *xp, const SweepDs &sd) {
   constexpr int NT = Kkt2Cfg<F>::NT, pstride = (F + 1) * PIV;
-  constexpr bool HELP = NT < SW_W0;   // (fronts of 208 slots and more have no idle helper waves: the planner leaves sw_on off)
+  constexpr bool HELP = NT < HW0;   // (fronts of 208 slots and more have no idle helper waves: the planner leaves sw_on off)
   const int NS = P.n_stages, n = P.n_sol;
   const int j = lane & 15, q = lane >> 4;
   const int vcol = 4 * (j & 3) + (j >> 2);   // where column j of a V row sits
@@ -304,12 +305,12 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
   if (lane < PIV) { red[wv * PIV + lane] = 0.0; red[256 + wv * PIV + lane] = 0.0; }   // (the last stage has no rows besides its pivots)
   swi4_t *swt = (swi4_t *)(xp + NS * PIV);   // (16-byte aligned: the callers' xp is)
   if (HELP && P.sw_on)
-    for (int i = wv * 64 + lane; i < P.sw_steps * SW_ROUND; i += KT2) swt[i] = *(const swi4_t *)(P.sw_tasks + i);
+    for (int i = wv * 64 + lane; i < P.sw_steps * SW_ROUND; i += NTHR) swt[i] = *(const swi4_t *)(P.sw_tasks + i);
   // waves NT+1 .. 15 have no rows: they only meet the barriers (a SIMD has one vector ALU: what they would execute on
   // dummies is time the working waves of their SIMD do not get)
   const bool active = wv <= NT;
   if (!active) {
-    if (!HELP || wv < SW_W0 || !P.sw_on) {
+    if (!HELP || wv < HW0 || !P.sw_on) {
       lds_barrier();
       for (int k0 = NS - 1; k0 >= 0; k0 -= SWD)
 #pragma unroll
@@ -318,7 +319,7 @@ __device__ __forceinline__ void sweep_backward(const DevPlan &P, const double *_
     }
     // round i (16 rows) runs in step i of the chain (stage NS - 1 - i); the planner's schedule puts a block's rows behind
     // its stage.  The three waves take turns: a wave's loads have three steps to arrive, one set of prefetch registers.
-    const int hq = lane & 3, hr = lane >> 2, hw = wv - SW_W0;
+    const int hq = lane & 3, hr = lane >> 2, hw = wv - HW0;
     const int nstep = ((NS + SWD - 1) / SWD) * SWD;   // (steps of the chain loop below)
     lds_barrier();
     // (the rows of a round come from the LDS copy of the schedule: a descriptor carried from turn to turn in registers is
@@ -1319,7 +1320,7 @@ __global__ __launch_bounds__(512) void k_residual(DevPlan P, DevWork W, int B, d
   for (int p = tid; p < NU; p += blockDim.x) {
     const int t0 = P.rhs_ptr[p], t1 = P.rhs_ptr[p + 1];
     const bool mult = t1 - t0 == 1 && P.rhs_gpos[t0] < 0;
-    double rhs = 0.0, kx = Gs[P.drec_off[p >> 4] + (p & 15)] * sol[p];
+    double rhs = 0.0, kx = Gs[P.diag_pos[p]] * sol[p];
     if (mult) rhs = -g[P.rhs_row[t0]];
     else
       for (int t = t0; t < t1; ++t) {

@@ -14,6 +14,7 @@
 #include "kkt2.hpp"
 #include "kkt3.hpp"
 #include "kkt4.hpp"
+#include "kkt5.hpp"
 
 using namespace qtos;
 
@@ -74,6 +75,7 @@ struct QtosPlanner {
   bool use_kkt3 = false;             // k_kkt3 (kkt3.hpp) instead of k_kkt2: chosen by qtos_planner_create
   int kkt3_mode = 0;                 // k_kkt3's MODE (QTOS_KKT=3: 0, QTOS_KKT=4: 1)
   bool use_kkt4 = false;             // k_kkt4 (kkt4.hpp), QTOS_KKT=5
+  bool use_kkt5 = false;             // k_kkt5 (kkt5.hpp): two stages per set of barriers, Symbolic::pair_mode
   bool counts_by_copy = false;       // the counts of unfinished problems reach the host by hipMemcpyAsync instead of k_post_counts (QTOS_COUNTS_COPY=1)
   int spec_next = 1;                 // blind iterations of the next call: the iterations the last one took
   int spec_cap = 1;                  // limit of the blind iterations (qtos_set_speculation): 1 = off, the measured optimum
@@ -125,6 +127,13 @@ static void (*kkt3_kernel(int F, int mode))(DevPlan, DevWork, int) {
 #define QTOS_KKT3(f) case f: return mode == 0 ? k_kkt3<f, 0> : k_kkt3<f, 1>;
   switch (F) { QTOS_KKT3(16) QTOS_KKT3(32) QTOS_KKT3(48) QTOS_KKT3(64) QTOS_KKT3(80) QTOS_KKT3(96) QTOS_KKT3(112) QTOS_KKT3(128) }
 #undef QTOS_KKT3
+  return nullptr;
+}
+// k_kkt5 (two 16-pivot stages per set of barriers, twelve waves): fronts up to 144 slots
+static void (*kkt5_kernel(int F))(DevPlan, DevWork, int) {
+#define QTOS_KKT5(f) case f: return k_kkt5<f>;
+  switch (F) { QTOS_KKT5(32) QTOS_KKT5(48) QTOS_KKT5(64) QTOS_KKT5(80) QTOS_KKT5(96) QTOS_KKT5(112) QTOS_KKT5(128) QTOS_KKT5(144) }
+#undef QTOS_KKT5
   return nullptr;
 }
 // k_kkt4 (panel chain and Schur updates side by side): fronts up to 128 slots
@@ -262,12 +271,30 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   //   k_kkt3, MODE 0    QTOS_KKT=3 only: inequality blocks condensed by matrix instructions (correct, slower)
   // QTOS_KKT=2 / 3 / 4 force k_kkt2 / MODE 0 / MODE 1.
   p->use_kkt3 = false;
+  p->use_kkt5 = false;
   {
     const char *e = getenv("QTOS_KKT");
     const int forced = e ? atoi(e) : 0;
+    if (forced == 6) {
+      // k_kkt5: the analysis in pair mode (one record per pair of stages); applicable without continuation records, with a
+      // front of at most 144 slots and everything within the LDS
+      p->M = HostModel();
+      p->S = Symbolic();
+      if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
+      p->S.cell_mode = 2;
+      p->S.pair_mode = true;
+      bool ok = p->S.build(p->M) == 0 && p->S.front >= 32 && p->S.front <= 144 && !(p->S.pack_src.size() & 1);
+      if (ok) {
+        int n_cont = 0;
+        for (int r = 0; r < p->S.n_records; ++r) n_cont += p->S.srec[p->S.srec_off[r] + 6];
+        ok = n_cont == 0 && kkt5_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) <= 160 * 1024 - 256;
+      }
+      p->use_kkt5 = ok;
+      if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: k_kkt5 %s (front %d, %s)\n", ok ? "selected" : "not applicable", p->S.front, p->S.err.c_str());
+    }
     p->kkt3_mode = forced == 3 ? 0 : 1;
     p->use_kkt4 = false;
-    if (forced != 2) {
+    if (forced != 2 && !p->use_kkt5) {
       p->M = HostModel();
       p->S = Symbolic();
       if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
@@ -294,7 +321,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   }
   bool want_kron = getenv("QTOS_KRON") && atoi(getenv("QTOS_KRON")) != 0;   // (experiment: Kronecker assembly of the range-of-motion blocks, k_kkt2<128> only)
   for (int cap : {0, 4096, 3072, 2048}) {
-    if (p->use_kkt3) break;
+    if (p->use_kkt3 || p->use_kkt5) break;
     p->M = HostModel();
     p->S = Symbolic();
     if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
@@ -417,7 +444,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.chord_shrink = M.P.chord_shrink > 0 ? M.P.chord_shrink : 1.0 / 3.0;
   D.n_cells = S.n_cells;
   D.n_cont = 0;
-  for (int k = 0; k < S.n_stages; ++k) D.n_cont += S.srec[S.srec_off[k] + 6];
+  for (int k = 0; k < S.n_records; ++k) D.n_cont += S.srec[S.srec_off[k] + 6];
   D.table = nullptr; D.tab_dx = D.tab_dy = nullptr; D.tab_ndx = D.tab_ndy = 0;
   D.off_lin = M.off_lin; D.off_ang = M.off_ang;
   for (int e = 0; e < NEE; ++e) D.off_eem[e] = M.off_eem[e];
@@ -487,6 +514,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.max_stage_g = S.max_stage_g;
   TRY(p->upload(S.srec, &D.srec)); TRY(p->upload(S.srec_off, &D.srec_off));
   TRY(p->upload(S.pack_src, &D.pack_src)); TRY(p->upload(S.drec_off, &D.drec_off));
+  TRY(p->upload(S.diag_pos, &D.diag_pos));
   TRY(p->upload(S.eq_pos, &D.eq_pos)); TRY(p->upload(S.rhs_pos, &D.rhs_pos));
   TRY(p->upload(S.sig_pos, &D.sig_pos)); TRY(p->upload(S.w_pos, &D.w_pos));
   D.max_srec = S.max_srec; D.max_drec = S.max_drec; D.stream_len = (int)S.pack_src.size();
@@ -503,23 +531,24 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.panel_stride = (long long)S.n_stages * (S.front + 1) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  p->kkt_lds = p->use_kkt4 ? kkt4_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : p->use_kkt3 ? kkt3_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
+  p->kkt_lds = p->use_kkt5 ? kkt5_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : p->use_kkt4 ? kkt4_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : p->use_kkt3 ? kkt3_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
   D.kron_lds_off = 0;
   if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: Kronecker assembly %s (kkt3 %d, most blocks in a record %d)\n", S.kron ? "on" : "off", (int)p->use_kkt3, S.max_kblocks);
   if (S.kron && !p->use_kkt3 && !p->use_kkt4) {
     D.kron_lds_off = (int)((p->kkt_lds + 15) & ~(size_t)15);
     p->kkt_lds = (size_t)D.kron_lds_off + sizeof(double) * Symbolic::KRON_SM * (size_t)S.max_kblocks;
   }
+  if (p->use_kkt5 && F > 128) D.sw_on = 0;   // (nine tile waves of twelve: fewer than three helper waves are left)
   if (D.sw_on) {
     // the helper waves' tables of the backward sweep (solution by position, rounds) behind the sweep's own: within the LDS
     // the forward pass needs anyway, or the kernel's allocation grows up to the limit; beyond that k_step forms ds itself
-    const size_t need = (p->use_kkt4 ? kkt4_sweep_base_bytes(F, S.n_stages) : kkt2_sweep_base_bytes(F, S.n_stages)) + sweep_ds_lds_bytes(S.n_stages, D.sw_steps);
+    const size_t need = (p->use_kkt5 ? kkt5_sweep_base_bytes(F, S.n_stages) : p->use_kkt4 ? kkt4_sweep_base_bytes(F, S.n_stages) : kkt2_sweep_base_bytes(F, S.n_stages)) + sweep_ds_lds_bytes(S.n_stages, D.sw_steps);
     if (need > 160 * 1024 - 256 || chord_lds_bytes(S.n_stages, D.sw_steps) > 96 * 1024) D.sw_on = 0;
     else p->kkt_lds = std::max(p->kkt_lds, need);
   }
-  p->kkt_threads = KT2;
+  p->kkt_threads = p->use_kkt5 ? KT5 : KT2;
   const int max_front = 208;
-  if (S.max_drec > 2 * 2 * KT || S.max_srec > 3 * 4 * KT || F > max_front || (S.pack_src.size() & 1)) {
+  if (!p->use_kkt5 && (S.max_drec > 2 * 2 * KT || S.max_srec > 3 * 4 * KT || F > max_front || (S.pack_src.size() & 1))) {
     p->err = "stage record exceeds the prefetch registers";
     fprintf(stderr, "qtos: stage records too long (%d doubles, %d ints) or front %d > %d\n", S.max_drec, S.max_srec, F, max_front);
     qtos_planner_destroy(p);
@@ -533,7 +562,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     return -4;
   }
   {
-    p->kkt_fn = p->use_kkt4 ? kkt4_kernel(F) : p->use_kkt3 ? kkt3_kernel(F, p->kkt3_mode) : kkt2_kernel(F, D.n_cont > 0, S.kron);
+    p->kkt_fn = p->use_kkt5 ? kkt5_kernel(F) : p->use_kkt4 ? kkt4_kernel(F) : p->use_kkt3 ? kkt3_kernel(F, p->kkt3_mode) : kkt2_kernel(F, D.n_cont > 0, S.kron);
     p->chord_fn = chord_kernel(F);
     if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
