@@ -117,6 +117,7 @@ struct DevPlan {
   int max_stage_g;
   const int *srec, *srec_off, *pack_src, *drec_off;  // packed records, one per stage or -- Symbolic::pair_mode -- per pair of stages (symbolic.hpp)
   const int *diag_pos;         // per position: stream position of its pivot diagonal (Symbolic::diag_pos)
+  const unsigned *pair_groups; // per pair: occupied 16-slot groups (Symbolic::pair_groups, k_kkt5)
   const int *eq_pos, *rhs_pos, *sig_pos, *w_pos;     // direct-write maps into the stream
   int max_srec, max_drec, stream_len;
   const double *con_lo, *con_hi;

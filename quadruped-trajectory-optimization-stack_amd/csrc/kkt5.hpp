@@ -48,7 +48,15 @@ struct Kkt5Cfg {
   // Row tile of a wave, -1: none.  The factor wave (0) shares its SIMD with waves 4 and 8: a SIMD has one vector ALU and it
   // stands still while an f64 matrix instruction runs, so the tiles go to the other three SIMDs heaviest first (row tile R
   // has R + 1 Schur tiles), serpentine, and the two lightest rows to waves 4 and 8.
-  static constexpr int slot_wave(int i) { constexpr int o[9] = {1, 2, 3, 7, 6, 5, 4, 8, 9}; return o[i]; }
+#ifndef QTOS_K5_PLACE
+#define QTOS_K5_PLACE 0
+#endif
+  // (PLACE 1: the service waves on the factor wave's SIMD -- no matrix instruction ever blocks their vector instructions --,
+  //  all row tiles on the other three)
+  static constexpr int slot_wave(int i) {
+    constexpr int o0[9] = {1, 2, 3, 7, 6, 5, 4, 8, 9}, o1[9] = {1, 2, 3, 7, 6, 5, 9, 10, 11};
+    return QTOS_K5_PLACE == 1 ? o1[i] : o0[i];
+  }
   static constexpr int row_of_wave(int w) {
     for (int i = 0; i < NT; ++i) if (slot_wave(i) == w) return NT - 1 - i;
     return -1;
@@ -109,13 +117,24 @@ inline size_t kkt5_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_ce
   return std::max(oi * sizeof(int), kkt5_sweep_base_bytes(F, NS));
 }
 
-// assembly of a pair record (Symbolic::pair_mode: 32 pivot slots / diagonals in front, target words (cell << 13) | first contribution)
+// assembly of a pair record (Symbolic::pair_mode: 32 pivot slots / diagonals in front, target words (cell << 13) | first contribution).
+// The waves that assemble do nothing else at that time: a thread's chain of dependent LDS round trips is what a round costs, so
+// four equality entries / W contributions of a target are in flight at once; the order of a target's sum does not change.
 __device__ __forceinline__ void assemble_pair_eq(double *A, const int *sbuf, const double *dbuf, int t0, int nth) {
   const int n = sbuf[0] + sbuf[1];   // equality entries, then the multipliers' right-hand sides: distinct cells
   const int *eidx = sbuf + SHDR + 2 * PIV;
   const double *eval = dbuf + 2 * PIV;
-  for (int i = t0; i < n; i += nth) A[eidx[i]] += eval[i];
+  // (every such cell has ONE contribution in the whole plan and was left zero by the gather that retired it: a store)
+  for (int i = t0; i < n; i += 4 * nth) {
+    int idx[4];
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int ii = min(i + u * nth, n - 1); idx[u] = eidx[ii]; v[u] = eval[ii]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i + u * nth < n) A[idx[u]] = v[u];
+  }
 }
+template <int W>
 __device__ __forceinline__ void assemble_pair_tgt(double *A, const int *sbuf, const double *dbuf, int t_begin, int t_end, int t0, int nth) {
   const int n_tgt = min(sbuf[5], t_end);
   const int *tg = sbuf + sbuf[4];
@@ -124,13 +143,45 @@ __device__ __forceinline__ void assemble_pair_tgt(double *A, const int *sbuf, co
     const int tv = tg[t], c0 = tv & 8191, c1 = tg[t + 1] & 8191;
     const double a_old = A[tv >> 13];
     double acc = 0;
-    for (int j = c0; j < c1; ++j) acc += gather_term(dbuf, cl[j]);
+    for (int j = c0; __builtin_amdgcn_ballot_w64(j < c1) != 0ull; j += W) {
+      int code[W];
+      double term[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w) code[w] = cl[min(j + w, c1 - 1)];
+#pragma unroll
+      for (int w = 0; w < W; ++w) term[w] = gather_term(dbuf, code[w]);
+#pragma unroll
+      for (int w = 0; w < W; ++w) acc = j + w < c1 ? acc + term[w] : acc;
+    }
     A[tv >> 13] = a_old + acc;
   }
 }
 
+#ifndef QTOS_K5_SB
+#define QTOS_K5_SB 0
+#endif
+#if QTOS_K5_SB
+#define K5_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define K5_SCHED_BARRIER() do {} while (0)
+#endif
+#ifndef QTOS_K5_ABL
+#define QTOS_K5_ABL 0   // diagnostic builds: bit mask of parts compiled out (1 assembly, 2 extraction, 4 Schur update, 8 next columns, 16 factor wave, 32 rhs chain, 64 V/W chain)
+#endif
+#ifndef QTOS_K5_ILPS
+#define QTOS_K5_ILPS 1   // contributions of a target in flight: service waves
+#endif
+#ifndef QTOS_K5_ILPT
+#define QTOS_K5_ILPT 1   // ... tile waves (their Schur tiles take half the registers)
+#endif
+#ifndef QTOS_K5_SKIP
+#define QTOS_K5_SKIP 1   // skip the matrix instructions of row tiles / Schur tiles whose 16-slot group holds no unknown during the pair
+#endif
+#ifndef QTOS_K5_ASMT
+#define QTOS_K5_ASMT 8   // row tiles 0 .. ASMT - 1 take part in the assembly of phase 3 (the heavy rows have their extraction)
+#endif
 #ifndef QTOS_K5_ASM2
-#define QTOS_K5_ASM2 3   // rounds of targets the service waves assemble during phase 2 (the tile waves join in phase 3)
+#define QTOS_K5_ASM2 1   // rounds of targets the service waves assemble during phase 2 (the tile waves join in phase 3)
 #endif
 
 template <int F>
@@ -185,78 +236,95 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
       if (with_jm) jm[(slot & ~15) + (slot & 3) * 4 + ((slot >> 2) & 3)] = (unsigned short)((lane >> 4) * PSZ + (lane & 15));
     }
   };
-  // Schur tiles of this wave: (R, C), C = 0 .. R
-  d4_t U[NT];
-#pragma unroll
-  for (int c = 0; c < NT; ++c) U[c] = d4_t{0.0, 0.0, 0.0, 0.0};
-  d4_t nW1 = {0.0, 0.0, 0.0, 0.0}, nW2 = {0.0, 0.0, 0.0, 0.0};   // -W1, -W2 of the pair (rows 16 R + li, columns lk + 4 g)
-  unsigned ge4_keep = 0u, gt4_keep = 0u;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) { ge4_keep |= (lk + 4 * g >= li ? 1u : 0u) << (4 * g); gt4_keep |= (lk + 4 * g > li ? 1u : 0u) << (4 * g); }
   typedef unsigned short us4_t __attribute__((ext_vector_type(4)));
-  const us4_t *ctab4 = (const us4_t *)P.ctab;
-  const int Rc = is_tile ? R : 0;
-  int tile_lane = (li * PLD + lk) * 8;   // (li, lk): row li, column lk of a 16 x 16 tile of a panel, in bytes
-  asm volatile("" : "+v"(tile_lane));
+#ifdef QTOS_STAMPS
+  // diagnostic build: per wave, cycles spent in each part of a step (fire-and-forget atomics of lane 0 into the trace rows):
+  // 0 phase 1 work | 1 barrier 1 | 2 phase 2 work | 3 barrier 2 | 4 phase 3 role work | 5 phase 3 assembly | 6 barrier 3 | 7 sweep
+  unsigned long long *st5 = (unsigned long long *)(W.trace + ((size_t)b * (P.max_iter + 1) + 16) * 4);
+  unsigned long long ts_ = 0;
+  if (tid < 192) st5[tid] = 0ull;
+  __syncthreads();
+#define K5S(i) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); atomicAdd(st5 + wv * 12 + (i), t_ - ts_); ts_ = t_; } } while (0)
+  if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) :: "memory");
+#else
+#define K5S(i) do {} while (0)
+#endif
+  // per-step pointers (pair q lives in panels 2 (q & 1), 2 (q & 1) + 1; rings by pair % 3)
+#define K5_STEP_POINTERS \
+    const bool live = j >= 0, has_next = j + 1 < NP, has_next2 = j + 2 < NP; \
+    const double *PA0 = pan(j, 0), *PA1 = pan(j, 1); \
+    double *PN0 = pan(j + 1, 0); \
+    const int *psj = psb + (((j + 3) % 3) * 2 * PIV), *psn = psb + (((j + 4) % 3) * 2 * PIV); \
+    const unsigned *pmj = pm + ((j + 3) % 3) * 8, *pmn = pm + ((j + 4) % 3) * 8, *pmn2 = pm + ((j + 5) % 3) * 8; \
+    (void)live; (void)has_next; (void)has_next2; (void)PA0; (void)PA1; (void)PN0; (void)psj; (void)psn; (void)pmj; (void)pmn; (void)pmn2;
+  constexpr int NASMT = QTOS_K5_ASMT < NT ? QTOS_K5_ASMT : NT;
+  const int n_tgt2 = NSVC * 64 * QTOS_K5_ASM2;   // targets of a record the service waves take during phase 2
 
-  // table words of the steps ahead, fetched a pair early (from global memory they are a microsecond away): cells of the columns
-  // of pair j + 1 (ctab), row masks of the panels of pair j (amask), right-hand-side cells of pair j + 1 (rtab)
-  us4_t ct_cur[2] = {us4_t{0, 0, 0, 0}, us4_t{0, 0, 0, 0}}, ct_nxt[2];
-  unsigned am_cur[2] = {0u, 0u}, am_nxt[2];
-  int rt_cur = 0, rt_nxt;
-  for (int j = -2; j < NP; ++j) {
-    const bool live = j >= 0, has_next = j + 1 < NP, has_next2 = j + 2 < NP;
-    {
-      const int q2 = min(j + 2, NP - 1), q1 = min(max(j + 1, 0), NP - 1);
+  // Role-specialised loops with the same three barriers per step: the register budget of a wave is its own role's (the Schur
+  // tiles are live across the whole loop of the tile waves only).
+  if (is_tile) {
+    // ================================================ tile waves ================================================
+    d4_t U[NT];   // Schur tiles (R, C), C = 0 .. R
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        ct_nxt[t] = ctab4[((size_t)(2 * q2 + t) * NT + Rc) * 64 + lane];
-        am_nxt[t] = P.amask[(2 * q1 + t) * 8 + (Rc >> 1)];
-      }
-      rt_nxt = P.rtab[2 * q2 * PIV + (lane & 31)];
-    }
-    const double *PA0 = pan(j, 0), *PA1 = pan(j, 1);
-    double *PN0 = pan(j + 1, 0);
-    const int *psj = psb + (((j + 3) % 3) * 2 * PIV), *psn = psb + (((j + 4) % 3) * 2 * PIV);   // pivot slots of pairs j, j + 1
-    const unsigned *pmj = pm + ((j + 3) % 3) * 8, *pmn = pm + ((j + 4) % 3) * 8, *pmn2 = pm + ((j + 5) % 3) * 8;
-    // ================================================== phase 1 ==================================================
-    if (is_tile) {
+    for (int c = 0; c < NT; ++c) U[c] = d4_t{0.0, 0.0, 0.0, 0.0};
+    d4_t nW1 = {0.0, 0.0, 0.0, 0.0}, nW2 = {0.0, 0.0, 0.0, 0.0};   // -W1, -W2 of the pair (rows 16 R + li, columns lk + 4 g)
+    const us4_t *ctab4 = (const us4_t *)P.ctab;
+    // table words of the steps ahead, fetched a pair early (from global memory they are a microsecond away): cells of the
+    // columns of pair j + 1 (ctab), row masks of the panels of pair j (amask)
+    us4_t ct_cur[2] = {us4_t{0, 0, 0, 0}, us4_t{0, 0, 0, 0}}, ct_nxt[2];
+    unsigned am_cur[2] = {0u, 0u}, am_nxt[2];
+    unsigned pg_cur = 0xffffu, pg_nxt;   // occupied 16-slot groups of pair j (Symbolic::pair_groups)
+    const int lane_outer = lane;
+    for (int j = -2; j < NP; ++j) {
+      K5_STEP_POINTERS
+      // (the lane's coordinates re-derived per step from an opaque copy: the address arithmetic below is recomputed, not
+      //  kept in registers across the loop -- at 168 registers every invariant the compiler hoists is a spill, and a spill
+      //  reload waits on the in-order memory counter for the table words in flight)
+      int lane = lane_outer;
+      asm volatile("" : "+v"(lane));
+      const int li = lane & 15, lk = lane >> 4, row = 16 * R + li;
+      const int tile_lane = (li * PLD + lk) * 8;   // (li, lk): row li, column lk of a 16 x 16 tile of a panel, in bytes
+      // (the table words fetched during the last step are taken NOW: the memory counter is in order, and a wait for them
+      //  placed behind the factor-panel stores below would wait for those stores)
+      asm volatile("" : "+v"(ct_cur[0]), "+v"(ct_cur[1]), "+v"(am_cur[0]), "+v"(am_cur[1]), "+v"(pg_cur));
+      const unsigned pg = QTOS_K5_SKIP ? (unsigned)__builtin_amdgcn_readfirstlane((int)pg_cur) : 0xffffu;
+      const bool rowlive = (pg >> R) & 1u;   // (an empty group: its rows of the pair's columns are zeros, V and W of them too)
+      // ---- phase 1 ----
       if (j >= -1) {
-        const int row = 16 * R + li;
         d4_t w1 = {0.0, 0.0, 0.0, 0.0}, w2 = {0.0, 0.0, 0.0, 0.0};
-        if (live) {
+        if (live && rowlive && !(QTOS_K5_ABL & 64)) {
           const int a = 2 * j;
           const unsigned ama = am_cur[0], amb = am_cur[1];
           const int sb_li = psj[PIV + li];                        // slot of pivot li of stage b
           const unsigned wj = pmj[R >> 1];
           const bool retiring = (wj >> ((R & 1) * 16 + li)) & 1u;   // this lane's row belongs to a pivot of the pair
-          double pa[4], pb[4], ma[4], mb[4], lt[4], a21[4];
+          // operands in the order they are needed (the compiler would hoist all 24 loads to the top: 48 registers)
+          double pa[4], ma[4], a21[4];
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             pa[s] = PA0[row * PLD + lk + 4 * s];
             ma[s] = MIVa[li * PLD + lk + 4 * s];
             a21[s] = -PA0[sb_li * PLD + lk + 4 * s];
-            pb[s] = PA1[row * PLD + lk + 4 * s];
-            mb[s] = MIVb[li * PLD + lk + 4 * s];
-            lt[s] = -L21[(lk + 4 * s) * PLD + li];
           }
           double zero = 0.0;
           asm volatile("" : "+v"(zero));
           d4_t v1 = {zero, zero, zero, zero};
 #pragma unroll
           for (int s = 0; s < 4; ++s) v1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[s], pa[s], v1, 0, 0, 0);       // V1 = P1 A11^-1
-          d4_t p2 = {pb[0], pb[1], pb[2], pb[3]};
+          double mb[4];
+          d4_t p2;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { p2[s] = PA1[row * PLD + lk + 4 * s]; mb[s] = MIVb[li * PLD + lk + 4 * s]; }
+          K5_SCHED_BARRIER();
 #pragma unroll
           for (int s = 0; s < 4; ++s) p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a21[s], v1[s], p2, 0, 0, 0);      // P2' = P2 - V1 A21'
-          // b's own pivot rows leave the panel (a's are zeros in the LDS already)
-          bool is_b = false;
-          {
-            // (row is a pivot of b: it is retiring and not a pivot of a -- a's rows of P1 are zero, so V1 of them is zero and
-            //  P2' = P2, whose rows at a's pivots the factor wave has zeroed as well: blanking every retiring row is the same)
-            is_b = retiring;
-          }
+          // the pair's own pivot rows leave the panel (b's: here; a's rows of P1 and P2 are zeros in the LDS already)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) p2[g] = is_b ? 0.0 : p2[g];
+          for (int g = 0; g < 4; ++g) p2[g] = retiring ? 0.0 : p2[g];
+          double lt[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) lt[s] = -L21[(lk + 4 * s) * PLD + li];
+          K5_SCHED_BARRIER();
           d4_t v2 = {zero, zero, zero, zero};
 #pragma unroll
           for (int s = 0; s < 4; ++s) v2 = __builtin_amdgcn_mfma_f64_16x16x4f64(mb[s], p2[s], v2, 0, 0, 0);       // V2 = P2' S22^-1
@@ -270,15 +338,25 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
           for (int s = 0; s < 4; ++s) w1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[s], v2[s], w1, 0, 0, 0);        // W1 = V1 - V2 L21
 #pragma unroll
           for (int g = 0; g < 4; ++g) { w1[g] = retiring ? 0.0 : w1[g]; w2[g] = retiring ? 0.0 : v2[g]; }
+          // right-hand sides of this tile's slots: the right-hand side is one more column of the matrix, its entries at the pair's
+          // pivots are row F of the panels:  UF[row] -= W1[row] . P1[F] + W2[row] . P2[F]   (the pair's own slots retire)
+          {
+            double d = 0.0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) d = fma(w1[s], PA0[F * PLD + lk + 4 * s], d);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) d = fma(w2[s], PA1[F * PLD + lk + 4 * s], d);
+            d = rowsum4(d);
+            if (lane < PIV) UF[row] = retiring ? 0.0 : UF[row] - d;
+          }
         }
-        if (has_next) {
+        K5S(8);
+        if (has_next && !(QTOS_K5_ABL & 8)) {
           const unsigned wn = pmn[R >> 1];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            const int stage = 2 * (j + 1) + t;
             double *PN = PN0 + t * PSZ;
             const us4_t ct = ct_cur[t];
-            (void)stage;
             const int st = psn[t * PIV + li];                       // slot of pivot li of that stage
             const double dgn = dgb[((j + 4) % 3) * 2 * PIV + t * PIV + li];
             d4_t acc;
@@ -287,7 +365,7 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
               const int r = 16 * R + lk + 4 * g;
               acc[g] = PN[r * PLD + li] + A[ct[g]] + (r == st ? dgn : 0.0);
             }
-            if (live) {
+            if (live && rowlive) {
               // a pivot that takes the slot of one of this pair's pivots enters with its own pair: zeros
               const bool fresh = (pmj[st >> 5] >> (st & 31)) & 1u;
               const int srow = fresh ? ZROW : st;
@@ -304,6 +382,7 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
               PN[(16 * R + lk + 4 * g) * PLD + li] = acc[g];
               A[ct[g]] = 0.0;   // retired (the zero cell stays zero)
             }
+            K5S(9 + t);
           }
           // operand A of the Schur update: the rows of the next pair's pivots leave it too
           const bool nextpiv = (wn >> ((R & 1) * 16 + li)) & 1u;
@@ -311,83 +390,11 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
           for (int g = 0; g < 4; ++g) { nW1[g] = nextpiv ? 0.0 : -w1[g]; nW2[g] = nextpiv ? 0.0 : -w2[g]; }
         }
       }
-    } else if (is_svc) {
-      // LDS-DMA of the record of pair j + 2 (its predecessor was assembled in the previous step), 1 KB per wave instruction
-      if (has_next2) {
-        const int q = j + 2;
-        int d0, d1, s0, s1;
-        sload2(P.drec_off + q, d0, d1);
-        sload2(P.srec_off + q, s0, s1);
-        const int nbd = (d1 - d0) * 8, nbs = (s1 - s0) * 4;
-        const char *gd = (const char *)(stream + d0), *gs = (const char *)(P.srec + s0);
-        typedef __attribute__((address_space(3))) char lds_char;
-        lds_char *ld = (lds_char *)dbuf, *ls = (lds_char *)sbuf;
-        for (int c = sidx; c * 1024 < nbd; c += NSVC)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gd + min(c * 1024 + lane * 16, nbd - 16)), (__attribute__((address_space(3))) void *)(ld + c * 1024), 16, 0, 0);
-        for (int c = sidx; c * 1024 < nbs; c += NSVC)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gs + min(c * 1024 + lane * 16, nbs - 16)), (__attribute__((address_space(3))) void *)(ls + c * 1024), 16, 0, 0);
-      }
-      if (sidx == 0 && j >= -1) {
-        // ---- the right-hand-side row (row F of the panels) --------------------------------------------------------
-        if (live) {
-          const int a = 2 * j;
-          const int sb_li = psj[PIV + li];
-          double part = 0.0;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) part = fma(MIVa[li * PLD + lk + 4 * s], PA0[F * PLD + lk + 4 * s], part);
-          const double w1 = rowsum4(part);                 // w_a[li] on every lane
-          if (lane < PIV) { panel[(size_t)a * pstride + lane] = w1; RSC[lane] = w1; }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          part = 0.0;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) part = fma(PA0[sb_li * PLD + lk + 4 * s], RSC[lk + 4 * s], part);
-          const double p2 = PA1[F * PLD + li] - rowsum4(part);   // right-hand side of b's pivots after a
-          if (lane < PIV) RSC[PIV + lane] = p2;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          part = 0.0;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) part = fma(MIVb[li * PLD + lk + 4 * s], RSC[PIV + lk + 4 * s], part);
-          double w2 = rowsum4(part);                       // w_b[li]
-          if (lane < PIV) { panel[(size_t)(a + 1) * pstride + lane] = w2; RSC[2 * PIV + lane] = w2; }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          part = 0.0;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) part = fma(L21[(lk + 4 * s) * PLD + li], RSC[2 * PIV + lk + 4 * s], part);
-          double w1f = w1 - rowsum4(part);                 // row F of W1
-          asm volatile("s_nop 4" : "+v"(w1f), "+v"(w2));   // DPP hazard distance for the broadcast reads below
-#pragma unroll
-          for (int c = 0; c < FR / 64; ++c) {
-            const int r = c * 64 + lane;
-            const int rr = min(r, F - 1);
-            double pq[PIV], pq2[PIV];
-#pragma unroll
-            for (int q = 0; q < PIV; ++q) { pq[q] = PA0[rr * PLD + q]; pq2[q] = PA1[rr * PLD + q]; }
-            const double uf = UF[r];
-            const bool retiring = (pmj[rr >> 5] >> (rr & 31)) & 1u;
-            double a0 = 0.0;
-            dot16_steps<0>(a0, w1f, pq);
-            dot16_steps<0>(a0, w2, pq2);
-            UF[r] = (r < F && !retiring) ? uf - a0 : 0.0;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        if (has_next && lane < 2 * PIV) {
-          const int rc = rt_cur;
-          const int st = psn[lane];
-          PN0[(lane >> 4) * PSZ + F * PLD + (lane & 15)] = A[rc] + UF[st];
-          A[rc] = 0.0;
-          UF[st] = 0.0;
-        }
-      }
-      if (sidx == NSVC - 1 && has_next2) publish_header(j + 2, true);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has landed
-    }
-    lds_barrier();
-    // ================================================== phase 2 ==================================================
-    const int n_tgt2 = min(NSVC * 64 * QTOS_K5_ASM2, 1 << 20);   // targets the service waves take in this phase
-    if (is_tile) {
-      if (live && has_next) {
-        // U(R, C) -= W1 P1[C]' + W2 P2[C]',  operand B blanked on load: rows of this pair's and of the next pair's pivots
+      K5S(0);
+      lds_barrier();
+      K5S(1);
+      // ---- phase 2:  U(R, C) -= W1 P1[C]' + W2 P2[C]',  operand B blanked on load (rows of this pair's and the next pair's pivots)
+      if (live && has_next && rowlive && !(QTOS_K5_ABL & 4)) {
         double b1[2][4], b2[2][4];
         auto tile_loads = [&](int C, double (&x1)[4], double (&x2)[4]) __attribute__((always_inline)) {
           const unsigned g16 = ((pmj[C >> 1] | pmn[C >> 1]) >> ((C & 1) * 16)) & 0xffffu;
@@ -402,15 +409,82 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
         for (int C = 0; C < NT; ++C) {
           if (C <= R) {
             if (C + 1 < NT && C + 1 <= R) tile_loads(C + 1, b1[(C + 1) & 1], b2[(C + 1) & 1]);
+            if ((pg >> C) & 1u) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) U[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(nW1[s], b1[C & 1][s], U[C], 0, 0, 0);
+              for (int s = 0; s < 4; ++s) U[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(nW1[s], b1[C & 1][s], U[C], 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) U[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(nW2[s], b2[C & 1][s], U[C], 0, 0, 0);
+              for (int s = 0; s < 4; ++s) U[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(nW2[s], b2[C & 1][s], U[C], 0, 0, 0);
+            }
           }
         }
       }
-    } else if (is_fac) {
-      if (j >= -1 && has_next) {
+      K5S(2);
+      lds_barrier();
+      K5S(3);
+      {
+        const int q2 = min(j + 2, NP - 1), q1 = min(max(j + 1, 0), NP - 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          ct_nxt[t] = ctab4[((size_t)(2 * q2 + t) * NT + R) * 64 + lane];
+          am_nxt[t] = P.amask[(2 * q1 + t) * 8 + (R >> 1)];
+        }
+        pg_nxt = P.pair_groups[q1];
+      }
+      // ---- phase 3: the columns (rows) of the pivots of pair j + 2 out of the tiles into the panels of pair j, which are dead;
+      //      zeroed in place
+      if (live && has_next2 && !(QTOS_K5_ABL & 2)) {
+        double *X = (double *)PA0;
+        double *dummy = red + 2 * 16 * PIV + lane;
+        // bit 4g of ge4 / gt4: row lk + 4g of a diagonal tile lies on or below / strictly below column li
+        unsigned ge4 = 0u, gt4 = 0u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { ge4 |= (lk + 4 * g >= li ? 1u : 0u) << (4 * g); gt4 |= (lk + 4 * g > li ? 1u : 0u) << (4 * g); }
+        const unsigned rw2 = (pmn2[R >> 1] >> ((R & 1) * 16)) & 0xffffu;
+        const us4_t jr4 = *(const us4_t *)(jm + 16 * R + 4 * lk);   // column offsets of the pivots in rows lk + 4 g of row tile R
+#pragma unroll
+        for (int C = 0; C < NT; ++C) {
+          if (C <= R) {
+            const unsigned cw2 = (pmn2[C >> 1] >> ((C & 1) * 16)) & 0xffffu;
+            if ((cw2 | rw2) != 0u) {
+              const int jc = jm[16 * C + (li & 3) * 4 + (li >> 2)];
+              const unsigned cm = ((cw2 >> li) & 1u) ? (R > C ? 0x1111u : ge4) : 0u;
+              const unsigned rmk = (rw2 >> lk) & (R > C ? 0x1111u : gt4);
+              double *xr = X + (16 * R + lk) * PLD + jc, *xc = X + (16 * C + li) * PLD;
+              if (cw2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(((cm >> (4 * g)) & 1u) ? xr + g * 4 * PLD : dummy) = U[C][g];
+              }
+              if (rw2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(((rmk >> (4 * g)) & 1u) ? xc + jr4[g] : dummy) = U[C][g];
+              }
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int z = ~__builtin_amdgcn_sbfe((int)(cm | rmk), 4 * g, 1);
+                U[C][g] = __hiloint2double(__double2hiint(U[C][g]) & z, __double2loint(U[C][g]) & z);
+              }
+            }
+          }
+        }
+      }
+      K5S(4);
+      // the rest of the record's targets: every wave but the factor wave (service waves first, then the tile waves by row)
+      if (has_next2 && !(QTOS_K5_ABL & 1) && R < NASMT) assemble_pair_tgt<QTOS_K5_ILPT>(A, sbuf, dbuf, n_tgt2, 1 << 30, (NSVC + R) * 64 + lane, (NSVC + NASMT) * 64);
+      K5S(5);
+      lds_barrier();
+      K5S(6);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { ct_cur[t] = ct_nxt[t]; am_cur[t] = am_nxt[t]; }
+      pg_cur = pg_nxt;
+    }
+  } else if (is_fac) {
+    // ================================================ factor wave ===============================================
+    for (int j = -2; j < NP; ++j) {
+      K5_STEP_POINTERS
+      K5S(0);
+      lds_barrier();
+      K5S(1);
+      if (j >= -1 && has_next && !(QTOS_K5_ABL & 16)) {
         __builtin_amdgcn_s_setprio(3);
         const int c = 2 * (j + 1);
         double *Pc = PN0, *Pd = PN0 + PSZ;
@@ -474,8 +548,9 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) a[g] = 4 * g + lk > li ? LIN[(4 * g + lk) * PLD + li] : LIN[li * PLD + 4 * g + lk];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // ---- barrier 2 in the middle of the chain ----
-        lds_barrier();
+        K5S(2);
+        lds_barrier();   // ---- barrier 2 in the middle of the chain ----
+        K5S(3);
         ldlt16s(a, wi, myinv, li, lk);
 #pragma unroll
         for (int g = 0; g < 4; ++g) LIN[li * PLD + 4 * g + lk] = wi[g];
@@ -494,58 +569,91 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
           minv_g[(size_t)(c + 1) * (PIV * PIV) + (lk + 4 * g) * PIV + li] = mi2[g];
         }
         __builtin_amdgcn_s_setprio(0);
-      } else lds_barrier();
-    } else if (is_svc) {
-      if (j + 2 >= 0 && has_next2) {
-        assemble_pair_eq(A, sbuf, dbuf, sidx * 64 + lane, NSVC * 64);
-        assemble_pair_tgt(A, sbuf, dbuf, 0, n_tgt2, sidx * 64 + lane, NSVC * 64);
+      } else {
+        K5S(2);
+        lds_barrier();
+        K5S(3);
       }
+      K5S(4);
+      lds_barrier();
+      K5S(6);
     }
-    if (!is_fac) lds_barrier();
-    // ================================================== phase 3 ==================================================
-    if (is_tile && live && has_next2) {
-      // the columns (rows) of the pivots of pair j + 2 out of the tiles into the panels of pair j, which are dead; zeroed in place
-      double *X = (double *)PA0;
-      const unsigned short *jmc = jm;
-      double *dummy = red + 2 * 16 * PIV + lane;
-      const unsigned ge4 = ge4_keep, gt4 = gt4_keep;
-      const unsigned rw2 = (pmn2[R >> 1] >> ((R & 1) * 16)) & 0xffffu;
-      const us4_t jr4 = *(const us4_t *)(jmc + 16 * R + 4 * lk);   // column offsets of the pivots in rows lk + 4 g of row tile R
+  } else {
+    // =============================================== service waves ==============================================
+    int rt_cur = 0, rt_nxt;   // right-hand-side cells of pair j + 1 (rtab), fetched a pair early
+    double rhs_keep = 0.0;
+    for (int j = -2; j < NP; ++j) {
+      K5_STEP_POINTERS
+      rt_nxt = P.rtab[2 * min(j + 2, NP - 1) * PIV + (lane & 31)];
+      // LDS-DMA of the record of pair j + 2 (its predecessor was assembled in the previous step), 1 KB per wave instruction
+      if (has_next2) {
+        const int q = j + 2;
+        int d0, d1, s0, s1;
+        sload2(P.drec_off + q, d0, d1);
+        sload2(P.srec_off + q, s0, s1);
+        const int nbd = (d1 - d0) * 8, nbs = (s1 - s0) * 4;
+        const char *gd = (const char *)(stream + d0), *gs = (const char *)(P.srec + s0);
+        typedef __attribute__((address_space(3))) char lds_char;
+        lds_char *ld = (lds_char *)dbuf, *ls = (lds_char *)sbuf;
+        for (int c = sidx; c * 1024 < nbd; c += NSVC)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gd + min(c * 1024 + lane * 16, nbd - 16)), (__attribute__((address_space(3))) void *)(ld + c * 1024), 16, 0, 0);
+        for (int c = sidx; c * 1024 < nbs; c += NSVC)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gs + min(c * 1024 + lane * 16, nbs - 16)), (__attribute__((address_space(3))) void *)(ls + c * 1024), 16, 0, 0);
+      }
+      if (sidx == 0 && j >= -1) {
+        // ---- the right-hand-side row (row F of the panels) --------------------------------------------------------
+        if (live && !(QTOS_K5_ABL & 32)) {
+          const int a = 2 * j;
+          const int sb_li = psj[PIV + li];
+          double part = 0.0;
 #pragma unroll
-      for (int C = 0; C < NT; ++C) {
-        if (C <= R) {
-          const unsigned cw2 = (pmn2[C >> 1] >> ((C & 1) * 16)) & 0xffffu;
-          if ((cw2 | rw2) != 0u) {
-            const int jc = jmc[16 * C + (li & 3) * 4 + (li >> 2)];
-            const unsigned cm = ((cw2 >> li) & 1u) ? (R > C ? 0x1111u : ge4) : 0u;
-            const unsigned rmk = (rw2 >> lk) & (R > C ? 0x1111u : gt4);
-            double *xr = X + (16 * R + lk) * PLD + jc, *xc = X + (16 * C + li) * PLD;
-            if (cw2) {
+          for (int s = 0; s < 4; ++s) part = fma(MIVa[li * PLD + lk + 4 * s], PA0[F * PLD + lk + 4 * s], part);
+          const double w1 = rowsum4(part);                 // w_a[li] on every lane
+          if (lane < PIV) { panel[(size_t)a * pstride + lane] = w1; RSC[lane] = w1; }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          part = 0.0;
 #pragma unroll
-              for (int g = 0; g < 4; ++g) *(((cm >> (4 * g)) & 1u) ? xr + g * 4 * PLD : dummy) = U[C][g];
-            }
-            if (rw2) {
+          for (int s = 0; s < 4; ++s) part = fma(PA0[sb_li * PLD + lk + 4 * s], RSC[lk + 4 * s], part);
+          const double p2 = PA1[F * PLD + li] - rowsum4(part);   // right-hand side of b's pivots after a
+          if (lane < PIV) RSC[PIV + lane] = p2;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          part = 0.0;
 #pragma unroll
-              for (int g = 0; g < 4; ++g) *(((rmk >> (4 * g)) & 1u) ? xc + jr4[g] : dummy) = U[C][g];
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int z = ~__builtin_amdgcn_sbfe((int)(cm | rmk), 4 * g, 1);
-              U[C][g] = __hiloint2double(__double2hiint(U[C][g]) & z, __double2loint(U[C][g]) & z);
-            }
-          }
+          for (int s = 0; s < 4; ++s) part = fma(MIVb[li * PLD + lk + 4 * s], RSC[PIV + lk + 4 * s], part);
+          const double w2 = rowsum4(part);                 // w_b[li]
+          if (lane < PIV) panel[(size_t)(a + 1) * pstride + lane] = w2;
         }
+        // the assembled right-hand sides of the next pair's pivots leave their cells now (the cells are re-issued to the record
+        // that is assembled in phases 2 and 3); they join the updated right-hand sides in phase 3
+        if (has_next && lane < 2 * PIV) { rhs_keep = A[rt_cur]; A[rt_cur] = 0.0; }
       }
+      if (sidx == NSVC - 1 && has_next2) publish_header(j + 2, true);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has landed
+      K5S(0);
+      lds_barrier();
+      K5S(1);
+      K5S(8);
+      if (has_next2 && !(QTOS_K5_ABL & 1)) {
+        assemble_pair_eq(A, sbuf, dbuf, sidx * 64 + lane, NSVC * 64);
+        K5S(9);
+        assemble_pair_tgt<QTOS_K5_ILPS>(A, sbuf, dbuf, 0, n_tgt2, sidx * 64 + lane, NSVC * 64);
+        K5S(10);
+      }
+      K5S(2);
+      lds_barrier();
+      K5S(3);
+      if (sidx == 0 && j >= -1 && has_next && lane < 2 * PIV) {
+        // right-hand-side row of the next pair's panels
+        const int st = psn[lane];
+        PN0[(lane >> 4) * PSZ + F * PLD + (lane & 15)] = rhs_keep + UF[st];
+        UF[st] = 0.0;
+      }
+      if (has_next2 && !(QTOS_K5_ABL & 1)) assemble_pair_tgt<QTOS_K5_ILPS>(A, sbuf, dbuf, n_tgt2, 1 << 30, sidx * 64 + lane, (NSVC + NASMT) * 64);
+      K5S(5);
+      lds_barrier();
+      K5S(6);
+      rt_cur = rt_nxt;
     }
-    if (!is_fac && j + 2 >= 0 && has_next2) {
-      // the rest of the record's targets: every wave but the factor wave (rank: service waves first)
-      const int rank = is_svc ? sidx : NSVC + Rc;   // (service waves, then the tile waves with the fewest tiles)
-      assemble_pair_tgt(A, sbuf, dbuf, n_tgt2, 1 << 30, rank * 64 + lane, (NSVC + NT) * 64);
-    }
-    lds_barrier();
-#pragma unroll
-    for (int t = 0; t < 2; ++t) { ct_cur[t] = ct_nxt[t]; am_cur[t] = am_nxt[t]; }
-    rt_cur = rt_nxt;
   }
   // ---- backward substitution (sweep_backward: one barrier per stage, one-stage look-ahead) ---------------------------
   __syncthreads();   // drains the factor-panel stores: they are read back below
@@ -558,6 +666,9 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
     const SweepDs sd = {W.stream + (size_t)b * P.stream_len, W.ds + (size_t)b * P.n_cons, W.g + (size_t)b * P.n_cons, W.s + (size_t)b * P.n_cons, nullptr};
     sweep_backward<F, KT5, 9>(P, panel, dx, W.sol + (size_t)b * P.n_stages * PIV, xs, red, nxp, wv, lane, lds + ((LY::PAN + NS * 6 + 1) & ~1), sd);
   }
+  K5S(7);
+#undef K5S
+#undef K5_STEP_POINTERS
 }
 
 }  // namespace qtos

@@ -111,11 +111,17 @@ struct QtosPlanner {
 // loop bound are compile-time constants
 // k_kkt2 (16 waves per problem): fronts up to 208 slots
 static void (*kkt2_kernel(int F, bool cont, bool kron = false))(DevPlan, DevWork, int) {
-  if (kron && !cont && F == 128) return k_kkt2<128, false, true>;   // (the Kronecker assembly: the benchmark's front only)
+#ifndef QTOS_DEV_F128
+  if (kron && !cont && F == 128) return k_kkt2<128, false, true>;
+#endif   // (the Kronecker assembly: the benchmark's front only)
 #define QTOS_KKT2(f) case f: return cont ? k_kkt2<f, true> : k_kkt2<f, false>;
   switch (F) {
+#ifdef QTOS_DEV_F128   // (development builds: the benchmark's fronts only, a quarter of the compile time)
+    QTOS_KKT2(112) QTOS_KKT2(128)
+#else
     QTOS_KKT2(16) QTOS_KKT2(32) QTOS_KKT2(48) QTOS_KKT2(64) QTOS_KKT2(80) QTOS_KKT2(96) QTOS_KKT2(112) QTOS_KKT2(128)
-#ifndef QTOS_DEV_SMALL
+#endif
+#if !defined(QTOS_DEV_SMALL) && !defined(QTOS_DEV_F128)
     QTOS_KKT2(144) QTOS_KKT2(160) QTOS_KKT2(176) QTOS_KKT2(192) QTOS_KKT2(208)
 #endif
   }
@@ -125,29 +131,41 @@ static void (*kkt2_kernel(int F, bool cont, bool kron = false))(DevPlan, DevWork
 // k_kkt3 (inequality blocks condensed on the matrix core): fronts up to 128 slots
 static void (*kkt3_kernel(int F, int mode))(DevPlan, DevWork, int) {
 #define QTOS_KKT3(f) case f: return mode == 0 ? k_kkt3<f, 0> : k_kkt3<f, 1>;
+#ifndef QTOS_DEV_F128
   switch (F) { QTOS_KKT3(16) QTOS_KKT3(32) QTOS_KKT3(48) QTOS_KKT3(64) QTOS_KKT3(80) QTOS_KKT3(96) QTOS_KKT3(112) QTOS_KKT3(128) }
+#endif
 #undef QTOS_KKT3
   return nullptr;
 }
 // k_kkt5 (two 16-pivot stages per set of barriers, twelve waves): fronts up to 144 slots
 static void (*kkt5_kernel(int F))(DevPlan, DevWork, int) {
 #define QTOS_KKT5(f) case f: return k_kkt5<f>;
+#ifdef QTOS_DEV_F128
+  switch (F) { QTOS_KKT5(112) QTOS_KKT5(128) }
+#else
   switch (F) { QTOS_KKT5(32) QTOS_KKT5(48) QTOS_KKT5(64) QTOS_KKT5(80) QTOS_KKT5(96) QTOS_KKT5(112) QTOS_KKT5(128) QTOS_KKT5(144) }
+#endif
 #undef QTOS_KKT5
   return nullptr;
 }
 // k_kkt4 (panel chain and Schur updates side by side): fronts up to 128 slots
 static void (*kkt4_kernel(int F))(DevPlan, DevWork, int) {
 #define QTOS_KKT4(f) case f: return k_kkt4<f>;
+#ifndef QTOS_DEV_F128
   switch (F) { QTOS_KKT4(16) QTOS_KKT4(32) QTOS_KKT4(48) QTOS_KKT4(64) QTOS_KKT4(80) QTOS_KKT4(96) QTOS_KKT4(112) QTOS_KKT4(128) }
+#endif
 #undef QTOS_KKT4
   return nullptr;
 }
 static void (*chord_kernel(int F))(DevPlan, DevWork, int) {
 #define QTOS_CHORD(f) case f: return k_chord<f>;
   switch (F) {
+#ifdef QTOS_DEV_F128
+    QTOS_CHORD(112) QTOS_CHORD(128)
+#else
     QTOS_CHORD(16) QTOS_CHORD(32) QTOS_CHORD(48) QTOS_CHORD(64) QTOS_CHORD(80) QTOS_CHORD(96) QTOS_CHORD(112) QTOS_CHORD(128)
-#ifndef QTOS_DEV_SMALL
+#endif
+#if !defined(QTOS_DEV_SMALL) && !defined(QTOS_DEV_F128)
     QTOS_CHORD(144) QTOS_CHORD(160) QTOS_CHORD(176) QTOS_CHORD(192) QTOS_CHORD(208)
 #endif
   }
@@ -515,6 +533,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(S.srec, &D.srec)); TRY(p->upload(S.srec_off, &D.srec_off));
   TRY(p->upload(S.pack_src, &D.pack_src)); TRY(p->upload(S.drec_off, &D.drec_off));
   TRY(p->upload(S.diag_pos, &D.diag_pos));
+  TRY(p->upload(S.pair_groups, &D.pair_groups));
   TRY(p->upload(S.eq_pos, &D.eq_pos)); TRY(p->upload(S.rhs_pos, &D.rhs_pos));
   TRY(p->upload(S.sig_pos, &D.sig_pos)); TRY(p->upload(S.w_pos, &D.w_pos));
   D.max_srec = S.max_srec; D.max_drec = S.max_drec; D.stream_len = (int)S.pack_src.size();

@@ -105,6 +105,7 @@ struct Symbolic {
   int rec_stages = 1;               // stages per record
   int tgt_shift = 12;               // a gather-table target word = (cell << tgt_shift) | first contribution
   std::vector<int> diag_pos;        // per position: stream position of its pivot diagonal (k_residual)
+  std::vector<unsigned> pair_groups; // pair mode, per pair: bit g = some slot of the 16-slot group g is in use during the pair (k_kkt5 skips the matrix instructions of empty groups)
   std::vector<int> stage_dummies;   // per stage: dummy pivots in it
   bool short_stages = true;
   std::vector<int> order;      // position -> var index, or n_vars + row for a multiplier
@@ -1043,6 +1044,14 @@ struct Symbolic {
       for (int k = 0; k < n_stages; ++k)
         active_count[k] = (int)(std::upper_bound(fs.begin(), fs.end(), k) - fs.begin()) - k * PIV;
     }
+    pair_groups.assign(pair_mode ? n_stages / 2 : 1, 0u);
+    if (pair_mode)
+      for (int k = 0; k < n_stages; ++k) {
+        unsigned g = 0;
+        for (int t = 0; t < 256; ++t) if ((amask[(size_t)k * 8 + (t >> 5)] >> (t & 31)) & 1u) g |= 1u << (t >> 4);
+        for (int i = 0; i < PIV; ++i) g |= 1u << (piv_slot[(size_t)k * PIV + i] >> 4);
+        pair_groups[k >> 1] |= g;
+      }
     amask2 = amask;
     nxt_pack.assign((size_t)n_stages * 4, -1);
     for (int k = 0; k + 1 < n_stages; ++k)

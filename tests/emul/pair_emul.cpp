@@ -214,7 +214,9 @@ extern "C" int qtos_pair_emul(const QtosParams *prm, int pair_mode, double *out,
       // right-hand sides of the live slots
       for (int r = 0; r < F; ++r) {
         double s = 0;
-        for (int k = 0; k < PIV; ++k) s += W1[(size_t)F * PIV + k] * P1[(size_t)r * PIV + k] + W2[(size_t)F * PIV + k] * P2[(size_t)r * PIV + k];
+        // (the right-hand side is one more column of the matrix; by the symmetry of W P' the kernel forms its update from the rows
+        //  of W it holds and the right-hand-side row of the pair's panels)
+        for (int k = 0; k < PIV; ++k) s += W1[(size_t)r * PIV + k] * P1[(size_t)F * PIV + k] + W2[(size_t)r * PIV + k] * P2[(size_t)F * PIV + k];
         UF[r] = in_pair(j, r) ? 0.0 : UF[r] - s;
       }
     }
