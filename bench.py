@@ -82,19 +82,16 @@ def parse_args():
     ap.add_argument("--child-timeout", type=float, default=1800.0, help="seconds after which the launcher ends its torchrun child")
     ap.add_argument("--no-trot", action="store_true",
                     help="skip the trot-gait leg that the default headline run times after the walk (BASELINE.json's metric names a trot)")
-    ap.add_argument("--trot-steps", type=int, default=10)
+    ap.add_argument("--trot-steps", type=int, default=20)
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per k_kkt launch from a separate rocprofv3 --pmc pass "
                          "(default: the newest profiles/*_pmc_hbm.json, collected with this same command)")
     return ap.parse_args()
 
 
-def kkt_kernel_name(front):
-    """The factor + solve kernel qtos_planner_create picks for a front size (csrc/qtos_planner.hip; QTOS_KKT overrides it)."""
-    forced = os.environ.get("QTOS_KKT")
-    if forced:
-        return {"2": "k_kkt2<%d>", "3": "k_kkt3<%d, 0>", "4": "k_kkt3<%d, 1>", "5": "k_kkt4<%d>"}.get(forced, "k_kkt2<%d>") % front
-    return ("k_kkt3<%d, 1>" if front <= 112 else "k_kkt2<%d>") % front
+def kkt_kernel_name(planner):
+    """The factor + solve kernel qtos_planner_create selected for this planner (qtos_kkt_kernel: what rocprofv3 lists)."""
+    return planner.kkt_kernel()
 
 
 def physical_cores():
@@ -530,12 +527,27 @@ def main():
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
     import glob
 
-    def newest(pattern):
+    def newest(pattern, kernel=None):
+        # newest round's file of that name whose counters belong to the kernel that ran here (a profile of another kernel --
+        # the trot's, or a kernel that is no longer the default -- says nothing about this launch)
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)),
                        key=lambda f: (os.path.basename(f)[:3], "final" in f, f))   # newest round, its final pass
-        return files[-1] if files else None
+        for f in reversed(files):
+            if kernel is None:
+                return f
+            try:
+                j = json.load(open(f))
+                name = j.get("k_kkt_kernel") or (j.get("k_kkt") or {}).get("kernel") or ""
+                if not name:   # (rounds 1 - 4: the walk's default kernel, recorded without its name)
+                    name = "k_kkt2<128>"
+                if kernel.replace(" ", "") in name.replace(" ", "").replace(",false", ""):
+                    return f
+            except Exception:
+                pass
+        return None
+    kernel_here = kkt_kernel_name(P)
     if traffic is None and headline:
-        f = newest("r*_pmc_hbm.json")
+        f = newest("r[0-9][0-9]_pmc_hbm.json", kernel_here)
         if f:
             try:
                 traffic = json.load(open(f))["k_kkt_traffic_bytes_per_launch"]["fetch_x2"]
@@ -555,7 +567,7 @@ def main():
                         "frac_if_priced_with_its_bytes": round(B * dfull.kkt_algorithmic_bytes / avg / 1e9 / HBM_PEAK_GBS, 5)}
         achieved = alg_bytes / avg / 1e9
         out["roofline"] = {
-            "kernel": kkt_kernel_name(d.front), "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "kernel": kernel_here, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
             "bytes_per_launch": alg_bytes, "avg_launch_ms": round(1e3 * avg, 4), "launches": kkt_n,
@@ -571,7 +583,7 @@ def main():
             "chord_launches_per_step": round(chord_n / max(args.steps, 1), 2),
             "chord_avg_launch_ms": round(1e3 * chord_s / chord_n, 4) if chord_n else None,
         }
-        f = newest("r*_pmc_sq.json") if headline else None
+        f = newest("r[0-9][0-9]_pmc_sq.json", kernel_here) if headline else None
         if f:
             try:
                 out["roofline"]["counters"] = dict(json.load(open(f))["k_kkt"], source=os.path.relpath(f, ROOT))
@@ -615,11 +627,26 @@ def main():
             "iterations_mean": round(titer / max(B * args.trot_steps, 1), 3),
             "kkt_unknowns": dt_.n_unknowns, "kkt_stages": dt_.n_stages, "front": dt_.front, "n_vars": dt_.n_vars,
             "gait": "diagonal-pair trot (config.TROT_UNNORMALISED; not pinned by any reference artefact)",
-            "roofline": {"kernel": kkt_kernel_name(dt_.front), "bound": "hbm", "achieved": round(B * dt_.kkt_algorithmic_bytes / tavg / 1e9, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": kkt_kernel_name(Pt), "bound": "hbm", "achieved": round(B * dt_.kkt_algorithmic_bytes / tavg / 1e9, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(B * dt_.kkt_algorithmic_bytes / tavg / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                          "bytes_per_launch": float(B) * dt_.kkt_algorithmic_bytes, "avg_launch_ms": round(1e3 * tavg, 4), "launches": tk_n,
                          "fp64_tflops": round(B * dt_.kkt_flops / tavg / 1e12, 3)},
         }
+        # HBM traffic and SQ counters of the trot's kernel from the committed PMC passes of `bench.py --gait trot` (separate
+        # rocprofv3 runs: profiles/rNN_trot_pmc_*.json, scratch/r5_trot_prof.sh)
+        ft = newest("r[0-9][0-9]_trot_pmc_hbm.json", kkt_kernel_name(Pt))
+        if ft:
+            try:
+                out["trot"]["roofline"]["traffic"] = json.load(open(ft))["k_kkt_traffic_bytes_per_launch"]["fetch_x2"]
+                out["trot"]["roofline"]["traffic_source"] = os.path.relpath(ft, ROOT)
+            except Exception:
+                pass
+        ft = newest("r[0-9][0-9]_trot_pmc_sq.json", kkt_kernel_name(Pt))
+        if ft:
+            try:
+                out["trot"]["roofline"]["counters"] = dict(json.load(open(ft))["k_kkt"], source=os.path.relpath(ft, ROOT))
+            except Exception:
+                pass
         Pt.close()
     if parity is not None:
         out["parity"] = parity
@@ -665,6 +692,7 @@ def main():
         worst = float(np.abs(xo[:len(qs_all)] - nodes_h).max()) if not lanes else None
         out["cpu_baseline"] = {
             "value": round(vall, 3), "unit": "plans/s", "cores": best, "kind": "port",
+            "kind_note": "port = the CHECKER (oracle/: complex-step Jacobians into a dense matrix per problem), not a tuned CPU solver: a stated baseline, the GPU / CPU ratio says nothing about kernel quality",
             "value_1_thread": round(v1, 3), "scaling_vs_1_thread": round(vall / max(v1, 1e-9), 2),
             "threads_ladder": {str(k): round(v, 1) for k, v in sorted(ladder.items())},
             "cpus_allowed": cores, "physical_cores": phys, "cgroup_cpu_quota": quota,

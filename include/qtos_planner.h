@@ -73,7 +73,9 @@ typedef struct QtosDims {
   int n_free, n_eq, n_ineq;         /* 1005 / 706 / 1024 (logs/towr_log.out:44-52)            */
   int n_ineq_lower, n_ineq_both, n_ineq_upper; /* 112 / 816 / 96                              */
   int n_eq_work;                    /* equality rows after dropping constant/duplicate rows   */
-  int n_unknowns;                   /* n_free + n_eq_work = KKT dimension                     */
+  int n_unknowns;                   /* unknowns of the KKT system the planner solves (with reduce_base: coefficients in place
+                                       of base node values); dummy pivots of short stages are NOT counted: arrays by
+                                       position have n_stages * pivots entries */
   int n_stages, pivots, front;      /* chain of n_stages fronts, `pivots` eliminated per stage */
   int n_base_nodes, n_dyn_times, n_rom_times, n_rows_csv;
   long long panel_doubles;          /* factor panel storage per problem                       */
@@ -252,8 +254,9 @@ int qtos_debug_chord(QtosPlanner *p, int B, double *dx_out);
  * reduce_base a copy. */
 int qtos_project_nodes(QtosPlanner *p, int B, const double *nodes, double *nodes_out);
 /* diagnostics (scratch/reduced_base_sweep.py, host-side emulations of the chain): the stage stream of problem b as the last
- * linearisation left it (qtos_debug_stream_len doubles), and the vector behind the last qtos_debug_residual call
- * (n_unknowns doubles, elimination order) */
+ * linearisation left it (qtos_debug_stream_len doubles), and the vector behind the last qtos_debug_residual call, by
+ * POSITION of the elimination order: n_stages * pivots doubles (QtosDims) -- the positions count the dummy pivots that
+ * fill short stages, QtosDims.n_unknowns does not */
 int qtos_debug_stream_len(const QtosPlanner *p);
 int qtos_debug_read_stream(QtosPlanner *p, int b, double *out);
 int qtos_debug_read_rhs(QtosPlanner *p, int b, double *out);
@@ -262,8 +265,10 @@ int qtos_debug_read_rhs(QtosPlanner *p, int b, double *out);
  * iterative refinement through the stored factorisation (r = b - K x, K e = r by k_chord, x += e); dx_out (B x n_vars,
  * may be NULL): the (refined) solution.  SURVEY.md section 7-5: accuracy of the KKT solve vs a CPU factorisation. */
 int qtos_debug_residual(QtosPlanner *p, int B, int refine, double *dx_out, double *res_rel_out);
-/* working-set description: row_kind[n_cons] (0 dropped, 1 equality, 2 inequality),
- * var_free[n_vars] (0/1), unknown order[n_unknowns] (var index, or n_vars + row for multipliers) */
+/* working-set description: row_kind[n_cons] (0 dropped, 1 equality, 2 inequality), var_free[n_vars] (0/1), and the
+ * elimination order BY POSITION: order[n_stages * pivots] (QtosDims) = var index, n_vars + row for a multiplier, or -1
+ * for a dummy pivot (short stages, the fill of the last stage, the all-dummy stage pair mode may append): size the
+ * buffer by n_stages * pivots, NOT by n_unknowns */
 int qtos_debug_structure(const QtosPlanner *p, int *row_kind, int *var_free, int *order);
 /* factor panels of problem b after the last KKT solve (n_stages x (front + 1) x 16 doubles: per stage
  * w = L^-T D^-1 y_F (16) then V = Y D^-1 L^-1 by front slot, column c of a row stored at
@@ -275,6 +280,18 @@ int qtos_debug_initial_guess(QtosPlanner *p, int B, const double *start, const d
 /* per-iteration trace of the last plan call for problem b: rows of (viol, theta, alpha, mu),
  * at most max_iter rows; returns the number of rows */
 int qtos_debug_trace(QtosPlanner *p, int b, double *trace_out);
+/* What this build of the library contains: bit 0 = the kernels that were built, measured and lost (k_kkt3 MODE 0, k_kkt4,
+ * the Kronecker assembly: -DQTOS_EXPERIMENTS, scratch/build.sh), bit 1 = per-wave cycle stamps (-DQTOS_STAMPS),
+ * bit 2 = a development build with the benchmark's fronts only (-DQTOS_DEV_F128).  The product library returns 0. */
+int qtos_build_flags(void);
+/* The factor + solve kernel qtos_planner_create selected for this planner, e.g. "k_kkt2<128>", "k_kkt3<112,1>",
+ * "k_kkt5<128>" (the name rocprofv3 lists it under, without the namespace and the trailing template defaults): at most
+ * n - 1 characters and a terminating zero into buf; returns the length of the full name.
+ * Selection (environment variable QTOS_KKT, read at creation): unset = k_kkt3 MODE 1 for fronts of at most 112 slots,
+ * k_kkt2 above; 2 = k_kkt2; 4 = k_kkt3 MODE 1 (fronts up to 128); 6 = k_kkt5 -- two 16-pivot stages per set of barriers,
+ * pair-mode analysis (fronts 96 .. 144 without continuation records; otherwise the default).  Every choice solves the same
+ * KKT systems; plans of different kernels differ by rounding (2e-8 on the walk, up to 5e-6 on the trot). */
+int qtos_kkt_kernel(const QtosPlanner *p, char *buf, int n);
 
 #ifdef __cplusplus
 }

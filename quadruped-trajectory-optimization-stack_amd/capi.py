@@ -59,7 +59,7 @@ EXPORTS = [
     "qtos_set_init_table", "qtos_debug_initial_guess", "qtos_shift_warm", "qtos_shift_warm_device",
     "qtos_last_timing_chord", "qtos_debug_chord", "qtos_plan_totals",
     "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation", "qtos_debug_residual", "qtos_project_nodes",
-    "qtos_debug_stream_len", "qtos_debug_read_stream", "qtos_debug_read_rhs",
+    "qtos_debug_stream_len", "qtos_debug_read_stream", "qtos_debug_read_rhs", "qtos_build_flags", "qtos_kkt_kernel",
 ]
 
 _lib = None
@@ -188,6 +188,11 @@ def params_from_config(cfg):
     p.chord_max, p.chord_shrink = int(cfg.chord_max), float(cfg.chord_shrink)
     p.stall_alpha = float(cfg.stall_alpha)
     return p
+
+
+def build_flags():
+    """Bit 0: the library contains the experiment kernels (QTOS_KKT=3 / 5, QTOS_KRON); bit 1: stamps; bit 2: development build."""
+    return int(load().qtos_build_flags())
 
 
 def analyze(cfg):
@@ -368,6 +373,13 @@ class Planner:
         mid = None if map_id is None else np.ascontiguousarray(map_id, np.int32)
         self._chk(self.lib.qtos_debug_initial_guess(self.h, start.shape[0], _dp(start), _dp(goal), _ip(mid), _dp(out)), "initial_guess")
         return out
+
+    def kkt_kernel(self):
+        """Name of the factor + solve kernel the planner selected (the one rocprofv3 lists), e.g. 'k_kkt5<128>'."""
+        buf = C.create_string_buffer(64)
+        self.lib.qtos_kkt_kernel.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        self._chk(min(self.lib.qtos_kkt_kernel(self.h, buf, 64), 0), "kkt_kernel")
+        return buf.value.decode()
 
     def timing(self):
         k, t = C.c_double(), C.c_double()

@@ -13,7 +13,9 @@
 #include "kernels.hpp"
 #include "kkt2.hpp"
 #include "kkt3.hpp"
+#ifdef QTOS_EXPERIMENTS   // kernels that were built, measured and lost: scratch/build.sh experiments
 #include "kkt4.hpp"
+#endif
 #include "kkt5.hpp"
 
 using namespace qtos;
@@ -111,7 +113,7 @@ struct QtosPlanner {
 // loop bound are compile-time constants
 // k_kkt2 (16 waves per problem): fronts up to 208 slots
 static void (*kkt2_kernel(int F, bool cont, bool kron = false))(DevPlan, DevWork, int) {
-#ifndef QTOS_DEV_F128
+#if defined(QTOS_EXPERIMENTS) && !defined(QTOS_DEV_F128)
   if (kron && !cont && F == 128) return k_kkt2<128, false, true>;
 #endif   // (the Kronecker assembly: the benchmark's front only)
 #define QTOS_KKT2(f) case f: return cont ? k_kkt2<f, true> : k_kkt2<f, false>;
@@ -130,7 +132,11 @@ static void (*kkt2_kernel(int F, bool cont, bool kron = false))(DevPlan, DevWork
 }
 // k_kkt3 (inequality blocks condensed on the matrix core): fronts up to 128 slots
 static void (*kkt3_kernel(int F, int mode))(DevPlan, DevWork, int) {
+#ifdef QTOS_EXPERIMENTS
 #define QTOS_KKT3(f) case f: return mode == 0 ? k_kkt3<f, 0> : k_kkt3<f, 1>;
+#else
+#define QTOS_KKT3(f) case f: return mode == 0 ? nullptr : k_kkt3<f, 1>;
+#endif
 #ifndef QTOS_DEV_F128
   switch (F) { QTOS_KKT3(16) QTOS_KKT3(32) QTOS_KKT3(48) QTOS_KKT3(64) QTOS_KKT3(80) QTOS_KKT3(96) QTOS_KKT3(112) QTOS_KKT3(128) }
 #endif
@@ -143,15 +149,19 @@ static void (*kkt5_kernel(int F))(DevPlan, DevWork, int) {
 #ifdef QTOS_DEV_F128
   switch (F) { QTOS_KKT5(112) QTOS_KKT5(128) }
 #else
-  switch (F) { QTOS_KKT5(32) QTOS_KKT5(48) QTOS_KKT5(64) QTOS_KKT5(80) QTOS_KKT5(96) QTOS_KKT5(112) QTOS_KKT5(128) QTOS_KKT5(144) }
+  switch (F) { QTOS_KKT5(96) QTOS_KKT5(112) QTOS_KKT5(128) QTOS_KKT5(144) }
 #endif
 #undef QTOS_KKT5
   return nullptr;
 }
-// k_kkt4 (panel chain and Schur updates side by side): fronts up to 128 slots
+// k_kkt4 (panel chain and Schur updates side by side): fronts up to 128 slots; experiment builds only
+#ifndef QTOS_EXPERIMENTS
+static inline size_t kkt4_lds_bytes(int, int, int, int, int) { return 0; }
+static inline size_t kkt4_sweep_base_bytes(int, int) { return 0; }
+#endif
 static void (*kkt4_kernel(int F))(DevPlan, DevWork, int) {
 #define QTOS_KKT4(f) case f: return k_kkt4<f>;
-#ifndef QTOS_DEV_F128
+#if defined(QTOS_EXPERIMENTS) && !defined(QTOS_DEV_F128)
   switch (F) { QTOS_KKT4(16) QTOS_KKT4(32) QTOS_KKT4(48) QTOS_KKT4(64) QTOS_KKT4(80) QTOS_KKT4(96) QTOS_KKT4(112) QTOS_KKT4(128) }
 #endif
 #undef QTOS_KKT4
@@ -292,7 +302,10 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   p->use_kkt5 = false;
   {
     const char *e = getenv("QTOS_KKT");
-    const int forced = e ? atoi(e) : 0;
+    int forced = e ? atoi(e) : 0;
+#ifndef QTOS_EXPERIMENTS
+    if (forced == 3 || forced == 5) { fprintf(stderr, "qtos: QTOS_KKT=%d selects an experiment that this build does not contain (scratch/build.sh -DQTOS_EXPERIMENTS): default kernel\n", forced); forced = 0; }
+#endif
     if (forced == 6) {
       // k_kkt5: the analysis in pair mode (one record per pair of stages); applicable without continuation records, with a
       // front of at most 144 slots and everything within the LDS
@@ -301,7 +314,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
       if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
       p->S.cell_mode = 2;
       p->S.pair_mode = true;
-      bool ok = p->S.build(p->M) == 0 && p->S.front >= 32 && p->S.front <= 144 && !(p->S.pack_src.size() & 1);
+      bool ok = p->S.build(p->M) == 0 && kkt5_kernel(p->S.front) != nullptr && !(p->S.pack_src.size() & 1);
       if (ok) {
         int n_cont = 0;
         for (int r = 0; r < p->S.n_records; ++r) n_cont += p->S.srec[p->S.srec_off[r] + 6];
@@ -324,6 +337,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
         for (int k = 0; k < p->S.n_stages; ++k) n_cont += p->S.srec[p->S.srec_off[k] + 6];
         ok = n_cont == 0 && kkt3_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) <= 160 * 1024 - 256;
       }
+#ifdef QTOS_EXPERIMENTS
       if (forced == 5) {   // k_kkt4: the standard records, its own LDS layout
         ok = p->S.err.empty() && p->S.front <= 128 && !(p->S.pack_src.size() & 1);
         if (ok) {
@@ -333,11 +347,16 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
         }
         p->use_kkt4 = ok;
       }
+#endif
       p->use_kkt3 = ok;
       if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: k_kkt3 MODE %d %s (%s)\n", p->kkt3_mode, ok ? "selected" : "not applicable", p->S.err.c_str());
     }
   }
+#ifdef QTOS_EXPERIMENTS
   bool want_kron = getenv("QTOS_KRON") && atoi(getenv("QTOS_KRON")) != 0;   // (experiment: Kronecker assembly of the range-of-motion blocks, k_kkt2<128> only)
+#else
+  bool want_kron = false;
+#endif
   for (int cap : {0, 4096, 3072, 2048}) {
     if (p->use_kkt3 || p->use_kkt5) break;
     p->M = HostModel();
@@ -1488,6 +1507,30 @@ int qtos_debug_residual(QtosPlanner *p, int B, int refine, double *dx_out, doubl
   return 0;
 }
 
+int qtos_build_flags(void) {
+  int f = 0;
+#ifdef QTOS_EXPERIMENTS
+  f |= 1;
+#endif
+#ifdef QTOS_STAMPS
+  f |= 2;
+#endif
+#ifdef QTOS_DEV_F128
+  f |= 4;
+#endif
+  return f;
+}
+int qtos_kkt_kernel(const QtosPlanner *p, char *buf, int n) {
+  if (!p) return -1;
+  char name[64];
+  const int F = p->S.front;
+  if (p->use_kkt5) snprintf(name, sizeof name, "k_kkt5<%d>", F);
+  else if (p->use_kkt4) snprintf(name, sizeof name, "k_kkt4<%d>", F);
+  else if (p->use_kkt3) snprintf(name, sizeof name, "k_kkt3<%d, %d>", F, p->kkt3_mode);
+  else snprintf(name, sizeof name, "k_kkt2<%d%s>", F, p->dp.n_cont > 0 ? ", true" : "");
+  if (buf && n > 0) snprintf(buf, (size_t)n, "%s", name);
+  return (int)strlen(name);
+}
 /* diagnostic: the stage stream of problem b (qtos_debug_stream_len doubles) */
 int qtos_debug_stream_len(const QtosPlanner *p) { return p ? (int)p->S.pack_src.size() : -1; }
 int qtos_debug_read_stream(QtosPlanner *p, int b, double *out) {
@@ -1496,7 +1539,8 @@ int qtos_debug_read_stream(QtosPlanner *p, int b, double *out) {
   HIPCHK(p, hipMemcpy(out, p->wk.stream + (size_t)b * p->S.pack_src.size(), p->S.pack_src.size() * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
-/* diagnostic: the vector W.rhs of problem b (n_unknowns doubles, elimination order): after qtos_debug_residual the residual */
+/* diagnostic: the vector W.rhs of problem b by position of the elimination order (n_stages x 16 doubles; S.n_unknowns counts
+ * positions, dummy pivots included): after qtos_debug_residual the residual */
 int qtos_debug_read_rhs(QtosPlanner *p, int b, double *out) {
   if (!p || !out || b < 0 || b >= p->max_batch) return -1;
   HIPCHK(p, hipSetDevice(p->device));

@@ -1,0 +1,118 @@
+"""Every factor + solve kernel the product library can select (QTOS_KKT, include/qtos_planner.h: qtos_kkt_kernel) on the
+driver's box: k_kkt2 (forced: 2), k_kkt3 MODE 1 (forced: 4; the default up to 112 slots) and k_kkt5 (6: two 16-pivot stages
+per set of barriers, pair-mode analysis).  The kernels that were built, measured and lost (k_kkt3 MODE 0, k_kkt4, the
+Kronecker assembly) live in the experiment build only (scratch/build.sh -DQTOS_EXPERIMENTS)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _planner(cfg, B, kkt):
+    from qtos_amd.capi import Planner
+    old = os.environ.get("QTOS_KKT")
+    if kkt is None:
+        os.environ.pop("QTOS_KKT", None)
+    else:
+        os.environ["QTOS_KKT"] = kkt
+    try:
+        return Planner(cfg, max_batch=B)
+    finally:
+        if old is None:
+            os.environ.pop("QTOS_KKT", None)
+        else:
+            os.environ["QTOS_KKT"] = old
+
+
+def _workload(name, B):
+    from qtos_amd import workloads
+    from qtos_amd.config import PlannerConfig
+    if name == "walk":
+        return PlannerConfig.knots100(), None, workloads.flat_goals(B, seed=0) + (None,)
+    if name == "trot":
+        return PlannerConfig.knots100(gait="trot"), None, workloads.flat_goals(B, seed=0) + (None,)
+    if name == "reference_compat":
+        return PlannerConfig.reference_compat(), None, workloads.flat_goals(B, seed=1) + (None,)
+    ter = workloads.mixed_terrains()
+    start, goal, mid = workloads.mixed_goals(B, seed=9, terrains=ter)
+    return PlannerConfig.knots100(), ter, (start, goal, mid)
+
+
+EXPECT = {   # kernel each choice resolves to on the front of the workload (pair mode: the trot's front grows from 112 to 128)
+    ("2", "walk"): "k_kkt2<128>", ("4", "walk"): "k_kkt3<128, 1>", ("6", "walk"): "k_kkt5<128>", (None, "walk"): "k_kkt2<128>",
+    ("2", "trot"): "k_kkt2<112>", ("4", "trot"): "k_kkt3<112, 1>", ("6", "trot"): "k_kkt5<128>", (None, "trot"): "k_kkt3<112, 1>",
+    ("2", "mixed"): "k_kkt2<128>", ("4", "mixed"): "k_kkt3<128, 1>", ("6", "mixed"): "k_kkt5<128>", (None, "mixed"): "k_kkt2<128>",
+}
+
+
+@pytest.mark.parametrize("workload", ["walk", "trot", "mixed"])
+@pytest.mark.parametrize("kkt", ["2", "4", "6"])
+def test_every_selectable_kernel_matches_the_oracle(kkt, workload):
+    """B = 32 problems through the forced kernel: all converge, the kernel that ran is the one asked for, and 8 of them equal the
+    oracle's plans (same iteration counts; walk / mixed 1e-6, trot 5e-6: DESIGN.md section 4 on the trot's sensitivity)."""
+    from test_gpu_parity import _batch_vs_oracle
+    B = 32
+    cfg, ter, (start, goal, mid) = _workload(workload, B)
+    P = _planner(cfg, B, kkt)
+    assert P.kkt_kernel() == EXPECT[(kkt, workload)], P.kkt_kernel()
+    if ter is not None:
+        P.set_heightfields(ter[0], ter[1])
+    nodes, status, iters, viol = P.plan(start, goal, map_id=mid)
+    P.close()
+    assert (status == 0).all() and viol.max() <= cfg.tol
+    tol = 5e-6 if workload == "trot" else 1e-6
+    same, worst = _batch_vs_oracle(cfg, start, goal, range(0, B, 4), maps=None if ter is None else ter[0], cell=None if ter is None else ter[1],
+                                   map_id=mid, status=status, iters=iters, nodes=nodes, tol=tol)
+    assert same == 8, (same, worst)
+
+
+@pytest.mark.parametrize("workload", ["trot", "reference_compat", "mixed"])
+def test_k_kkt3_mode_1_gives_the_bits_of_k_kkt2(workload):
+    """k_kkt3 MODE 1 is k_kkt2's arithmetic on another schedule (the assembly on the waves that idle in phase AB): nodes,
+    status, iterations and violations are equal bit for bit -- the claim the default for fronts of at most 112 slots rests on."""
+    B = 64
+    cfg, ter, (start, goal, mid) = _workload(workload, B)
+    res = {}
+    for kkt in ("2", "4"):
+        P = _planner(cfg, B, kkt)
+        assert P.kkt_kernel().startswith("k_kkt2" if kkt == "2" else "k_kkt3")
+        if ter is not None:
+            P.set_heightfields(ter[0], ter[1])
+        res[kkt] = P.plan(start, goal, map_id=mid)
+        P.close()
+    for a, b in zip(res["2"], res["4"]):
+        assert np.array_equal(a, b)
+
+
+def test_default_selection_and_fallback():
+    """Unset: k_kkt3 MODE 1 up to 112 slots, k_kkt2 above.  A choice that is not applicable (k_kkt5 on a horizon whose pair-mode
+    front has no instantiation, an experiment this build does not contain) falls back to the default instead of failing."""
+    from qtos_amd.capi import build_flags
+    from qtos_amd.config import PlannerConfig
+    for workload in ("walk", "trot"):
+        cfg, _, _ = _workload(workload, 4)
+        P = _planner(cfg, 4, None)
+        assert P.kkt_kernel() == EXPECT[(None, workload)]
+        P.close()
+    P = _planner(PlannerConfig.reference_compat(duration=20.0), 2, "6")
+    assert P.kkt_kernel().startswith("k_kkt2")       # (`-duration 20`: a front of 160 slots and more, no k_kkt5 for it)
+    P.close()
+    if not build_flags() & 1:
+        P = _planner(PlannerConfig.knots100(), 2, "5")
+        assert P.kkt_kernel() == "k_kkt2<128>"
+        P.close()
+
+
+@pytest.mark.parametrize("kkt", ["2", "6"])
+def test_factor_panels_of_either_kernel_match_the_block_elimination(kkt, oracle, gv1, cfg):
+    """test_gpu_parity.check_factor_panels (w and V of every ninth stage against a numpy block elimination in the planner's own
+    elimination order, full system of the reference's NLP) through k_kkt2 and through k_kkt5: the pair kernel leaves the same
+    per-stage panels for k_chord and the sweeps."""
+    import dataclasses
+    from test_gpu_parity import check_factor_panels
+    P = _planner(dataclasses.replace(cfg, reduce_base=False), 8, kkt)
+    assert P.kkt_kernel().startswith("k_kkt5" if kkt == "6" else "k_kkt2")
+    check_factor_panels(P, oracle, gv1, cfg)
+    P.close()

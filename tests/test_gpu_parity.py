@@ -522,8 +522,10 @@ def test_kronecker_assembly_of_the_range_of_motion_blocks(workload):
     (a few 1e-8 on the nodes), same iteration counts, and the oracle's plans within the usual tolerance."""
     from oracle.oracle import Oracle, oracle_dict
     from qtos_amd import workloads
-    from qtos_amd.capi import Planner
+    from qtos_amd.capi import Planner, build_flags
     from qtos_amd.config import PlannerConfig
+    if not build_flags() & 1:
+        pytest.skip("the Kronecker assembly lives in the experiment build (scratch/build.sh -DQTOS_EXPERIMENTS), not in the product library")
     cfg = PlannerConfig.knots100()      # (the 128-slot front of the benchmark: the experiment's only kernel)
     B = 64
     mid = None
@@ -1067,9 +1069,9 @@ def test_trot_gap_to_the_oracle_is_rounding_sensitivity_not_the_oracles_regulari
     """Where the 5e-6 of the trot (2e-8 on the walk) comes from.  Round 3 blamed the oracle's eps_dual = 1e-8 on the
     multipliers of the acceleration-continuity rows (the reduced base satisfies those rows identically).  Measured here, that
     is NOT it: with the ORACLE's eps_dual taken to 1e-10 (the product untouched) the gap stays where it was.  What the gap is:
-    the sensitivity of the iterates of a cost-free NLP to rounding -- the two KKT kernels of the product (k_kkt2, and k_kkt3
-    through QTOS_KKT=3: the same system, the same algorithm, the inequality blocks summed in another order) already differ
-    by a good part of it on the trot and by 1e-8 on the walk.  Both kernels' plans are feasible to the tolerance and take the
+    the sensitivity of the iterates of a cost-free NLP to rounding -- two KKT kernels of the product (k_kkt2, and k_kkt5
+    through QTOS_KKT=6: the same system, the same algorithm, another slot assignment and another order of every sum: two
+    stages per step in W form) already differ by a good part of it on the trot and by 1e-8 on the walk.  Both kernels' plans are feasible to the tolerance and take the
     same iterations; neither side of the comparison is 'the wrong one' at this level."""
     from qtos_amd import workloads
     from qtos_amd.capi import Planner
@@ -1080,7 +1082,7 @@ def test_trot_gap_to_the_oracle_is_rounding_sensitivity_not_the_oracles_regulari
         B = 32
         start, goal = workloads.flat_goals(B, seed=0)
         plans = {}
-        for kkt in ("2", "3"):
+        for kkt in ("2", "6"):
             os.environ["QTOS_KKT"] = kkt
             try:
                 P = Planner(cfg, max_batch=B)
@@ -1088,7 +1090,7 @@ def test_trot_gap_to_the_oracle_is_rounding_sensitivity_not_the_oracles_regulari
                 del os.environ["QTOS_KKT"]
             plans[kkt] = P.plan(start, goal)
             P.close()
-        (n2, s2, i2, v2), (n3, s3, i3, v3) = plans["2"], plans["3"]
+        (n2, s2, i2, v2), (n3, s3, i3, v3) = plans["2"], plans["6"]
         assert (s2 == 0).all() and (s3 == 0).all() and np.array_equal(i2, i3) and max(v2.max(), v3.max()) <= cfg.tol
         order_gap = float(np.abs(n2 - n3).max())
         gaps = {}
@@ -1257,6 +1259,10 @@ def test_stall_detection_returns_best_iterate(cfg):
 
 @pytest.mark.gpu
 def test_factor_panels_match_block_elimination(planner_full, oracle, gv1, cfg):
+    check_factor_panels(planner_full, oracle, gv1, cfg)
+
+
+def check_factor_panels(planner_full, oracle, gv1, cfg):
     """The factor panels k_kkt leaves in HBM (per stage w = L^-T D^-1 y_F and V = Y D^-1 L^-1) against
     an independent numpy block elimination of the same KKT matrix in the planner_full's elimination order
     (16 pivots per stage, unpivoted LDL^T of the pivot block, explicit L^-1), stage by stage: this
