@@ -690,6 +690,7 @@ def main():
         vall = ladder.get(best, v1)
         _, xo, infos = timed(best, len(qs_all))
         worst = float(np.abs(xo[:len(qs_all)] - nodes_h).max()) if not lanes else None
+        O.release_buffers(cores)   # (the per-thread Jacobians of the ladder: up to 30 MB x cores)
         out["cpu_baseline"] = {
             "value": round(vall, 3), "unit": "plans/s", "cores": best, "kind": "port",
             "kind_note": "port = the CHECKER (oracle/: complex-step Jacobians into a dense matrix per problem), not a tuned CPU solver: a stated baseline, the GPU / CPU ratio says nothing about kernel quality",

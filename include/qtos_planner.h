@@ -172,16 +172,17 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
  * then shares the GPU with the next ones.  This is the form bench.py times.
  *
  * Environment (read by qtos_planner_create; diagnostics and measured alternatives, defaults are the measured optimum):
- *   QTOS_KKT=2 | 3 | 4 | 5   force the factor + solve kernel: k_kkt2 / k_kkt3 MODE 0 / k_kkt3 MODE 1 / k_kkt4 (default: MODE 1 for
- *                            fronts of up to 112 slots, k_kkt2 above)
+ *   QTOS_KKT=2 | 4 | 6       force the factor + solve kernel: k_kkt2 / k_kkt3 MODE 1 / k_kkt5 (default: k_kkt3 MODE 1 for fronts of up
+ *                            to 112 slots, k_kkt2 above; see qtos_kkt_kernel below and DESIGN.md section 5).  3 and 5 (k_kkt3 MODE 0,
+ *                            k_kkt4) exist in experiment builds only (qtos_build_flags bit 0) and mean "default" elsewhere
  *   QTOS_LANES=n             a call of more problems than the GPU has compute units is cut into up to n (<= 4) contiguous parts,
  *                            each with its own host-driven loop on a stream of the planner; bit-identical plans; default 1
  *                            (measured slower than one lock-step loop at 1024 problems per call)
- *   QTOS_SHORT_STAGES=1 / QTOS_NO_SHORT_STAGES=1   stage boundaries by dynamic programming for every front size / never
- *                            (default: only where they take a 16-slot group off a front above 128 slots)
- *   QTOS_KRON=1              experiment (128-slot fronts, k_kkt2 only): the range-of-motion blocks are assembled through their
- *                            Kronecker structure -- 33 sums per block and one product of static weights per entry instead of a
- *                            three-term sum per entry; plans equal to rounding (1e-8), -0.4 % per launch: off by default
+ *   QTOS_SHORT_STAGES=1 | 0  stage boundaries by dynamic programming for every front size / never (unset: only where they take a
+ *                            16-slot group off a front above 128 slots).  QTOS_NO_SHORT_STAGES=1 is the older spelling of 0
+ *   QTOS_KRON=1              experiment builds only (128-slot fronts, k_kkt2): the range-of-motion blocks are assembled through
+ *                            their Kronecker structure -- 33 sums per block and one product of static weights per entry instead
+ *                            of a three-term sum per entry; plans equal to rounding (1e-8), -0.4 % per launch
  *   QTOS_SWEEP_DS=0          k_step forms the slack steps ds = Ji dx + (g - s) itself (default 1: three waves that idle in the
  *                            backward sweep of the KKT kernels form them, block by block behind the stage that solves the
  *                            block's earliest column; bit-identical plans)

@@ -247,3 +247,10 @@ class Oracle:
             raise RuntimeError("qo_solve_batch failed")
         return x, list(infos)
 
+    @staticmethod
+    def release_buffers(n_threads=0):
+        """Give back the per-thread dense Jacobians the solver keeps between batches (30 MB each on the 100-knot problem)."""
+        lib().qo_release_buffers.argtypes = [C.c_int]
+        lib().qo_release_buffers.restype = None
+        lib().qo_release_buffers(int(n_threads))
+

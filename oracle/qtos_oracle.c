@@ -996,6 +996,11 @@ static int cmp_keyed(const void *a, const void *b) {
   return x->id - y->id;
 }
 
+/* the dense Jacobian of a solve, kept per thread between the solves of one batch (qo_solve_batch releases it) */
+static _Thread_local double *tls_J = NULL;
+static _Thread_local size_t tls_J_cap = 0;
+static void tls_J_release(void) { free(tls_J); tls_J = NULL; tls_J_cap = 0; }
+
 int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, double *x, qo_info *info) {
   qo_model *M = (qo_model *)malloc(sizeof(qo_model));
   if (build_model(p, M)) { free(M); return -1; }
@@ -1015,14 +1020,13 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
   double *g = (double *)malloc(sizeof(double) * m), *gt = (double *)malloc(sizeof(double) * m);
   /* the dense Jacobian (30 MB on the 100-knot problem) is kept per thread between solves: allocated and freed per solve
    * it is an mmap / munmap pair with page faults and TLB shoot-downs across every thread of the process (qo_solve_batch) */
-  static _Thread_local double *tls_J = NULL;
-  static _Thread_local size_t tls_J_cap = 0;
   if (tls_J_cap < (size_t)m * n) {
     free(tls_J);
     tls_J = (double *)malloc(sizeof(double) * (size_t)m * n);
     tls_J_cap = tls_J ? (size_t)m * n : 0;
   }
   double *J = tls_J;
+  if (!J) { free(xl); free(cl); free(g); free(gt); return -1; }   /* (without it eval_all would silently skip the Jacobian) */
   double *xt = (double *)malloc(sizeof(double) * n);
 
   /* ---- working sets: free variables, de-duplicated equality rows, inequality rows ---------- */
@@ -1348,5 +1352,19 @@ int qo_solve_batch(const qo_params *p, int n_problems, const qo_problem *q, cons
   for (int i = 0; i < n_problems; ++i)
     if (qo_solve(p, q + i, o, x_io + (size_t)i * L.n_vars, info + i) < 0) bad++;
   return bad ? -1 : 0;
+}
+
+/* Every thread of the OpenMP team (and the caller) gives its dense Jacobian back -- 30 MB each on the 100-knot problem, kept
+ * between batches so that a timed pass does not pay for first-touch page faults -- and the allocator gets its defaults again.
+ * bench.py calls it behind the cpu_baseline leg; a host process that runs one batch and goes on should too. */
+void qo_release_buffers(int n_threads) {
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel
+#endif
+  tls_J_release();
+  tls_J_release();
+  mallopt(M_MMAP_THRESHOLD, 128 * 1024);
+  mallopt(M_TRIM_THRESHOLD, 128 * 1024);
 }
 

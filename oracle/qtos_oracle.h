@@ -131,6 +131,8 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
 /* n_problems independent solves, OpenMP over the problems (n_threads <= 0: the runtime's default) */
 int qo_solve_batch(const qo_params *p, int n_problems, const qo_problem *q, const qo_options *o,
                    double *x_io, qo_info *info, int n_threads);
+/* frees the per-thread Jacobian buffers qo_solve keeps between calls and restores the allocator's thresholds */
+void qo_release_buffers(int n_threads);
 /* max violation of all 1730 rows (equalities and two-sided bounds) + violated fixed vars */
 double qo_max_violation(const qo_params *p, const double *x);
 

@@ -771,7 +771,10 @@ struct Symbolic {
     // 1.81 ms per launch; the full system of `-duration 12`: 160 -> 144, 1.74 -> 1.69 --, the 100-knot walk does not (128 ->
     // 112 slots: 0.643 -> 0.656 ms: twelve update waves of three tiles next to a factor wave with a SIMD of its own are the
     // better shape than fourteen of two).  So: only above 128 slots, unless QTOS_SHORT_STAGES=1 asks for it.
-    if (F0 <= 128 && !getenv("QTOS_SHORT_STAGES")) return;
+    // (QTOS_SHORT_STAGES: 1 = for every front size, 0 = never; parsed like every other switch -- a baseline run that sets it to 0
+    //  must not silently measure the variant)
+    const char *ess = getenv("QTOS_SHORT_STAGES");
+    if (ess ? atoi(ess) == 0 : F0 <= 128) return;
     std::vector<int> cut;   // boundaries of the chosen partition
     for (int target = F0 - PIV; target >= 2 * PIV; target -= PIV) {
       const int INF = 1 << 29;
@@ -875,7 +878,10 @@ struct Symbolic {
       first[hi] = std::min(first[hi], lo);
     }
     n_real_unknowns = n_unknowns;
-    if (short_stages && !getenv("QTOS_NO_SHORT_STAGES")) shorten_stages(first, block_minpos, n, m);
+    {
+      const char *ens = getenv("QTOS_NO_SHORT_STAGES");
+      if (short_stages && !(ens && atoi(ens) != 0)) shorten_stages(first, block_minpos, n, m);
+    }
     n_stages = (n_unknowns + PIV - 1) / PIV;
     if (pair_mode) {
       // whole pairs: dummy positions fill the last stage and, if the number of stages is odd, one more stage
