@@ -66,6 +66,14 @@ typedef struct QtosParams {
   double stall_alpha;  /* a problem whose step length stays below stall_alpha for two iterations in a row is jammed against its
                           bounds (it would sit there until a division overflows, and its batch with it): it stops like a
                           stalled one -- status 1, best iterate returned; 0 = never */
+  int reduce_swing;    /* 1: the swing rule (towr SwingConstraint: the x, y of a swing's mid node = centre of the neighbouring
+                          footholds, its v_x, v_y = their distance / t_swing_avg -- constant coefficients) leaves the KKT system:
+                          inside the solve the four mid-node variables of every swing are their linear image of the two footholds
+                          (no variables, no multipliers for them: 8 unknowns per swing), exactly as reduce_base treats the base's
+                          continuity rows.  The iterate, results and CSV keep the mid nodes.  The rows then hold for every
+                          iterate only if they hold for the first: the starting point's mid nodes are placed on the rule
+                          (towr's straight-line guess has another v_xy there).  Nearest-cell terrain only (terrain_mode 1);
+                          0 = every swing row keeps its multiplier */
 } QtosParams;
 
 typedef struct QtosDims {

@@ -58,7 +58,7 @@ class QoOptions(C.Structure):
         ("mu_min", C.c_double), ("delta_x", C.c_double), ("eps_dual", C.c_double), ("slack_push", C.c_double), ("warm_slack_push", C.c_double),
         ("warm_start", C.c_int), ("verbose", C.c_int), ("stall_iters", C.c_int),
         ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double), ("chord_tol", C.c_double),
-        ("stall_alpha", C.c_double), ("chord_max", C.c_int), ("chord_shrink", C.c_double),
+        ("stall_alpha", C.c_double), ("chord_max", C.c_int), ("chord_shrink", C.c_double), ("swing_start_on_rule", C.c_int),
     ]
 
 
@@ -118,7 +118,10 @@ def oracle_dict(cfg):
                 force_polys_per_stance=cfg.force_polys_per_stance, mass=cfg.mass,
                 gravity=cfg.gravity, inertia_b=cfg.inertia_b, max_dev=cfg.max_deviation,
                 mu=cfg.friction, f_max=cfg.force_limit, t_swing_avg=cfg.t_swing_avg,
-                terrain_mode=cfg.terrain_mode)
+                terrain_mode=cfg.terrain_mode,
+                # the product's reduce_swing (nearest-cell terrain only, model.hpp) places a starting point's swing mid nodes on
+                # the swing rule: the oracle's solves start from the same point
+                swing_start_on_rule=bool(getattr(cfg, "reduce_swing", False)) and cfg.terrain_mode == 1)
 
 
 def oracle_options(cfg, O):
@@ -130,6 +133,8 @@ def oracle_options(cfg, O):
                                                              cfg.foothold_hold_weight, cfg.foothold_hold_tol)
     o.chord_tol, o.chord_max, o.chord_shrink = cfg.chord_tol, cfg.chord_max, cfg.chord_shrink
     o.stall_alpha = cfg.stall_alpha
+    # (the product's reduce_swing applies with nearest-cell terrain only: model.hpp)
+    o.swing_start_on_rule = int(bool(getattr(cfg, "reduce_swing", False)) and cfg.terrain_mode == 1)   # (== O.swing_start_on_rule for an Oracle(oracle_dict(cfg)))
     return o
 
 
@@ -155,6 +160,7 @@ class Oracle:
             p.max_dev[k] = cfg["max_dev"][k]
         p.mu, p.f_max, p.t_swing_avg = cfg["mu"], cfg["f_max"], cfg["t_swing_avg"]
         p.terrain_mode = int(cfg.get("terrain_mode", 0))
+        self.swing_start_on_rule = bool(cfg.get("swing_start_on_rule", False))
         self._height = None
         if height is not None:
             self._height = np.ascontiguousarray(height, dtype=np.float64)
@@ -223,7 +229,24 @@ class Oracle:
     def default_options(self):
         o = QoOptions()
         lib().qo_default_options(C.byref(o))
+        o.swing_start_on_rule = int(self.swing_start_on_rule)
         return o
+
+    def start_point(self, q):
+        """towr's straight-line guess as a solve starts from it: with swing_start_on_rule the swing mid nodes on the swing rule."""
+        x = self.initial_guess(q)
+        if self.swing_start_on_rule:
+            lib().qo_project_swings.argtypes = [C.POINTER(QoParams), C.POINTER(C.c_double)]
+            if lib().qo_project_swings(C.byref(self.p), _dp(x)):
+                raise RuntimeError("qo_project_swings failed")
+        return x
+
+    def project_swings(self, x):
+        """A copy of x with the swing mid nodes on the swing rule (what a warm start becomes under swing_start_on_rule)."""
+        y = np.array(x, dtype=np.float64, copy=True)
+        lib().qo_project_swings.argtypes = [C.POINTER(QoParams), C.POINTER(C.c_double)]
+        lib().qo_project_swings(C.byref(self.p), _dp(y))
+        return y
 
     def solve(self, q, x0=None, opts=None):
         o = opts or self.default_options()

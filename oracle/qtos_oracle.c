@@ -937,6 +937,7 @@ void qo_default_options(qo_options *o) {
   o->hold_tol = 0.25;
   o->warm_start = 0;
   o->verbose = 0;
+  o->swing_start_on_rule = 0;
 }
 
 /* time stamp of every variable / constraint row: used only to order the KKT unknowns */
@@ -996,6 +997,29 @@ static int cmp_keyed(const void *a, const void *b) {
   return x->id - y->id;
 }
 
+/* The swing mid nodes (x, y, v_x, v_y) placed on the swing rule (UPSTREAM swing_constraint.cc, solved for the mid node):
+ * mirrors what the product's reduce_swing does to a starting point, see qo_options.swing_start_on_rule. */
+static void project_swings(const qo_params *p, const qo_model *M, double *x) {
+  for (int e = 0; e < QO_NEE; ++e) {
+    const qo_spline *S = &M->eem[e];
+    for (int node = 1; node < S->n_polys; ++node) {
+      if (S->idx[node][1][0] < 0) continue;
+      for (int d = 0; d < 2; ++d) {
+        const int ip = S->idx[node - 1][0][d], in = S->idx[node + 1][0][d], ic = S->idx[node][0][d], iv = S->idx[node][1][d];
+        x[ic] = fma(0.5, x[ip], 0.5 * x[in]);
+        x[iv] = fma(-1.0 / p->t_swing_avg, x[ip], (1.0 / p->t_swing_avg) * x[in]);
+      }
+    }
+  }
+}
+int qo_project_swings(const qo_params *p, double *x) {
+  qo_model *M = (qo_model *)malloc(sizeof(qo_model));
+  if (!M || build_model(p, M)) { free(M); return -1; }
+  project_swings(p, M, x);
+  free(M);
+  return 0;
+}
+
 /* the dense Jacobian of a solve, kept per thread between the solves of one batch (qo_solve_batch releases it) */
 static _Thread_local double *tls_J = NULL;
 static _Thread_local size_t tls_J_cap = 0;
@@ -1016,6 +1040,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
   if (!o->warm_start) qo_initial_guess(p, q, x);
   for (int i = 0; i < n; ++i)
     if (xl[i] == xh[i]) x[i] = xl[i];
+  if (o->swing_start_on_rule) project_swings(p, M, x);
 
   double *g = (double *)malloc(sizeof(double) * m), *gt = (double *)malloc(sizeof(double) * m);
   /* the dense Jacobian (30 MB on the 100-knot problem) is kept per thread between solves: allocated and freed per solve

@@ -114,6 +114,10 @@ typedef struct {
   int chord_max;       /* chord steps in a row with one factorisation: a further one follows a full chord step that
                           brought the violation down to chord_shrink times what it was (and to chord_tol)      */
   double chord_shrink;
+  int swing_start_on_rule; /* 1: the starting point's swing mid nodes (x, y, v_x, v_y) are placed on the swing rule before the
+                          first evaluation -- the product's reduce_swing takes those rows out of its KKT system, so they must
+                          hold at its first iterate; from there this solver's Newton steps keep them (linear rows) and the two
+                          take the same path.  0 = towr's straight-line guess as it is (the logged 19.4 at iteration 0) */
 } qo_options;
 
 typedef struct {
@@ -133,6 +137,8 @@ int qo_solve_batch(const qo_params *p, int n_problems, const qo_problem *q, cons
                    double *x_io, qo_info *info, int n_threads);
 /* frees the per-thread Jacobian buffers qo_solve keeps between calls and restores the allocator's thresholds */
 void qo_release_buffers(int n_threads);
+/* the swing mid nodes of x placed on the swing rule (what swing_start_on_rule does to a starting point) */
+int qo_project_swings(const qo_params *p, double *x);
 /* max violation of all 1730 rows (equalities and two-sided bounds) + violated fixed vars */
 double qo_max_violation(const qo_params *p, const double *x);
 

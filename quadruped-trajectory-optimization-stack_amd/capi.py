@@ -32,6 +32,7 @@ class QtosParams(C.Structure):
         ("chord_tol", C.c_double),
         ("reduce_base", C.c_int),
         ("chord_max", C.c_int), ("chord_shrink", C.c_double), ("stall_alpha", C.c_double),
+        ("reduce_swing", C.c_int),
     ]
 
 
@@ -187,6 +188,7 @@ def params_from_config(cfg):
     p.reduce_base = int(cfg.reduce_base)
     p.chord_max, p.chord_shrink = int(cfg.chord_max), float(cfg.chord_shrink)
     p.stall_alpha = float(cfg.stall_alpha)
+    p.reduce_swing = int(getattr(cfg, "reduce_swing", False))
     return p
 
 

@@ -114,6 +114,14 @@ class PlannerConfig:
     # those rows, half the base unknowns (2885 -> 1721 unknowns, 181 -> 108 stages on the 100-knot transcription), the same
     # Newton step.  False: every row of the reference's NLP has its multiplier (what the internals' tests pin).
     reduce_base: bool = True
+    # Reduced swings (round 5): towr's swing rule -- the x, y of a swing's mid node = centre of the neighbouring footholds, its
+    # v_x, v_y = their distance / t_swing_avg -- has constant coefficients like the base's continuity rows: inside the KKT solve
+    # the four mid-node variables of every swing are their linear image of the two footholds (8 unknowns per swing leave the
+    # system: 108 -> 100 stages on the 100-knot walk, 127 -> 113 on the trot); iterate, results and CSV keep the mid nodes.  The
+    # rows hold for every iterate only if they hold for the first: the starting point's mid nodes are placed on the rule (towr's
+    # straight-line guess has the plan's mean velocity there).  Nearest-cell terrain only.  False: every swing row keeps its
+    # multiplier and towr's guess is the starting point as it is (the reference's logged 19.4 at iteration 0).
+    reduce_swing: bool = True
     phase_durations: List[List[float]] = field(default=None)
 
     def __post_init__(self):

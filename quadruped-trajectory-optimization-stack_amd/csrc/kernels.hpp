@@ -32,6 +32,7 @@ struct TerrDev {
   int px, py, pz;
   int d0, d1;
   int pad;
+  double ex, ey;   // static part of those diagonals beyond delta_x (reduced swings: the proximal term of the replaced mid nodes)
 };
 
 struct DevPlan {
@@ -44,6 +45,11 @@ struct DevPlan {
   const double *rec_w;
   // projection of a warm start onto the space of the coefficients (model.hpp: pc_*, pz_*); n_coef = 0 without reduce_base
   int n_coef, n_pz;
+  // reduced swings (QtosParams.reduce_swing): a starting point's mid-node x, y, v_x, v_y are placed on the swing rule:
+  // x[psw_var[i]] = psw_w[2 i] x[psw_src[2 i]] + psw_w[2 i + 1] x[psw_src[2 i + 1]]; n_psw = 0 without
+  int n_psw;
+  const int *psw_var, *psw_src;
+  const double *psw_w;
   const int *pc_var, *pz_var, *pz_col;
   const double *pc_w, *pz_w;
   int n_dyn, n_rom, n_terr, n_force, n_lin, n_blocks;
@@ -474,8 +480,8 @@ __device__ inline void eval_terr(const DevPlan &P, const TerrDev &I, int map, co
     // KKT system of this iterate -- delta_x while the feet are being placed, hold_weight afterwards
     // (hold = -1, the introspection calls: delta_x)
     const double wgt = hold > 0 ? P.hold_weight : P.delta_x;
-    if (I.d0 >= 0) Gp[I.d0] = wgt;
-    if (I.d1 >= 0) Gp[I.d1] = wgt;
+    if (I.d0 >= 0) Gp[I.d0] = wgt + I.ex;
+    if (I.d1 >= 0) Gp[I.d1] = wgt + I.ey;
     if (I.px >= 0) Gp[I.px] = -t.hx;
     if (I.py >= 0) Gp[I.py] = -t.hy;
     if (I.pz >= 0) Gp[I.pz] = 1.0;
@@ -807,6 +813,16 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     evl[v] = val;                       // (the evaluation below reads the nodes from LDS)
   }
   __syncthreads();
+  // reduced swings: the swing rows left the KKT system and hold for every iterate only if they hold for the first (towr's
+  // straight-line guess has the whole-plan mean velocity at the mid nodes, given nodes hold the rule to their print precision)
+  for (int i = tid; i < P.n_psw; i += blockDim.x) {
+    const double val = fma(P.psw_w[2 * i], x[P.psw_src[2 * i]], P.psw_w[2 * i + 1] * x[P.psw_src[2 * i + 1]]);
+    const int v = P.psw_var[i];
+    x[v] = val;
+    W.xbest[(size_t)b * n + v] = val;
+    evl[v] = val;
+  }
+  if (P.n_psw) __syncthreads();
   const bool project = P.n_coef && (W.warm || P.table);
   if (project) {
     // reduced base: given nodes need not be a spline of the coefficients' space (the reference's plans violate the
@@ -1498,8 +1514,8 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     double *Gp = W.stream + (size_t)b * P.stream_len;
     for (int ti = tid; ti < P.n_terr; ti += nt) {
       const TerrDev TI = P.terr[ti];
-      if (TI.d0 >= 0) Gp[TI.d0] = P.hold_weight;
-      if (TI.d1 >= 0) Gp[TI.d1] = P.hold_weight;
+      if (TI.d0 >= 0) Gp[TI.d0] = P.hold_weight + TI.ex;
+      if (TI.d1 >= 0) Gp[TI.d1] = P.hold_weight + TI.ey;
     }
   }
   __syncthreads();

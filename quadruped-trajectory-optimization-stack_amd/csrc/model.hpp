@@ -195,6 +195,18 @@ inline void bspline_ders(const std::vector<double> &U, int i, double t, double d
   }
 }
 
+// a 3-vector input in SOLVER space with a weight per slot AND dimension (host only: the column structure and the weights of
+// a Jacobian block; the values are evaluated in node space through VecIn)
+struct VecInW {
+  double w[12];
+  int var[12];
+};
+inline VecInW widen(const VecIn &v) {
+  VecInW o;
+  for (int i = 0; i < 12; ++i) { o.var[i] = v.var[i]; o.w[i] = v.w[i / 3]; }
+  return o;
+}
+
 inline VecIn make_in_poly(const Spline &S, int k, double tau, int deriv) {
   VecIn v;
   hermite_weights(S.dur[k], tau, deriv, v.w);
@@ -259,7 +271,7 @@ struct HostModel {
   std::vector<int> pc_var, pz_var, pz_col;
   std::vector<double> pc_w, pz_w;
   bool is_unknown(int v) const {
-    if (v < n_vars) return init[v].fix_src < 0 && !(reduce_base && replaced[v]);
+    if (v < n_vars) return init[v].fix_src < 0 && !replaced[v];
     return coef_unknown[v - n_vars] != 0;
   }
   // base input in solver space: the four B-spline coefficients that live on the polynomial containing t
@@ -280,6 +292,41 @@ struct HostModel {
   }
   struct BaseIn { VecIn r, a, th, thd, thdd; };   // solver-space inputs of an instance (column structure and weights of its Jacobian)
   std::vector<BaseIn> dyn_sol, rom_sol;
+  // ---- reduced swings (QtosParams.reduce_swing): the swing rule -- mid node x, y = centre of the neighbouring footholds,
+  // v_x, v_y = their distance / t_swing_avg -- has constant coefficients: inside the KKT solve the four mid-node variables are
+  // their linear image of the two footholds (`replaced`, recovery through rec_var / rec_col like the base's node values; the
+  // proximal term of the replaced variables becomes static entries between the footholds).  A foot position that a Jacobian
+  // block depends on is then a combination of footholds with one weight per slot and dimension (x, y folded; z as before).
+  int reduce_swing = 0;
+  std::vector<std::array<VecInW, NEE>> dyn_psol;   // per dynamics knot: the feet in solver space
+  std::vector<VecInW> rom_psol;                    // per range-of-motion instance: its foot
+  // projection of a starting point onto the rule: x[psw_var] = psw_w[2 i] x[psw_src[2 i]] + psw_w[2 i + 1] x[psw_src[2 i + 1]]
+  std::vector<int> psw_var, psw_src;
+  std::vector<double> psw_w;
+  VecInW make_foot_sol(int e, double t) const {
+    const VecIn in = make_in(eem[e], t, 0);
+    VecInW o = widen(in);
+    if (!reduce_swing) return o;
+    for (int d = 0; d < 2; ++d) {
+      // the (variable, weight) list of this dimension with every replaced mid-node variable expanded
+      int vars[8], nv = 0;
+      double ws[8];
+      auto addv = [&](int v, double w) {
+        if (v < 0 || w == 0.0) return;
+        for (int i = 0; i < nv; ++i) if (vars[i] == v) { ws[i] += w; return; }
+        vars[nv] = v; ws[nv] = w; ++nv;
+      };
+      for (int a = 0; a < 4; ++a) {
+        const int v = in.var[3 * a + d];
+        if (v < 0) continue;
+        if (!replaced[v]) { addv(v, in.w[a]); continue; }
+        for (size_t q = 0; q < psw_var.size(); ++q)
+          if (psw_var[q] == v) { addv(psw_src[2 * q], in.w[a] * psw_w[2 * q]); addv(psw_src[2 * q + 1], in.w[a] * psw_w[2 * q + 1]); }
+      }
+      for (int a = 0; a < 4; ++a) { o.var[3 * a + d] = a < nv ? vars[a] : -1; o.w[3 * a + d] = a < nv ? ws[a] : 0.0; }
+    }
+    return o;
+  }
 
   static std::vector<double> time_grid(double T, double dt) {
     // towr time_discretization_constraint.cc: 0, dt, ..., floor(T/dt)*dt (accumulated), T
@@ -307,6 +354,9 @@ struct HostModel {
       return (short)(cols.size() - 1);
     }
     void group(const VecIn &in, short out[12]) {
+      for (int i = 0; i < 12; ++i) out[i] = add(in.var[i]);
+    }
+    void group(const VecInW &in, short out[12]) {
       for (int i = 0; i < 12; ++i) out[i] = add(in.var[i]);
     }
   };
@@ -341,6 +391,25 @@ struct HostModel {
     for (auto &i : terr) fix(i.goff);
     for (auto &i : force) fix(i.goff);
     // column descriptors: every G entry of a dynamics / range-of-motion block is written once
+    auto addw = [](std::vector<ColDesc> &cols, size_t first, int inst, int gbase0, int ncol, int kind,
+                   const short cmap[12], const VecInW *in0) {
+      for (int s = 0; s < 4; ++s)
+        for (int d = 0; d < 3; ++d) {
+          const int c = cmap[3 * s + d];
+          if (c < 0) continue;
+          ColDesc *cd = nullptr;
+          for (size_t i = first; i < cols.size(); ++i)
+            if (cols[i].gbase == gbase0 + c) { cd = &cols[i]; break; }
+          if (!cd) {
+            ColDesc nw;
+            std::memset(&nw, 0, sizeof(nw));
+            nw.inst = inst; nw.gbase = gbase0 + c; nw.ncol = ncol; nw.kind = (short)kind; nw.dim = (short)d;
+            cols.push_back(nw);
+            cd = &cols.back();
+          }
+          cd->w0 += in0->w[3 * s + d];
+        }
+    };
     auto add = [](std::vector<ColDesc> &cols, size_t first, int inst, int gbase0, int ncol, int kind,
                   const short cmap[12], const VecIn *in0, const VecIn *in1, const VecIn *in2) {
       for (int s = 0; s < 4; ++s)
@@ -372,7 +441,7 @@ struct HostModel {
       add(dyn_cols, first, (int)k, I.goff, I.ncol, 0, I.c_lin, &Bi.r, &Bi.a, nullptr);
       add(dyn_cols, first, (int)k, I.goff, I.ncol, 1, I.c_ang, &Bi.th, &Bi.thd, &Bi.thdd);
       for (int e = 0; e < NEE; ++e) {
-        add(dyn_cols, first, (int)k, I.goff, I.ncol, 2 + e, I.c_p[e], &I.p[e], nullptr, nullptr);
+        addw(dyn_cols, first, (int)k, I.goff, I.ncol, 2 + e, I.c_p[e], &dyn_psol[k][e]);
         add(dyn_cols, first, (int)k, I.goff, I.ncol, 6 + e, I.c_f[e], &I.f[e], nullptr, nullptr);
       }
     }
@@ -382,7 +451,7 @@ struct HostModel {
       const BaseIn &Bi = rom_sol[k];
       add(rom_cols, first, (int)k, I.goff, I.ncol, 0, I.c_lin, &Bi.r, nullptr, nullptr);
       add(rom_cols, first, (int)k, I.goff, I.ncol, 1, I.c_ang, &Bi.th, nullptr, nullptr);
-      add(rom_cols, first, (int)k, I.goff, I.ncol, 2, I.c_p, &I.p, nullptr, nullptr);
+      addw(rom_cols, first, (int)k, I.goff, I.ncol, 2, I.c_p, &rom_psol[k]);
     }
   }
 
@@ -559,6 +628,7 @@ struct HostModel {
     n_coef = 0;
     replaced.assign(n_vars, 0);
     sol_diag.assign(n_vars, P.delta_x);
+    std::vector<std::vector<std::pair<int, double>>> quad;   // per recovered node value: (solver column, weight)
     if (reduce_base) {
       // clamped knots: t_0 x 4, the interior node times, t_nb x 4; coefficient j lives on the polynomials j-3 .. j
       // The first and the last interior junction are DOUBLE knots (C1 there): towr's starting point -- constant node
@@ -614,7 +684,6 @@ struct HostModel {
             for (int d = 0; d < 3; ++d) replaced[S.idx[k][q * 3 + d]] = 1;
       }
       // recovery dx_nodes = Z dc and the proximal term delta |Z dc|^2 over the free node values
-      std::vector<std::vector<std::pair<int, double>>> quad;   // per node value: (solver column, weight)
       for (int which = 0; which < 2; ++which) {
         const Spline &S = which ? ang : lin;
         for (int k = 0; k <= nb; ++k) {
@@ -678,6 +747,46 @@ struct HostModel {
           }
         }
       }
+    }
+    // ---- reduced swings: the mid node's x, y, v_x, v_y as the linear image of the neighbouring footholds ----
+    // (nearest-cell terrain only: a bilinear heightfield puts the slopes dh/dx, dh/dy of the swing's terrain row on the mid
+    //  node's x, y)
+    reduce_swing = P.reduce_swing != 0 && P.terrain_mode == 1;
+    if (reduce_swing) {
+      for (int e = 0; e < NEE; ++e) {
+        const Spline &S = eem[e];
+        for (int node = 1; node < S.n_polys; ++node) {
+          if (S.idx[node][3] < 0) continue;   // (a mid node has velocities)
+          for (int d = 0; d < 2; ++d) {
+            const int ip = S.idx[node - 1][d], in = S.idx[node + 1][d], ic = S.idx[node][d], iv = S.idx[node][3 + d];
+            const int vv[2] = {ic, iv};
+            const double ww[2][2] = {{0.5, 0.5}, {-1.0 / P.t_swing_avg, 1.0 / P.t_swing_avg}};
+            for (int q = 0; q < 2; ++q) {
+              replaced[vv[q]] = 1;
+              psw_var.push_back(vv[q]);
+              psw_src.push_back(ip); psw_src.push_back(in);
+              psw_w.push_back(ww[q][0]); psw_w.push_back(ww[q][1]);
+              std::vector<std::pair<int, double>> row;
+              if (is_free(ip)) row.push_back({ip, ww[q][0]});
+              if (is_free(in)) row.push_back({in, ww[q][1]});
+              rec_var.push_back(vv[q]);
+              for (int a = 0; a < 4; ++a) {
+                rec_col.push_back(a < (int)row.size() ? row[a].first : -1);
+                rec_w.push_back(a < (int)row.size() ? row[a].second : 0.0);
+              }
+              quad.push_back(row);
+            }
+            // the foothold in front of the swing now feeds the rows of the whole swing (it used to end with its stance): its place
+            // in the elimination order moves to the end of the swing -- eliminated at the end of its stance, every unknown of the
+            // swing's rows would enter the front with it (long swings: fronts of 288 slots instead of 208)
+            if (ip >= 0) var_time[ip] = std::max(var_time[ip], S.node_time(node + 1));
+          }
+        }
+      }
+    }
+    if (n_sol > (int)sol_diag.size()) sol_diag.resize(n_sol, 0.0);
+    {
+      // the proximal term delta |dx|^2 over the recovered node values in the unknowns they are recovered from
       std::vector<std::pair<std::pair<int, int>, double>> acc;
       for (auto &row : quad)
         for (size_t i = 0; i < row.size(); ++i)
@@ -750,7 +859,12 @@ struct HostModel {
       ColBuilder cb{{}, this};
       cb.group(bi.r, di.c_lin);
       cb.group(bi.th, di.c_ang);
-      for (int e = 0; e < NEE; ++e) { cb.group(di.p[e], di.c_p[e]); cb.group(di.f[e], di.c_f[e]); }
+      {
+        std::array<VecInW, NEE> ps;
+        for (int e = 0; e < NEE; ++e) ps[e] = make_foot_sol(e, t);
+        dyn_psol.push_back(ps);
+      }
+      for (int e = 0; e < NEE; ++e) { cb.group(dyn_psol.back()[e], di.c_p[e]); cb.group(di.f[e], di.c_f[e]); }
       di.ncol = (int)cb.cols.size();
       // the grid repeats T when floor(T/dt)*dt == T: the repeated block is the same six equations
       bool dup = k > 0 && std::fabs(t - t_dyn[k - 1]) < 1e-9;
@@ -799,7 +913,8 @@ struct HostModel {
         bi.r = make_in_sol(0, lin, t, 0); bi.th = make_in_sol(1, ang, t, 0);
         rom_sol.push_back(bi);
         ColBuilder cb{{}, this};
-        cb.group(bi.r, ri.c_lin); cb.group(bi.th, ri.c_ang); cb.group(ri.p, ri.c_p);
+        rom_psol.push_back(make_foot_sol(e, t));
+        cb.group(bi.r, ri.c_lin); cb.group(bi.th, ri.c_ang); cb.group(rom_psol.back(), ri.c_p);
         ri.ncol = (int)cb.cols.size();
         for (int d = 0; d < 3; ++d) {
           con_lo[ri.row0 + d] = P.nominal_stance[e][d] - P.max_dev[d];
@@ -861,7 +976,7 @@ struct HostModel {
       std::vector<double> vals;
       bool on_base = false;
       for (int i = 0; i < lr.n; ++i) {
-        if (reduce_base && replaced[lr.var[i]]) on_base = true;
+        if (replaced[lr.var[i]]) on_base = true;
         if (is_free(lr.var[i])) { cols.push_back(lr.var[i]); vals.push_back(lr.coef[i]); }
       }
       if (on_base) {
@@ -872,6 +987,13 @@ struct HostModel {
         double amax = 0.0;
         for (size_t i = 0; i < cols.size(); ++i) {
           amax = std::max(amax, std::fabs(vals[i]));
+          if (!replaced[cols[i]]) {   // (an unknown of its own, e.g. the footholds of a swing row)
+            size_t at = 0;
+            while (at < ccols.size() && ccols[at] != cols[i]) ++at;
+            if (at == ccols.size()) { ccols.push_back(cols[i]); cvals.push_back(0.0); }
+            cvals[at] += vals[i];
+            continue;
+          }
           for (size_t q = 0; q < rec_var.size(); ++q) {
             if (rec_var[q] != cols[i]) continue;
             for (int a = 0; a < 4; ++a) {

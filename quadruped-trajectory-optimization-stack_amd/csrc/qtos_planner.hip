@@ -409,6 +409,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(M.rec_var, &D.rec_var)); TRY(p->upload(M.rec_col, &D.rec_col)); TRY(p->upload(M.rec_w, &D.rec_w));
   D.n_coef = M.reduce_base ? M.n_coef : 0; D.n_pz = (int)M.pz_var.size();
   TRY(p->upload(M.pc_var, &D.pc_var)); TRY(p->upload(M.pc_w, &D.pc_w));
+  D.n_psw = (int)M.psw_var.size();
+  TRY(p->upload(M.psw_var, &D.psw_var)); TRY(p->upload(M.psw_src, &D.psw_src)); TRY(p->upload(M.psw_w, &D.psw_w));
   TRY(p->upload(M.pz_var, &D.pz_var)); TRY(p->upload(M.pz_col, &D.pz_col)); TRY(p->upload(M.pz_w, &D.pz_w));
   D.n_dyn = (int)M.dyn.size(); D.n_rom = (int)M.rom.size(); D.n_terr = (int)M.terr.size();
   D.n_force = (int)M.force.size(); D.n_lin = (int)M.linrow.size(); D.n_blocks = (int)M.blocks.size();
@@ -496,12 +498,15 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
       }
     std::vector<TerrDev> td;
     for (const TerrInst &t : M.terr) {
-      TerrDev d = {t.vx, t.vy, t.vz, t.row, -1, -1, -1, -1, -1, 0};
+      TerrDev d = {t.vx, t.vy, t.vz, t.row, -1, -1, -1, -1, -1, 0, 0.0, 0.0};
       if (t.in_kkt) {
         const bool stance = M.row_kind[t.row] == 1;   // equality block: entries at their own stream positions
         auto pos = [&](int c) { return c < 0 ? -1 : (stance ? S.eq_pos[t.goff + c] : t.goff + c); };
         d.px = pos(t.cx); d.py = pos(t.cy); d.pz = pos(t.cz);
-        if (M.P.hold_from > 0 && stance) { d.d0 = dpos_of_var[t.vx]; d.d1 = dpos_of_var[t.vy]; }
+        if (M.P.hold_from > 0 && stance) {
+          d.d0 = dpos_of_var[t.vx]; d.d1 = dpos_of_var[t.vy];
+          d.ex = M.sol_diag[t.vx] - M.P.delta_x; d.ey = M.sol_diag[t.vy] - M.P.delta_x;
+        }
       }
       td.push_back(d);
     }
@@ -1281,6 +1286,10 @@ __global__ __launch_bounds__(256) void k_debug_guess(DevPlan P, DevWork W, int B
   const int map = W.map_id ? W.map_id[b] : 0;
   const TableCell tc = table_cell(P, st, gl);
   for (int v = threadIdx.x; v < P.n_vars; v += blockDim.x) out[(size_t)b * P.n_vars + v] = initial_value(P, W, b, v, st, gl, map, tc);
+  __syncthreads();
+  double *y = out + (size_t)b * P.n_vars;
+  for (int i = threadIdx.x; i < P.n_psw; i += blockDim.x)   // (reduced swings: k_start places the mid nodes on the swing rule)
+    y[P.psw_var[i]] = fma(P.psw_w[2 * i], y[P.psw_src[2 * i]], P.psw_w[2 * i + 1] * y[P.psw_src[2 * i + 1]]);
 }
 
 // reduced base: what given nodes become when a solve starts from them (k_start's projection onto the coefficients' space)
@@ -1291,6 +1300,8 @@ __global__ __launch_bounds__(256) void k_project_nodes(DevPlan P, const double *
   const double *x = in + (size_t)b * n;
   double *y = out + (size_t)b * n;
   for (int v = threadIdx.x; v < n; v += blockDim.x) y[v] = x[v];
+  for (int i = threadIdx.x; i < P.n_psw; i += blockDim.x)   // (reduced swings: mid nodes onto the swing rule; their sources are footholds)
+    y[P.psw_var[i]] = fma(P.psw_w[2 * i], x[P.psw_src[2 * i]], P.psw_w[2 * i + 1] * x[P.psw_src[2 * i + 1]]);
   for (int c = threadIdx.x; c < P.n_coef; c += blockDim.x) {
     double acc = 0.0;
     for (int a = 0; a < 4; ++a) acc = fma(P.pc_w[4 * c + a], x[P.pc_var[4 * c + a]], acc);

@@ -260,7 +260,7 @@ struct Symbolic {
   KMeta kron_meta(const HostModel &M, int bi) const {
     KMeta K;
     const Block &b = M.blocks[bi];
-    if (b.kind != 1 || b.m != 3 || b.n > 32) return K;
+    if (b.kind != 1 || b.m != 3 || b.n > 32 || M.reduce_swing) return K;   // (reduced swings: the foot's columns carry per-dimension weights)
     int inst = -1;
     for (size_t k = 0; k < M.rom.size(); ++k)
       if (M.rom[k].goff == bi) { inst = (int)k; break; }

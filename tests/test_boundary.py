@@ -86,10 +86,13 @@ def test_planner_dimensions_match_reference_log(hip_lib, cfg):
     import dataclasses
     dims = json.load(open(os.path.join(GOLDEN, "nlp_dims.json")))
     # (the NLP's own counts do not depend on how the KKT system is formed; the unknowns of the system do)
-    dr, actr = capi.analyze(dataclasses.replace(cfg, reduce_base=True))
+    dr, actr = capi.analyze(dataclasses.replace(cfg, reduce_base=True, reduce_swing=False))
     assert (dr.n_vars, dr.n_cons, dr.n_free, dr.n_eq, dr.n_ineq) == (1040, 1730, dims["n_vars_free"], dims["n_eq"], dims["n_ineq"])
     assert (dr.n_unknowns, dr.n_stages, dr.front) == (1121, 71, 96) and actr.max() <= dr.front
-    d, act = capi.analyze(dataclasses.replace(cfg, reduce_base=False))
+    ds, acts = capi.analyze(cfg)      # the default: reduced base and reduced swings (8 unknowns per swing leave the system)
+    assert cfg.reduce_base and cfg.reduce_swing and (ds.n_unknowns, ds.n_stages, ds.front) == (1121 - 8 * 16, 63, 96) and acts.max() <= ds.front
+    assert (ds.n_vars, ds.n_cons, ds.n_free, ds.n_eq, ds.n_ineq) == (dr.n_vars, dr.n_cons, dr.n_free, dr.n_eq, dr.n_ineq)
+    d, act = capi.analyze(dataclasses.replace(cfg, reduce_base=False, reduce_swing=False))
     assert (d.n_unknowns, d.n_stages, d.front) == (1685, 106, 112)
     assert (d.n_vars, d.n_cons, d.n_free) == (1040, 1730, dims["n_vars_free"])
     assert (d.n_eq, d.n_ineq) == (dims["n_eq"], dims["n_ineq"])
@@ -118,11 +121,13 @@ def test_knots200_structure(hip_lib):
     assert [len(f) for f in cfg.phase_durations] == [17] * 4
     assert all(abs(sum(f) - 10.0) < 1e-12 for f in cfg.phase_durations)
     import dataclasses
-    d, act = capi.analyze(dataclasses.replace(cfg, reduce_base=False))
+    d, act = capi.analyze(dataclasses.replace(cfg, reduce_base=False, reduce_swing=False))
     assert (d.n_base_nodes, d.n_dyn_times, d.n_vars, d.n_cons) == (201, 202, 3160, 4558)
     assert act.max() <= d.front == 128 and d.n_stages == 356
-    dr, actr = capi.analyze(cfg)     # reduced base (the default): 5685 -> 3321 unknowns
+    dr, actr = capi.analyze(dataclasses.replace(cfg, reduce_swing=False))     # reduced base: 5685 -> 3321 unknowns
     assert (dr.n_vars, dr.n_cons) == (3160, 4558) and actr.max() <= dr.front == 128 and dr.n_stages == 208
+    ds, acts = capi.analyze(cfg)     # ... and reduced swings (the default): 32 swings x 8 unknowns fewer
+    assert (ds.n_unknowns, ds.n_stages) == (dr.n_unknowns - 8 * 32, 192) and acts.max() <= ds.front == 128
     d2, _ = capi.analyze(PlannerConfig.knots100(duration=10.0, reduce_base=False))
     assert d2.front > 128
 
@@ -164,9 +169,11 @@ def test_kronecker_structure_of_the_range_of_motion_blocks():
     G' S G and G' w through the 33 sums of a block equals the direct three-term sum to rounding (random matrices and weights)."""
     from qtos_amd import capi
     from qtos_amd.config import PlannerConfig
-    n_blocks, n_kron, most, worst = capi.analyze_kron(PlannerConfig.knots100())
+    # (the structure as found with every swing row in the system: reduce_swing folds the mid nodes' columns onto the footholds,
+    #  whose weights then differ per dimension -- the experiment's analysis does not cover that)
+    n_blocks, n_kron, most, worst = capi.analyze_kron(PlannerConfig.knots100(reduce_swing=False))
     assert (n_blocks, n_kron, most) == (320, 252, 8) and worst < 1e-11
-    n_blocks, n_kron, most, worst = capi.analyze_kron(PlannerConfig.knots100(gait="trot"))
+    n_blocks, n_kron, most, worst = capi.analyze_kron(PlannerConfig.knots100(gait="trot", reduce_swing=False))
     assert 0 < n_kron < n_blocks and worst < 1e-11
 
 

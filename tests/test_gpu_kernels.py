@@ -112,7 +112,7 @@ def test_factor_panels_of_either_kernel_match_the_block_elimination(kkt, oracle,
     per-stage panels for k_chord and the sweeps."""
     import dataclasses
     from test_gpu_parity import check_factor_panels
-    P = _planner(dataclasses.replace(cfg, reduce_base=False), 8, kkt)
+    P = _planner(dataclasses.replace(cfg, reduce_base=False, reduce_swing=False), 8, kkt)
     assert P.kkt_kernel().startswith("k_kkt5" if kkt == "6" else "k_kkt2")
     check_factor_panels(P, oracle, gv1, cfg)
     P.close()

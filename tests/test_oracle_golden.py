@@ -226,7 +226,7 @@ def test_oracle_stall_rule_stops_cycling_problems():
     from oracle.oracle import Oracle, oracle_dict
     from qtos_amd import workloads
     from qtos_amd.config import PlannerConfig
-    c = PlannerConfig.reference_compat()
+    c = PlannerConfig.reference_compat(reduce_swing=False)   # (towr's starting point as it is: problem 31 cycles from there)
     hxy, cell = workloads.exp5_terrain()
     start, goal = workloads.step_goals(256, seed=1, terrain=(hxy, cell))
     O = Oracle(oracle_dict(c), height=hxy, hcell=cell)
@@ -266,6 +266,6 @@ def test_oracle_knots200_on_random_heightfield():
     assert info.status == 0 and O.max_violation(x) <= 1e-4 + 1e-9
     row = O.sample(x, hz=50.0, n_rows=2)[1]
     x2, info2 = O.solve(O.problem(row[1:4], row[4:7], row[7:19].reshape(4, 3), goal[0], row[19:22], row[22:25]), x0=x)
-    assert info2.status == 0 and info2.iters < info.iters
+    assert info2.status == 0 and info2.iters <= info.iters   # (the cold solve starts with its swing mid nodes on the swing rule: 4 iterations too)
     # the gait schedule restarts with the replan: the new plan is the old one begun 20 ms further on
     assert np.abs(O.sample(x2, hz=100.0)[:, 1:4] - O.sample(x, hz=100.0)[:, 1:4]).max() < 0.05

@@ -37,6 +37,10 @@ def test_projection_is_the_identity_on_the_spline_space_and_z_is_scipys_bspline(
                 pv, vv = nodes_of_coefficients(knots, rng.normal(size=len(knots) - 4), t)
                 row[off + 6 * np.arange(nb + 1) + d] = pv
                 row[off + 6 * np.arange(nb + 1) + 3 + d] = vv
+    # (reduce_swing, the default: given nodes also get their swing mid nodes placed on the swing rule -- the oracle's own
+    #  restatement of towr's swing_constraint.cc puts these on it beforehand)
+    assert O.swing_start_on_rule
+    x = np.array([O.project_swings(row) for row in x])
     y = P.project(x)
     P.close()
     assert np.abs(y - x).max() < 1e-12 * max(1.0, np.abs(x).max())
@@ -54,11 +58,15 @@ def test_projection_of_arbitrary_nodes_equals_the_numpy_projection(gait):
     x = rng.normal(size=(8, P.n))
     y = P.project(x)
     P.close()
-    z = project_nodes(x, O.L, vf)
+    # (reduce_swing: and the swing mid nodes on the swing rule, by the oracle's restatement of it; the two projections touch
+    #  disjoint sets of variables)
+    z = np.array([O.project_swings(row) for row in project_nodes(x, O.L, vf)])
     assert np.abs(y - z).max() < 1e-12 * max(1.0, np.abs(x).max())
     nb = O.L.n_base_nodes - 1
     base = np.concatenate([np.arange(O.L.off_lin, O.L.off_lin + 6 * (nb + 1)), np.arange(O.L.off_ang, O.L.off_ang + 6 * (nb + 1))])
-    other = np.setdiff1d(np.arange(P.n), base)
+    swing = np.nonzero(np.abs(np.array([O.project_swings(row) for row in x]) - x).max(axis=0) > 0)[0]
+    assert len(swing) % 4 == 0 and len(swing) >= 16          # (four mid-node variables per swing; the walk has 4 x 4 swings)
+    other = np.setdiff1d(np.arange(P.n), np.concatenate([base, swing]))
     assert np.array_equal(y[:, other], x[:, other])
     fixed = base[vf[base] == 0]
     assert len(fixed) > 0 and np.array_equal(y[:, fixed], x[:, fixed])
