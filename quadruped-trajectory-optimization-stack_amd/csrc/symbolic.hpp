@@ -767,14 +767,14 @@ struct Symbolic {
       F0 = std::max(F0, alive(a, b) + (PIV - (b - a)));
     }
     F0 = ((F0 + PIV - 1) / PIV) * PIV;
-    // Measured (round 4, profiles/r04_short_stages.txt): fronts above 128 slots gain -- `-duration 20`: 176 -> 160 slots, 2.63 ->
-    // 1.81 ms per launch; the full system of `-duration 12`: 160 -> 144, 1.74 -> 1.69 --, the 100-knot walk does not (128 ->
-    // 112 slots: 0.643 -> 0.656 ms: twelve update waves of three tiles next to a factor wave with a SIMD of its own are the
-    // better shape than fourteen of two).  So: only above 128 slots, unless QTOS_SHORT_STAGES=1 asks for it.
-    // (QTOS_SHORT_STAGES: 1 = for every front size, 0 = never; parsed like every other switch -- a baseline run that sets it to 0
-    //  must not silently measure the variant)
+    // Measured: fronts above 128 slots gain even at 2 % more stages (round 4, profiles/r04_short_stages.txt: `-duration 20` 176 ->
+    // 160 slots, 2.63 -> 1.81 ms per launch).  Up to 128 slots a smaller front pays only where it costs NO stage (round 4: the
+    // walk 128 -> 112 slots at two more stages, 0.643 -> 0.656 ms; round 5, with the reduced swings: the trot 112 -> 96 slots at
+    // the same 113 stages, 0.668 -> 0.592 ms per launch, the walk 128 -> 112 at the same 100: equal).  QTOS_SHORT_STAGES=1: the
+    // 2 % rule for every front size; 0: never.
     const char *ess = getenv("QTOS_SHORT_STAGES");
-    if (ess ? atoi(ess) == 0 : F0 <= 128) return;
+    if (ess && atoi(ess) == 0) return;
+    const bool no_extra_stage = !ess && F0 <= 128;
     std::vector<int> cut;   // boundaries of the chosen partition
     for (int target = F0 - PIV; target >= 2 * PIV; target -= PIV) {
       const int INF = 1 << 29;
@@ -788,7 +788,7 @@ struct Symbolic {
           if (best[a] + 1 < best[a + r]) { best[a + r] = best[a] + 1; prev[a + r] = a; }
         }
       }
-      if (best[N] > NS0 + NS0 / 50) break;
+      if (best[N] > (no_extra_stage ? NS0 : NS0 + NS0 / 50)) break;
       cut.clear();
       for (int b = N; b > 0; b = prev[b]) cut.push_back(b);
       cut.push_back(0);

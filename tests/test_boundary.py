@@ -93,7 +93,7 @@ def test_planner_dimensions_match_reference_log(hip_lib, cfg):
     assert cfg.reduce_base and cfg.reduce_swing and (ds.n_unknowns, ds.n_stages, ds.front) == (1121 - 8 * 16, 63, 96) and acts.max() <= ds.front
     assert (ds.n_vars, ds.n_cons, ds.n_free, ds.n_eq, ds.n_ineq) == (dr.n_vars, dr.n_cons, dr.n_free, dr.n_eq, dr.n_ineq)
     d, act = capi.analyze(dataclasses.replace(cfg, reduce_base=False, reduce_swing=False))
-    assert (d.n_unknowns, d.n_stages, d.front) == (1685, 106, 112)
+    assert (d.n_unknowns, d.n_stages, d.front) == (1685, 106, 96)      # (112 slots with stage boundaries at multiples of 16 unknowns: short stages)
     assert (d.n_vars, d.n_cons, d.n_free) == (1040, 1730, dims["n_vars_free"])
     assert (d.n_eq, d.n_ineq) == (dims["n_eq"], dims["n_ineq"])
     assert (d.n_ineq_lower, d.n_ineq_both, d.n_ineq_upper) == (112, 816, 96)
@@ -127,7 +127,7 @@ def test_knots200_structure(hip_lib):
     dr, actr = capi.analyze(dataclasses.replace(cfg, reduce_swing=False))     # reduced base: 5685 -> 3321 unknowns
     assert (dr.n_vars, dr.n_cons) == (3160, 4558) and actr.max() <= dr.front == 128 and dr.n_stages == 208
     ds, acts = capi.analyze(cfg)     # ... and reduced swings (the default): 32 swings x 8 unknowns fewer
-    assert (ds.n_unknowns, ds.n_stages) == (dr.n_unknowns - 8 * 32, 192) and acts.max() <= ds.front == 128
+    assert (ds.n_unknowns, ds.n_stages) == (dr.n_unknowns - 8 * 32, 192) and acts.max() <= ds.front == 112
     d2, _ = capi.analyze(PlannerConfig.knots100(duration=10.0, reduce_base=False))
     assert d2.front > 128
 

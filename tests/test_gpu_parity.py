@@ -1356,7 +1356,7 @@ def test_knots200_receding_window_on_random_heightfields():
     cfg = PlannerConfig.knots200(honor_start_velocity=True)   # a replan continues the motion it starts in
     B, NCHK = 64, 3
     P = Planner(cfg, max_batch=B)
-    assert (P.dims.n_dyn_times, P.dims.front, P.dims.n_stages) == (202, 128, 192)   # (208 without reduce_swing, 356 with every continuity row in the system too)
+    assert (P.dims.n_dyn_times, P.dims.front, P.dims.n_stages) == (202, 112, 192)   # (128 slots / 208 stages without reduce_swing, 356 with every continuity row in the system too)
     maps, cell = workloads.random_terrains()
     P.set_heightfields(maps, cell)
     start, goal, mid = workloads.mpc_goals(B, terrains=(maps, cell))

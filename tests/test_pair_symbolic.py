@@ -38,15 +38,15 @@ def emul():
     return run
 
 
-CASES = {   # name: (config, stages and front of the standard analysis, of the pair-mode analysis)
+CASES = {   # name: (config, stages and front of the standard analysis -- short stages where they cost none --, of the pair-mode analysis)
     "reference_compat": (lambda: PlannerConfig.reference_compat(reduce_swing=False), 71, 96, 72, 112),
-    "reference_compat_full": (lambda: PlannerConfig.reference_compat(reduce_base=False, reduce_swing=False), 106, 112, 106, 112),
-    "knots100_walk": (lambda: PlannerConfig.knots100(reduce_swing=False), 108, 128, 108, 128),
+    "reference_compat_full": (lambda: PlannerConfig.reference_compat(reduce_base=False, reduce_swing=False), 106, 96, 106, 112),
+    "knots100_walk": (lambda: PlannerConfig.knots100(reduce_swing=False), 108, 112, 108, 128),
     "knots100_trot": (lambda: PlannerConfig.knots100(gait="trot", reduce_swing=False), 127, 112, 128, 128),
     # the default: reduced swings (the mid nodes' columns folded onto the footholds)
     "reference_compat_swing": (lambda: PlannerConfig.reference_compat(), 63, 96, 64, 112),
-    "knots100_walk_swing": (lambda: PlannerConfig.knots100(), 100, 128, 100, 128),
-    "knots100_trot_swing": (lambda: PlannerConfig.knots100(gait="trot"), 113, 112, 114, 128),
+    "knots100_walk_swing": (lambda: PlannerConfig.knots100(), 100, 112, 100, 128),
+    "knots100_trot_swing": (lambda: PlannerConfig.knots100(gait="trot"), 113, 96, 114, 112),
 }
 
 
