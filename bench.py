@@ -76,6 +76,9 @@ def parse_args():
     ap.add_argument("--full-system", action="store_true",
                     help="every row of the reference's NLP in the KKT system (PlannerConfig.reduce_base off: 2885 unknowns / 181 "
                          "stages instead of 1721 / 108 on the 100-knot transcription) -- the system rounds 1 and 2 solved")
+    ap.add_argument("--full-swings", action="store_true",
+                    help="the swing mid nodes as unknowns with their rule as equality rows (PlannerConfig.reduce_swing off: 1721 "
+                         "unknowns / 108 stages instead of 1593 / 100 on the walk) -- the system of rounds 3 and 4")
     ap.add_argument("--force-torchrun", action="store_true",
                     help="launch the ranks through torch.distributed.run even for --gpus 1 (exercises the child-process path "
                          "and the RCCL all-gather at world size 1)")
@@ -267,6 +270,8 @@ def main():
         kw["gait"] = "trot"
     if args.full_system:
         kw["reduce_base"] = False
+    if args.full_swings:
+        kw["reduce_swing"] = False
     if mpc and args.inflight > 1 and args.batch % args.inflight:
         raise SystemExit("--inflight must divide --batch for mpc_random (the windows are split into that many sets)")
     cfg = {"knots100": PlannerConfig.knots100, "knots200": PlannerConfig.knots200,
@@ -508,7 +513,7 @@ def main():
             "iterations_max_last_step": int(itn.max()),
             "iterations_mean": round(float(iters_dev.item()) / max(B * args.steps, 1), 3) if (solved_inflight is None or lanes) else None,
             "parallelism": "batch-shard x%d + 1 %s" % (world, "RCCL all-gather" if use_dist else "all-gather (not launched under torch.distributed: single process)"),
-            "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front, "reduce_base": bool(cfg.reduce_base),
+            "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front, "reduce_base": bool(cfg.reduce_base), "reduce_swing": bool(cfg.reduce_swing),
             "batches_in_flight": args.inflight, "max_iter": cfg.max_iter, "chord_tol": cfg.chord_tol, "chord_max": cfg.chord_max,
             "initial_guess": "towr straight line" if args.init == "straight_line" else
                              "interpolated table of %d nominal plans (solved before the timed region)" % (P.init_table[2].shape[0] * P.init_table[2].shape[1]),

@@ -1,15 +1,18 @@
-"""Copy the artefacts of scratch/final_measure3.sh (gpurun_out/*_<tag>*) into profiles/ as the round's set and derive
-the per-launch HBM traffic and the SQ-counter summary of the KKT kernel from the PMC passes.
-usage: python scratch/collect_profiles.py <tag> [r02]"""
-import csv, collections, json, os, shutil, sys
+"""Copy the artefacts of scratch/final_measure5.sh (gpurun_out/*_<tag>*) into profiles/ as the round's set: one bench line per
+configuration, then -- through scratch/collect_kernel_evidence.py -- kernel stats, per-launch HBM traffic and the SQ-counter summary
+of the KKT kernel for the default command (walk), the trot and k_kkt5 (QTOS_KKT=6).
+usage: python scratch/collect_profiles.py <tag> [r05]"""
+import json, os, shutil, subprocess, sys
 tag = sys.argv[1]
-R = sys.argv[2] if len(sys.argv) > 2 else "r04"
+R = sys.argv[2] if len(sys.argv) > 2 else "r05"
 G = "gpurun_out/"
 names = {"default": "bench", "compat": "bench_reference_compat", "exp5": "bench_exp5", "mixed": "bench_mixed", "trot": "bench_trot",
          "tol1e-3": "bench_tol1e-3", "batch512": "bench_batch512", "batch1024": "bench_batch1024", "knots200": "bench_knots200",
          "mpc": "bench_knots200_mpc_random", "mpc_1set": "bench_knots200_mpc_random_one_set", "table": "bench_init_table", "inflight2": "bench_flat_inflight2",
          "nochord": "bench_no_chord_step", "torchrun1": "bench_torchrun_1rank", "full_system": "bench_full_system",
-         "exp5_lanes3": "bench_exp5_lanes3", "exp5_batch1024": "bench_exp5_batch1024", "mixed_batch1024": "bench_mixed_batch1024", "mixed_lanes3": "bench_mixed_lanes3", "lanes2": "bench_flat_lanes2", "steps500": "bench_steps500"}
+         "exp5_lanes3": "bench_exp5_lanes3", "exp5_batch1024": "bench_exp5_batch1024", "mixed_batch1024": "bench_mixed_batch1024", "mixed_lanes3": "bench_mixed_lanes3", "lanes2": "bench_flat_lanes2", "steps500": "bench_steps500",
+         "kkt5_walk": "bench_kkt5_walk", "kkt5_trot": "bench_kkt5_trot", "kkt5_compat": "bench_kkt5_reference_compat", "kkt5_knots200": "bench_kkt5_knots200",
+         "kkt2_trot": "bench_kkt2_trot", "kkt2_walk": "bench_kkt2_walk", "no_swing": "bench_no_reduce_swing", "no_swing_trot": "bench_no_reduce_swing_trot"}
 for src, dst in names.items():
     f = G + "bench_%s_%s.json" % (tag, src)
     if not os.path.exists(f):
@@ -19,71 +22,12 @@ for src, dst in names.items():
         print("empty", f); continue
     json.loads(lines[-1])
     open("profiles/%s_%s.json" % (R, dst), "w").write(lines[-1] + "\n")
-shutil.copy(G + "prof_%s/runc_kernel_stats.csv" % tag, "profiles/%s_bench_kernel_stats.csv" % R)
-
-def per_kernel(f, launches="full"):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        if "qtos::" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return agg
-
-out = {}
-for name, f in (("FETCH_SIZE", G + "pmc_fetch_%s/runc_counter_collection.csv" % tag), ("WRITE_SIZE", G + "pmc_write_%s/runc_counter_collection.csv" % tag)):
-    agg = per_kernel(f)
-    out[name] = {k: {"dispatches": len(v[name]), "mean_KB": sum(v[name]) / len(v[name])} for k, v in agg.items()}
-kk = [k for k in out["FETCH_SIZE"] if "k_kkt" in k][0]
-f, w = out["FETCH_SIZE"][kk]["mean_KB"], out["WRITE_SIZE"][kk]["mean_KB"]
-out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of `python3 bench.py --steps 3 --warmup 1 "
-               "--cpu-sample 0 --no-parity --no-trot` (batch 256, knots100). KB per dispatch. gfx950: FETCH_SIZE reports 1/2 of the bytes of wide "
-               "coalesced reads (calibrated for 16 B/lane; the kernel reads 8-16 B/lane) -> HBM bytes per launch between (F+W)*1024 and "
-               "(2F+W)*1024; bench.py reports the larger.")
-out["k_kkt_traffic_bytes_per_launch"] = {"raw": (f + w) * 1024, "fetch_x2": (2 * f + w) * 1024}
-kc = [k for k in out["FETCH_SIZE"] if "k_chord" in k]
-if kc:
-    f2, w2 = out["FETCH_SIZE"][kc[0]]["mean_KB"], out["WRITE_SIZE"][kc[0]]["mean_KB"]
-    out["k_chord_traffic_bytes_per_launch"] = {"raw": (f2 + w2) * 1024, "fetch_x2": (2 * f2 + w2) * 1024}
-json.dump(out, open("profiles/%s_pmc_hbm.json" % R, "w"), indent=1)
-print(json.dumps(out["k_kkt_traffic_bytes_per_launch"]), json.dumps(out.get("k_chord_traffic_bytes_per_launch")))
-
-# SQ counters: two passes (pmc_sq: matrix pipe / waits / LDS, pmc_sq2: instruction counts); SQ cycle counters are in
-# units of 4 cycles and summed over all SIMDs / waves of the dispatch
-sq = {}
-for sub in ("pmc_sq_%s" % tag, "pmc_sq2_%s" % tag):
-    f = G + sub + "/runc_counter_collection.csv"
-    if not os.path.exists(f):
-        continue
-    for k, v in per_kernel(f).items():
-        d = sq.setdefault(k, {})
-        for c, x in v.items():
-            d[c] = sum(x) / len(x)
-            d["dispatches"] = len(x)
-summ = {"note": "rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-parity --no-trot`; means per dispatch, "
-                "summed over the chip by the profiler. SQ_*_CYCLES / SQ_WAIT* / SQ_ACTIVE_INST_* count quad-cycles (x4 = cycles); "
-                "SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD. 256 CUs x 4 SIMDs, 16 waves per CU.",
-        "raw": sq}
-for k, d in sq.items():
-    if "k_kkt" in k and "SQ_WAVE_CYCLES" in d:
-        wave_cycles = 4.0 * d["SQ_WAVE_CYCLES"] / 4096.0          # lifetime of a wave = kernel duration in cycles
-        e = {"kernel": k, "cycles_per_launch": round(wave_cycles)}
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in d:
-            e["mfma_busy_frac_of_simd_cycles"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / wave_cycles, 4)
-        if "SQ_ACTIVE_INST_VALU" in d:
-            e["valu_busy_frac_of_simd_cycles"] = round(4.0 * d["SQ_ACTIVE_INST_VALU"] / 1024.0 / wave_cycles, 4)
-        if "SQ_ACTIVE_INST_LDS" in d:
-            e["lds_inst_busy_frac_of_cu_cycles"] = round(4.0 * d["SQ_ACTIVE_INST_LDS"] / 256.0 / wave_cycles, 4)
-        if "SQ_WAIT_INST_ANY" in d:
-            e["wave_cycles_waiting_on_instructions_frac"] = round(d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], 4)
-            e["wave_cycles_waiting_any_frac"] = round(d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], 4)
-        if "SQ_LDS_BANK_CONFLICT" in d and "SQ_LDS_IDX_ACTIVE" in d:
-            e["lds_bank_conflict_frac_of_lds_active"] = round(d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1.0), 4)
-        if "SQ_INSTS_VALU" in d:
-            e["valu_instructions_per_problem"] = round(d["SQ_INSTS_VALU"] / 256.0)
-            e["lds_instructions_per_problem"] = round(d.get("SQ_INSTS_LDS", 0) / 256.0)
-        summ["k_kkt"] = e
-json.dump(summ, open("profiles/%s_pmc_sq.json" % R, "w"), indent=1)
-print(json.dumps(summ.get("k_kkt")))
-for l in open("profiles/%s_bench_kernel_stats.csv" % R).read().splitlines()[:6]:
-    print(l[:160])
+here = os.path.dirname(os.path.abspath(__file__))
+for t, pre in ((tag, R), (tag + "trot", R + "_trot"), (tag + "k5", R + "_kkt5")):
+    if not os.path.exists(G + "prof_%s/runc_kernel_stats.csv" % t):
+        print("no kernel evidence for", t); continue
+    subprocess.check_call([sys.executable, os.path.join(here, "collect_kernel_evidence.py"), t, pre])
+shutil.copy("profiles/%s_kernel_stats.csv" % R, "profiles/%s_bench_kernel_stats.csv" % R)   # (the name of rounds 1 - 4)
+os.remove("profiles/%s_kernel_stats.csv" % R)
 d = json.loads(open("profiles/%s_bench.json" % R).read())
 print(d["value"], d["ms_per_step"], d["roofline"], d["cpu_baseline"])

@@ -37,6 +37,10 @@ QTOS_KKT=6 b kkt5_trot $X --gait trot
 QTOS_KKT=6 b kkt5_compat $X --transcription reference_compat
 QTOS_KKT=6 b kkt5_knots200 $X --transcription knots200
 QTOS_KKT=2 b kkt2_trot $X --gait trot
+QTOS_KKT=2 b kkt2_walk $X
+# the system of round 4 (swing mid nodes as unknowns) on the same box
+b no_swing $X --full-swings
+b no_swing_trot $X --full-swings --gait trot
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o runc -- python3 $R/bench.py --cpu-sample 0 --no-parity --no-trot > $O/prof_$T.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$T -o runc -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-parity --no-trot > $O/pmc_fetch_$T.log 2>&1
