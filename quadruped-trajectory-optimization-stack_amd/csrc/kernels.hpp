@@ -522,6 +522,18 @@ __device__ inline void eval_force(const DevPlan &P, const ForceInst &I, int map,
 // range-of-motion instances
 __device__ __forceinline__ int eval_loc_offset(int n_vars) { return (n_vars + 1) & ~1; }
 constexpr int DYN_VIN = 39, ROM_VIN = 9;   // pre-evaluated spline inputs per instance
+// The barriers inside eval_all order LDS traffic only (the nodes, the pre-evaluated inputs, the local Jacobians); what an evaluation
+// writes to memory (g, the stream) is read behind the caller's __syncthreads().  A barrier that also drains the memory counter would
+// put every section behind the stores of the one before it.
+__device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifndef QTOS_EVAL_LDSBAR
+#define QTOS_EVAL_LDSBAR 1
+#endif
+#if QTOS_EVAL_LDSBAR
+#define EVAL_BARRIER() wg_lds_barrier()
+#else
+#define EVAL_BARRIER() __syncthreads()
+#endif
 template <bool JAC>
 __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, double *g, double *G, double *lds, double *dbg = nullptr,
                                 int hold = -1) {
@@ -541,13 +553,13 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
     for (int v = tid; v < P.n_vars; v += nt) x[v] = xg[v];
   if (JAC && P.coef_in_lds)
     for (int v = tid; v < P.n_lin_coef; v += nt) coef_lds[v] = P.lin_coef[v];
-  __syncthreads();
+  EVAL_BARRIER();
   // the dynamics knots go through the LDS scratch in chunks of P.dyn_chunk (one chunk up to 128 knots)
   for (int c0 = 0, ch = 0; c0 < P.n_dyn; c0 += P.dyn_chunk, ++ch) {
     const int cnt = min(P.dyn_chunk, P.n_dyn - c0);
-    if (c0) __syncthreads();   // the previous chunk is done with vin / loc
+    if (c0) EVAL_BARRIER();   // the previous chunk is done with vin / loc
     vec_prepass(P.pre_dyn_var + c0 * DYN_VIN, P.pre_dyn_wa + c0 * DYN_VIN, P.pre_dyn_wb + c0 * DYN_VIN, cnt * DYN_VIN, x, vin);
-    __syncthreads();
+    EVAL_BARRIER();
     ESTAMP();
     if (JAC) {
       // four work items per knot -- the value pass and the three groups of forward-mode passes --, a whole number of
@@ -565,11 +577,11 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
         else if (what == 2) eval_dyn_pass<1>(P, I, li, th, thd, thdd, tg);
         else eval_dyn_pass<2>(P, I, li, th, thd, thdd, tg);
       }
-      __syncthreads();
+      EVAL_BARRIER();
       ESTAMP();
       write_terms1(P.dyn_t1, P.dyn_t1_off[ch], P.dyn_t1_off[ch + 1], loc, coef, G);
       write_terms3(P.dyn_t3, P.dyn_t3_off[ch], P.dyn_t3_off[ch + 1], loc, coef, G);
-      __syncthreads();
+      EVAL_BARRIER();
       ESTAMP();
     } else {
       for (int i = tid; i < cnt; i += nt) {
@@ -582,13 +594,13 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
   }
   for (int c0 = 0, ch = 0; c0 < P.n_rom; c0 += P.rom_chunk, ++ch) {
     const int cnt = min(P.rom_chunk, P.n_rom - c0);
-    __syncthreads();   // the dynamics knots / the previous chunk are done with vin and loc
+    EVAL_BARRIER();   // the dynamics knots / the previous chunk are done with vin and loc
     vec_prepass(P.pre_rom_var + c0 * ROM_VIN, P.pre_rom_wa + c0 * ROM_VIN, P.pre_rom_wb + c0 * ROM_VIN, cnt * ROM_VIN, x, vin);
-    __syncthreads();
+    EVAL_BARRIER();
     for (int i = tid; i < cnt; i += nt) eval_rom<JAC>(P, P.rom[c0 + i], vin + (size_t)i * ROM_VIN, g, JAC ? loc + (size_t)i * ROM_LOC : nullptr);
     if (!JAC) ESTAMP();
     if (JAC) {
-      __syncthreads();
+      EVAL_BARRIER();
       ESTAMP();
       write_terms1(P.rom_t1, P.rom_t1_off[ch], P.rom_t1_off[ch + 1], loc, coef, G);
       ESTAMP();
@@ -632,22 +644,49 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
 #endif
 constexpr int ET = QTOS_ET;   // threads of the evaluation kernels (k_start, k_step): one workgroup per problem
 // ---- workgroup reductions (fixed tree => bitwise reproducible) --------------------------------
+// The tree: a[t] = op(a[t], a[t + s]) for s = nt/2 ... 1, the result in a[0] (rounds 1 - 4 ran it level by level through LDS:
+// twelve workgroup barriers per reduction, each behind the kernel's outstanding memory traffic, six reductions per k_step
+// launch).  The same tree, the same bits, with ONE trip through LDS: the levels that pair waves (s >= 64) are lane-wise --
+// every wave reads the ET / 64 values of its lane and combines them in the tree's order --, the levels inside a wave pair lane t
+// with lane t + s: rows 0, 1 with rows 2, 3 and row 0 with row 1 by the gfx950 lane swaps, then 8, 4, 2, 1 lanes inside a row
+// by DPP rotations (lane t < s reads lane t + s: all the tree needs).  Both barriers wait for LDS only.
+template <int OP>
+__device__ __forceinline__ double wg_op(double a, double b) { return OP == 0 ? a + b : (OP == 1 ? fmax(a, b) : fmin(a, b)); }
+template <int CTRL>
+__device__ __forceinline__ double wg_dpp(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false));
+}
 template <int OP>  // 0 sum, 1 max, 2 min
 __device__ inline double wg_reduce(double v, double *scratch) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  __syncthreads();
+  constexpr int NW = ET / 64;   // (k_start and k_step: ET threads)
+  const int tid = threadIdx.x, lane = tid & 63;
+  wg_lds_barrier();             // the previous reduction's readers are done with the scratch
   scratch[tid] = v;
-  __syncthreads();
-  for (int s = nt >> 1; s > 0; s >>= 1) {
-    if (tid < s) {
-      double a = scratch[tid], b = scratch[tid + s];
-      scratch[tid] = OP == 0 ? a + b : (OP == 1 ? fmax(a, b) : fmin(a, b));
-    }
-    __syncthreads();
+  wg_lds_barrier();
+  double a[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) a[w] = scratch[64 * w + lane];
+#pragma unroll
+  for (int s = NW / 2; s > 0; s >>= 1)
+#pragma unroll
+    for (int w = 0; w < s; ++w) a[w] = wg_op<OP>(a[w], a[w + s]);
+  double r = a[0];
+  {
+    int lo = __double2loint(r), hi = __double2hiint(r);
+    auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);   // [0]: rows (0, 1, 0, 1), [1]: rows (2, 3, 2, 3)
+    auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    r = wg_op<OP>(__hiloint2double(h[0], l[0]), __hiloint2double(h[1], l[1]));
+    lo = __double2loint(r); hi = __double2hiint(r);
+    auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // [0]: the even rows of the source, [1]: the odd ones
+    auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    r = wg_op<OP>(__hiloint2double(h2[0], l2[0]), __hiloint2double(h2[1], l2[1]));
   }
-  double r = scratch[0];
-  __syncthreads();
-  return r;
+  r = wg_op<OP>(r, wg_dpp<0x128>(r));   // row_ror:8  (lane i reads lane i - n mod 16: i + 8)
+  r = wg_op<OP>(r, wg_dpp<0x12C>(r));   // row_ror:12 (i + 4)
+  r = wg_op<OP>(r, wg_dpp<0x12E>(r));   // row_ror:14 (i + 2)
+  r = wg_op<OP>(r, wg_dpp<0x12F>(r));   // row_ror:15 (i + 1)
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(r)), __builtin_amdgcn_readfirstlane(__double2loint(r)));
 }
 
 // barrier weights of every inequality row: sig = zl/(s-l) + zu/(u-s), w = sig (g - s) - mu/(s-l) + mu/(u-s)
@@ -665,8 +704,9 @@ __device__ inline void barrier_terms(const DevPlan &P, const double *__restrict_
     const double l = P.iq_lo[i], u = P.iq_hi[i];
     const bool hl = l > -1e19, hu = u < 1e19;
     const double dl = hl ? s[r] - l : 1.0, du = hu ? u - s[r] : 1.0;
-    const double sg = (hl ? zl[r] / dl : 0.0) + (hu ? zu[r] / du : 0.0);
-    const double gmu = -(hl ? mu / dl : 0.0) + (hu ? mu / du : 0.0);
+    const double zql = zl[r] / dl, zqu = zu[r] / du, ml = mu / dl, mq = mu / du;   // (unconditional: the four division chains interleave)
+    const double sg = (hl ? zql : 0.0) + (hu ? zqu : 0.0);
+    const double gmu = -(hl ? ml : 0.0) + (hu ? mq : 0.0);
     const double wr = sg * (g[r] - s[r]) + gmu;
     sig[r] = sg;
     w[r] = wr;
@@ -1193,6 +1233,11 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
 #else
 #define KSTAMP(i) do {} while (0)
 #endif
+#ifdef QTOS_STEP_CUT   // (diagnostic builds: the kernel ends behind section i, nothing of the launch is kept -- wrong results)
+#define KCUT(i) do { if (QTOS_STEP_CUT == (i)) return; } while (0)
+#else
+#define KCUT(i) do {} while (0)
+#endif
   // ds = Ji dx + (g - s), dx staged in LDS.  Every pass over a table below is a chain of memory round trips (index ->
   // value -> ...) of a microsecond each: the table reads that depend on nothing this kernel computes are issued first.
   const int nt = blockDim.x;
@@ -1313,6 +1358,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   }
   __syncthreads();
   KSTAMP(0);
+  KCUT(0);
   const double tau = fmax(0.99, 1.0 - mu);
   double amax = 1.0, az = 1.0;
   double rds[KR], rdzl[KR], rdzu[KR];
@@ -1320,23 +1366,28 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   for (int k = 0; k < KR; ++k) rds[k] = ds[rr[k]];
   // ratio tests and the step of the multipliers (one row; the formulas of the passes below are these lambdas, on registers
   // for the thread's own rows and on memory for the rest)
-  auto ratio_row = [&](double l, double u, double sv, double d, double zlv, double zuv, double &a, double &c) __attribute__((always_inline)) {
-    const bool hl = l > -1e19, hu = u < 1e19;
+  // (an IEEE division is a chain of a dozen dependent f64 instructions, and the compiler leaves one that sits behind a condition
+  //  in a branch of its own: eight divisions of a row ran one after the other, 16 k cycles for the thread's two rows.  Every
+  //  quotient is formed unconditionally -- on 1.0 where the row has no such bound -- and selected: the chains interleave)
+  auto ratio_row = [&](bool valid, double l, double u, double sv, double d, double zlv, double zuv, double &a, double &c) __attribute__((always_inline)) {
+    const bool hl = valid && l > -1e19, hu = valid && u < 1e19;
     const double dl = hl ? sv - l : 1.0, du = hu ? u - sv : 1.0;
-    a = hl ? mu / dl - zlv - zlv / dl * d : 0.0;
-    c = hu ? mu / du - zuv + zuv / du * d : 0.0;
-    if (hl && d < 0) amax = fmin(amax, tau * dl / -d);
-    if (hu && d > 0) amax = fmin(amax, tau * du / d);
-    if (hl && a < 0) az = fmin(az, tau * zlv / -a);
-    if (hu && c < 0) az = fmin(az, tau * zuv / -c);
+    const double ml = mu / dl, zql = zlv / dl, mq = mu / du, zqu = zuv / du;
+    const double a_ = ml - zlv - zql * d, c_ = mq - zuv + zqu * d;
+    a = hl ? a_ : 0.0;
+    c = hu ? c_ : 0.0;
+    const double r1 = tau * dl / -d, r2 = tau * du / d, r3 = tau * zlv / -a_, r4 = tau * zuv / -c_;
+    amax = (hl && d < 0) ? fmin(amax, r1) : amax;
+    amax = (hu && d > 0) ? fmin(amax, r2) : amax;
+    az = (hl && a_ < 0) ? fmin(az, r3) : az;
+    az = (hu && c_ < 0) ? fmin(az, r4) : az;
   };
 #pragma unroll
-  for (int k = 0; k < KR; ++k)
-    if (tid + k * nt < P.n_iq) ratio_row(rl[k], ru[k], rs[k], rds[k], rzl[k], rzu[k], rdzl[k], rdzu[k]);
+  for (int k = 0; k < KR; ++k) ratio_row(tid + k * nt < P.n_iq, rl[k], ru[k], rs[k], rds[k], rzl[k], rzu[k], rdzl[k], rdzu[k]);
   for (int i = tid + KR * nt; i < P.n_iq; i += nt) {
     const int r = P.iq_idx[i];
     double a, c;
-    ratio_row(P.iq_lo[i], P.iq_hi[i], s[r], ds[r], zl[r], zu[r], a, c);
+    ratio_row(true, P.iq_lo[i], P.iq_hi[i], s[r], ds[r], zl[r], zu[r], a, c);
     dzl[r] = a;
     dzu[r] = c;
   }
@@ -1361,6 +1412,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   };
   const double th0 = l1_rows(rg, eg, g, 0.0);
   KSTAMP(1);
+  KCUT(1);
   // backtracking on the l1 infeasibility of (c_E, c_I - s)
   double al = amax, th = 0;
   double rgt[KR], egt[KE];
@@ -1385,6 +1437,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     if (ls < 5) al *= 0.5;
   }
   KSTAMP(2);
+  KCUT(2);
   // a chord step is taken whole or not at all: cut by the fraction-to-the-boundary rule or by the line search it
   // is discarded (the iterate stays, the next iteration factors): a damped chord step can park a slack right on
   // its bound, and the KKT matrix of that point is too badly scaled for the block elimination
@@ -1407,19 +1460,23 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     const bool hl = l > -1e19, hu = u < 1e19;
     const double sn = sv + al * d;
     sv = sn;
-    double a = zlv + az * dl_, c = zuv + az * du_;
+    const double a = zlv + az * dl_, c = zuv + az * du_;
     const double kap = 1e10;
-    if (hl) a = fmin(fmax(a, mu / (kap * (sn - l))), kap * mu / (sn - l));
-    if (hu) c = fmin(fmax(c, mu / (kap * (u - sn))), kap * mu / (u - sn));
-    zlv = a;
-    zuv = c;
+    const double gl = hl ? sn - l : 1.0, gu = hu ? u - sn : 1.0;   // (the four quotients side by side, as in ratio_row)
+    const double lo_l = mu / (kap * gl), hi_l = kap * mu / gl, lo_u = mu / (kap * gu), hi_u = kap * mu / gu;
+    zlv = hl ? fmin(fmax(a, lo_l), hi_l) : a;
+    zuv = hu ? fmin(fmax(c, lo_u), hi_u) : c;
   };
 #pragma unroll
-  for (int k = 0; k < KR; ++k)
-    if (tid + k * nt < P.n_iq) {
-      update_row(rl[k], ru[k], rs[k], rds[k], rzl[k], rzu[k], rdzl[k], rdzu[k]);
-      s[rr[k]] = rs[k]; zl[rr[k]] = rzl[k]; zu[rr[k]] = rzu[k];
+  for (int k = 0; k < KR; ++k) {
+    const bool valid = tid + k * nt < P.n_iq;
+    double sv = rs[k], zlv = rzl[k], zuv = rzu[k];
+    update_row(rl[k], ru[k], sv, rds[k], zlv, zuv, rdzl[k], rdzu[k]);
+    if (valid) {
+      rs[k] = sv; rzl[k] = zlv; rzu[k] = zuv;
+      s[rr[k]] = sv; zl[rr[k]] = zlv; zu[rr[k]] = zuv;
     }
+  }
   for (int i = tid + KR * nt; i < P.n_iq; i += nt) {
     const int r = P.iq_idx[i];
     double sv = s[r], zlv = zl[r], zuv = zu[r];
@@ -1457,6 +1514,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     theta = wg_reduce<1>(t, scratch);
   }
   KSTAMP(3);
+  KCUT(3);
   const bool conv = viol <= P.tol && theta <= P.tol;
   const bool bad = !(viol < INFINITY) || !(th < INFINITY);
   // stall detection: the iterate with the lowest violation is kept; a problem that has not improved
@@ -1520,6 +1578,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   }
   __syncthreads();
   KSTAMP(4);
+  KCUT(4);
   {
     // barrier weights of every inequality row, right-hand sides of the equality rows (barrier_terms, on the rows in registers;
     // their constraint values as the linearisation above has just written them: the same point as the last line-search
@@ -1529,30 +1588,36 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
 #pragma unroll
     for (int k = 0; k < KE; ++k) eg[k] = g[er[k]];
     double *__restrict__ sigp = W.sig + (size_t)b * m, *__restrict__ wp = W.w + (size_t)b * m, *__restrict__ strm = W.stream + (size_t)b * P.stream_len;
-    auto bar_row = [&](int r, double l, double u, double sv, double zlv, double zuv, double gv) __attribute__((always_inline)) {
+    auto bar_row = [&](bool valid, int r, int sp, int wpos, double l, double u, double sv, double zlv, double zuv, double gv) __attribute__((always_inline)) {
       const bool hl = l > -1e19, hu = u < 1e19;
       const double dl = hl ? sv - l : 1.0, du = hu ? u - sv : 1.0;
-      const double sg = (hl ? zlv / dl : 0.0) + (hu ? zuv / du : 0.0);
-      const double gmu = -(hl ? mu / dl : 0.0) + (hu ? mu / du : 0.0);
+      const double zql = zlv / dl, zqu = zuv / du, ml = mu / dl, mq = mu / du;   // (side by side, as in ratio_row)
+      const double sg = (hl ? zql : 0.0) + (hu ? zqu : 0.0);
+      const double gmu = -(hl ? ml : 0.0) + (hu ? mq : 0.0);
       const double wrv = sg * (gv - sv) + gmu;
-      sigp[r] = sg;
-      wp[r] = wrv;
-      strm[P.sig_pos[r]] = sg;
-      strm[P.w_pos[r]] = wrv;
+      if (valid) {
+        sigp[r] = sg;
+        wp[r] = wrv;
+        strm[sp] = sg;
+        strm[wpos] = wrv;
+      }
     };
 #pragma unroll
     for (int k = 0; k < KE; ++k)
       if (tid + k * nt < P.n_eqw) strm[P.rhs_pos[er[k]]] = -eg[k];
     for (int i = tid + KE * nt; i < P.n_eqw; i += nt) { const int r = P.eq_idx[i]; strm[P.rhs_pos[r]] = -g[r]; }
+    int spos[KR], wpos[KR];   // (the positions first: their loads are in flight during the divisions)
 #pragma unroll
-    for (int k = 0; k < KR; ++k)
-      if (tid + k * nt < P.n_iq) bar_row(rr[k], rl[k], ru[k], rs[k], rzl[k], rzu[k], rg[k]);
+    for (int k = 0; k < KR; ++k) { spos[k] = P.sig_pos[rr[k]]; wpos[k] = P.w_pos[rr[k]]; }
+#pragma unroll
+    for (int k = 0; k < KR; ++k) bar_row(tid + k * nt < P.n_iq, rr[k], spos[k], wpos[k], rl[k], ru[k], rs[k], rzl[k], rzu[k], rg[k]);
     for (int i = tid + KR * nt; i < P.n_iq; i += nt) {
       const int r = P.iq_idx[i];
-      bar_row(r, P.iq_lo[i], P.iq_hi[i], s[r], zl[r], zu[r], g[r]);
+      bar_row(true, r, P.sig_pos[r], P.w_pos[r], P.iq_lo[i], P.iq_hi[i], s[r], zl[r], zu[r], g[r]);
     }
   }
   KSTAMP(5);
+  KCUT(5);
   if (tid == 0) {
     W.chord[b] = next_chord ? 1 : (chord_off ? 2 : 0);
     W.chord_run[b] = next_chord ? (was_chord ? chord_run + 1 : 1) : 0;

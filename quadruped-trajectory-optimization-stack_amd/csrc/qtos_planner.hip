@@ -927,7 +927,12 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
   if (hipSetDevice(p->device) != hipSuccess) return fail(-2);
   p->call_open = true;
   p->call_stream = st;
-  p->seq = p->seq >= 0xfffeu ? 1u : p->seq + 1u;   // (0xffff = the reset pattern of the slots)
+  // 16 bits of sequence number in the count word (0xffff = the reset pattern of the slots): the number wraps after 65 534 calls
+  // of the handle.  A stale word can only be taken for this call's if a blind launch of the call 65 534 submits earlier were
+  // still to store -- but a call is submitted only after the previous one was collected (p->busy above) and a call queues at
+  // most max_iter blind launches, each a few microseconds of work once its problems are done: the launches of call n - 65 534
+  // ran tens of thousands of collected calls ago.  Blind iterations are off by default (spec_cap 1).
+  p->seq = p->seq >= 0xfffeu ? 1u : p->seq + 1u;
   DevWork W = p->wk;
   W.start = d_start; W.goal = d_goal; W.map_id = d_map_id; W.warm = d_warm;
   // (the kernel that finishes a problem writes its result: kernels.hpp export_problem)

@@ -8,7 +8,7 @@ R = sys.argv[2] if len(sys.argv) > 2 else "r05"
 G = "gpurun_out/"
 names = {"default": "bench", "compat": "bench_reference_compat", "exp5": "bench_exp5", "mixed": "bench_mixed", "trot": "bench_trot",
          "tol1e-3": "bench_tol1e-3", "batch512": "bench_batch512", "batch1024": "bench_batch1024", "knots200": "bench_knots200",
-         "mpc": "bench_knots200_mpc_random", "mpc_1set": "bench_knots200_mpc_random_one_set", "table": "bench_init_table", "inflight2": "bench_flat_inflight2",
+         "mpc": "bench_knots200_mpc_random", "mpc_1set": "bench_knots200_mpc_random_one_set", "table": "bench_init_table",
          "nochord": "bench_no_chord_step", "torchrun1": "bench_torchrun_1rank", "full_system": "bench_full_system",
          "exp5_lanes3": "bench_exp5_lanes3", "exp5_batch1024": "bench_exp5_batch1024", "mixed_batch1024": "bench_mixed_batch1024", "mixed_lanes3": "bench_mixed_lanes3", "lanes2": "bench_flat_lanes2", "steps500": "bench_steps500",
          "kkt5_walk": "bench_kkt5_walk", "kkt5_trot": "bench_kkt5_trot", "kkt5_compat": "bench_kkt5_reference_compat", "kkt5_knots200": "bench_kkt5_knots200",
