@@ -41,6 +41,11 @@ QTOS_KKT=2 b kkt2_walk $X
 # the system of round 4 (swing mid nodes as unknowns) on the same box
 b no_swing $X --full-swings
 b no_swing_trot $X --full-swings --gait trot
+# ... and without the short stages below 128 slots: the configuration of round 4's final pass
+QTOS_SHORT_STAGES=0 b r4_system $X --full-swings
+QTOS_SHORT_STAGES=0 b r4_system_trot $X --full-swings --gait trot
+QTOS_SHORT_STAGES=0 b no_short $X
+QTOS_SHORT_STAGES=0 b no_short_trot $X --gait trot
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o runc -- python3 $R/bench.py --cpu-sample 0 --no-parity --no-trot > $O/prof_$T.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$T -o runc -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-parity --no-trot > $O/pmc_fetch_$T.log 2>&1

@@ -1,0 +1,37 @@
+"""bench.py's command line on the CPU: the defaults the driver relies on, and every bench command README.md prints parses
+(the eight-GPU commands of BASELINE configs[3] / configs[4] are the driver's to run; here they must at least be commands)."""
+import os
+import re
+import shlex
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_defaults_are_the_headline_run():
+    import bench
+    a = bench.parse_args([])
+    assert (a.gpus, a.steps, a.warmup, a.batch) == (1, 100, 5, 256)
+    assert (a.transcription, a.gait, a.workload) == ("knots100", "walk", "exp1_flat")
+    # the trot (the gait BASELINE.json's metric names) is timed by the default command, 20 steps of its own
+    assert not a.no_trot and a.trot_steps == 20
+    assert not a.full_system and not a.full_swings and not a.force_torchrun
+    assert a.cpu_sample > 0 and not a.no_parity
+
+
+def test_readme_bench_commands_parse():
+    import bench
+    text = open(os.path.join(ROOT, "README.md")).read()
+    cmds = [l.strip() for l in text.splitlines() if l.startswith("    python ") and "bench.py" in l]
+    assert len(cmds) >= 3
+    seen = set()
+    for c in cmds:
+        argv = shlex.split(c.split("#")[0])
+        argv = argv[argv.index("bench.py") + 1:]
+        a = bench.parse_args(argv)
+        seen.add((a.gpus, a.workload, a.transcription))
+        if "torch.distributed.run" in c:   # the launcher's process count is the --gpus the ranks are told
+            assert re.search(r"--nproc-per-node (\d+)", c).group(1) == str(a.gpus) and "--master-addr 127.0.0.1" in c
+    # BASELINE configs[3]: batch 2048 mixed terrains over 8 GPUs; configs[4]: 200-knot receding windows over 8 GPUs
+    assert (8, "mixed", "knots100") in seen and (8, "mpc_random", "knots200") in seen
