@@ -545,6 +545,11 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
 #else
 #define ESTAMP() do {} while (0)
 #endif
+#ifdef QTOS_EVAL_CUT   // (diagnostic builds, with QTOS_STEP_CUT: the evaluation with Jacobian ends behind its section i -- wrong results)
+#define ECUT(i) do { if (JAC && QTOS_EVAL_CUT == (i)) return; } while (0)
+#else
+#define ECUT(i) do {} while (0)
+#endif
   double *x = lds, *loc = lds + eval_loc_offset(P.n_vars);
   double *vin = loc + max(DYN_LOC * P.dyn_chunk, ROM_LOC * P.rom_chunk);
   double *coef_lds = vin + max(DYN_VIN * P.dyn_chunk, ROM_VIN * P.rom_chunk);   // coefficients of the entry lists (JAC only)
@@ -561,6 +566,7 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
     vec_prepass(P.pre_dyn_var + c0 * DYN_VIN, P.pre_dyn_wa + c0 * DYN_VIN, P.pre_dyn_wb + c0 * DYN_VIN, cnt * DYN_VIN, x, vin);
     EVAL_BARRIER();
     ESTAMP();
+    ECUT(0);
     if (JAC) {
       // four work items per knot -- the value pass and the three groups of forward-mode passes --, a whole number of
       // waves per kind (a chunk of 128 knots is one item per thread)
@@ -579,10 +585,12 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
       }
       EVAL_BARRIER();
       ESTAMP();
+      ECUT(1);
       write_terms1(P.dyn_t1, P.dyn_t1_off[ch], P.dyn_t1_off[ch + 1], loc, coef, G);
       write_terms3(P.dyn_t3, P.dyn_t3_off[ch], P.dyn_t3_off[ch + 1], loc, coef, G);
       EVAL_BARRIER();
       ESTAMP();
+      ECUT(2);
     } else {
       for (int i = tid; i < cnt; i += nt) {
         const DynInst &I = P.dyn[c0 + i];
@@ -602,8 +610,10 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
     if (JAC) {
       EVAL_BARRIER();
       ESTAMP();
+      if (c0 + P.rom_chunk >= P.n_rom) ECUT(3);
       write_terms1(P.rom_t1, P.rom_t1_off[ch], P.rom_t1_off[ch + 1], loc, coef, G);
       ESTAMP();
+      if (c0 + P.rom_chunk >= P.n_rom) ECUT(4);
     }
   }
   // force, terrain and constant-coefficient rows: the descriptors of a thread's items are read before the first of them is
@@ -1433,6 +1443,9 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
 #pragma unroll
     for (int k = 0; k < KE; ++k) egt[k] = gv[er[k]];
     th = l1_rows(rgt, egt, gv, al);
+#ifdef QTOS_EVAL_CUT
+    break;   // (a cut evaluation leaves garbage: one pass, as a launch that accepts its first trial point)
+#endif
     if (th <= (1.0 - 1e-4 * al) * th0 || th < 1e-9) { lin_done = spec && ls == 0; break; }
     if (ls < 5) al *= 0.5;
   }
