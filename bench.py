@@ -79,6 +79,9 @@ def parse_args(argv=None):
     ap.add_argument("--full-swings", action="store_true",
                     help="the swing mid nodes as unknowns with their rule as equality rows (PlannerConfig.reduce_swing off: 1721 "
                          "unknowns / 108 stages instead of 1593 / 100 on the walk) -- the system of rounds 3 and 4")
+    ap.add_argument("--plain-mu", action="store_true",
+                    help="the barrier parameter shrinks by mu <- 0.2 mu (PlannerConfig.mu_superlinear off: rounds 1 - 4) instead of "
+                         "Ipopt's monotone update mu <- max(tol, min(0.2 mu, mu^1.5))")
     ap.add_argument("--force-torchrun", action="store_true",
                     help="launch the ranks through torch.distributed.run even for --gpus 1 (exercises the child-process path "
                          "and the RCCL all-gather at world size 1)")
@@ -272,6 +275,8 @@ def main():
         kw["reduce_base"] = False
     if args.full_swings:
         kw["reduce_swing"] = False
+    if args.plain_mu:
+        kw["mu_superlinear"] = False
     if mpc and args.inflight > 1 and args.batch % args.inflight:
         raise SystemExit("--inflight must divide --batch for mpc_random (the windows are split into that many sets)")
     cfg = {"knots100": PlannerConfig.knots100, "knots200": PlannerConfig.knots200,
@@ -513,7 +518,7 @@ def main():
             "iterations_max_last_step": int(itn.max()),
             "iterations_mean": round(float(iters_dev.item()) / max(B * args.steps, 1), 3) if (solved_inflight is None or lanes) else None,
             "parallelism": "batch-shard x%d + 1 %s" % (world, "RCCL all-gather" if use_dist else "all-gather (not launched under torch.distributed: single process)"),
-            "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front, "reduce_base": bool(cfg.reduce_base), "reduce_swing": bool(cfg.reduce_swing),
+            "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front, "reduce_base": bool(cfg.reduce_base), "reduce_swing": bool(cfg.reduce_swing), "mu_superlinear": bool(cfg.mu_superlinear),
             "batches_in_flight": args.inflight, "max_iter": cfg.max_iter, "chord_tol": cfg.chord_tol, "chord_max": cfg.chord_max,
             "initial_guess": "towr straight line" if args.init == "straight_line" else
                              "interpolated table of %d nominal plans (solved before the timed region)" % (P.init_table[2].shape[0] * P.init_table[2].shape[1]),

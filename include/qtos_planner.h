@@ -74,6 +74,13 @@ typedef struct QtosParams {
                           iterate only if they hold for the first: the starting point's mid nodes are placed on the rule
                           (towr's straight-line guess has another v_xy there).  Nearest-cell terrain only (terrain_mode 1);
                           0 = every swing row keeps its multiplier */
+  int mu_superlinear;  /* 1: the barrier parameter follows Ipopt's monotone update, mu <- max(tol, mu_min, min(0.2 mu, mu^1.5)) behind a
+                          step longer than 0.3 (Ipopt's mu_linear_decrease_factor 0.2 and mu_superlinear_decrease_power 1.5, the
+                          defaults the reference's solver runs with; mu^1.5 formed as mu * sqrt(mu)): from mu = 0.02 on the
+                          superlinear term is the smaller one.  The floor -- Ipopt's is a tenth of ITS tolerance, 1e-3 in the
+                          reference's runs: the same 1e-4 as this planner's tol -- keeps the KKT systems of late iterations
+                          as well scaled as those of the fourth (with tol / 10 the GPU <-> oracle gaps of the long horizons
+                          doubled).  0: mu <- max(mu_min, 0.2 mu) (rounds 1 - 4) */
 } QtosParams;
 
 typedef struct QtosDims {

@@ -59,6 +59,7 @@ class QoOptions(C.Structure):
         ("warm_start", C.c_int), ("verbose", C.c_int), ("stall_iters", C.c_int),
         ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double), ("chord_tol", C.c_double),
         ("stall_alpha", C.c_double), ("chord_max", C.c_int), ("chord_shrink", C.c_double), ("swing_start_on_rule", C.c_int),
+        ("mu_superlinear", C.c_int),
     ]
 
 
@@ -133,6 +134,7 @@ def oracle_options(cfg, O):
                                                              cfg.foothold_hold_weight, cfg.foothold_hold_tol)
     o.chord_tol, o.chord_max, o.chord_shrink = cfg.chord_tol, cfg.chord_max, cfg.chord_shrink
     o.stall_alpha = cfg.stall_alpha
+    o.mu_superlinear = int(bool(getattr(cfg, "mu_superlinear", False)))
     # (the product's reduce_swing applies with nearest-cell terrain only: model.hpp)
     o.swing_start_on_rule = int(bool(getattr(cfg, "reduce_swing", False)) and cfg.terrain_mode == 1)   # (== O.swing_start_on_rule for an Oracle(oracle_dict(cfg)))
     return o

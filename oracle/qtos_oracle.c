@@ -938,6 +938,7 @@ void qo_default_options(qo_options *o) {
   o->warm_start = 0;
   o->verbose = 0;
   o->swing_start_on_rule = 0;
+  o->mu_superlinear = 1;
 }
 
 /* time stamp of every variable / constraint row: used only to order the KKT unknowns */
@@ -1339,7 +1340,7 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
       if (hl) zl[i] = fmin(fmax(zl[i], mu / (kap * (s[i] - l))), kap * mu / (s[i] - l));
       if (hu) zu[i] = fmin(fmax(zu[i], mu / (kap * (u - s[i]))), kap * mu / (u - s[i]));
     }
-    if (al > 0.3) mu = fmax(o->mu_min, 0.2 * mu);
+    if (al > 0.3) mu = o->mu_superlinear ? fmax(fmax(o->mu_min, o->tol), fmin(0.2 * mu, mu * sqrt(mu))) : fmax(o->mu_min, 0.2 * mu);   /* Ipopt's monotone update (qo_options) */
     chord_ok = !chord && al == 1.0;
     chord_run = chord ? chord_run + 1 : 0;
     chord_again = chord && al == 1.0 && chord_run < o->chord_max;

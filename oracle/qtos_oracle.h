@@ -118,6 +118,8 @@ typedef struct {
                           first evaluation -- the product's reduce_swing takes those rows out of its KKT system, so they must
                           hold at its first iterate; from there this solver's Newton steps keep them (linear rows) and the two
                           take the same path.  0 = towr's straight-line guess as it is (the logged 19.4 at iteration 0) */
+  int mu_superlinear;  /* 1: mu <- max(tol, mu_min, min(0.2 mu, mu sqrt(mu))) behind a step longer than 0.3 (Ipopt's monotone update:
+                          mu_linear_decrease_factor 0.2, mu_superlinear_decrease_power 1.5); 0: mu <- max(mu_min, 0.2 mu) */
 } qo_options;
 
 typedef struct {

@@ -33,6 +33,7 @@ class QtosParams(C.Structure):
         ("reduce_base", C.c_int),
         ("chord_max", C.c_int), ("chord_shrink", C.c_double), ("stall_alpha", C.c_double),
         ("reduce_swing", C.c_int),
+        ("mu_superlinear", C.c_int),
     ]
 
 
@@ -189,6 +190,7 @@ def params_from_config(cfg):
     p.chord_max, p.chord_shrink = int(cfg.chord_max), float(cfg.chord_shrink)
     p.stall_alpha = float(cfg.stall_alpha)
     p.reduce_swing = int(getattr(cfg, "reduce_swing", False))
+    p.mu_superlinear = int(getattr(cfg, "mu_superlinear", False))
     return p
 
 

@@ -133,6 +133,7 @@ struct DevPlan {
   double mass, gravity, Ib[9], mu_fric, f_max, T;
   double nominal[NEE][3];
   double tol, mu_init, mu_min, delta_x, eps_dual, slack_push, warm_slack_push;
+  int mu_superlinear;   // QtosParams.mu_superlinear: Ipopt's monotone update of the barrier parameter
   int max_iter, stall_iters;
   double stall_alpha;          // QtosParams.stall_alpha
   const double *height;
@@ -1496,7 +1497,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     update_row(P.iq_lo[i], P.iq_hi[i], sv, ds[r], zlv, zuv, dzl[r], dzu[r]);
     s[r] = sv; zl[r] = zlv; zu[r] = zuv;
   }
-  if (al > 0.3) mu = fmax(P.mu_min, 0.2 * mu);
+  if (al > 0.3) mu = P.mu_superlinear ? fmax(fmax(P.mu_min, P.tol), fmin(0.2 * mu, mu * sqrt(mu))) : fmax(P.mu_min, 0.2 * mu);
   __syncthreads();
   // max violation of the working rows (viol) and of the slack form (theta): infeasibility() on the rows in registers
   double viol, theta;

@@ -566,6 +566,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   for (int e = 0; e < NEE; ++e)
     for (int d = 0; d < 3; ++d) D.nominal[e][d] = M.P.nominal_stance[e][d];
   D.tol = M.P.tol; D.mu_init = M.P.mu_init; D.mu_min = M.P.mu_min; D.delta_x = M.P.delta_x;
+  D.mu_superlinear = M.P.mu_superlinear != 0;
   D.eps_dual = M.P.eps_dual; D.max_iter = M.P.max_iter; D.stall_iters = M.P.stall_iters; D.stall_alpha = M.P.stall_alpha;
   D.slack_push = M.P.slack_push > 0 ? M.P.slack_push : 0.01;
   D.warm_slack_push = M.P.warm_slack_push > 0 ? M.P.warm_slack_push : 0.01;

@@ -13,7 +13,9 @@ names = {"default": "bench", "compat": "bench_reference_compat", "exp5": "bench_
          "exp5_lanes3": "bench_exp5_lanes3", "exp5_batch1024": "bench_exp5_batch1024", "mixed_batch1024": "bench_mixed_batch1024", "mixed_lanes3": "bench_mixed_lanes3", "lanes2": "bench_flat_lanes2", "steps500": "bench_steps500",
          "kkt5_walk": "bench_kkt5_walk", "kkt5_trot": "bench_kkt5_trot", "kkt5_compat": "bench_kkt5_reference_compat", "kkt5_knots200": "bench_kkt5_knots200",
          "kkt2_trot": "bench_kkt2_trot", "kkt2_walk": "bench_kkt2_walk", "no_swing": "bench_no_reduce_swing", "no_swing_trot": "bench_no_reduce_swing_trot",
-         "r4_system": "bench_round4_system", "r4_system_trot": "bench_round4_system_trot", "no_short": "bench_no_short_stages", "no_short_trot": "bench_no_short_stages_trot"}
+         "r4_system": "bench_round4_system", "r4_system_trot": "bench_round4_system_trot", "no_short": "bench_no_short_stages", "no_short_trot": "bench_no_short_stages_trot",
+         "plain_mu": "bench_plain_mu", "plain_mu_trot": "bench_plain_mu_trot", "plain_mu_exp5": "bench_plain_mu_exp5", "plain_mu_mixed": "bench_plain_mu_mixed",
+         "plain_mu_knots200": "bench_plain_mu_knots200", "plain_mu_mpc": "bench_plain_mu_knots200_mpc_random"}
 for src, dst in names.items():
     f = G + "bench_%s_%s.json" % (tag, src)
     if not os.path.exists(f):

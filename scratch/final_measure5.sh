@@ -42,8 +42,15 @@ QTOS_KKT=2 b kkt2_walk $X
 b no_swing $X --full-swings
 b no_swing_trot $X --full-swings --gait trot
 # ... and without the short stages below 128 slots: the configuration of round 4's final pass
-QTOS_SHORT_STAGES=0 b r4_system $X --full-swings
-QTOS_SHORT_STAGES=0 b r4_system_trot $X --full-swings --gait trot
+QTOS_SHORT_STAGES=0 b r4_system $X --full-swings --plain-mu
+QTOS_SHORT_STAGES=0 b r4_system_trot $X --full-swings --plain-mu --gait trot
+# the barrier parameter's update of rounds 1 - 4 alone
+b plain_mu $X --plain-mu
+b plain_mu_trot $X --plain-mu --gait trot
+b plain_mu_exp5 $X --plain-mu --workload exp5_step
+b plain_mu_mixed $X --plain-mu --workload mixed
+b plain_mu_knots200 $X --plain-mu --transcription knots200
+b plain_mu_mpc $X --plain-mu --transcription knots200 --workload mpc_random --steps 200
 QTOS_SHORT_STAGES=0 b no_short $X
 QTOS_SHORT_STAGES=0 b no_short_trot $X --gait trot
 cd /tmp && export TMPDIR=/tmp

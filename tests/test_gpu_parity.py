@@ -1036,7 +1036,9 @@ def test_second_chord_step_finishes_the_trot_batch():
     from qtos_amd import workloads
     from qtos_amd.capi import Planner
     from qtos_amd.config import PlannerConfig
-    cfg = PlannerConfig.knots100(gait="trot")
+    # (under the plain mu <- 0.2 mu of rounds 1 - 4: with Ipopt's update of the barrier parameter, the default since round 5,
+    #  every problem of this batch converges behind its first chord step -- test_trot_gait_batch_matches_oracle)
+    cfg = PlannerConfig.knots100(gait="trot", mu_superlinear=False)
     assert cfg.chord_max == 2
     start, goal = workloads.flat_goals(128, seed=0)
     out = {}
@@ -1073,7 +1075,8 @@ def test_trot_gait_batch_matches_oracle(reduce_base):
     nodes, status, iters, viol = P.plan(start, goal)
     P.close()
     assert (status == 0).all() and viol.max() <= cfg.tol
-    assert iters.max() <= 6
+    # (round 5, Ipopt's update of the barrier parameter: the whole batch in four iterations -- it was 4: 58 %, 5: 42 %)
+    assert iters.max() <= (4 if reduce_base else 6)
     # (reduce_swing moves the full system's 1e-6 to the reduced base's 5e-6: the oracle's multipliers of the swing rows)
     same, worst = _batch_vs_oracle(cfg, start, goal, range(32), status=status, iters=iters, nodes=nodes, tol=5e-6)
     assert same == 32, (same, worst)
@@ -1232,7 +1235,7 @@ def test_stall_detection_returns_best_iterate(cfg):
     """A problem that stops lowering its violation (a foot cycling across a ledge edge of the
     piecewise-constant exp_5 terrain) stops `stall_iters` iterations after its best iterate with
     status 1 and returns that iterate; converged problems are untouched; with the rule switched
-    off the same problems run to the iteration limit.  The oracle applies the same rule.
+    off the same problems run on, most of them to the iteration limit.  The oracle applies the same rule.
     (Footholds left free for the whole solve, `foothold_hold_from` = 0; chord steps off: the rule under test is
     about the cycling iterates of the plain Newton sequence.)"""
     import dataclasses
@@ -1268,8 +1271,10 @@ def test_stall_detection_returns_best_iterate(cfg):
     nodes0, status0, iters0, _ = P0.plan(start, goal)
     P0.close()
     ok = status == 0
-    assert np.array_equal(status0 == 0, ok) and np.array_equal(nodes0[ok], nodes[ok]) and np.array_equal(iters0[ok], iters[ok])
-    assert (iters0[stuck] == cfg.max_iter).all()
+    assert (status0[ok] == 0).all() and np.array_equal(nodes0[ok], nodes[ok]) and np.array_equal(iters0[ok], iters[ok])
+    # (the stopped problems go on without the rule: to the iteration limit, or -- the barrier parameter stays at its floor,
+    #  round 5 -- to a late convergence the batch would have waited for)
+    assert (iters0[stuck] > iters[stuck]).all() and (iters0[stuck] == cfg.max_iter).any()
 
 
 @pytest.mark.gpu

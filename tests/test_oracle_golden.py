@@ -238,10 +238,12 @@ def test_oracle_stall_rule_stops_cycling_problems():
     assert ih.status == 0 and ih.iters <= 6 and O.max_violation(xh) <= 1e-4 + 1e-9
     o.hold_from = 0
     o.chord_tol = 0.0
+    o.mu_superlinear = 0   # (the cycling problem was found under the plain mu <- 0.2 mu: with Ipopt's update it converges)
     x5, i5 = O.solve(q, opts=o)
     o = O.default_options()
     o.hold_from = 0
     o.chord_tol = 0.0
+    o.mu_superlinear = 0
     o.stall_iters = 0
     x0, i0 = O.solve(q, opts=o)
     assert i5.status == 1 and i0.status == 1 and i5.iters < i0.iters == o.max_iter
