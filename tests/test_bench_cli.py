@@ -16,7 +16,7 @@ def test_defaults_are_the_headline_run():
     assert (a.transcription, a.gait, a.workload) == ("knots100", "walk", "exp1_flat")
     # the trot (the gait BASELINE.json's metric names) is timed by the default command, 20 steps of its own
     assert not a.no_trot and a.trot_steps == 20
-    assert not a.full_system and not a.full_swings and not a.force_torchrun
+    assert not a.full_system and not a.full_swings and not a.plain_mu and not a.force_torchrun
     assert a.cpu_sample > 0 and not a.no_parity
 
 
