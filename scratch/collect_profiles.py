@@ -15,7 +15,7 @@ names = {"default": "bench", "compat": "bench_reference_compat", "exp5": "bench_
          "kkt2_trot": "bench_kkt2_trot", "kkt2_walk": "bench_kkt2_walk", "no_swing": "bench_no_reduce_swing", "no_swing_trot": "bench_no_reduce_swing_trot",
          "r4_system": "bench_round4_system", "r4_system_trot": "bench_round4_system_trot", "no_short": "bench_no_short_stages", "no_short_trot": "bench_no_short_stages_trot",
          "plain_mu": "bench_plain_mu", "plain_mu_trot": "bench_plain_mu_trot", "plain_mu_exp5": "bench_plain_mu_exp5", "plain_mu_mixed": "bench_plain_mu_mixed",
-         "plain_mu_knots200": "bench_plain_mu_knots200", "plain_mu_mpc": "bench_plain_mu_knots200_mpc_random"}
+         "plain_mu_knots200": "bench_plain_mu_knots200", "superlinear_mu_mpc": "bench_superlinear_mu_knots200_mpc_random"}
 for src, dst in names.items():
     f = G + "bench_%s_%s.json" % (tag, src)
     if not os.path.exists(f):

@@ -50,7 +50,7 @@ b plain_mu_trot $X --plain-mu --gait trot
 b plain_mu_exp5 $X --plain-mu --workload exp5_step
 b plain_mu_mixed $X --plain-mu --workload mixed
 b plain_mu_knots200 $X --plain-mu --transcription knots200
-b plain_mu_mpc $X --plain-mu --transcription knots200 --workload mpc_random --steps 200
+b superlinear_mu_mpc $X --superlinear-mu --transcription knots200 --workload mpc_random --steps 200
 QTOS_SHORT_STAGES=0 b no_short $X
 QTOS_SHORT_STAGES=0 b no_short_trot $X --gait trot
 cd /tmp && export TMPDIR=/tmp
