@@ -13,10 +13,16 @@ start/goal on the exp_1 flat heightfield, BASELINE.json configs[1]; a fresh seed
 all resident in HBM before the timed region) solved to convergence on the device -- initial guess,
 constraint/Jacobian assembly, KKT factor+solve, line search --, followed for N > 1 by the single RCCL
 all-gather that re-assembles the plan batch on every rank.  `value` = converged plans of all ranks /
-wall time (max over ranks).
+wall time (max over ranks).  The default line is the TROT (the gait BASELINE.json's metric names); the
+walk of the reference's golden plans is timed right behind it with the same --steps as the `walk` block.
+Behind the W warm-up steps further untimed steps run until three in a row agree to 2 % (--settle, at
+most 50; `warmup_extra` on the line), then EXACTLY K steps are timed.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel (k_kkt2): algorithmic bytes per launch (SURVEY.md 8d formula on the
+  step_ms, step_ms_series, gap_ms_per_step, device_ms_per_step, host_round_trips_per_step ...
+               where a step's time went: the host's clock around every timed step (distribution + the first 25)
+               and the planner's own HIP events split into kernels and the gaps between them.
+  roofline     dominant kernel (k_kkt3 / k_kkt2): algorithmic bytes per launch (SURVEY.md 8d formula on the
                planner's actual stage sizes) / average launch duration from HIP events; counter-based
                matrix-pipe utilisation from the newest profiles/*_pmc_sq.json (same command).
   cpu_baseline the CPU oracle (a port of the same algorithm) on a bounded sample of the same workload,
@@ -47,9 +53,10 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="plans per GPU per step")
     ap.add_argument("--transcription", default="knots100", choices=["knots100", "reference_compat", "knots200"])
-    ap.add_argument("--gait", default="walk", choices=["walk", "trot"],
-                    help="walk = the gait of the reference's golden plans (default); trot = the diagonal-pair trot "
-                         "BASELINE.json's headline names (not pinned by any reference artefact)")
+    ap.add_argument("--gait", default=None, choices=["walk", "trot"],
+                    help="trot = the diagonal-pair trot BASELINE.json's metric names (default: `metric` / `value` / `roofline` of "
+                         "the line; not pinned by any reference artefact); walk = the gait of the reference's golden plans (the "
+                         "default command times it right behind the trot, with the same --steps, as the line's `walk` block)")
     ap.add_argument("--workload", default="exp1_flat", choices=["exp1_flat", "exp5_step", "mixed", "mpc_random"],
                     help="mixed = BASELINE configs[3] (with --gpus 8: 2048 plans); mpc_random = configs[4]: every "
                          "step is one 50 Hz replan of all windows on randomized heightfields (use with --transcription knots200)")
@@ -89,13 +96,25 @@ def parse_args(argv=None):
                     help="launch the ranks through torch.distributed.run even for --gpus 1 (exercises the child-process path "
                          "and the RCCL all-gather at world size 1)")
     ap.add_argument("--child-timeout", type=float, default=1800.0, help="seconds after which the launcher ends its torchrun child")
-    ap.add_argument("--no-trot", action="store_true",
-                    help="skip the trot-gait leg that the default headline run times after the walk (BASELINE.json's metric names a trot)")
-    ap.add_argument("--trot-steps", type=int, default=20)
+    ap.add_argument("--no-second-gait", "--no-walk", "--no-trot", dest="no_second_gait", action="store_true",
+                    help="skip the second leg of the default headline run (the other gait -- the walk behind the trot --, timed with the "
+                         "same --steps / --warmup right behind the first)")
+    ap.add_argument("--settle", type=int, default=50,
+                    help="adaptive warm-up: behind the --warmup untimed steps, further untimed steps until three in a row lie within "
+                         "--settle-tol of each other, at most this many (0 = none); the line reports how many ran")
+    ap.add_argument("--settle-tol", type=float, default=0.02)
+    ap.add_argument("--no-pattern", action="store_true",
+                    help="qtos_set_pattern_speculation(0): the host reads the counts in front of every Newton iteration and launches it "
+                         "(rounds 1 - 5) instead of queueing the handle's launch pattern at submit time")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per k_kkt launch from a separate rocprofv3 --pmc pass "
                          "(default: the newest profiles/*_pmc_hbm.json, collected with this same command)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.gait is None:
+        # the metric's gait on the metric's workload (flat exp_1 goals); the terrain workloads and the 200-knot receding windows keep
+        # the walk their goals, schedules (PlannerConfig.knots200) and -m gpu tests are written for
+        a.gait = "trot" if (a.workload == "exp1_flat" and a.transcription != "knots200") else "walk"
+    return a
 
 
 def kkt_kernel_name(planner):
@@ -234,6 +253,74 @@ def golden_parity(Planner, PlannerConfig, device):
     return out
 
 
+def percentile(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, int(round(q * (len(xs) - 1))))] if xs else None
+
+
+def settle(step_fn, sync_fn, max_steps, tol):
+    """Adaptive warm-up: untimed steps until three in a row lie within `tol` of each other (host clock around a step that ends
+    with the device idle), at most max_steps.  Returns the number of steps run."""
+    import time as _t
+    last, n = [], 0
+    while n < max_steps:
+        sync_fn()
+        t0 = _t.perf_counter()
+        step_fn()
+        sync_fn()
+        last.append(_t.perf_counter() - t0)
+        n += 1
+        if len(last) >= 3 and max(last[-3:]) <= (1.0 + tol) * min(last[-3:]):
+            break
+    return n
+
+
+class LegTimes:
+    """Per-step records of one timed leg: the host's clock around every step and the planner's own events (qtos_last_timing,
+    qtos_last_timing_detail) -- what lets a reader of the line tell a slow host from a slow kernel."""
+
+    def __init__(self):
+        self.step_s, self.kkt_s, self.kkt_n, self.tot_s, self.chord_s, self.chord_n = [], 0.0, 0, 0.0, 0.0, 0
+        self.gap_s, self.solve_s, self.stepk_s, self.start_s, self.informed, self.at_submit, self.slots = 0.0, 0.0, 0.0, 0.0, 0, 0, 0
+        self.pattern_calls = self.pattern_misses = 0
+        self.have_detail = True
+
+    def add(self, P, wall):
+        self.step_s.append(wall)
+        tm = P.timing()   # HIP events recorded on the launch stream around every k_kkt launch
+        self.kkt_s += tm["kkt_seconds"]; self.kkt_n += tm["kkt_launches"]; self.tot_s += tm["total_seconds"]
+        self.chord_s += tm.get("chord_seconds", 0.0); self.chord_n += tm.get("chord_launches", 0)
+        if self.have_detail and hasattr(P.lib, "qtos_last_timing_detail"):
+            d = P.timing_detail()
+            self.gap_s += d["gap_seconds"]; self.solve_s += d["solve_seconds"]; self.stepk_s += d["step_seconds"]; self.start_s += d["start_seconds"]
+            self.informed += d["informed_launches"]; self.at_submit += d["slots_at_submit"]; self.slots += d["slots"]
+            self.pattern_calls, self.pattern_misses = d["pattern_calls"], d["pattern_misses"]
+        else:
+            self.have_detail = False
+
+    def summary(self, elapsed):
+        n = max(len(self.step_s), 1)
+        ms = [1e3 * x for x in self.step_s]
+        out = {"step_ms": {"min": round(min(ms), 4), "p50": round(percentile(ms, 0.5), 4), "p90": round(percentile(ms, 0.9), 4), "max": round(max(ms), 4)} if ms else None,
+               "step_ms_series": [round(x, 3) for x in ms[:25]],
+               # the timed region also holds, per step, the read-out of the planner's events (hipEventSynchronize + elapsed times)
+               "timed_region_minus_steps_ms_per_step": round(1e3 * (elapsed - sum(self.step_s)) / n, 4)}
+        if self.have_detail:
+            out.update({
+                "device_ms_per_step": round(1e3 * self.tot_s / n, 4),
+                # between the kernels of a call: a launch slot's last event -> the next slot's first (the host reading the counts and
+                # launching; ~0 between slots queued at submit time) + what lies between the last slot and the end of the call
+                "gap_ms_per_step": round(1e3 * self.gap_s / n, 4),
+                "kernel_ms_per_step": {"k_start": round(1e3 * self.start_s / n, 4), "solve": round(1e3 * self.solve_s / n, 4), "k_step_and_counts": round(1e3 * self.stepk_s / n, 4)},
+                "launch_slots_per_step": round(self.slots / n, 2), "slots_queued_at_submit_per_step": round(self.at_submit / n, 2),
+                "host_round_trips_per_step": round(self.informed / n + 1, 2),   # (launches that waited for the counts + the end of the call)
+                "pattern_calls": self.pattern_calls, "pattern_misses": self.pattern_misses,
+                # the host's share of a step: submit latency + the wait for the word that says the batch is finished
+                "host_ms_per_step_outside_device_time": round(1e3 * (sum(self.step_s) - self.tot_s) / n, 4),
+            })
+        return out
+
+
 def main():
     args = parse_args()
     if (args.gpus > 1 or args.force_torchrun) and "WORLD_SIZE" not in os.environ:
@@ -291,6 +378,8 @@ def main():
            "reference_compat": PlannerConfig.reference_compat}[args.transcription](**kw)
     B = args.batch
     P = Planner(cfg, max_batch=B, device=local_rank)
+    if args.no_pattern:
+        P.set_pattern_speculation(False)
     d = P.dims
     n_sets = 1 if (args.same_batch or mpc) else args.steps + args.warmup   # one seeded batch per step
     terrain = None
@@ -429,12 +518,23 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # adaptive warm-up (untimed; the K timed steps follow): a fresh box has been seen to run its first tens of milliseconds with
+    # 0.5 ms per batch between the kernels (BENCH_r05) -- host clocks, first touches -- and a 20-step window must not average that in
+    warmup_extra = 0
+    if args.settle > 0 and not mpc and not (args.inflight > 1):
+        warmup_extra = settle(step, sync, args.settle, args.settle_tol)
+        if use_dist:   # (every rank runs the same number of steps: the collective inside a step must pair up)
+            we = torch.tensor([warmup_extra], dtype=torch.int64, device=dev)
+            dist.all_reduce(we, op=dist.ReduceOp.MAX)
+            for _ in range(int(we.item()) - warmup_extra):
+                step()
+            warmup_extra = int(we.item())
+    sync()
     state["timed"] = 0
     solved_dev.zero_()
     iters_dev.zero_()
     P.totals(reset=True)
-    kkt_s, kkt_n, tot_s = 0.0, 0, 0.0
-    chord_s, chord_n = 0.0, 0
+    leg = LegTimes()
     solved_inflight = None
     if lanes:
         for j in range(2 * args.inflight):
@@ -475,15 +575,12 @@ def main():
     else:
         t0 = time.perf_counter()
     for _ in range(0 if (lanes or (mpc and mpc_pool is not None)) else args.steps):
+        ts = time.perf_counter()
         all_nodes, all_status = step()
-        tm = P.timing()   # HIP events recorded on the launch stream around every k_kkt launch
-        kkt_s += tm["kkt_seconds"]
-        kkt_n += tm["kkt_launches"]
-        tot_s += tm["total_seconds"]
-        chord_s += tm.get("chord_seconds", 0.0)
-        chord_n += tm.get("chord_launches", 0)
+        leg.add(P, time.perf_counter() - ts)
     sync()
     elapsed = time.perf_counter() - t0
+    kkt_s, kkt_n, tot_s, chord_s, chord_n = leg.kkt_s, leg.kkt_n, leg.tot_s, leg.chord_s, leg.chord_n
     if not mpc and not lanes:
         tc, ti = P.totals()
         solved_dev.fill_(tc)
@@ -510,7 +607,7 @@ def main():
         "metric": "NLP solves/sec (%d-knot SOLO12 %s gait, %g s horizon, converged to %s); CoM L-inf vs TOWR in `parity`" %
                   (d.n_dyn_times - 2, args.gait, cfg.duration, ("%.0e" % cfg.tol).replace("e-0", "e-")),
         "value": round(value, 2), "unit": "plans/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "timed_region_s": round(elapsed, 4),
+        "warmup": args.warmup, "warmup_extra": warmup_extra, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "timed_region_s": round(elapsed, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {
@@ -533,6 +630,16 @@ def main():
         },
     }
     out["per_rank_plans_per_s"] = {"min": round(float(rate_min.item()), 1), "max": round(float(rate_max.item()), 1)}
+    if leg.step_s:
+        # where a step's time went, per step: distribution over the timed steps, the first 25 of them, the gaps between the kernels
+        out.update(leg.summary(elapsed))
+        out["launch_pattern"] = "off (--no-pattern): the host reads the counts in front of every iteration" if args.no_pattern else \
+            "qtos_plan_submit queues the kernels the handle's last two calls both needed per launch slot; informed launches behind that prefix"
+        if use_dist and leg.have_detail:   # a slow rank shows here, a slow collective in allgather_ms
+            g = torch.tensor([out["gap_ms_per_step"], -out["gap_ms_per_step"], out["device_ms_per_step"], -out["device_ms_per_step"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            out["per_rank_gap_ms_per_step"] = {"min": round(-float(g[1]), 4), "max": round(float(g[0]), 4)}
+            out["per_rank_device_ms_per_step"] = {"min": round(-float(g[3]), 4), "max": round(float(g[2]), 4)}
     if use_dist:
         out["allgather_ms"] = None if allgather_ms is None else round(allgather_ms, 4)
     if mpc:
@@ -541,7 +648,8 @@ def main():
         out["config"]["hand_over_s_into_newest_plan"] = args.advance
         out["config"]["episode_resets"] = 0
         out["config"]["converged_fraction"] = round(n_solved / max(total_plans * args.steps, 1), 4)
-    headline = args.transcription == "knots100" and args.workload == "exp1_flat" and B == 256 and args.gait == "walk"
+    headline = args.transcription == "knots100" and args.workload == "exp1_flat" and B == 256
+    prof_tag = "" if args.gait == "walk" else "trot_"      # profiles/rNN_pmc_*.json: the walk's command; rNN_trot_pmc_*.json: the trot's
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
     import glob
 
@@ -565,7 +673,7 @@ def main():
         return None
     kernel_here = kkt_kernel_name(P)
     if traffic is None and headline:
-        f = newest("r[0-9][0-9]_pmc_hbm.json", kernel_here)
+        f = newest("r[0-9][0-9]_%spmc_hbm.json" % prof_tag, kernel_here)
         if f:
             try:
                 traffic = json.load(open(f))["k_kkt_traffic_bytes_per_launch"]["fetch_x2"]
@@ -601,68 +709,81 @@ def main():
             "chord_launches_per_step": round(chord_n / max(args.steps, 1), 2),
             "chord_avg_launch_ms": round(1e3 * chord_s / chord_n, 4) if chord_n else None,
         }
-        f = newest("r[0-9][0-9]_pmc_sq.json", kernel_here) if headline else None
+        f = newest("r[0-9][0-9]_%spmc_sq.json" % prof_tag, kernel_here) if headline else None
         if f:
             try:
                 out["roofline"]["counters"] = dict(json.load(open(f))["k_kkt"], source=os.path.relpath(f, ROOT))
             except Exception:
                 pass
-    if headline and world == 1 and rank == 0 and not args.no_trot and not lanes and args.trot_steps > 0:
-        # BASELINE.json's metric names a trot; the reference's committed plans (and so the headline above) are the walk.
-        # The same batch size and goals with the diagonal-pair trot schedule, timed right behind the walk.
-        cfg_t = PlannerConfig.knots100(gait="trot", **{k: v for k, v in kw.items() if k != "gait"})
+    if headline and world == 1 and rank == 0 and not args.no_second_gait and not lanes and args.init == "straight_line":
+        # BASELINE.json's metric names a trot: the line's `value`.  The reference's committed plans -- what the oracle is pinned on
+        # and the `parity` block re-solves -- are the WALK: the same batch size and goals with the other gait's schedule, timed
+        # right behind the first leg with the same --steps / --warmup and the same adaptive warm-up.
+        other = "walk" if args.gait == "trot" else "trot"
+        cfg_t = PlannerConfig.knots100(gait=other, **{k: v for k, v in kw.items() if k != "gait"})
         Pt = Planner(cfg_t, max_batch=B, device=local_rank)
+        if args.no_pattern:
+            Pt.set_pattern_speculation(False)
         Pt.set_heightfields(terrain[0], terrain[1])
         dt_ = Pt.dims
         nodes_t = torch.empty((B, dt_.n_vars), dtype=torch.float64, device=dev)
         status_t, iters_t, viol_t = torch.empty_like(status), torch.empty_like(iters), torch.empty_like(viol)
+        tstate = {"i": 0}
 
-        def trot_step(i):
-            i %= n_sets
+        def leg2_step():
+            i = tstate["i"] % n_sets
+            tstate["i"] += 1
             rc = Pt.lib.qtos_plan_batch_device(Pt.h, B, start_all[i].data_ptr(), goal_all[i].data_ptr(), None, None,
                                                nodes_t.data_ptr(), status_t.data_ptr(), iters_t.data_ptr(), viol_t.data_ptr(),
                                                C.c_void_p(stream.cuda_stream))
             if rc != 0:
-                raise RuntimeError("qtos_plan_batch_device (trot) failed: %d" % rc)
-        for i in range(2):
-            trot_step(i)
-        torch.cuda.synchronize(dev)
+                raise RuntimeError("qtos_plan_batch_device (%s) failed: %d" % (other, rc))
+        dev_sync = lambda: torch.cuda.synchronize(dev)
+        for i in range(args.warmup):
+            leg2_step()
+        dev_sync()
+        extra2 = settle(leg2_step, dev_sync, args.settle, args.settle_tol) if args.settle > 0 else 0
+        dev_sync()
         Pt.totals(reset=True)
-        tk_s, tk_n = 0.0, 0
+        leg2 = LegTimes()
         tt0 = time.perf_counter()
-        for i in range(args.trot_steps):
-            trot_step(2 + i)
-            tm = Pt.timing()
-            tk_s += tm["kkt_seconds"]
-            tk_n += tm["kkt_launches"]
-        torch.cuda.synchronize(dev)
+        for i in range(args.steps):
+            ts = time.perf_counter()
+            leg2_step()
+            leg2.add(Pt, time.perf_counter() - ts)
+        dev_sync()
         tel = time.perf_counter() - tt0
         tconv, titer = Pt.totals()
-        tavg = tk_s / max(tk_n, 1)
-        out["trot"] = {
-            "value": round(tconv / tel, 2), "unit": "plans/s", "steps": args.trot_steps, "ms_per_step": round(1e3 * tel / args.trot_steps, 4),
-            "timed_region_s": round(tel, 4), "plans_timed": B * args.trot_steps, "converged": int(tconv),
-            "iterations_mean": round(titer / max(B * args.trot_steps, 1), 3),
+        tavg = leg2.kkt_s / max(leg2.kkt_n, 1)
+        tag2 = "" if other == "walk" else "trot_"
+        out[other] = {
+            "value": round(tconv / tel, 2), "unit": "plans/s", "steps": args.steps, "warmup": args.warmup, "warmup_extra": extra2,
+            "ms_per_step": round(1e3 * tel / args.steps, 4),
+            "timed_region_s": round(tel, 4), "plans_timed": B * args.steps, "converged": int(tconv),
+            "iterations_mean": round(titer / max(B * args.steps, 1), 3),
             "kkt_unknowns": dt_.n_unknowns, "kkt_stages": dt_.n_stages, "front": dt_.front, "n_vars": dt_.n_vars,
-            "gait": "diagonal-pair trot (config.TROT_UNNORMALISED; not pinned by any reference artefact)",
+            "gait": "walk of the reference's golden plans (config.REFERENCE_WALK_UNNORMALISED: the gait the oracle is pinned on and the `parity` block re-solves)" if other == "walk"
+                    else "diagonal-pair trot (config.TROT_UNNORMALISED; not pinned by any reference artefact)",
             "roofline": {"kernel": kkt_kernel_name(Pt), "bound": "hbm", "achieved": round(B * dt_.kkt_algorithmic_bytes / tavg / 1e9, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(B * dt_.kkt_algorithmic_bytes / tavg / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                         "bytes_per_launch": float(B) * dt_.kkt_algorithmic_bytes, "avg_launch_ms": round(1e3 * tavg, 4), "launches": tk_n,
-                         "fp64_tflops": round(B * dt_.kkt_flops / tavg / 1e12, 3)},
+                         "bytes_per_launch": float(B) * dt_.kkt_algorithmic_bytes, "avg_launch_ms": round(1e3 * tavg, 4), "launches": leg2.kkt_n,
+                         "fp64_tflops": round(B * dt_.kkt_flops / tavg / 1e12, 3),
+                         "chord_avg_launch_ms": round(1e3 * leg2.chord_s / leg2.chord_n, 4) if leg2.chord_n else None},
         }
-        # HBM traffic and SQ counters of the trot's kernel from the committed PMC passes of `bench.py --gait trot` (separate
-        # rocprofv3 runs: profiles/rNN_trot_pmc_*.json, scratch/r5_trot_prof.sh)
-        ft = newest("r[0-9][0-9]_trot_pmc_hbm.json", kkt_kernel_name(Pt))
+        out[other].update(leg2.summary(tel))
+        # HBM traffic and SQ counters of this gait's kernel from the committed PMC passes of its own bench command (separate
+        # rocprofv3 runs: profiles/rNN_[trot_]pmc_*.json)
+        ft = newest("r[0-9][0-9]_%spmc_hbm.json" % tag2, kkt_kernel_name(Pt))
         if ft:
             try:
-                out["trot"]["roofline"]["traffic"] = json.load(open(ft))["k_kkt_traffic_bytes_per_launch"]["fetch_x2"]
-                out["trot"]["roofline"]["traffic_source"] = os.path.relpath(ft, ROOT)
+                out[other]["roofline"]["traffic"] = json.load(open(ft))["k_kkt_traffic_bytes_per_launch"]["fetch_x2"]
+                out[other]["roofline"]["traffic_source"] = os.path.relpath(ft, ROOT)
             except Exception:
                 pass
-        ft = newest("r[0-9][0-9]_trot_pmc_sq.json", kkt_kernel_name(Pt))
+        ft = newest("r[0-9][0-9]_%spmc_sq.json" % tag2, kkt_kernel_name(Pt))
         if ft:
             try:
-                out["trot"]["roofline"]["counters"] = dict(json.load(open(ft))["k_kkt"], source=os.path.relpath(ft, ROOT))
+                out[other]["roofline"]["counters"] = dict(json.load(open(ft))["k_kkt"], source=os.path.relpath(ft, ROOT))
             except Exception:
                 pass
         Pt.close()

@@ -167,12 +167,16 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
  * reference's pool of `docker exec ./main` workers pulling probes from a queue (QTOS/generateHeightField.py:344-352,
  * 375-377; scripts/main.py:49-50 for the single call):
  *
- *   qtos_plan_submit   queues the initial guess and the first Newton iteration(s), and returns at once (a problem's
+ *   qtos_plan_submit   queues the initial guess and the LAUNCH PATTERN of the handle -- per launch slot the solve kernels
+ *                      its last two calls both needed there (a flat walk or trot batch: factorisation x 3, chord solve,
+ *                      every time) -- and returns at once: the whole solve is in the queue, the host is not part of the
+ *                      Newton loop (round 6).  The first call of a handle queues its first iteration only.  A problem's
  *                      result is written to the output buffers by the kernel that finishes it -- converged, stalled,
- *                      failed or out of iterations --: there is no export step).  With qtos_set_speculation(n > 1) it queues as
- *                      many iterations as the previous call of this handle needed, up to n, without a host round
- *                      trip ("blind" iterations: both solve kernels are launched, the workgroups of problems that
- *                      are finished or belong to the other kernel leave at once).
+ *                      failed or out of iterations --: there is no export step.  A problem that finds the wrong solve
+ *                      kernel in a slot of the pattern sits that launch out and takes its step behind a later one: the
+ *                      plans are bit for bit those of the informed loop, whatever was queued.
+ *                      (qtos_set_speculation(n > 1), rounds 3 - 5: n "blind" iterations instead -- both solve kernels in
+ *                      every slot; switches the pattern off.)
  *   qtos_plan_poll     non-blocking: reads the counts of unfinished problems the iterations sent back; a batch that
  *                      needs more iterations gets them queued one by one (only the kernels with work);
  *                      *done = 1 once the counts say that every problem is finished (the results are then in the
@@ -181,20 +185,27 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
  *
  * qtos_plan_batch_device = submit + wait: it returns when the last iteration has reported that no problem is left; work
  * queued on `stream` afterwards sees the results, and so does the host after synchronising `stream`.  For a batch whose problems all finish within the blind
- * iterations (qtos_set_speculation; off by default) the host does nothing between the submit and the end.  One planner handle serves one call at a time (a second submit before the first is done returns -5);
+ * slots of the pattern the host does nothing between the submit and the end but wait for one word.  One planner handle serves one call at a time (a second submit before the first is done returns -5);
  * handles are independent: several handles on their own streams keep several batches in flight from ONE host thread
  * (qtos_amd.pool.PlannerPool: submit to a free handle, poll the others) -- a batch that waits for its slowest problem
  * then shares the GPU with the next ones.  This is the form bench.py times.
  *
- * Environment (read by qtos_planner_create; diagnostics and measured alternatives, defaults are the measured optimum):
+ * Environment.  Read ONCE, by qtos_planner_create (and by the host-only qtos_analyze* calls for themselves), in one place
+ * (csrc/env.hpp); the planner keeps what it found and qtos_env() hands it back.  Diagnostics and measured alternatives, the
+ * defaults are the measured optimum:
  *   QTOS_KKT=2 | 4 | 6       force the factor + solve kernel: k_kkt2 / k_kkt3 MODE 1 / k_kkt5 (default: k_kkt3 MODE 1 for fronts of up
  *                            to 112 slots, k_kkt2 above; see qtos_kkt_kernel below and DESIGN.md section 5).  3 and 5 (k_kkt3 MODE 0,
  *                            k_kkt4) exist in experiment builds only (qtos_build_flags bit 0) and mean "default" elsewhere
  *   QTOS_LANES=n             a call of more problems than the GPU has compute units is cut into up to n (<= 4) contiguous parts,
  *                            each with its own host-driven loop on a stream of the planner; bit-identical plans; default 1
  *                            (measured slower than one lock-step loop at 1024 problems per call)
- *   QTOS_SHORT_STAGES=1 | 0  stage boundaries by dynamic programming for every front size / never (unset: only where they take a
- *                            16-slot group off a front above 128 slots).  QTOS_NO_SHORT_STAGES=1 is the older spelling of 0
+ *   QTOS_SHORT_STAGES=1 | 0  stage boundaries by dynamic programming: 1 = for every front size even at 2 % more stages, 0 = never;
+ *                            unset = for fronts above 128 slots by that rule and for smaller fronts only where a 16-slot group
+ *                            comes off the front at NO extra stage (walk 128 -> 112 slots, trot 112 -> 96).
+ *                            QTOS_NO_SHORT_STAGES=1 is the older spelling of 0
+ *   QTOS_SPEC_PATTERN=0      qtos_plan_submit queues the first iteration only and the host reads the counts in front of every
+ *                            further one (default 1: the launch pattern below; qtos_set_pattern_speculation does the same per handle)
+ *   QTOS_PLACE=1..4          slot placement rule of the analysis (0 = the measured best: a group that hosts the stage's siblings)
  *   QTOS_KRON=1              experiment builds only (128-slot fronts, k_kkt2): the range-of-motion blocks are assembled through
  *                            their Kronecker structure -- 33 sums per block and one product of static weights per entry instead
  *                            of a three-term sum per entry; plans equal to rounding (1e-8), -0.4 % per launch
@@ -232,17 +243,28 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
                      int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream);
 int qtos_plan_poll(QtosPlanner *p, int *done);
 int qtos_plan_wait(QtosPlanner *p);
-/* Upper limit of the iterations qtos_plan_submit queues blind.  Default 1: the host looks at the counts in front of
- * every iteration but the first and launches only the kernels that have work (measured faster on every workload:
- * the gaps between dependent kernels of a stream are launch latency either way, and a blind iteration pays for
- * launches without work).  A larger limit buys a host that is free for the whole solve. */
+/* Rounds 3 - 5: upper limit of the iterations qtos_plan_submit queues "blind" -- BOTH solve kernels per iteration, as many
+ * iterations as the previous call needed (measured slower than the informed loop: a blind iteration pays for launches
+ * without work).  Default 1 = off; a limit above 1 replaces the launch pattern for this handle. */
 int qtos_set_speculation(QtosPlanner *p, int max_blind_iterations);
+/* The launch pattern of qtos_plan_submit (above) on / off for this handle (default on; off also forgets what was learnt:
+ * the next call queues its first iteration and the host reads the counts in front of every further launch, as in rounds 1 - 5). */
+int qtos_set_pattern_speculation(QtosPlanner *p, int on);
+/* The environment switches this handle runs with, as text ("QTOS_KKT=0 QTOS_LANES=1 ..."): at most n - 1 characters and a
+ * terminating zero into buf; returns the length of the full text.  Read once by qtos_planner_create (csrc/env.hpp). */
+int qtos_env(const QtosPlanner *p, char *buf, int n);
 
 /* Seconds spent in the KKT kernels / all kernels during the last qtos_plan_batch* call, from HIP
  * events on the launch stream (valid after the stream has been synchronised), and the number of
  * KKT launches.  Used by bench.py for the roofline figure. */
 int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, double *total_seconds,
                      int *iterations);
+/* Where the time of the last call went (same events, lane 0), seconds: out[0] first kernel -> end of the call, out[1] initial
+ * guess, out[2] solve kernels, out[3] line-search / linearisation kernels with their counts, out[4] GAPS (a slot's last event
+ * -> the next slot's first: the host reading the counts and launching; zero between slots queued at submit time), then counts:
+ * out[5] launch slots with work, out[6] slots queued at submit time, out[7] launches that waited for the host, out[8] calls of
+ * the handle that followed a launch pattern so far, out[9] of those, calls in which a problem sat a slot out.  n_out >= 10. */
+int qtos_last_timing_detail(QtosPlanner *p, double *out, int n_out);
 /* The same for the chord-step launches (k_chord, QtosParams.chord_tol) of the last call. */
 int qtos_last_timing_chord(QtosPlanner *p, double *chord_seconds, int *chord_launches);
 /* Running totals over all qtos_plan_batch* calls of the handle since the last reset: problems returned with
@@ -300,7 +322,7 @@ int qtos_debug_trace(QtosPlanner *p, int b, double *trace_out);
  * the Kronecker assembly: -DQTOS_EXPERIMENTS, scratch/build.sh), bit 1 = per-wave cycle stamps (-DQTOS_STAMPS),
  * bit 2 = a development build with the benchmark's fronts only (-DQTOS_DEV_F128).  The product library returns 0. */
 int qtos_build_flags(void);
-/* The factor + solve kernel qtos_planner_create selected for this planner, e.g. "k_kkt2<128>", "k_kkt3<112,1>",
+/* The factor + solve kernel qtos_planner_create selected for this planner, e.g. "k_kkt2<128>", "k_kkt3<112, 1>",
  * "k_kkt5<128>" (the name rocprofv3 lists it under, without the namespace and the trailing template defaults): at most
  * n - 1 characters and a terminating zero into buf; returns the length of the full name.
  * Selection (environment variable QTOS_KKT, read at creation): unset = k_kkt3 MODE 1 for fronts of at most 112 slots,

@@ -62,6 +62,7 @@ EXPORTS = [
     "qtos_last_timing_chord", "qtos_debug_chord", "qtos_plan_totals",
     "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation", "qtos_debug_residual", "qtos_project_nodes",
     "qtos_debug_stream_len", "qtos_debug_read_stream", "qtos_debug_read_rhs", "qtos_build_flags", "qtos_kkt_kernel",
+    "qtos_last_timing_detail", "qtos_set_pattern_speculation", "qtos_env",
 ]
 
 _lib = None
@@ -128,6 +129,10 @@ def load():
         lib.qtos_plan_poll.argtypes = [vp, ip]
         lib.qtos_plan_wait.argtypes = [vp]
         lib.qtos_set_speculation.argtypes = [vp, C.c_int]
+    if hasattr(lib, "qtos_last_timing_detail"):   # (round 6)
+        lib.qtos_last_timing_detail.argtypes = [vp, dp, C.c_int]
+        lib.qtos_set_pattern_speculation.argtypes = [vp, C.c_int]
+        lib.qtos_env.argtypes = [vp, C.c_char_p, C.c_int]
     if hasattr(lib, "qtos_shift_warm"):   # (absent from older builds loaded through QTOS_LIB for A/B timing)
         lib.qtos_shift_warm.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, dp]
         lib.qtos_shift_warm_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
@@ -311,6 +316,24 @@ class Planner:
 
     def set_speculation(self, max_blind_iterations):
         self._chk(self.lib.qtos_set_speculation(self.h, int(max_blind_iterations)), "set_speculation")
+
+    def set_pattern_speculation(self, on):
+        """The launch pattern of qtos_plan_submit on / off (off forgets what was learnt)."""
+        self._chk(self.lib.qtos_set_pattern_speculation(self.h, int(bool(on))), "set_pattern_speculation")
+
+    def env(self):
+        """The environment switches the handle runs with (read once at creation), as a dict of strings."""
+        buf = C.create_string_buffer(512)
+        self._chk(min(self.lib.qtos_env(self.h, buf, 512), 0), "env")
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split())
+
+    def timing_detail(self):
+        """Where the time of the last call went (qtos_last_timing_detail): seconds and launch counts."""
+        a = (C.c_double * 10)()
+        self._chk(self.lib.qtos_last_timing_detail(self.h, a, 10), "last_timing_detail")
+        keys = ("total_seconds", "start_seconds", "solve_seconds", "step_seconds", "gap_seconds", "slots", "slots_at_submit",
+                "informed_launches", "pattern_calls", "pattern_misses")
+        return {k: (a[i] if i < 5 else int(a[i])) for i, k in enumerate(keys)}
 
     def sample(self, nodes, t0, hz=1000.0, n_rows=None):
         nodes = np.ascontiguousarray(nodes, np.float64).reshape(-1, self.n)

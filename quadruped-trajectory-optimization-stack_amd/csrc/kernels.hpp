@@ -151,7 +151,8 @@ struct DevWork {
   double *best_viol, *xbest;   // stall detection: lowest violation seen and the iterate that had it
   int *held;                   // two-phase solve: 1 once the problem's footholds are held
   int *best_it;
-  int *status, *iters, *done, *n_active;   // n_active[0]: unfinished problems, n_active[1]: of those, flagged for a chord step
+  int *status, *iters, *done, *n_active;   // n_active[0]: unfinished problems, [1]: of those, flagged for a chord step, [2]: (1 << 20) - the earliest launch slot a
+                                           // problem sat out (k_step; 0 = none), [3]: launch slots of the call in which some problem took a step
   int *chord;                  // per problem: the next KKT solve reuses the stored factorisation (k_chord)
   int *chord_run;              // per problem: chord steps taken with the stored factorisation
   int *jam;                    // per problem: steps in a row shorter than stall_alpha
@@ -934,20 +935,20 @@ __global__ __launch_bounds__(ET) void k_start(DevPlan P, DevWork W, int B) {
     W.viol[b] = viol;
     W.iters[b] = 0;
     W.status[b] = conv ? 0 : (bad ? 2 : 1);
-    W.done[b] = (conv || bad) ? 1 : 0;
+    W.done[b] = (conv || bad || P.max_iter <= 0) ? 1 : 0;   // (done = nothing left to launch for: the host stops on the count alone)
     W.best_viol[b] = viol;
     W.best_it[b] = 0;
     W.held[b] = 0;
     W.chord[b] = 0;
     W.chord_run[b] = 0;
     W.jam[b] = 0;
-    if (!conv && !bad) atomicAdd(W.n_active, 1);
+    if (!conv && !bad && P.max_iter > 0) atomicAdd(W.n_active, 1);
     record_trace(P, W, b, 0, viol, theta, 0.0, mu);
   }
   if (conv || bad || P.max_iter <= 0) {
     __syncthreads();   // (x of the other threads)
     export_problem(P, W, b, x, conv ? 0 : (bad ? 2 : 1), 0, viol);
-    if (conv || bad) return;
+    return;
   }
   __syncthreads();
   barrier_terms(P, g, s, zl, zu, mu, W.sig + (size_t)b * m, W.w + (size_t)b * m, W.stream + (size_t)b * P.stream_len);
@@ -1204,9 +1205,15 @@ __device__ __forceinline__ double quadsum(double t) {
 }
 
 // =================================================================================================
-__global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it) {
+// slot: the number of this launch within its call; kinds: the solve kernels launched in front of it (bit 0 the factorising
+// kernel, bit 1 k_chord).  A launch queued from a PATTERN (qtos_plan_submit: the kernels the handle's last calls needed, without
+// a look at the counts) may not have run the kernel a problem was waiting for: that problem sits the launch out -- nothing of
+// its state moves, it reports the slot in n_active[2] -- and takes the step behind a later launch.  Its iteration number is
+// therefore its own (W.iters), not the launch's: the plans do not depend on how the launches were queued.
+__global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int slot, int kinds) {
   const int b = blockIdx.x;
   if (b >= B) return;
+  const int it = W.iters[b];
   // (a finished problem leaves behind the first barrier, not here: the test of its flag is a memory round trip, and everything
   //  the kernel reads first would queue behind it)
   const int done_flag = W.done[b];
@@ -1225,6 +1232,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   const int best_it = W.best_it[b];
   const int chord_state = W.chord[b];        // 1: this iteration's dx came from a chord step; 2: chord steps are off for this solve
   const bool was_chord = chord_state == 1;
+  const bool missed = !((was_chord ? 2 : 1) & kinds);   // the solve this problem waits for was not part of the launch
   const int chord_run = W.chord_run[b];
   const int jam_prev = W.jam[b];
   const double prev_viol = W.viol[b];        // violation in front of this step
@@ -1302,6 +1310,10 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
   for (int k = 0; k < KE; ++k) eg[k] = g[er[k]];
   lds_barrier();   // (LDS only: the loads of the thread's rows stay in flight across it)
   if (done_flag) return;
+  if (missed) {
+    if (tid == 0) atomicMax(W.n_active + 2, (1 << 20) - slot);   // (the EARLIEST slot somebody sat out; 0 = nobody)
+    return;
+  }
   if (P.n_rec) {
     for (int i0 = tid;;) {
 #pragma unroll
@@ -1552,12 +1564,13 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     W.jam[b] = jam;
     if (improved) { W.best_viol[b] = viol; W.best_it[b] = it + 1; }
     record_trace(P, W, b, it + 1, viol, theta, al, mu);
-    if (conv || bad || stalled) {
-      W.status[b] = conv ? 0 : (bad ? 2 : 1);
+    if (conv || bad || stalled) W.status[b] = conv ? 0 : (bad ? 2 : 1);
+    if (conv || bad || stalled || it + 1 >= P.max_iter) {   // (out of iterations: the status k_start gave, 1)
       W.done[b] = 1;
       W.chord[b] = 0;
       atomicAdd(W.n_active, -1);
     }
+    atomicMax(W.n_active + 3, slot + 1);   // launches of the call that had work
   }
   // finished, or out of iterations: the result leaves now (x as restored above; a problem out of iterations keeps the status
   // k_start gave it: 1)
@@ -1565,7 +1578,7 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int it
     __syncthreads();
     export_problem(P, W, b, x, conv ? 0 : (bad ? 2 : 1), it + 1, restore ? (improved ? viol : best_viol) : viol);
   }
-  if (conv || bad || stalled) return;
+  if (conv || bad || stalled || it + 1 >= P.max_iter) return;
   // chord step next?  (an iterate this close, reached by a full step of a freshly factored system)
   // (one discarded chord step and the solve factors every iteration from then on: near a terrain edge the attempt
   //  fails again and again, and every failure is an iteration the whole batch waits for)

@@ -55,14 +55,17 @@ struct QtosPlanner {
   struct Lane {
     bool open = false;
     int B = 0, b0 = 0, spec = 0, enq = 0, chk = 0;   // problems, first problem; iterations queued blind / queued in all / whose preceding counts have been read
+    int n_informed = 0;                      // launches of the call that waited for the host to read the counts
+    bool by_pattern = false;                 // the blind slots of this call follow the handle's launch pattern (counts behind the last one only)
     unsigned spins = 0;                      // polls that found no counts yet
     hipStream_t st = nullptr;                // where this lane's kernels go in the call in flight
     hipStream_t own = nullptr, side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
     DevWork W;
-    int *h_active = nullptr;      // pinned + mapped, two words per Newton iteration: unfinished problems after it, of those flagged for a chord step
+    int *h_active = nullptr;      // pinned + mapped, four words per launch slot: {unfinished problems behind it, of those flagged for a chord step, sequence number}
+                                  // packed into the first two, then the code of the earliest slot a problem sat out and the slots that had work
     int *h_active_dev = nullptr;  // the same memory as the device sees it (k_post_counts stores there: no copy engine between two kernels)
-    int *d_n_active = nullptr;    // the lane's two device counters
+    int *d_n_active = nullptr;    // the lane's four device counters (DevWork::n_active)
     std::vector<hipEvent_t> ev;   // 5 per iteration (kkt begin / end, chord begin / end, counts posted) + 3
     std::vector<char> was_kkt, was_chord;   // per iteration of the last call: which solve kernels were launched
     int last_launches = 0, last_iters = 0;
@@ -78,9 +81,18 @@ struct QtosPlanner {
   int kkt3_mode = 0;                 // k_kkt3's MODE (QTOS_KKT=3: 0, QTOS_KKT=4: 1)
   bool use_kkt4 = false;             // k_kkt4 (kkt4.hpp), QTOS_KKT=5
   bool use_kkt5 = false;             // k_kkt5 (kkt5.hpp): two stages per set of barriers, Symbolic::pair_mode
-  bool counts_by_copy = false;       // the counts of unfinished problems reach the host by hipMemcpyAsync instead of k_post_counts (QTOS_COUNTS_COPY=1)
+  QtosEnv env;                       // the environment as qtos_planner_create found it (env.hpp; qtos_env reports it)
   int spec_next = 1;                 // blind iterations of the next call: the iterations the last one took
-  int spec_cap = 1;                  // limit of the blind iterations (qtos_set_speculation): 1 = off, the measured optimum
+  int spec_cap = 1;                  // limit of the blind iterations (qtos_set_speculation): 1 = off
+  // Launch pattern (round 6): the solve kernels every launch slot of the handle's last two calls needed (bit 0 the
+  // factorising kernel, bit 1 k_chord), as far as the two agree -- the walk's and the trot's batches take kkt, kkt, kkt, chord
+  // every time.  qtos_plan_submit queues that prefix at once, without a look at the counts; the counts behind its last slot
+  // say whether anything is left (qtos_plan_poll goes on informed) and whether a problem found the wrong kernel (it sat the
+  // launch out, kernels.hpp k_step: the pattern is cut in front of that slot).
+  bool spec_pattern = true;
+  std::vector<char> pat, obs_prev;   // the prefix queued blind by the next call; the kinds the last call's slots ran
+  int max_slots = 0;                 // launch slots a call may use (iterations + launches a problem sat out)
+  long long n_pattern_calls = 0, n_pattern_misses = 0;
   std::atomic<int> busy{0};
   size_t kkt_lds = 0, eval_lds = 0;
   void (*chord_fn)(DevPlan, DevWork, int) = nullptr; // k_chord instantiated for this front size (null: chord steps off)
@@ -272,7 +284,7 @@ static int build_sweep_tasks(const HostModel &M, const Symbolic &S, std::vector<
   while (step < nstep) round_of(nullptr, 0);
   if (cpos.empty()) cpos.push_back(0);
   while (c16.size() < 20) c16.push_back(0);
-  if (getenv("QTOS_DEBUG_SYMBOLIC")) {
+  if (S.env.debug) {
     size_t mx = 0, tot = 0;
     for (auto &v : by_stage) { mx = std::max(mx, v.size()); tot += v.size(); }
     fprintf(stderr, "qtos: sweep ds: %d rounds for %d stages (chain %d steps), %zu rows, most in a stage %zu; rows by stage:", step, NS, nstep, tot, mx);
@@ -300,9 +312,11 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   // QTOS_KKT=2 / 3 / 4 force k_kkt2 / MODE 0 / MODE 1.
   p->use_kkt3 = false;
   p->use_kkt5 = false;
+  p->env = QtosEnv::parse();   // the ONE place a planner reads the environment
+  const QtosEnv &env = p->env;
+  p->spec_pattern = env.spec_pattern != 0;
   {
-    const char *e = getenv("QTOS_KKT");
-    int forced = e ? atoi(e) : 0;
+    int forced = env.kkt;
 #ifndef QTOS_EXPERIMENTS
     if (forced == 3 || forced == 5) { fprintf(stderr, "qtos: QTOS_KKT=%d selects an experiment that this build does not contain (scratch/build.sh -DQTOS_EXPERIMENTS): default kernel\n", forced); forced = 0; }
 #endif
@@ -311,6 +325,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
       // front of at most 144 slots and everything within the LDS
       p->M = HostModel();
       p->S = Symbolic();
+      p->S.env = env;
       if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
       p->S.cell_mode = 2;
       p->S.pair_mode = true;
@@ -321,13 +336,14 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
         ok = n_cont == 0 && kkt5_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) <= 160 * 1024 - 256;
       }
       p->use_kkt5 = ok;
-      if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: k_kkt5 %s (front %d, %s)\n", ok ? "selected" : "not applicable", p->S.front, p->S.err.c_str());
+      if (env.debug) fprintf(stderr, "qtos: k_kkt5 %s (front %d, %s)\n", ok ? "selected" : "not applicable", p->S.front, p->S.err.c_str());
     }
     p->kkt3_mode = forced == 3 ? 0 : 1;
     p->use_kkt4 = false;
     if (forced != 2 && !p->use_kkt5) {
       p->M = HostModel();
       p->S = Symbolic();
+      p->S.env = env;
       if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
       p->S.cell_mode = 2;
       p->S.iq_mfma = p->kkt3_mode == 0;
@@ -349,11 +365,11 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
       }
 #endif
       p->use_kkt3 = ok;
-      if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: k_kkt3 MODE %d %s (%s)\n", p->kkt3_mode, ok ? "selected" : "not applicable", p->S.err.c_str());
+      if (env.debug) fprintf(stderr, "qtos: k_kkt3 MODE %d %s (%s)\n", p->kkt3_mode, ok ? "selected" : "not applicable", p->S.err.c_str());
     }
   }
 #ifdef QTOS_EXPERIMENTS
-  bool want_kron = getenv("QTOS_KRON") && atoi(getenv("QTOS_KRON")) != 0;   // (experiment: Kronecker assembly of the range-of-motion blocks, k_kkt2<128> only)
+  bool want_kron = env.kron != 0;   // (experiment: Kronecker assembly of the range-of-motion blocks, k_kkt2<128> only)
 #else
   bool want_kron = false;
 #endif
@@ -361,6 +377,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     if (p->use_kkt3 || p->use_kkt5) break;
     p->M = HostModel();
     p->S = Symbolic();
+    p->S.env = env;
     if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
     p->S.cell_mode = 2;
     p->S.rec_cap_ints = cap;
@@ -372,9 +389,10 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
       for (int k = 0; k < p->S.n_stages; ++k) n_cont += p->S.srec[p->S.srec_off[k] + 6];
       const size_t need = kkt2_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) + 16 + sizeof(double) * Symbolic::KRON_SM * (size_t)p->S.max_kblocks;
       if (p->S.front != 128 || n_cont != 0 || p->S.max_kblocks == 0 || need > 160 * 1024 - 256) {
-        if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: Kronecker assembly not applicable (front %d, %d continuation records, %zu B of LDS)\n", p->S.front, n_cont, need);
+        if (env.debug) fprintf(stderr, "qtos: Kronecker assembly not applicable (front %d, %d continuation records, %zu B of LDS)\n", p->S.front, n_cont, need);
         want_kron = false;
         p->M = HostModel(); p->S = Symbolic();
+        p->S.env = env;
         if (p->M.build(*params)) { delete p; return -1; }
         p->S.cell_mode = 2; p->S.rec_cap_ints = cap;
         if (p->S.build(p->M)) { delete p; return -1; }
@@ -512,7 +530,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     }
     TRY(p->upload(td, &D.terr));
     D.hold_from = M.P.hold_from;
-    { const char *e = getenv("QTOS_SPEC_JAC"); D.spec_jac = e ? atoi(e) : 1; }
+    D.spec_jac = env.spec_jac;
     D.hold_weight = M.P.hold_weight > 0 ? M.P.hold_weight : 1e6;
     D.hold_tol = M.P.hold_tol;
   }
@@ -530,8 +548,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     std::vector<int> cpos, c16;
     D.sw_steps = build_sweep_tasks(M, S, tasks, cpos, c16);
     const bool ok = D.sw_steps > 0;
-    const char *e = getenv("QTOS_SWEEP_DS");
-    D.sw_on = ok && D.n_iq_rows > 0 && S.front / PIV < SW_W0 && (e ? atoi(e) != 0 : true);   // (waves 13 .. 15 must be without rows)
+    D.sw_on = ok && D.n_iq_rows > 0 && S.front / PIV < SW_W0 && env.sweep_ds != 0;   // (waves 13 .. 15 must be without rows)
     TRY(p->upload(tasks, &D.sw_tasks)); TRY(p->upload(cpos, &D.sw_cpos)); TRY(p->upload(c16, &D.sw_c16));
   }
   {
@@ -577,7 +594,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   const int F = S.front;
   p->kkt_lds = p->use_kkt5 ? kkt5_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : p->use_kkt4 ? kkt4_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : p->use_kkt3 ? kkt3_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
   D.kron_lds_off = 0;
-  if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: Kronecker assembly %s (kkt3 %d, most blocks in a record %d)\n", S.kron ? "on" : "off", (int)p->use_kkt3, S.max_kblocks);
+  if (env.debug) fprintf(stderr, "qtos: Kronecker assembly %s (kkt3 %d, most blocks in a record %d)\n", S.kron ? "on" : "off", (int)p->use_kkt3, S.max_kblocks);
   if (S.kron && !p->use_kkt3 && !p->use_kkt4) {
     D.kron_lds_off = (int)((p->kkt_lds + 15) & ~(size_t)15);
     p->kkt_lds = (size_t)D.kron_lds_off + sizeof(double) * Symbolic::KRON_SM * (size_t)S.max_kblocks;
@@ -598,7 +615,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     qtos_planner_destroy(p);
     return -4;
   }
-  if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: front %d, k_kkt LDS %zu B\n", F, p->kkt_lds);
+  if (env.debug) fprintf(stderr, "qtos: front %d, k_kkt LDS %zu B\n", F, p->kkt_lds);
   if (p->kkt_lds > 160 * 1024 - 256) {
     p->err = "front too large for LDS";
     fprintf(stderr, "qtos: front %d needs %zu B of LDS\n", F, p->kkt_lds);
@@ -668,7 +685,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
 #endif
   TRY(p->alloc(&W.trace, Bm * (size_t)(M.P.max_iter + 1) * 4));
   TRY(p->alloc(&W.status, Bm)); TRY(p->alloc(&W.iters, Bm)); TRY(p->alloc(&W.done, Bm));
-  TRY(p->alloc(&W.n_active, 2 * 4));   // two counters per lane
+  TRY(p->alloc(&W.n_active, 4 * 4));   // four counters per lane
   TRY(p->alloc(&W.chord, Bm));
   TRY(p->alloc(&W.chord_run, Bm));
   TRY(p->alloc(&W.jam, Bm));
@@ -681,8 +698,8 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   if (hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
   if (hipMalloc(&p->d_totals, 2 * sizeof(long long)) != hipSuccess || hipMemset(p->d_totals, 0, 2 * sizeof(long long)) != hipSuccess) { qtos_planner_destroy(p); return -3; }
   p->last_stream = p->own_stream;
-  if (const char *e = getenv("QTOS_SPEC_CAP")) p->spec_cap = std::max(0, atoi(e));
-  if (const char *e = getenv("QTOS_COUNTS_COPY")) p->counts_by_copy = atoi(e) != 0;   // (diagnostic: limit of the blind iterations)
+  // launch slots of a call: its iterations plus the launches some problem sat out (at most one per blind slot)
+  p->max_slots = 2 * M.P.max_iter + 2;
   {  // lanes: one per part of a call that is larger than the GPU -- QTOS_LANES: at most that many; default ONE: measured at 1024
      // problems per call (round 4, profiles/r04_lanes.txt), parts that start together also reach their stragglers together, and
      // four lock-step loops of 256 pay four tails where one loop of 1024 pays one (exp_5 75.8 K plans/s on four lanes, 84.0 K
@@ -690,23 +707,22 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     p->lane_chunk = cus;
-    int want = 1;
-    if (const char *e = getenv("QTOS_LANES")) want = std::max(1, std::min(4, atoi(e)));
+    const int want = env.lanes;
     const int n_lanes = std::max(1, std::min(want, (max_batch + cus - 1) / cus));
     p->lanes.resize(n_lanes);
     if (hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming) != hipSuccess) { qtos_planner_destroy(p); return -2; }
     for (int j = 0; j < n_lanes; ++j) {
       QtosPlanner::Lane &L = p->lanes[j];
-      if (hipHostMalloc((void **)&L.h_active, 2 * sizeof(int) * ((size_t)M.P.max_iter + 1), hipHostMallocMapped) != hipSuccess) { qtos_planner_destroy(p); return -3; }
+      if (hipHostMalloc((void **)&L.h_active, 4 * sizeof(int) * ((size_t)p->max_slots + 1), hipHostMallocMapped) != hipSuccess) { qtos_planner_destroy(p); return -3; }
       if (hipHostGetDevicePointer((void **)&L.h_active_dev, L.h_active, 0) != hipSuccess) { qtos_planner_destroy(p); return -2; }
-      L.was_kkt.assign(M.P.max_iter + 1, 0);
-      L.was_chord.assign(M.P.max_iter + 1, 0);
-      L.d_n_active = W.n_active + 2 * j;
+      L.was_kkt.assign(p->max_slots + 1, 0);
+      L.was_chord.assign(p->max_slots + 1, 0);
+      L.d_n_active = W.n_active + 4 * j;
       if (j > 0 && hipStreamCreateWithFlags(&L.own, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
       if (hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking) != hipSuccess) { qtos_planner_destroy(p); return -2; }
       if (hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess) { qtos_planner_destroy(p); return -2; }
-      L.ev.resize(5 * (size_t)M.P.max_iter + 3);
+      L.ev.resize(5 * (size_t)p->max_slots + 3);
       for (auto &e : L.ev)
         if (hipEventCreate(&e) != hipSuccess) { qtos_planner_destroy(p); return -2; }
     }
@@ -752,10 +768,11 @@ int qtos_analyze(const QtosParams *params, QtosDims *d, int *stage_active, int m
   if (!params || !d) return -1;
   HostModel M;
   Symbolic S;
+  S.env = QtosEnv::parse();
   if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
-  if (getenv("QTOS_DEBUG_KRON")) S.kron = true;
+  if (S.env.debug_kron) S.kron = true;
   if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
-  if (getenv("QTOS_DEBUG_KRON")) {
+  if (S.env.debug_kron) {
     int nb = 0;
     const double worst = S.check_kron(&nb);
     size_t tot = 0;
@@ -763,7 +780,7 @@ int qtos_analyze(const QtosParams *params, QtosDims *d, int *stage_active, int m
     fprintf(stderr, "qtos: Kronecker blocks %d of %zu inequality blocks, most in a record %d, worst relative difference %.2e, max record %d ints / %d doubles\n", nb, tot, S.max_kblocks, worst, S.max_srec, S.max_drec);
   }
   fill_dims(M, S, d);
-  if (getenv("QTOS_DEBUG_SYMBOLIC")) { std::vector<SwTask> t; std::vector<int> c, c2; (void)build_sweep_tasks(M, S, t, c, c2); }
+  if (S.env.debug) { std::vector<SwTask> t; std::vector<int> c, c2; (void)build_sweep_tasks(M, S, t, c, c2); }
   if (stage_active)
     for (int k = 0; k < S.n_stages && k < max_stages; ++k) stage_active[k] = S.stages[k].n_active;
   return 0;
@@ -776,6 +793,7 @@ int qtos_analyze_kron(const QtosParams *params, int *n_blocks, int *n_kron, int 
   if (!params || !n_blocks || !n_kron || !max_in_record || !worst) return -1;
   HostModel M;
   Symbolic S;
+  S.env = QtosEnv::parse();
   if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
   S.kron = true;
   if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
@@ -793,6 +811,7 @@ int qtos_analyze_sweep(const QtosParams *params, int *n_rounds, int *rows, int *
   if (!params || !n_rounds) return -1;
   HostModel M;
   Symbolic S;
+  S.env = QtosEnv::parse();
   if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
   if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
   std::vector<SwTask> tasks;
@@ -850,8 +869,12 @@ int qtos_set_heightfields(QtosPlanner *p, int n_maps, const double *height, int 
 // still store into their slots AFTER the next call of the handle has reset them (qtos_plan_submit), and a word of another
 // call must read as "no counts yet", not as "nothing left to do" (24 bits per count: qtos_planner_create limits max_batch).
 __global__ void k_post_counts(const int *n_active, int *host_slot, unsigned seq) {
-  // both counts in ONE eight-byte store: the host spins on the slot (qtos_plan_poll) and must never see half of it
+  // the two diagnostics first (earliest launch slot a problem sat out, launch slots with work), then both counts in ONE
+  // eight-byte store: the host spins on that word (qtos_plan_poll) and must never see half of it
   if (threadIdx.x == 0) {
+    const unsigned long long d = (unsigned long long)(unsigned)n_active[2] | ((unsigned long long)(unsigned)n_active[3] << 32);
+    *(volatile unsigned long long *)(host_slot + 2) = d;
+    __threadfence_system();
     const unsigned long long v = (unsigned long long)((unsigned)n_active[0] & 0xffffffu) | ((unsigned long long)((unsigned)n_active[1] & 0xffffffu) << 24) |
                                  ((unsigned long long)(seq & 0xffffu) << 48);
     *(volatile unsigned long long *)host_slot = v;
@@ -859,18 +882,21 @@ __global__ void k_post_counts(const int *n_active, int *host_slot, unsigned seq)
   __threadfence_system();
 }
 
-// One Newton iteration of the call in flight, queued on its stream.  informed: the counts of unfinished problems (n) and of
-// problems flagged for a chord step (nc) before this iteration are known -- only the kernels with work are launched, and
-// next to a factorisation of other problems the chord solve runs on the side stream (the workgroups of k_kkt2 that belong
-// to its problems leave at once and k_chord gets their CUs: the batch pays max(k_kkt2, k_chord), not the sum).  Blind
-// (queued before the counts of the preceding iteration have come back): both solve kernels are launched, each leaves at
-// once for the problems that are not its own (a launch whose workgroups all leave costs a few microseconds).
-static int queue_iteration(QtosPlanner *p, QtosPlanner::Lane &c, int it, bool informed, int n, int nc) {
+// One launch slot of the call in flight, queued on its stream: the solve kernels named by `kinds` (bit 0 the factorising
+// kernel, bit 1 k_chord), then k_step, then (post) the counts to the host.
+//   informed  the counts of unfinished problems (n) and of problems flagged for a chord step (nc) in front of the slot are
+//             known: kinds = the kernels with work; next to a factorisation of other problems the chord solve runs on the
+//             side stream (the workgroups of the factorising kernel that belong to its problems leave at once and k_chord
+//             gets their CUs: the batch pays max(k_kkt, k_chord), not the sum).
+//   pattern   kinds = what this slot of the handle's last calls needed (QtosPlanner::pat), queued before any count of this
+//             call has come back; a problem that waits for the other kernel sits the launch out (k_step).
+//   blind     both kernels (qtos_set_speculation; each leaves at once for the problems that are not its own).
+static int queue_iteration(QtosPlanner *p, QtosPlanner::Lane &c, int it, int kinds, bool post) {
   const DevPlan &D = p->dp;
   hipStream_t st = c.st;
-  const bool do_kkt = informed ? n - nc > 0 : true;
-  const bool do_chord = p->chord_fn && (informed ? nc > 0 : it >= 1);
-  c.was_kkt[it] = do_kkt;       // (blind iterations: corrected once their counts are known)
+  if (!p->chord_fn) kinds &= 1;
+  const bool do_kkt = kinds & 1, do_chord = (kinds & 2) != 0;
+  c.was_kkt[it] = do_kkt;
   c.was_chord[it] = do_chord;
   const bool fork = do_kkt && do_chord;
   hipStream_t cs = fork ? c.side : st;
@@ -892,9 +918,8 @@ static int queue_iteration(QtosPlanner *p, QtosPlanner::Lane &c, int it, bool in
     HIPCHK(p, hipEventRecord(c.ev_join, cs));
     HIPCHK(p, hipStreamWaitEvent(st, c.ev_join, 0));
   }
-  hipLaunchKernelGGL(k_step, dim3(c.B), dim3(ET), p->eval_lds, st, D, c.W, c.B, it);
-  if (p->counts_by_copy) HIPCHK(p, hipMemcpyAsync(c.h_active + 2 * it, c.W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, c.h_active_dev + 2 * it, p->seq);
+  hipLaunchKernelGGL(k_step, dim3(c.B), dim3(ET), p->eval_lds, st, D, c.W, c.B, it, kinds);
+  if (post) hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, c.h_active_dev + 4 * it, p->seq);
   HIPCHK(p, hipEventRecord(c.ev[6 + 5 * it], st));
   return 0;
 }
@@ -946,28 +971,40 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
   const int per = (B + n_used - 1) / n_used;
   p->lanes_used = n_used;
   if (n_used > 1) SUBCHK(hipEventRecord(p->ev_in, st));
-  const int ev_start = 2 + 5 * D.max_iter;
+  const int ev_start = 2 + 5 * p->max_slots;
+  // the launch pattern serves calls of one lane (a call cut into lanes keeps the informed loop per lane)
+  const bool by_pattern = p->spec_pattern && n_used == 1 && !p->pat.empty() && p->spec_cap <= 1;
+  if (by_pattern) p->n_pattern_calls++;
   for (int j = 0; j < n_used; ++j) {
     QtosPlanner::Lane &c = p->lanes[j];
-    c.open = true; c.b0 = j * per; c.B = std::min(per, B - c.b0); c.spec = c.enq = c.chk = 0; c.spins = 0;
+    c.open = true; c.b0 = j * per; c.B = std::min(per, B - c.b0); c.spec = c.enq = c.chk = 0; c.spins = 0; c.n_informed = 0;
+    c.by_pattern = by_pattern;
     c.st = j == 0 ? st : c.own;
     c.W = work_slice(p, W, c.b0, c.d_n_active);
     if (j > 0) SUBCHK(hipStreamWaitEvent(c.st, p->ev_in, 0));
-    std::memset(c.h_active, 0xff, 2 * sizeof(int) * ((size_t)D.max_iter + 1));   // no counts yet (late stores of an earlier call carry another sequence number)
-    SUBCHK(hipMemsetAsync(c.W.n_active, 0, 2 * sizeof(int), c.st));
+    std::memset(c.h_active, 0xff, 4 * sizeof(int) * ((size_t)p->max_slots + 1));   // no counts yet (late stores of an earlier call carry another sequence number)
+    SUBCHK(hipMemsetAsync(c.W.n_active, 0, 4 * sizeof(int), c.st));
     SUBCHK(hipEventRecord(c.ev[0], c.st));
     hipLaunchKernelGGL(k_start, dim3(c.B), dim3(ET), p->eval_lds, c.st, D, c.W, c.B);
-    // counts after k_start (slot max_iter of the pinned array), event ev_start
-    if (p->counts_by_copy) SUBCHK(hipMemcpyAsync(c.h_active + 2 * D.max_iter, c.W.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, c.st));
-    else hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, c.st, c.W.n_active, c.h_active_dev + 2 * D.max_iter, p->seq);
+    // counts after k_start (slot max_slots of the pinned array), event ev_start; a call that follows the pattern reads no
+    // counts in front of the pattern's last slot and posts none
+    if (!by_pattern) hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, c.st, c.W.n_active, c.h_active_dev + 4 * p->max_slots, p->seq);
     SUBCHK(hipEventRecord(c.ev[ev_start], c.st));
-    // Blind iterations: as many as the previous call of this handle needed (its slowest problem), queued without a host
-    // round trip (qtos_set_speculation; 1 by default: the first iteration).  A batch that needs more is continued by
-    // qtos_plan_poll from the counts the iterations send back; blind launches behind the end find every problem done.
-    c.spec = std::max(0, std::min(std::min(p->spec_next, p->spec_cap), D.max_iter));
-    for (int it = 0; it < c.spec; ++it)
-      if (int rc = queue_iteration(p, c, it, false, 0, 0)) return fail(rc);
-    c.enq = c.spec;
+    if (by_pattern) {
+      // the prefix of launch slots the handle's last two calls agree on, queued at once
+      c.spec = std::min((int)p->pat.size(), p->max_slots);
+      for (int it = 0; it < c.spec; ++it)
+        if (int rc = queue_iteration(p, c, it, p->pat[it], it + 1 == c.spec)) return fail(rc);
+      c.enq = c.chk = c.spec;     // (the first counts the host reads are those behind slot spec - 1)
+    } else {
+      // Blind iterations: as many as the previous call of this handle needed (its slowest problem), queued without a host
+      // round trip (qtos_set_speculation; 1 by default: the first iteration).  A batch that needs more is continued by
+      // qtos_plan_poll from the counts the iterations send back; blind launches behind the end find every problem done.
+      c.spec = std::max(0, std::min(std::min(p->spec_next, p->spec_cap), D.max_iter));
+      for (int it = 0; it < c.spec; ++it)
+        if (int rc = queue_iteration(p, c, it, it >= 1 ? 3 : 1, true)) return fail(rc);
+      c.enq = c.spec;
+    }
   }
 #undef SUBCHK
   if (n_used == 1 && hipEventRecord(p->lanes[0].ev[1], st) != hipSuccess) return fail(-2);
@@ -977,51 +1014,45 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
 
 // One lane as far as the counts that have arrived allow.  *lane_done: every problem of the part has handed its result over.
 static int advance_lane(QtosPlanner *p, QtosPlanner::Lane &c, bool *lane_done, bool *device_set) {
-  const DevPlan &D = p->dp;
-  const int ev_start = 2 + 5 * D.max_iter;
   *lane_done = false;
   for (;;) {
-    // counts in front of iteration c.chk (behind k_start / iteration c.chk - 1): the slot itself says when they are there
+    // counts in front of slot c.chk (behind k_start / slot c.chk - 1): the word itself says when they are there
     // (k_post_counts stores into mapped host memory; qtos_plan_submit left -1 in every slot) -- an event query on top of
     // it is a driver call and waits for the end-of-kernel signal of the command processor
-    const int *h = c.h_active + 2 * (c.chk == 0 ? D.max_iter : c.chk - 1);
-    int n, nc;
-    if (p->counts_by_copy) {
-      const hipError_t q = hipEventQuery(c.ev[c.chk == 0 ? ev_start : 6 + 5 * (c.chk - 1)]);
-      if (q == hipErrorNotReady) return 0;
-      if (q != hipSuccess) { p->err = std::string("hipEventQuery: ") + hipGetErrorString(q); return -2; }
-      n = h[0]; nc = h[1];
-    } else {
-      const unsigned long long v = __atomic_load_n((const unsigned long long *)h, __ATOMIC_ACQUIRE);
-      if (v == ~0ull || (unsigned)(v >> 48) != p->seq) {   // nothing yet, or the late store of a blind launch of an earlier call
-        // (a failed launch never fills the slot: look at the stream now and then)
-        if ((++c.spins & 0xfffff) == 0) {
-          const hipError_t q = hipStreamQuery(c.st);
-          if (q != hipSuccess && q != hipErrorNotReady) { p->err = std::string("hipStreamQuery: ") + hipGetErrorString(q); return -2; }
-        }
-        return 0;
+    const int *h = c.h_active + 4 * (c.chk == 0 ? p->max_slots : c.chk - 1);
+    const unsigned long long v = __atomic_load_n((const unsigned long long *)h, __ATOMIC_ACQUIRE);
+    if (v == ~0ull || (unsigned)(v >> 48) != p->seq) {   // nothing yet, or the late store of a blind launch of an earlier call
+      // (a failed launch never fills the slot: look at the stream now and then)
+      if ((++c.spins & 0xfffff) == 0) {
+        const hipError_t q = hipStreamQuery(c.st);
+        if (q != hipSuccess && q != hipErrorNotReady) { p->err = std::string("hipStreamQuery: ") + hipGetErrorString(q); return -2; }
       }
-      n = (int)(unsigned)(v & 0xffffffull); nc = (int)(unsigned)((v >> 24) & 0xffffffull);
+      return 0;
     }
-    if (n <= 0 || c.chk >= D.max_iter) {
-      // finished in front of iteration c.chk (every problem has handed its result over: export_problem)
-      const int iters = c.chk;
-      for (int j = iters; j < c.enq; ++j) { c.was_kkt[j] = 0; c.was_chord[j] = 0; }   // blind launches behind the end: no work
-      c.last_launches = iters;
-      c.last_iters = iters;
+    const int n = (int)(unsigned)(v & 0xffffffull), nc = (int)(unsigned)((v >> 24) & 0xffffffull);
+    if (n <= 0 || c.chk >= p->max_slots) {
+      // finished in front of slot c.chk (every problem has handed its result over: export_problem; a problem out of
+      // iterations counts as finished)
+      // (a call that followed the pattern learns here how many of its slots had work: h[3], the slots in which some problem
+      //  took a step; the others read every slot's counts and stop at the first without work)
+      const int slots = c.by_pattern ? std::max(0, std::min(h[3], c.chk)) : c.chk;
+      for (int j = slots; j < c.enq; ++j) { c.was_kkt[j] = 0; c.was_chord[j] = 0; }   // blind launches behind the end: no work
+      c.last_launches = slots;
+      c.last_iters = slots;
       c.open = false;
       *lane_done = true;
       return 0;
     }
-    if (c.chk < c.spec) {
+    if (c.chk < c.spec && !c.by_pattern) {
       // a blind iteration that did run: which of its two solve kernels had work
       c.was_kkt[c.chk] = n - nc > 0;
       c.was_chord[c.chk] = nc > 0 && p->chord_fn && c.chk >= 1;
     }
     if (c.chk == c.enq) {
       if (!*device_set) { HIPCHK(p, hipSetDevice(p->device)); *device_set = true; }
-      if (int rc = queue_iteration(p, c, c.chk, true, n, nc)) return rc;
+      if (int rc = queue_iteration(p, c, c.chk, (n - nc > 0 ? 1 : 0) | (nc > 0 && c.chk >= 1 ? 2 : 0), true)) return rc;
       c.enq++;
+      c.n_informed++;
       if (p->lanes_used == 1) HIPCHK(p, hipEventRecord(c.ev[1], c.st));   // (the end-of-call event sits behind the last launch)
     }
     c.chk++;
@@ -1053,7 +1084,24 @@ int qtos_plan_poll(QtosPlanner *p, int *done) {
   }
   int iters = 0;
   for (int j = 0; j < p->lanes_used; ++j) iters = std::max(iters, p->lanes[j].last_iters);
-  p->spec_next = std::max(1, iters);
+  p->spec_next = std::max(1, std::min(iters, p->dp.max_iter));
+  if (p->lanes_used == 1) {
+    // The launch pattern of the next call: the kinds this call's slots ran, as far as they agree with the call before it
+    // (the first call of a handle is trusted as it is).  A problem that sat a slot of the pattern out (the code in the last
+    // count words: (1 << 20) - slot) cuts this call's observation in front of that slot -- what the slots behind it ran
+    // was the pattern's choice, not the batch's.
+    const QtosPlanner::Lane &c = p->lanes[0];
+    const int *h = c.h_active + 4 * (c.chk == 0 ? p->max_slots : c.chk - 1);
+    int n_obs = c.last_launches;
+    if (h[2] > 0) { n_obs = std::min(n_obs, (1 << 20) - h[2]); p->n_pattern_misses++; }
+    std::vector<char> obs((size_t)std::max(n_obs, 0));
+    for (int i = 0; i < n_obs; ++i) obs[i] = (char)((c.was_kkt[i] ? 1 : 0) | (c.was_chord[i] ? 2 : 0));
+    size_t k = 0;
+    if (p->obs_prev.empty()) k = obs.size();
+    else while (k < obs.size() && k < p->obs_prev.size() && obs[k] == p->obs_prev[k]) ++k;
+    p->pat.assign(obs.begin(), obs.begin() + k);
+    p->obs_prev.swap(obs);
+  }
   p->call_open = false;
   p->busy.store(0);
   *done = 1;
@@ -1146,6 +1194,65 @@ int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, dou
   if (total_seconds) *total_seconds = tot * 1e-3;
   if (iterations) *iterations = iters;
   return 0;
+}
+
+// Where the time of the last call went, from the same events (lane 0; one lane per call is what bench.py times):
+//   out[0] first kernel -> end of the call            out[1] memset + k_start (+ its counts)
+//   out[2] solve kernels (a slot's factorisation and chord solve side by side count once)
+//   out[3] k_step + counts of every slot (from the end of the slot's solve to its last event)
+//   out[4] GAPS: from a slot's last event to the first event of the next slot's solve -- the host reading the counts and
+//          launching (zero between slots queued at submit time) -- plus whatever lies between the last slot and the end event
+//   out[5] launch slots with work, out[6] slots queued at submit time (pattern / blind), out[7] launches that waited for the host
+//   out[8] calls of the handle that followed a pattern so far, out[9] of those, calls in which a problem sat a slot out
+int qtos_last_timing_detail(QtosPlanner *p, double *out, int n_out) {
+  if (!p || !out || n_out < 10) return -1;
+  HIPCHK(p, hipSetDevice(p->device));
+  HIPCHK(p, hipEventSynchronize(p->lanes[0].ev[1]));
+  const QtosPlanner::Lane &L = p->lanes[0];
+  const int ev_start = 2 + 5 * p->max_slots;
+  auto ms = [&](hipEvent_t a, hipEvent_t b, double *d) { float t = 0; hipError_t e = hipEventElapsedTime(&t, a, b); *d = t * 1e-3; return e; };
+  double tot = 0, start = 0, solve = 0, step = 0, gaps = 0;
+  HIPCHK(p, ms(L.ev[0], L.ev[1], &tot));
+  HIPCHK(p, ms(L.ev[0], L.ev[ev_start], &start));
+  hipEvent_t prev = L.ev[ev_start];
+  for (int i = 0; i < L.enq; ++i) {
+    if (!L.was_kkt[i] && !L.was_chord[i] && i >= L.last_launches) continue;   // (queued behind the end: nothing ran)
+    hipEvent_t b0 = L.was_kkt[i] ? L.ev[2 + 5 * i] : (L.was_chord[i] ? L.ev[4 + 5 * i] : nullptr);
+    double g = 0, sk = 0, sc = 0, st = 0;
+    if (b0) {
+      HIPCHK(p, ms(prev, b0, &g));
+      if (L.was_kkt[i]) HIPCHK(p, ms(b0, L.ev[3 + 5 * i], &sk));
+      if (L.was_chord[i]) HIPCHK(p, ms(b0, L.ev[5 + 5 * i], &sc));
+      const double sv = std::max(sk, sc);
+      double whole = 0;
+      HIPCHK(p, ms(b0, L.ev[6 + 5 * i], &whole));
+      st = std::max(0.0, whole - sv);
+      gaps += std::max(0.0, g); solve += sv; step += st;
+    } else {
+      HIPCHK(p, ms(prev, L.ev[6 + 5 * i], &st));
+      step += st;
+    }
+    prev = L.ev[6 + 5 * i];
+  }
+  gaps += std::max(0.0, tot - start - solve - step - gaps);
+  out[0] = tot; out[1] = start; out[2] = solve; out[3] = step; out[4] = gaps;
+  out[5] = L.last_launches; out[6] = L.spec; out[7] = L.n_informed;
+  out[8] = (double)p->n_pattern_calls; out[9] = (double)p->n_pattern_misses;
+  return 0;
+}
+
+int qtos_set_pattern_speculation(QtosPlanner *p, int on) {
+  if (!p) return -1;
+  p->spec_pattern = on != 0;
+  if (!on) { p->pat.clear(); p->obs_prev.clear(); }
+  return 0;
+}
+
+int qtos_env(const QtosPlanner *p, char *buf, int n) {
+  if (!p || !buf || n < 1) return -1;
+  const std::string d = p->env.describe();
+  snprintf(buf, (size_t)n, "%s", d.c_str());
+  return (int)d.size();
 }
 
 int qtos_last_timing_chord(QtosPlanner *p, double *chord_seconds, int *chord_launches) {

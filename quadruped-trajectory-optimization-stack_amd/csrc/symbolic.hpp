@@ -23,6 +23,7 @@
 #include <numeric>
 #include <vector>
 
+#include "env.hpp"
 #include "model.hpp"
 
 namespace qtos {
@@ -81,6 +82,7 @@ struct KMeta {
 };
 
 struct Symbolic {
+  QtosEnv env;               // the environment switches of this analysis (parsed once by the caller: env.hpp)
   int n_unknowns = 0, n_free = 0, n_eq = 0, n_stages = 0, front = 0;
   bool kron = false;                 // range-of-motion blocks of the main records assembled through their Kronecker structure (QTOS_KRON)
   std::vector<KMeta> iq_kron;        // parallel to iq_blocks
@@ -720,7 +722,7 @@ struct Symbolic {
       ctab[((((size_t)k * NT + R) * 64) + lk * 16 + col) * 4 + g] = (unsigned short)kv.second;
     }
     n_cells = (n_cells + 1) & ~1;
-    if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: %d cells for the assembled entries (dense triangle: %d)\n", n_cells, (F + 1) * (F + 2) / 2);
+    if (env.debug) fprintf(stderr, "qtos: %d cells for the assembled entries (dense triangle: %d)\n", n_cells, (F + 1) * (F + 2) / 2);
     return 0;
   }
 
@@ -772,9 +774,8 @@ struct Symbolic {
     // walk 128 -> 112 slots at two more stages, 0.643 -> 0.656 ms; round 5, with the reduced swings: the trot 112 -> 96 slots at
     // the same 113 stages, 0.668 -> 0.592 ms per launch, the walk 128 -> 112 at the same 100: equal).  QTOS_SHORT_STAGES=1: the
     // 2 % rule for every front size; 0: never.
-    const char *ess = getenv("QTOS_SHORT_STAGES");
-    if (ess && atoi(ess) == 0) return;
-    const bool no_extra_stage = !ess && F0 <= 128;
+    if (env.short_stages == 0) return;
+    const bool no_extra_stage = env.short_stages < 0 && F0 <= 128;
     std::vector<int> cut;   // boundaries of the chosen partition
     for (int target = F0 - PIV; target >= 2 * PIV; target -= PIV) {
       const int INF = 1 << 29;
@@ -878,10 +879,7 @@ struct Symbolic {
       first[hi] = std::min(first[hi], lo);
     }
     n_real_unknowns = n_unknowns;
-    {
-      const char *ens = getenv("QTOS_NO_SHORT_STAGES");
-      if (short_stages && !(ens && atoi(ens) != 0)) shorten_stages(first, block_minpos, n, m);
-    }
+    if (short_stages) shorten_stages(first, block_minpos, n, m);
     n_stages = (n_unknowns + PIV - 1) / PIV;
     if (pair_mode) {
       // whole pairs: dummy positions fill the last stage and, if the number of stages is odd, one more stage
@@ -900,8 +898,8 @@ struct Symbolic {
     stage_dummies.resize(n_stages, 0);
     // the stage at which an unknown enters the front
     auto enter_stage = [&](int j) { const int e = first[j] / PIV; return pair_mode ? (e & ~1) : e; };
-    if (const char *dump = getenv("QTOS_DUMP_FIRST")) {   // diagnostic: envelope of the ordered matrix (position -> first coupled position, unknown id)
-      if (FILE *f = fopen(dump, "w")) {
+    if (!env.dump_first.empty()) {   // diagnostic: envelope of the ordered matrix (position -> first coupled position, unknown id)
+      if (FILE *f = fopen(env.dump_first.c_str(), "w")) {
         for (int j = 0; j < n_unknowns; ++j) fprintf(f, "%d %d %d\n", j, first[j], order[j]);
         fclose(f);
       }
@@ -964,7 +962,7 @@ struct Symbolic {
               else nfree++;
             }
             if (!nfree) continue;
-            static const int place = getenv("QTOS_PLACE") ? atoi(getenv("QTOS_PLACE")) : 0;
+            const int place = env.place;
             int score = same > 0 ? 2000 + same : (used == 0 ? 1000 : nfree);
             if (place == 1) score = 1000 - grp;                                   // lowest free slot
             if (place == 2) score = same > 0 ? 2000 + same : 1000 - grp;           // siblings, else lowest group
@@ -1291,8 +1289,8 @@ struct Symbolic {
       srec[srec_off[rec] + 6] = n_cont;
       srec[srec_off[rec] + 7] = first_cont;
     }
-    if (getenv("QTOS_DEBUG_SYMBOLIC")) fprintf(stderr, "qtos: %d stages, %d continuation records, max record %d ints / %d doubles\n", n_stages, (int)cont.size() / 4, max_srec, max_drec);
-    if (getenv("QTOS_DEBUG_SYMBOLIC2")) {
+    if (env.debug) fprintf(stderr, "qtos: %d stages, %d continuation records, max record %d ints / %d doubles\n", n_stages, (int)cont.size() / 4, max_srec, max_drec);
+    if (env.debug >= 2) {
       // lifetimes
       std::map<int,int> hist;
       for (int j = 0; j < n_unknowns; ++j) hist[j / PIV - first[j] / PIV]++;

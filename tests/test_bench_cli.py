@@ -13,9 +13,16 @@ def test_defaults_are_the_headline_run():
     import bench
     a = bench.parse_args([])
     assert (a.gpus, a.steps, a.warmup, a.batch) == (1, 100, 5, 256)
-    assert (a.transcription, a.gait, a.workload) == ("knots100", "walk", "exp1_flat")
-    # the trot (the gait BASELINE.json's metric names) is timed by the default command, 20 steps of its own
-    assert not a.no_trot and a.trot_steps == 20
+    # the line's metric / value / roofline are the TROT's (the gait BASELINE.json's metric names); the walk of the reference's golden
+    # plans is the second leg of the same command, timed with the same --steps
+    assert (a.transcription, a.gait, a.workload) == ("knots100", "trot", "exp1_flat")
+    assert not a.no_second_gait and not hasattr(a, "trot_steps")
+    assert a.settle == 50 and a.settle_tol == 0.02 and not a.no_pattern     # adaptive warm-up on, launch pattern on
+    # the terrain workloads and the receding windows keep the walk (their goals, schedules and parity tests are the walk's)
+    assert bench.parse_args(["--workload", "exp5_step"]).gait == "walk"
+    assert bench.parse_args(["--workload", "mixed"]).gait == "walk"
+    assert bench.parse_args(["--transcription", "knots200", "--workload", "mpc_random"]).gait == "walk"
+    assert bench.parse_args(["--gait", "walk"]).gait == "walk" and bench.parse_args(["--no-trot"]).no_second_gait
     assert not a.full_system and not a.full_swings and not a.plain_mu and not a.force_torchrun
     assert a.cpu_sample > 0 and not a.no_parity
 

@@ -406,6 +406,70 @@ def test_gather_plans_on_device_world_1():
     assert r.returncode == 0 and "GATHER_OK" in r.stdout, r.stderr[-2000:]
 
 
+def test_launch_pattern_is_bit_identical_and_survives_a_mismatch():
+    """Round 6: qtos_plan_submit queues the LAUNCH PATTERN of the handle (per launch slot the solve kernels its last two calls
+    both needed) instead of asking the host in front of every Newton iteration.  (1) Flat walk and trot batches at the BASELINE
+    size take kkt, kkt, kkt, chord every time: from the third call on the whole solve is queued at submit time (four slots,
+    no launch waits for the host) and the plans, statuses and iteration counts are bit for bit those of the informed loop.
+    (2) A batch that does NOT follow the pattern -- the same handle is handed mixed-terrain problems, then warm starts that
+    converge at once, then cold ones again -- still gives the informed loop's bits: a problem that finds the wrong solve kernel
+    in a slot sits that launch out (k_step) and steps behind a later one; the handle reports that it happened."""
+    from qtos_amd import workloads
+    from qtos_amd.capi import Planner
+    from qtos_amd.config import PlannerConfig
+    for gait in ("walk", "trot"):
+        c = PlannerConfig.knots100(gait=gait)
+        B = 256
+        batches = [workloads.flat_goals(B, seed=300 + i) for i in range(5)]
+        Pi = Planner(c, max_batch=B)
+        Pi.set_pattern_speculation(False)
+        ref = [Pi.plan(s, g) for s, g in batches]
+        d = Pi.timing_detail()
+        assert d["slots_at_submit"] == 1 and d["informed_launches"] == d["slots"] - 1 == 3     # the premise: 3 + 1 launches, the host in front of three
+        Pi.close()
+        Pp = Planner(c, max_batch=B)
+        got = []
+        for k, (s, g) in enumerate(batches):
+            got.append(Pp.plan(s, g))
+            d = Pp.timing_detail()
+            if k >= 1:      # (the first call is trusted as it is: the second already follows its pattern)
+                assert d["slots_at_submit"] == 4 and d["informed_launches"] == 0 and d["slots"] == 4, (gait, k, d)
+        assert d["pattern_calls"] == 4 and d["pattern_misses"] == 0
+        for a, b in zip(ref, got):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), gait
+        Pp.close()
+    # (2) the pattern breaks: flat problems (kkt, kkt, kkt, chord) teach the handle a pattern that the mixed-terrain batches
+    # behind them do not follow (stragglers that factor a fourth time where the pattern launches k_chord only), warm starts
+    # that converge at once leave every queued slot empty, and cold batches follow again
+    c = PlannerConfig.knots100()
+    B = 64
+    maps, cell = workloads.mixed_terrains()
+    mixed = [workloads.mixed_goals(B, seed=40 + i, terrains=(maps, cell)) for i in range(4)]
+    flat = [workloads.flat_goals(B, seed=60 + i) + (np.zeros(B, np.int32),) for i in range(2)]     # (map 0 is exp_1's plane)
+    Pi = Planner(c, max_batch=B)
+    Pi.set_pattern_speculation(False)
+    Pi.set_heightfields(maps, cell)
+    Pp = Planner(c, max_batch=B)
+    Pp.set_heightfields(maps, cell)
+    seq = [(flat[0], False), (flat[1], False), (mixed[0], False), (flat[0], False), (flat[1], False), (mixed[1], False), (mixed[0], True),
+           (flat[0], False), (flat[0], False), (mixed[2], False), (mixed[0], True), (mixed[0], True), (mixed[3], False), (mixed[3], False)]
+    warm0 = None
+    lens, misses = set(), []
+    for k, ((s_, g_, m_), w) in enumerate(seq):
+        a = Pi.plan(s_, g_, map_id=m_, warm=warm0 if w else None)
+        b = Pp.plan(s_, g_, map_id=m_, warm=warm0 if w else None)
+        if k == 2:
+            warm0 = a[0].copy()               # (the solved plans of mixed[0])
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), (k, w)
+        lens.add(int(a[2].max()))
+        misses.append(Pp.timing_detail()["pattern_misses"])
+    d = Pp.timing_detail()
+    assert len(lens) > 2 and min(lens) <= 1   # the premise: calls of different lengths followed each other, the warm ones end behind their first step
+    assert d["pattern_calls"] >= 8 and d["pattern_misses"] >= 1, (d, misses)      # ... and at least one found the pattern wrong
+    Pi.close()
+    Pp.close()
+
+
 def test_pool_of_handles_equals_one_call_after_the_other(cfg):
     """The asynchronous boundary (qtos_plan_submit / qtos_plan_poll, qtos_amd.pool.PlannerPool): six batches of mixed
     terrain kept in flight on three planner handles by one host thread give bit for bit the plans, statuses and
@@ -422,7 +486,8 @@ def test_pool_of_handles_equals_one_call_after_the_other(cfg):
     batches = [workloads.mixed_goals(B, seed=20 + i, terrains=(maps, cell)) for i in range(NB)]
     P = Planner(cfg, max_batch=B)
     P.set_heightfields(maps, cell)
-    P.set_speculation(1)                                   # the host looks at the counts in front of every iteration
+    P.set_speculation(1)
+    P.set_pattern_speculation(False)                       # the host looks at the counts in front of every iteration
     ref = [P.plan(s, g, map_id=m) for s, g, m in batches]
     P.set_speculation(8)
     again = [P.plan(s, g, map_id=m) for s, g, m in batches]   # from the second call on: as many blind iterations as the last call took
