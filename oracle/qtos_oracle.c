@@ -1385,12 +1385,18 @@ int qo_solve_batch(const qo_params *p, int n_problems, const qo_problem *q, cons
  * bench.py calls it behind the cpu_baseline leg; a host process that runs one batch and goes on should too. */
 void qo_release_buffers(int n_threads) {
 #ifdef _OPENMP
+  /* the team that allocated the buffers frees them; the caller's OpenMP thread count is left as it was */
+  const int before = omp_get_max_threads();
   if (n_threads > 0) omp_set_num_threads(n_threads);
 #pragma omp parallel
 #endif
   tls_J_release();
   tls_J_release();
-  mallopt(M_MMAP_THRESHOLD, 128 * 1024);
-  mallopt(M_TRIM_THRESHOLD, 128 * 1024);
+#ifdef _OPENMP
+  omp_set_num_threads(before);
+#endif
+  /* (glibc: a freed block above M_MMAP_THRESHOLD went back to the system at once; below it, malloc_trim returns what the
+   *  arenas hold.  No mallopt: setting a threshold would switch glibc's dynamic adjustment off for the rest of the process.) */
+  malloc_trim(0);
 }
 

@@ -161,3 +161,17 @@ class PlannerConfig:
             table = [list(f[:-1]) + [f[-1] + f[0]] + list(f[1:]) for f in REFERENCE_WALK_UNNORMALISED]
             kw["phase_durations"] = scaled_phases(table, kw["duration"])
         return cls(**kw)
+
+    @classmethod
+    def receding_windows(cls, **kw):
+        """BASELINE.json configs[4] as the product runs it (`replan.ShiftedWindows`, `bench.py --workload mpc_random`): the 200-knot
+        transcription with the two solver settings that belong to REPLANNED windows -- the windows of a set are at different points
+        of their solves in every iteration, so a chord step saves no launch (the batch still factors for the others) and a
+        discarded one costs an iteration: `chord_tol = 0`; and without a chord step to finish, Ipopt's superlinear decrease of the
+        barrier parameter has nothing to gain and lengthens the tail (the slowest of 256 windows takes 9.0 instead of 8.45
+        factorisations per replan): `mu_superlinear = False`.  ONE place: the bench, the tests
+        (`test_shifted_windows_match_oracle_over_five_replans[receding_windows]`) and library users get the same configuration;
+        `knots200()` stays the plain 200-knot transcription with the defaults of every other workload."""
+        kw.setdefault("chord_tol", 0.0)
+        kw.setdefault("mu_superlinear", False)
+        return cls.knots200(**kw)

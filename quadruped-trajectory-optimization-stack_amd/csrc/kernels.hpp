@@ -547,11 +547,6 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
 #else
 #define ESTAMP() do {} while (0)
 #endif
-#ifdef QTOS_EVAL_CUT   // (diagnostic builds, with QTOS_STEP_CUT: the evaluation with Jacobian ends behind its section i -- wrong results)
-#define ECUT(i) do { if (JAC && QTOS_EVAL_CUT == (i)) return; } while (0)
-#else
-#define ECUT(i) do {} while (0)
-#endif
   double *x = lds, *loc = lds + eval_loc_offset(P.n_vars);
   double *vin = loc + max(DYN_LOC * P.dyn_chunk, ROM_LOC * P.rom_chunk);
   double *coef_lds = vin + max(DYN_VIN * P.dyn_chunk, ROM_VIN * P.rom_chunk);   // coefficients of the entry lists (JAC only)
@@ -568,7 +563,6 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
     vec_prepass(P.pre_dyn_var + c0 * DYN_VIN, P.pre_dyn_wa + c0 * DYN_VIN, P.pre_dyn_wb + c0 * DYN_VIN, cnt * DYN_VIN, x, vin);
     EVAL_BARRIER();
     ESTAMP();
-    ECUT(0);
     if (JAC) {
       // four work items per knot -- the value pass and the three groups of forward-mode passes --, a whole number of
       // waves per kind (a chunk of 128 knots is one item per thread)
@@ -587,12 +581,10 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
       }
       EVAL_BARRIER();
       ESTAMP();
-      ECUT(1);
       write_terms1(P.dyn_t1, P.dyn_t1_off[ch], P.dyn_t1_off[ch + 1], loc, coef, G);
       write_terms3(P.dyn_t3, P.dyn_t3_off[ch], P.dyn_t3_off[ch + 1], loc, coef, G);
       EVAL_BARRIER();
       ESTAMP();
-      ECUT(2);
     } else {
       for (int i = tid; i < cnt; i += nt) {
         const DynInst &I = P.dyn[c0 + i];
@@ -612,10 +604,8 @@ __device__ inline void eval_all(const DevPlan &P, int map, const double *xg, dou
     if (JAC) {
       EVAL_BARRIER();
       ESTAMP();
-      if (c0 + P.rom_chunk >= P.n_rom) ECUT(3);
       write_terms1(P.rom_t1, P.rom_t1_off[ch], P.rom_t1_off[ch + 1], loc, coef, G);
       ESTAMP();
-      if (c0 + P.rom_chunk >= P.n_rom) ECUT(4);
     }
   }
   // force, terrain and constant-coefficient rows: the descriptors of a thread's items are read before the first of them is
@@ -669,9 +659,15 @@ __device__ __forceinline__ double wg_dpp(double v) {
   return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false),
                           __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false));
 }
-template <int OP>  // 0 sum, 1 max, 2 min
+// NT = the workgroup's thread count (the evaluation kernels' ET): scratch holds NT doubles, and EVERY lane of every wave must
+// be active (the lane swaps and readfirstlane below read across the whole wave) -- no calls from divergent control flow.
+template <int OP, int NT = ET>  // 0 sum, 1 max, 2 min
 __device__ inline double wg_reduce(double v, double *scratch) {
-  constexpr int NW = ET / 64;   // (k_start and k_step: ET threads)
+  static_assert(NT % 64 == 0 && (NT / 64 & (NT / 64 - 1)) == 0, "wg_reduce: a power-of-two number of full waves");
+  constexpr int NW = NT / 64;
+#ifdef QTOS_CHECKS   // (development builds: a kernel launched with another thread count would read stale scratch)
+  if (blockDim.x != NT) __builtin_trap();
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   wg_lds_barrier();             // the previous reduction's readers are done with the scratch
   scratch[tid] = v;
@@ -1252,11 +1248,6 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int sl
 #else
 #define KSTAMP(i) do {} while (0)
 #endif
-#ifdef QTOS_STEP_CUT   // (diagnostic builds: the kernel ends behind section i, nothing of the launch is kept -- wrong results)
-#define KCUT(i) do { if (QTOS_STEP_CUT == (i)) return; } while (0)
-#else
-#define KCUT(i) do {} while (0)
-#endif
   // ds = Ji dx + (g - s), dx staged in LDS.  Every pass over a table below is a chain of memory round trips (index ->
   // value -> ...) of a microsecond each: the table reads that depend on nothing this kernel computes are issued first.
   const int nt = blockDim.x;
@@ -1381,7 +1372,6 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int sl
   }
   __syncthreads();
   KSTAMP(0);
-  KCUT(0);
   const double tau = fmax(0.99, 1.0 - mu);
   double amax = 1.0, az = 1.0;
   double rds[KR], rdzl[KR], rdzu[KR];
@@ -1435,7 +1425,6 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int sl
   };
   const double th0 = l1_rows(rg, eg, g, 0.0);
   KSTAMP(1);
-  KCUT(1);
   // backtracking on the l1 infeasibility of (c_E, c_I - s)
   double al = amax, th = 0;
   double rgt[KR], egt[KE];
@@ -1456,14 +1445,10 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int sl
 #pragma unroll
     for (int k = 0; k < KE; ++k) egt[k] = gv[er[k]];
     th = l1_rows(rgt, egt, gv, al);
-#ifdef QTOS_EVAL_CUT
-    break;   // (a cut evaluation leaves garbage: one pass, as a launch that accepts its first trial point)
-#endif
     if (th <= (1.0 - 1e-4 * al) * th0 || th < 1e-9) { lin_done = spec && ls == 0; break; }
     if (ls < 5) al *= 0.5;
   }
   KSTAMP(2);
-  KCUT(2);
   // a chord step is taken whole or not at all: cut by the fraction-to-the-boundary rule or by the line search it
   // is discarded (the iterate stays, the next iteration factors): a damped chord step can park a slack right on
   // its bound, and the KKT matrix of that point is too badly scaled for the block elimination
@@ -1540,7 +1525,6 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int sl
     theta = wg_reduce<1>(t, scratch);
   }
   KSTAMP(3);
-  KCUT(3);
   const bool conv = viol <= P.tol && theta <= P.tol;
   const bool bad = !(viol < INFINITY) || !(th < INFINITY);
   // stall detection: the iterate with the lowest violation is kept; a problem that has not improved
@@ -1605,7 +1589,6 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int sl
   }
   __syncthreads();
   KSTAMP(4);
-  KCUT(4);
   {
     // barrier weights of every inequality row, right-hand sides of the equality rows (barrier_terms, on the rows in registers;
     // their constraint values as the linearisation above has just written them: the same point as the last line-search
@@ -1644,7 +1627,6 @@ __global__ __launch_bounds__(ET) void k_step(DevPlan P, DevWork W, int B, int sl
     }
   }
   KSTAMP(5);
-  KCUT(5);
   if (tid == 0) {
     W.chord[b] = next_chord ? 1 : (chord_off ? 2 : 0);
     W.chord_run[b] = next_chord ? (was_chord ? chord_run + 1 : 1) : 0;

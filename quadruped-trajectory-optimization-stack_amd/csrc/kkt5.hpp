@@ -165,9 +165,6 @@ __device__ __forceinline__ void assemble_pair_tgt(double *A, const int *sbuf, co
 #else
 #define K5_SCHED_BARRIER() do {} while (0)
 #endif
-#ifndef QTOS_K5_ABL
-#define QTOS_K5_ABL 0   // diagnostic builds: bit mask of parts compiled out (1 assembly, 2 extraction, 4 Schur update, 8 next columns, 16 factor wave, 32 rhs chain, 64 V/W chain)
-#endif
 #ifndef QTOS_K5_ILPS
 #define QTOS_K5_ILPS 1   // contributions of a target in flight: service waves
 #endif
@@ -292,7 +289,7 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
       // ---- phase 1 ----
       if (j >= -1) {
         d4_t w1 = {0.0, 0.0, 0.0, 0.0}, w2 = {0.0, 0.0, 0.0, 0.0};
-        if (live && rowlive && !(QTOS_K5_ABL & 64)) {
+        if (live && rowlive) {
           const int a = 2 * j;
           const unsigned ama = am_cur[0], amb = am_cur[1];
           const int sb_li = psj[PIV + li];                        // slot of pivot li of stage b
@@ -351,7 +348,7 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
           }
         }
         K5S(8);
-        if (has_next && !(QTOS_K5_ABL & 8)) {
+        if (has_next) {
           const unsigned wn = pmn[R >> 1];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
@@ -394,7 +391,7 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
       lds_barrier();
       K5S(1);
       // ---- phase 2:  U(R, C) -= W1 P1[C]' + W2 P2[C]',  operand B blanked on load (rows of this pair's and the next pair's pivots)
-      if (live && has_next && rowlive && !(QTOS_K5_ABL & 4)) {
+      if (live && has_next && rowlive) {
         double b1[2][4], b2[2][4];
         auto tile_loads = [&](int C, double (&x1)[4], double (&x2)[4]) __attribute__((always_inline)) {
           const unsigned g16 = ((pmj[C >> 1] | pmn[C >> 1]) >> ((C & 1) * 16)) & 0xffffu;
@@ -432,7 +429,7 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
       }
       // ---- phase 3: the columns (rows) of the pivots of pair j + 2 out of the tiles into the panels of pair j, which are dead;
       //      zeroed in place
-      if (live && has_next2 && !(QTOS_K5_ABL & 2)) {
+      if (live && has_next2) {
         double *X = (double *)PA0;
         double *dummy = red + 2 * 16 * PIV + lane;
         // bit 4g of ge4 / gt4: row lk + 4g of a diagonal tile lies on or below / strictly below column li
@@ -469,7 +466,7 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
       }
       K5S(4);
       // the rest of the record's targets: every wave but the factor wave (service waves first, then the tile waves by row)
-      if (has_next2 && !(QTOS_K5_ABL & 1) && R < NASMT) assemble_pair_tgt<QTOS_K5_ILPT>(A, sbuf, dbuf, n_tgt2, 1 << 30, (NSVC + R) * 64 + lane, (NSVC + NASMT) * 64);
+      if (has_next2 && R < NASMT) assemble_pair_tgt<QTOS_K5_ILPT>(A, sbuf, dbuf, n_tgt2, 1 << 30, (NSVC + R) * 64 + lane, (NSVC + NASMT) * 64);
       K5S(5);
       lds_barrier();
       K5S(6);
@@ -484,7 +481,7 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
       K5S(0);
       lds_barrier();
       K5S(1);
-      if (j >= -1 && has_next && !(QTOS_K5_ABL & 16)) {
+      if (j >= -1 && has_next) {
         __builtin_amdgcn_s_setprio(3);
         const int c = 2 * (j + 1);
         double *Pc = PN0, *Pd = PN0 + PSZ;
@@ -602,7 +599,7 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
       }
       if (sidx == 0 && j >= -1) {
         // ---- the right-hand-side row (row F of the panels) --------------------------------------------------------
-        if (live && !(QTOS_K5_ABL & 32)) {
+        if (live) {
           const int a = 2 * j;
           const int sb_li = psj[PIV + li];
           double part = 0.0;
@@ -633,7 +630,7 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
       lds_barrier();
       K5S(1);
       K5S(8);
-      if (has_next2 && !(QTOS_K5_ABL & 1)) {
+      if (has_next2) {
         assemble_pair_eq(A, sbuf, dbuf, sidx * 64 + lane, NSVC * 64);
         K5S(9);
         assemble_pair_tgt<QTOS_K5_ILPS>(A, sbuf, dbuf, 0, n_tgt2, sidx * 64 + lane, NSVC * 64);
@@ -648,7 +645,7 @@ __global__ __launch_bounds__(KT5) void k_kkt5(DevPlan P, DevWork W, int B) {
         PN0[(lane >> 4) * PSZ + F * PLD + (lane & 15)] = rhs_keep + UF[st];
         UF[st] = 0.0;
       }
-      if (has_next2 && !(QTOS_K5_ABL & 1)) assemble_pair_tgt<QTOS_K5_ILPS>(A, sbuf, dbuf, n_tgt2, 1 << 30, sidx * 64 + lane, (NSVC + NASMT) * 64);
+      if (has_next2) assemble_pair_tgt<QTOS_K5_ILPS>(A, sbuf, dbuf, n_tgt2, 1 << 30, sidx * 64 + lane, (NSVC + NASMT) * 64);
       K5S(5);
       lds_barrier();
       K5S(6);

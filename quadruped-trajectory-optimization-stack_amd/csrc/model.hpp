@@ -303,6 +303,7 @@ struct HostModel {
   // projection of a starting point onto the rule: x[psw_var] = psw_w[2 i] x[psw_src[2 i]] + psw_w[2 i + 1] x[psw_src[2 i + 1]]
   std::vector<int> psw_var, psw_src;
   std::vector<double> psw_w;
+  mutable bool foot_sol_overflow = false;   // make_foot_sol met more than four (variable, weight) pairs in one dimension
   VecInW make_foot_sol(int e, double t) const {
     const VecIn in = make_in(eem[e], t, 0);
     VecInW o = widen(in);
@@ -323,6 +324,9 @@ struct HostModel {
         for (size_t q = 0; q < psw_var.size(); ++q)
           if (psw_var[q] == v) { addv(psw_src[2 * q], in.w[a] * psw_w[2 * q]); addv(psw_src[2 * q + 1], in.w[a] * psw_w[2 * q + 1]); }
       }
+      // (a VecInW has four slots per dimension; today's gaits give at most two pairs -- a schedule with several mid nodes per
+      //  swing or neighbouring swings could give more: build() reports it instead of dropping Jacobian columns)
+      if (nv > 4) foot_sol_overflow = true;
       for (int a = 0; a < 4; ++a) { o.var[3 * a + d] = a < nv ? vars[a] : -1; o.w[3 * a + d] = a < nv ? ws[a] : 0.0; }
     }
     return o;
@@ -925,6 +929,7 @@ struct HostModel {
         ri.goff = add_block(1, 3, ri.row0, cb.cols, false, nullptr);
         rom.push_back(ri);
       }
+    if (foot_sol_overflow) { err = "reduce_swing: a foot position depends on more than four footholds per dimension (VecInW has four slots): this schedule needs reduce_swing = 0"; return -1; }
     // ---- force: unilateral + friction pyramid at every optimised force node ----
     for (int e = 0; e < NEE; ++e)
       for (size_t j = 0; j < fnode[e].size(); ++j) {

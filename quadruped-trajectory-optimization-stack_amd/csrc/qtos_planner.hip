@@ -13,9 +13,6 @@
 #include "kernels.hpp"
 #include "kkt2.hpp"
 #include "kkt3.hpp"
-#ifdef QTOS_EXPERIMENTS   // kernels that were built, measured and lost: scratch/build.sh experiments
-#include "kkt4.hpp"
-#endif
 #include "kkt5.hpp"
 
 using namespace qtos;
@@ -78,8 +75,6 @@ struct QtosPlanner {
   hipEvent_t ev_in = nullptr;                // the caller's stream at submit time: the other lanes start behind it
   unsigned call_seq = 0;             // sequence number of the last call submitted
   bool use_kkt3 = false;             // k_kkt3 (kkt3.hpp) instead of k_kkt2: chosen by qtos_planner_create
-  int kkt3_mode = 0;                 // k_kkt3's MODE (QTOS_KKT=3: 0, QTOS_KKT=4: 1)
-  bool use_kkt4 = false;             // k_kkt4 (kkt4.hpp), QTOS_KKT=5
   bool use_kkt5 = false;             // k_kkt5 (kkt5.hpp): two stages per set of barriers, Symbolic::pair_mode
   QtosEnv env;                       // the environment as qtos_planner_create found it (env.hpp; qtos_env reports it)
   int spec_next = 1;                 // blind iterations of the next call: the iterations the last one took
@@ -142,13 +137,9 @@ static void (*kkt2_kernel(int F, bool cont, bool kron = false))(DevPlan, DevWork
 #undef QTOS_KKT2
   return nullptr;
 }
-// k_kkt3 (inequality blocks condensed on the matrix core): fronts up to 128 slots
-static void (*kkt3_kernel(int F, int mode))(DevPlan, DevWork, int) {
-#ifdef QTOS_EXPERIMENTS
-#define QTOS_KKT3(f) case f: return mode == 0 ? k_kkt3<f, 0> : k_kkt3<f, 1>;
-#else
-#define QTOS_KKT3(f) case f: return mode == 0 ? nullptr : k_kkt3<f, 1>;
-#endif
+// k_kkt3 (k_kkt2's records and arithmetic, the assembly on the waves that idle in phase AB): fronts up to 128 slots
+static void (*kkt3_kernel(int F))(DevPlan, DevWork, int) {
+#define QTOS_KKT3(f) case f: return k_kkt3<f, 1>;
 #ifndef QTOS_DEV_F128
   switch (F) { QTOS_KKT3(16) QTOS_KKT3(32) QTOS_KKT3(48) QTOS_KKT3(64) QTOS_KKT3(80) QTOS_KKT3(96) QTOS_KKT3(112) QTOS_KKT3(128) }
 #endif
@@ -164,19 +155,6 @@ static void (*kkt5_kernel(int F))(DevPlan, DevWork, int) {
   switch (F) { QTOS_KKT5(96) QTOS_KKT5(112) QTOS_KKT5(128) QTOS_KKT5(144) }
 #endif
 #undef QTOS_KKT5
-  return nullptr;
-}
-// k_kkt4 (panel chain and Schur updates side by side): fronts up to 128 slots; experiment builds only
-#ifndef QTOS_EXPERIMENTS
-static inline size_t kkt4_lds_bytes(int, int, int, int, int) { return 0; }
-static inline size_t kkt4_sweep_base_bytes(int, int) { return 0; }
-#endif
-static void (*kkt4_kernel(int F))(DevPlan, DevWork, int) {
-#define QTOS_KKT4(f) case f: return k_kkt4<f>;
-#if defined(QTOS_EXPERIMENTS) && !defined(QTOS_DEV_F128)
-  switch (F) { QTOS_KKT4(16) QTOS_KKT4(32) QTOS_KKT4(48) QTOS_KKT4(64) QTOS_KKT4(80) QTOS_KKT4(96) QTOS_KKT4(112) QTOS_KKT4(128) }
-#endif
-#undef QTOS_KKT4
   return nullptr;
 }
 static void (*chord_kernel(int F))(DevPlan, DevWork, int) {
@@ -308,8 +286,10 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   //                     assembly of the records on the waves that have no job in phase AB (-5 % per launch on the trot's
   //                     112 slots, -6 % on reference_compat's 96; +4 % on 128 slots, where seven idle waves are too few;
   //                     profiles/r04_experiments)
-  //   k_kkt3, MODE 0    QTOS_KKT=3 only: inequality blocks condensed by matrix instructions (correct, slower)
-  // QTOS_KKT=2 / 3 / 4 force k_kkt2 / MODE 0 / MODE 1.
+  //   k_kkt5            QTOS_KKT=6: two 16-pivot stages per set of barriers (pair-mode analysis)
+  // QTOS_KKT=2 / 4 / 6 force k_kkt2 / k_kkt3 / k_kkt5.  (k_kkt3 MODE 0 -- inequality blocks condensed by matrix instructions --
+  // and k_kkt4 -- the pipelined stage --, QTOS_KKT=3 / 5 of rounds 4 - 5, were correct and slower: scratch/experiments/, last
+  // built from commit 991d29f.)
   p->use_kkt3 = false;
   p->use_kkt5 = false;
   p->env = QtosEnv::parse();   // the ONE place a planner reads the environment
@@ -317,9 +297,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   p->spec_pattern = env.spec_pattern != 0;
   {
     int forced = env.kkt;
-#ifndef QTOS_EXPERIMENTS
-    if (forced == 3 || forced == 5) { fprintf(stderr, "qtos: QTOS_KKT=%d selects an experiment that this build does not contain (scratch/build.sh -DQTOS_EXPERIMENTS): default kernel\n", forced); forced = 0; }
-#endif
+    if (forced == 3 || forced == 5) { fprintf(stderr, "qtos: QTOS_KKT=%d selected an experiment of rounds 4 - 5 that left the library (scratch/experiments/): default kernel\n", forced); forced = 0; }
     if (forced == 6) {
       // k_kkt5: the analysis in pair mode (one record per pair of stages); applicable without continuation records, with a
       // front of at most 144 slots and everything within the LDS
@@ -338,34 +316,20 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
       p->use_kkt5 = ok;
       if (env.debug) fprintf(stderr, "qtos: k_kkt5 %s (front %d, %s)\n", ok ? "selected" : "not applicable", p->S.front, p->S.err.c_str());
     }
-    p->kkt3_mode = forced == 3 ? 0 : 1;
-    p->use_kkt4 = false;
     if (forced != 2 && !p->use_kkt5) {
       p->M = HostModel();
       p->S = Symbolic();
       p->S.env = env;
       if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
       p->S.cell_mode = 2;
-      p->S.iq_mfma = p->kkt3_mode == 0;
       bool ok = p->S.build(p->M) == 0 && p->S.front <= (forced ? 128 : 112) && !(p->S.pack_src.size() & 1);
       if (ok) {
         int n_cont = 0;
         for (int k = 0; k < p->S.n_stages; ++k) n_cont += p->S.srec[p->S.srec_off[k] + 6];
         ok = n_cont == 0 && kkt3_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) <= 160 * 1024 - 256;
       }
-#ifdef QTOS_EXPERIMENTS
-      if (forced == 5) {   // k_kkt4: the standard records, its own LDS layout
-        ok = p->S.err.empty() && p->S.front <= 128 && !(p->S.pack_src.size() & 1);
-        if (ok) {
-          int n_cont = 0;
-          for (int k = 0; k < p->S.n_stages; ++k) n_cont += p->S.srec[p->S.srec_off[k] + 6];
-          ok = n_cont == 0 && kkt4_lds_bytes(p->S.front, p->S.n_stages, p->S.max_srec, p->S.max_drec, p->S.n_cells) <= 160 * 1024 - 256;
-        }
-        p->use_kkt4 = ok;
-      }
-#endif
       p->use_kkt3 = ok;
-      if (env.debug) fprintf(stderr, "qtos: k_kkt3 MODE %d %s (%s)\n", p->kkt3_mode, ok ? "selected" : "not applicable", p->S.err.c_str());
+      if (env.debug) fprintf(stderr, "qtos: k_kkt3 %s (%s)\n", ok ? "selected" : "not applicable", p->S.err.c_str());
     }
   }
 #ifdef QTOS_EXPERIMENTS
@@ -592,10 +556,10 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   D.panel_stride = (long long)S.n_stages * (S.front + 1) * PIV;
   // LDS budget of k_kkt
   const int F = S.front;
-  p->kkt_lds = p->use_kkt5 ? kkt5_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : p->use_kkt4 ? kkt4_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : p->use_kkt3 ? kkt3_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
+  p->kkt_lds = p->use_kkt5 ? kkt5_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : p->use_kkt3 ? kkt3_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells) : kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
   D.kron_lds_off = 0;
   if (env.debug) fprintf(stderr, "qtos: Kronecker assembly %s (kkt3 %d, most blocks in a record %d)\n", S.kron ? "on" : "off", (int)p->use_kkt3, S.max_kblocks);
-  if (S.kron && !p->use_kkt3 && !p->use_kkt4) {
+  if (S.kron && !p->use_kkt3) {
     D.kron_lds_off = (int)((p->kkt_lds + 15) & ~(size_t)15);
     p->kkt_lds = (size_t)D.kron_lds_off + sizeof(double) * Symbolic::KRON_SM * (size_t)S.max_kblocks;
   }
@@ -603,7 +567,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   if (D.sw_on) {
     // the helper waves' tables of the backward sweep (solution by position, rounds) behind the sweep's own: within the LDS
     // the forward pass needs anyway, or the kernel's allocation grows up to the limit; beyond that k_step forms ds itself
-    const size_t need = (p->use_kkt5 ? kkt5_sweep_base_bytes(F, S.n_stages) : p->use_kkt4 ? kkt4_sweep_base_bytes(F, S.n_stages) : kkt2_sweep_base_bytes(F, S.n_stages)) + sweep_ds_lds_bytes(S.n_stages, D.sw_steps);
+    const size_t need = (p->use_kkt5 ? kkt5_sweep_base_bytes(F, S.n_stages) : kkt2_sweep_base_bytes(F, S.n_stages)) + sweep_ds_lds_bytes(S.n_stages, D.sw_steps);
     if (need > 160 * 1024 - 256 || chord_lds_bytes(S.n_stages, D.sw_steps) > 96 * 1024) D.sw_on = 0;
     else p->kkt_lds = std::max(p->kkt_lds, need);
   }
@@ -623,7 +587,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     return -4;
   }
   {
-    p->kkt_fn = p->use_kkt5 ? kkt5_kernel(F) : p->use_kkt4 ? kkt4_kernel(F) : p->use_kkt3 ? kkt3_kernel(F, p->kkt3_mode) : kkt2_kernel(F, D.n_cont > 0, S.kron);
+    p->kkt_fn = p->use_kkt5 ? kkt5_kernel(F) : p->use_kkt3 ? kkt3_kernel(F) : kkt2_kernel(F, D.n_cont > 0, S.kron);
     p->chord_fn = chord_kernel(F);
     if (!p->kkt_fn) { p->err = "no k_kkt instantiation for this front size"; qtos_planner_destroy(p); return -4; }
     hipError_t e = hipFuncSetAttribute((const void *)p->kkt_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->kkt_lds);
@@ -1649,8 +1613,7 @@ int qtos_kkt_kernel(const QtosPlanner *p, char *buf, int n) {
   char name[64];
   const int F = p->S.front;
   if (p->use_kkt5) snprintf(name, sizeof name, "k_kkt5<%d>", F);
-  else if (p->use_kkt4) snprintf(name, sizeof name, "k_kkt4<%d>", F);
-  else if (p->use_kkt3) snprintf(name, sizeof name, "k_kkt3<%d, %d>", F, p->kkt3_mode);
+  else if (p->use_kkt3) snprintf(name, sizeof name, "k_kkt3<%d, 1>", F);
   else snprintf(name, sizeof name, "k_kkt2<%d%s>", F, p->dp.n_cont > 0 ? ", true" : "");
   if (buf && n > 0) snprintf(buf, (size_t)n, "%s", name);
   return (int)strlen(name);

@@ -31,8 +31,7 @@ namespace qtos {
 constexpr int PIV = 16;
 
 // Which update wave holds which 16 x 16 tile of the Schur complement (k_kkt2 / k_kkt3): update index u holds the tiles
-// t = u + NU i of the lower triangle, row by row.  Shared by the kernels and by the analysis (the per-wave chunk masks of the
-// inequality blocks, Symbolic::iq_mfma).
+// t = u + NU i of the lower triangle, row by row.  Shared by the kernels and by the analysis.
 #ifndef QTOS_NU112
 #define QTOS_NU112 0
 #endif
@@ -123,7 +122,6 @@ struct Symbolic {
   std::vector<EqRhs> eq_rhs;
   std::vector<IqBlock> iq_blocks;
   std::vector<short> iq_slots;    // front slot of every column of every inequality block
-  std::vector<char> iq_class;     // iq_mfma: class (0 / 1) of every column of every inequality block (color_columns)
   int max_stage_g = 0;            // longest G slice of a stage
   // Packed per-stage records consumed by k_kkt (each is ONE contiguous, coalesced read):
   //   static  srec[srec_off[k] ..]: n_ent, n_rhs, n_iq, hi, gather offset, n_tgt, number of continuation
@@ -148,10 +146,6 @@ struct Symbolic {
   // with unknown kx_col[e] through the stream value at kx_pos[e], e in [kx_ptr[p], kx_ptr[p + 1])
   std::vector<int> kx_ptr, kx_col, kx_pos;
   int cell_mode = 2;
-  // k_kkt3: the inequality blocks J' S J are not summed entry by entry through the gather table: ONE wave forms every block's
-  // G' S G on the matrix core and adds the entries of its lower triangle to their cells (emit_iq_section).  The gather table
-  // keeps the static entries only.  Header int [2] of a record = offset of its inequality section.
-  bool iq_mfma = false;
   std::vector<int> rtab;              // n_stages x 16: cell of the assembled right-hand side of every pivot (0 = none)
   std::vector<unsigned> amask;   // per stage 256 bits (8 words): front slots whose row of the factor panel V is stored (live, not a pivot of the stage)
   // substitution sweeps with a one-stage look-ahead (k_chord, backward pass of k_kkt2): the rows of V_k that belong to
@@ -405,11 +399,6 @@ struct Symbolic {
       const int kints = kron ? 6 + KRON_STRIDE * ((int)mine.size() + 1) : 0;   // (the Kronecker section, if every block had one)
       bool fits = rest.empty() && dyn < 4096 && dyn + d <= REC_MAX_DOUBLES - 2 && contrib + c < (1 << tgt_shift) &&
                   fixed + (int)t2.size() + 1 + contrib + c + kints <= REC_MAX_INTS - 8;
-      if (iq_mfma) {   // (no gather table: a block costs its tables, 4 + 128 per tile + 16 ints)
-        int ints = fixed + 8 + 8 + 4 * 16;
-        for (int q2 : mine) ints += 32 + (iq_blocks[S.iq_begin + q2].n > 16 ? 384 : 256);
-        fits = rest.empty() && dyn < 4096 && dyn + d <= REC_MAX_DOUBLES - 2 && ints + 32 + (Q.n > 16 ? 384 : 256) <= REC_MAX_INTS - 8 && (int)mine.size() < 16;
-      }
       if (fits) { mine.push_back(q); dyn += d; contrib += c; targets.swap(t2); }
       else rest.push_back(q);
     }
@@ -433,7 +422,7 @@ struct Symbolic {
     // contribution of column a).  One thread owns one target, so the blocks of a record are assembled
     // in ONE pass without conflicts and in a fixed order.
     std::map<int, std::vector<int>> tmap;
-    for (size_t bi = 0; bi < blks.size() && !iq_mfma; ++bi) {
+    for (size_t bi = 0; bi < blks.size(); ++bi) {
       const IqBlock &Q = iq_blocks[S.iq_begin + blks[bi]];
       for (int a = 0; a < Q.n; ++a) {
         const int sa = iq_slots[Q.slot_off + a];
@@ -442,15 +431,13 @@ struct Symbolic {
       }
     }
     // static contributions: code = offset of the value in the dynamic record | 62 << 18 (a one-by-one "block")
-    std::vector<int> static_list[3];   // iq_mfma, per tile type: (triangle index << 12) | offset of the value in the dynamic record
     if (syms)
       for (const auto &e : *syms) {
         const int off = (int)pack_src.size() - d0;
         if (off >= 4096) { err = "static entry beyond the reach of the packed gather records"; return -1; }
         sym_pp.push_back({e[3], e[4], (int)pack_src.size()});
         pack_src.push_back((1 << 28) | e[2]);
-        if (iq_mfma) static_list[e[5]].push_back((trs(e[0], e[1]) << 12) | off);
-        else tmap[trs(e[0], e[1])].push_back(-(off + 1));   // (marked: rewritten below)
+        tmap[trs(e[0], e[1])].push_back(-(off + 1));   // (marked: rewritten below)
       }
     srec[s0 + 4] = (int)srec.size() - s0;
     srec[s0 + 5] = (int)tmap.size();
@@ -530,71 +517,9 @@ struct Symbolic {
       kron_off_of_record[s0] = (n_k << 5) | (koff << 9);   // (header int [2]: blocks of the record | Kronecker blocks << 5 | offset of their section << 9)
       max_kblocks = std::max(max_kblocks, n_k);
     }
-    if (iq_mfma && emit_iq_section(S, blks, blk_goff, s0, static_list)) return -1;
     return 0;
   }
   std::map<int, int> kron_off_of_record;   // record start -> offset of its Kronecker section (the header int [2] is set by the caller)
-  // Inequality section of a record (iq_mfma), ints relative to its start:
-  //   [0] number of blocks (at most 16); [1..3] number of static entries of tile type 0 / 1 / 2; [4..6] their offsets
-  //   [8 .. 72)  per block {offset of G in the dynamic record, m | n << 8 | tile types present << 16, offset of its data, 0}
-  //   static entries: (cell << 12) | offset of the value in the dynamic record, per tile type (they share cells with the
-  //              blocks' entries of that type and are added by the same wave, in front of them)
-  //   per block: 16 ints "columns": lane li -> column at local position li | column at position 16 + li << 8 (255: none);
-  //              16 ints right-hand-side cells of those two columns (16 bit each);
-  //              per tile type present, (0,0) (1,0) (1,1) in this order: 64 lanes x 4 cells (16 bit, two ints per lane) --
-  //              lane (li, lk) holds rows lk + 4 g, column li of the tile after the matrix instruction.
-  // Cells are written as triangle indices here and turned into cell numbers by compact_cells; IQ_NONE = no target (above the
-  // diagonal or beyond the block: those sums go to the lane's trash cell).
-  static constexpr int IQ_NONE = 0xffff, IQ_TRASH_CELL = 1;   // cells 1 .. 64: one trash cell per lane (adds of many lanes to one address are serialised)
-  static constexpr int IQ_MAX_BLOCKS = 16, IQ_HDR = 8 + 4 * IQ_MAX_BLOCKS;
-  int emit_iq_section(const StageDesc &S, const std::vector<int> &blks, const std::vector<int> &blk_goff, int s0, const std::vector<int> (&static_list)[3]) {
-    auto trs = [](int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
-    if ((int)blks.size() > IQ_MAX_BLOCKS) { err = "too many inequality blocks in one record"; return -1; }
-    while ((srec.size() - s0) & 1) srec.push_back(0);   // (the tables are read two ints at a time)
-    const int q0 = (int)srec.size();
-    srec[s0 + 2] = q0 - s0;
-    for (int i = 0; i < IQ_HDR; ++i) srec.push_back(0);
-    srec[q0] = (int)blks.size();
-    for (int ty = 0; ty < 3; ++ty) {
-      srec[q0 + 1 + ty] = (int)static_list[ty].size();
-      srec[q0 + 4 + ty] = (int)srec.size() - q0;
-      srec.insert(srec.end(), static_list[ty].begin(), static_list[ty].end());
-    }
-    while ((srec.size() - q0) & 1) srec.push_back(0);
-    for (size_t bi = 0; bi < blks.size(); ++bi) {
-      const IqBlock &Q = iq_blocks[S.iq_begin + blks[bi]];
-      if (Q.m > 8 || Q.n > 32) { err = "inequality block too large for the matrix-core condensation"; return -1; }
-      int pos[32];   // local position -> column of the block, -1 = none
-      int n0 = 0, n1 = 0;
-      for (int i = 0; i < 32; ++i) pos[i] = -1;
-      for (int a = 0; a < Q.n; ++a) {
-        if (iq_class[Q.slot_off + a] == 0) pos[n0++] = a;
-        else pos[16 + n1++] = a;
-      }
-      if (n0 > 16 || n1 > 16) { err = "inequality block with more than 16 columns of one class"; return -1; }
-      const int present = (n0 ? 1 : 0) | (n0 && n1 ? 2 : 0) | (n1 ? 4 : 0);
-      int *h = &srec[q0 + 8 + 4 * bi];
-      h[0] = blk_goff[bi]; h[1] = Q.m | (Q.n << 8) | (present << 16); h[2] = (int)srec.size() - q0;
-      for (int li = 0; li < 16; ++li) srec.push_back((pos[li] < 0 ? 255 : pos[li]) | ((pos[16 + li] < 0 ? 255 : pos[16 + li]) << 8));
-      auto rhs_cell = [&](int p2) { return pos[p2] < 0 ? IQ_NONE : front * (front + 1) / 2 + iq_slots[Q.slot_off + pos[p2]]; };
-      for (int li = 0; li < 16; ++li) srec.push_back(rhs_cell(li) | (rhs_cell(16 + li) << 16));
-      static const int TR[3] = {0, 1, 1}, TC[3] = {0, 0, 1};
-      for (int ti = 0; ti < 3; ++ti) {
-        if (!((present >> ti) & 1)) continue;
-        for (int lane = 0; lane < 64; ++lane) {
-          const int li = lane & 15, lk = lane >> 4;
-          int cw[4];
-          for (int g = 0; g < 4; ++g) {
-            const int pa = 16 * TR[ti] + lk + 4 * g, pc = 16 * TC[ti] + li;
-            cw[g] = pos[pa] >= 0 && pos[pc] >= 0 && pc <= pa ? trs(iq_slots[Q.slot_off + pos[pa]], iq_slots[Q.slot_off + pos[pc]]) : IQ_NONE;
-          }
-          srec.push_back(cw[0] | (cw[1] << 16));
-          srec.push_back(cw[2] | (cw[3] << 16));
-        }
-      }
-    }
-    return 0;
-  }
 
   // The assembled (original) entries of K waiting in LDS for their pivot column used to live in a dense
   // lower triangle over the front's slots ((F+1)(F+2)/2 doubles: 67 KB at F = 128), of which only a few
@@ -615,7 +540,7 @@ struct Symbolic {
     std::map<std::pair<int, int>, int> cell;
     std::vector<std::vector<int>> retire(n_stages);
     std::vector<int> free_cells;
-    n_cells = cell_mode == 2 ? (iq_mfma ? 1 + 64 : 1) : 1 + F;   // (iq_mfma: cells 1 .. 64 = the lanes' trash cells)
+    n_cells = cell_mode == 2 ? 1 : 1 + F;
     const int RHS = 1 << 30;
     auto target = [&](int k, int t) -> int {
       if (t >= ntri_rhs && cell_mode != 2) return 1 + (t - ntri_rhs);
@@ -659,41 +584,6 @@ struct Symbolic {
         if (c < 0) return -1;
         tg[t] = (c << tgt_shift) | (tg[t] & tmask);
       }
-      if (iq_mfma) {   // inequality section: triangle indices -> cells (static lists: 20 bits, tables: 16 bits)
-        int *q = &srec[s0 + srec[s0 + 2]];
-        const int nb = q[0];
-        for (int ty = 0; ty < 3; ++ty)
-          for (int i = 0; i < q[1 + ty]; ++i) {
-            int &v = q[q[4 + ty] + i];
-            const int c = target(k, v >> 12);
-            if (c < 0) return -1;
-            v = (c << 12) | (v & 4095);
-          }
-        auto cell16 = [&](int t, int lane_of) {
-          const int c = t == IQ_NONE ? IQ_TRASH_CELL + lane_of : target(k, t);
-          if (c >= 65536) { err = "too many cells for the 16-bit tables of the inequality blocks"; return -1; }
-          return c;
-        };
-        for (int b = 0; b < nb; ++b) {
-          const int present = (q[8 + 4 * b + 1] >> 16) & 7;
-          int *tb = q + q[8 + 4 * b + 2] + 16;   // behind the column table: right-hand-side cells, then the tile tables
-          for (int li = 0; li < 16; ++li) {
-            const int c0 = cell16(tb[li] & 0xffff, li), c1 = cell16((tb[li] >> 16) & 0xffff, li);
-            if (c0 < 0 || c1 < 0) return -1;
-            tb[li] = c0 | (c1 << 16);
-          }
-          tb += 16;
-          for (int ti = 0; ti < 3; ++ti) {
-            if (!((present >> ti) & 1)) continue;
-            for (int i = 0; i < 128; ++i) {
-              const int c0 = cell16(tb[i] & 0xffff, i >> 1), c1 = cell16((tb[i] >> 16) & 0xffff, i >> 1);
-              if (c0 < 0 || c1 < 0) return -1;
-              tb[i] = c0 | (c1 << 16);
-            }
-            tb += 128;
-          }
-        }
-      }
       return 0;
     };
     ctab.assign((size_t)n_stages * F * PIV, 0);
@@ -726,35 +616,6 @@ struct Symbolic {
     return 0;
   }
 
-  // iq_mfma: the condensation of the inequality blocks is shared by THREE waves whose cells never meet.  Every variable gets a
-  // class (0 / 1), a block lists its class-0 columns at the local positions 0 .. 15 and its class-1 columns at 16 .. 31: the
-  // entry of a pair of variables then always falls into the same 16 x 16 tile of a block's G' S G -- (0,0) both class 0,
-  // (1,1) both class 1, (1,0) one of each -- whichever block it comes from, so the wave that owns a tile type owns its cells
-  // for good, and each wave adds in its own program order.  Greedy colouring over the blocks in elimination order: a block's
-  // uncoloured columns go to the class with fewer members in that block (small blocks: all to one class); every block must
-  // end up with at most 16 columns per class.
-  std::vector<char> var_class;
-  int color_columns(const HostModel &M, const std::vector<int> &block_minpos) {
-    var_class.assign(M.n_sol, -1);
-    std::vector<int> ord;
-    for (size_t bi = 0; bi < M.blocks.size(); ++bi)
-      if (M.blocks[bi].kind == 1) ord.push_back((int)bi);
-    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return block_minpos[a] < block_minpos[b]; });
-    for (int bi : ord) {
-      const Block &b = M.blocks[bi];
-      int cnt[2] = {0, 0};
-      for (int a = 0; a < b.n; ++a) { const int c = var_class[M.block_cols[b.col_off + a]]; if (c >= 0) cnt[c]++; }
-      for (int a = 0; a < b.n; ++a) {
-        char &c = var_class[M.block_cols[b.col_off + a]];
-        if (c >= 0) continue;
-        c = b.n <= 16 ? (cnt[1] > cnt[0] && cnt[1] < 16 ? 1 : (cnt[0] < 16 ? 0 : 1)) : (cnt[1] < cnt[0] ? 1 : 0);
-        cnt[(int)c]++;
-      }
-      if (cnt[0] > 16 || cnt[1] > 16) { err = "inequality block with more than 16 columns of one class"; return -1; }
-    }
-    for (char &c : var_class) if (c < 0) c = 0;
-    return 0;
-  }
 
   // see short_stages.  first: position -> smallest coupled position (rewritten in positions that count the dummies).
   void shorten_stages(std::vector<int> &first, std::vector<int> &block_minpos, int n_sol, int n_cons) {
@@ -1082,7 +943,6 @@ struct Symbolic {
     // K[multiplier][variable] is assembled at the stage that eliminates the earlier of the two
     // (both have a slot by then); equality G blocks follow the inequality slices in the buffer.
     std::vector<std::vector<int>> owned(n_stages);
-    if (iq_mfma && color_columns(M, block_minpos)) return -1;
     for (size_t bi = 0; bi < M.blocks.size(); ++bi)
       if (M.blocks[bi].kind == 1) owned[block_minpos[bi] / PIV].push_back((int)bi);
     g_doubles = 0;
@@ -1100,7 +960,6 @@ struct Symbolic {
         q.pad0 = q.pad1 = q.pad2 = 0;
         for (int a = 0; a < b.n; ++a) {
           iq_slots.push_back((short)var_slot[M.block_cols[b.col_off + a]]);
-          iq_class.push_back(iq_mfma ? var_class[M.block_cols[b.col_off + a]] : 0);
         }
         iq_blocks.push_back(q);
         iq_kron.push_back(kron ? kron_meta(M, bi) : KMeta());
@@ -1183,7 +1042,7 @@ struct Symbolic {
     for (const HostModel::SymEntry &se : M.sym_static) {
       const int pa = var_pos[se.a], pb = var_pos[se.b];
       if (pa < 0 || pb < 0) continue;
-      sym_of[std::min(pa, pb) / PIV].push_back({var_slot[se.a], var_slot[se.b], (int)M.g_static.size(), pa, pb, iq_mfma ? var_class[se.a] + var_class[se.b] : 0});
+      sym_of[std::min(pa, pb) / PIV].push_back({var_slot[se.a], var_slot[se.b], (int)M.g_static.size(), pa, pb, 0});
       M.g_static.push_back(se.val);
     }
     sym_pp.clear();
@@ -1250,7 +1109,7 @@ struct Symbolic {
         if (split_blocks(S, all, (int)pack_src.size() - drec_off[rec], (int)srec.size() - srec_off[rec], trs, mine, rest, (int)syms.size())) return -1;
       }
       if (emit_blocks(k0, S, mine, srec_off[rec], drec_off[rec], trs, &syms)) return -1;
-      if (!iq_mfma) srec[srec_off[rec] + 2] = (int)mine.size() | (kron_off_of_record.count(srec_off[rec]) ? kron_off_of_record[srec_off[rec]] : 0);
+      srec[srec_off[rec] + 2] = (int)mine.size() | (kron_off_of_record.count(srec_off[rec]) ? kron_off_of_record[srec_off[rec]] : 0);
       pending.push_back(rest);
       max_srec = std::max(max_srec, (int)srec.size() - srec_off[rec]);
       max_drec = std::max(max_drec, (int)pack_src.size() - drec_off[rec]);

@@ -1,24 +1,139 @@
-// kkt3.hpp -- k_kkt3: the factor + solve kernel for fronts of up to 128 slots without continuation records (the default up to
-// 112 slots; larger fronts and records with continuation parts stay with k_kkt2).  Same chain of fronts, cells, records,
-// panels, sweeps and k_chord as kkt2.hpp -- and the same arithmetic: bit-identical plans.  What differs:
+// kkt3.hpp -- k_kkt3: the factor + solve kernel of round 4 for fronts of up to 128 slots (larger fronts and records with
+// continuation parts stay with k_kkt2).  Same chain of fronts, cells, panels, sweeps and k_chord as kkt2.hpp; what changed:
 //
-//   * The assembly of record k+2 starts in phase AB, on the waves that have no job there (their cells are not the ones the
-//     tile waves read in that phase: those belong to stage k+1's columns, and a retired cell is re-issued two stages later):
-//     equality entries and the first QTOS_AB_ROUNDS targets per thread of the gather table; the rest on every wave but the
-//     factor wave at the end of phase C.  -5 % per launch on 112 slots, -6 % on 96; +4 % on 128, where seven idle waves are
-//     too few (profiles/r04_experiments).
+//   * The inequality blocks J' S J are condensed ON THE MATRIX CORE by one wave.  k_kkt2 summed them entry by entry into the
+//     cells through a gather table -- one thread per target, three barrier weights, six Jacobian values and a decoded
+//     contribution word per term: a third of the kernel's vector instructions, spread over fifteen waves.  Here wave 15, which
+//     has no job in phase AB, takes a record's blocks one after the other in that phase: G' S G of a block of
+//     up to 32 columns is three 16 x 16 tiles (one for up to 16 columns), one f64 matrix instruction per four rows each; a
+//     lane then holds four entries of the lower triangle and adds each to its cell with ds_add_f64 -- the cells come from a
+//     table in the record (Symbolic::emit_iq_section), entries above the diagonal go to a trash cell.  One wave, LDS
+//     operations in program order: the summation order of a cell is fixed.  Right-hand sides -G' w by a row sum across the
+//     wave's four row groups.  (Round 2 tried the products with read-modify-write cells: three to four LDS round trips per
+//     block in sequence; the atomic add has none.  Experiment A1 of this round condensed into the Schur tiles instead: 48
+//     products per stage, slower -- profiles/r04_experiments.)
 //   * No special prologue: the stage loop starts two stages early (k = -2, -1 build the panels of stages 0 and 1 through the
 //     same path as every other stage).
-//
-// The template keeps its second parameter (the kernel's name in every committed profile is k_kkt3<F, 1>): MODE 0 of rounds
-// 4 - 5 -- the inequality blocks G' S G condensed on the matrix core, correct and slower -- lives in
-// scratch/experiments/kkt3_mode0.hpp.
 #pragma once
 #include "kkt2.hpp"
 
 namespace qtos {
 
 inline size_t kkt3_lds_bytes(int F, int NS, int max_srec, int max_drec, int n_cells) { return kkt2_lds_bytes(F, NS, max_srec, max_drec, n_cells); }
+
+// The inequality blocks of one record, by ONE wave (section layout: Symbolic::emit_iq_section).  abase = LDS byte address of
+// the cells.
+// The inequality blocks and static entries of one record (section layout: Symbolic::emit_iq_section), shared by THREE waves:
+// wave TY takes the 16 x 16 tiles of type TY of every block -- (0,0): class-0 columns x class-0 columns, (1,0): class 1 x
+// class 0, (2 = (1,1)): class 1 x class 1 -- and the static entries of that type.  A pair of variables has the same type in
+// every block (Symbolic::color_columns), so the three waves' cells never meet and each wave's adds (LDS atomics: no value
+// comes back, nothing waits for them) are executed in its own program order: the summation order of a cell is fixed.
+// abase = LDS byte address of the cells.  Two-stage software pipeline over the blocks: tables of block b + 2 and Jacobian
+// values of block b + 1 are in flight while block b is multiplied.
+struct IqS1 { int colt, rct, ta, tb; };
+struct IqS2 { IqS1 s; double gA, gB, sg, ww, hA, hB, sh, wh; };
+template <int TY>
+__device__ __forceinline__ void condense_type(unsigned abase, const int *sbuf, const double *dbuf, int lane, int part, unsigned long long *stp = nullptr) {
+#ifdef QTOS_STAMPS
+  unsigned long long tq_ = 0;
+#define IQ_ST0() do { if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq_) :: "memory"); } while (0)
+#define IQ_ST(i) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stp[i] += t_ - tq_; tq_ = t_; } } while (0)
+#else
+#define IQ_ST0() do {} while (0)
+#define IQ_ST(i) do {} while (0)
+#endif
+  IQ_ST0();
+  const int li = lane & 15, lk = lane >> 4;
+  const int *q = sbuf + sbuf[2];
+  const int hv = q[8 + lane];        // the headers of up to 16 blocks, one int per lane
+  // part 0 (phase AB): the static entries and the first QTOS_IQ_SPLIT-th of the blocks; part 1 (phase C, another wave: the
+  // barrier between the phases orders the two): the rest
+#ifndef QTOS_IQ_SPLIT
+#define QTOS_IQ_SPLIT 2
+#endif
+  const int nb_all = __builtin_amdgcn_readfirstlane(q[0]), nb_ab = (nb_all + QTOS_IQ_SPLIT - 1) / QTOS_IQ_SPLIT;
+  const int b_first = part == 0 ? 0 : nb_ab, nb = part == 0 ? nb_ab : nb_all;
+  const int nst = part == 0 ? __builtin_amdgcn_readfirstlane(q[1 + TY]) : 0, sto = __builtin_amdgcn_readfirstlane(q[4 + TY]);
+  for (int i = lane; i < nst; i += 64) {
+    const int v = q[sto + i];
+    const unsigned a = abase + 8u * (unsigned)(v >> 12);
+    const double x = dbuf[v & 4095];
+    asm volatile("ds_add_f64 %0, %1" :: "v"(a), "v"(x));
+  }
+  IQ_ST(9);
+  auto present = [&](int b) { return b < nb && ((__builtin_amdgcn_readlane(hv, 4 * b + 1) >> (16 + TY)) & 1); };
+  auto stage1 = [&](int b, IqS1 &o) __attribute__((always_inline)) {
+    o.colt = 0xffff; o.rct = 0; o.ta = 0; o.tb = 0;
+    if (!present(b)) return;
+    const int pres = (__builtin_amdgcn_readlane(hv, 4 * b + 1) >> 16) & 7;
+    const int *d = q + __builtin_amdgcn_readlane(hv, 4 * b + 2);
+    typedef int i2_t __attribute__((ext_vector_type(2)));
+    const i2_t t = ((const i2_t *)(d + 32 + 128 * __builtin_popcount(pres & ((1 << TY) - 1))))[lane];
+    o.colt = d[li]; o.rct = d[16 + li]; o.ta = t[0]; o.tb = t[1];
+  };
+  auto stage2 = [&](int b, const IqS1 &s1, IqS2 &o) __attribute__((always_inline)) {
+    o.s = s1;
+    o.gA = o.gB = o.sg = o.ww = o.hA = o.hB = o.sh = o.wh = 0.0;
+    if (!present(b)) return;
+    const int mn = __builtin_amdgcn_readlane(hv, 4 * b + 1), m = mn & 255, n = (mn >> 8) & 255;
+    const double *G = dbuf + __builtin_amdgcn_readlane(hv, 4 * b);
+    const int a0 = s1.colt & 255, a1 = (s1.colt >> 8) & 255;
+    const int cA = TY == 0 ? a0 : a1, cB = TY == 2 ? a1 : a0;
+    const bool rv = lk < m, rv2 = 4 + lk < m;
+    if (rv && cA != 255) o.gA = G[lk * n + cA];
+    if (rv2 && cA != 255) o.hA = G[(4 + lk) * n + cA];       // rows 4 .. 7 (friction pyramids: five rows)
+    if (TY == 1) {
+      if (rv && cB != 255) o.gB = G[lk * n + cB];
+      if (rv2 && cB != 255) o.hB = G[(4 + lk) * n + cB];
+    }
+    if (rv) { o.sg = G[m * n + lk]; o.ww = G[m * n + m + lk]; }
+    if (rv2) { o.sh = G[m * n + 4 + lk]; o.wh = G[m * n + m + 4 + lk]; }
+  };
+  auto multiply_add = [&](int b, const IqS2 &o) __attribute__((always_inline)) {
+    if (!present(b)) return;
+    const int m = __builtin_amdgcn_readlane(hv, 4 * b + 1) & 255;
+    const double gB = TY == 1 ? o.gB : o.gA, hB = TY == 1 ? o.hB : o.hA;
+    double zero = 0.0;
+    asm volatile("" : "+v"(zero));
+    d4_t D = {zero, zero, zero, zero};
+    D = __builtin_amdgcn_mfma_f64_16x16x4f64(o.sg * o.gA, gB, D, 0, 0, 0);
+    if (m > 4) D = __builtin_amdgcn_mfma_f64_16x16x4f64(o.sh * o.hA, hB, D, 0, 0, 0);
+    const unsigned c0 = abase + 8u * ((unsigned)o.s.ta & 0xffffu), c1 = abase + 8u * ((unsigned)o.s.ta >> 16);
+    const unsigned c2 = abase + 8u * ((unsigned)o.s.tb & 0xffffu), c3 = abase + 8u * ((unsigned)o.s.tb >> 16);
+    asm volatile("ds_add_f64 %0, %1" :: "v"(c0), "v"(D[0]));
+    asm volatile("ds_add_f64 %0, %1" :: "v"(c1), "v"(D[1]));
+    asm volatile("ds_add_f64 %0, %1" :: "v"(c2), "v"(D[2]));
+    asm volatile("ds_add_f64 %0, %1" :: "v"(c3), "v"(D[3]));
+    if (TY != 1) {
+      // right-hand sides of the class's columns: -sum_r G[r][c] w_r, column c on lane li of every row group
+      double r = o.gA * o.ww;
+      if (m > 4) r = fma(o.hA, o.wh, r);
+      r = -rowsum4(r);
+      if (lk == 0) {
+        const unsigned ar = abase + 8u * (TY == 0 ? (unsigned)o.s.rct & 0xffffu : (unsigned)o.s.rct >> 16);
+        asm volatile("ds_add_f64 %0, %1" :: "v"(ar), "v"(r));
+      }
+    }
+  };
+  if (nb > b_first) {
+    IqS1 s1a, s1b;
+    IqS2 s2;
+    stage1(b_first, s1a);
+    stage1(b_first + 1, s1b);
+    stage2(b_first, s1a, s2);
+    for (int b = b_first; b < nb; ++b) {
+      IqS1 s1c;
+      IqS2 s2n;
+      stage1(b + 2, s1c);
+      stage2(b + 1, s1b, s2n);
+      multiply_add(b, s2);
+      s2 = s2n; s1b = s1c;
+    }
+  }
+  IQ_ST(10);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the cells are read and written by ordinary accesses from here on
+  IQ_ST(11);
+}
 
 // The rest of a record: equality Jacobian entries and multiplier right-hand sides are distinct cells of their own (any thread).
 __device__ __forceinline__ void assemble_eq(double *A, const int *sbuf, const double *dbuf, int t0, int nth) {
@@ -46,13 +161,12 @@ __device__ __forceinline__ void assemble_targets(double *A, const int *sbuf, con
 #ifndef QTOS_AB_ROUNDS
 #define QTOS_AB_ROUNDS 64
 #endif
-// The records and the gather-table assembly of k_kkt2 (assemble_stage), its first QTOS_AB_ROUNDS targets per thread moved into
-// phase AB onto the waves that have no job there (with the equality entries), the rest on every wave but the factor wave at the
-// end of phase C.
+// MODE 0: the inequality blocks condensed by matrix instructions (records of Symbolic::iq_mfma); MODE 1: the records and the
+// gather-table assembly of k_kkt2 (assemble_stage), its first QTOS_AB_ROUNDS targets per thread moved into phase AB onto the
+// waves that have no job there (with the equality entries), the rest on every wave but the factor wave at the end of phase C.
 template <int F, int MODE>
 __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
   static_assert(F <= 128 && F % 16 == 0, "k_kkt3: fronts of up to 128 slots (waves 9 .. 15 must be free in phase AB)");
-  static_assert(MODE == 1, "k_kkt3: MODE 0 left the library (scratch/experiments/kkt3_mode0.hpp)");
   const int b = blockIdx.x;
   if (b >= B || W.done[b] || W.chord[b] == 1) return;   // (a problem flagged for a chord step is k_chord's)
   extern __shared__ double lds[];
@@ -288,9 +402,27 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
     else if (k + 2 < NS) {
       // ---- the waves without a job in this phase assemble record k+2 into the cells.  None of the cells they touch is read
       //      or retired by the tile waves here: those belong to the columns of stage k+1, and a retired cell is handed out
-      //      again two stages later (Symbolic::compact_cells).
-      assemble_eq(A, sbuf, dbuf, (wv - NT - 1) * 64 + lane, (15 - NT) * 64);
-      assemble_targets(A, sbuf, dbuf, 0, QTOS_AB_ROUNDS * (15 - NT) * 64, (wv - NT - 1) * 64 + lane, (15 - NT) * 64);
+      //      again two stages later (Symbolic::compact_cells).  Waves 13 .. 15: the inequality blocks and static entries, one
+      //      tile type each (condense_type); the others: equality entries and multiplier right-hand sides.
+      if constexpr (MODE == 1) {
+        assemble_eq(A, sbuf, dbuf, (wv - NT - 1) * 64 + lane, (15 - NT) * 64);
+        assemble_targets(A, sbuf, dbuf, 0, QTOS_AB_ROUNDS * (15 - NT) * 64, (wv - NT - 1) * 64 + lane, (15 - NT) * 64);
+      } else {
+      typedef __attribute__((address_space(3))) double lds_double;
+      const unsigned abase = (unsigned)(size_t)(lds_double *)A;
+#if !(defined(QTOS_IQ_ABL) && (QTOS_IQ_ABL & 4))
+#ifdef QTOS_STAMPS
+      unsigned long long *stp = &st2[wv][0];
+#else
+      unsigned long long *stp = nullptr;
+#endif
+      if (wv == 13) condense_type<0>(abase, sbuf, dbuf, lane, 0, stp);
+      else if (wv == 14) condense_type<1>(abase, sbuf, dbuf, lane, 0, stp);
+      else if (wv == 15) condense_type<2>(abase, sbuf, dbuf, lane, 0, stp);
+      else
+#endif
+        assemble_eq(A, sbuf, dbuf, (wv - NT - 1) * 64 + lane, (12 - NT) * 64);
+      }
     }
     KS2(0);
     lds_barrier();
@@ -378,7 +510,7 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
       }
     }
     KS2(2);
-    {
+    if constexpr (MODE == 1) {
       // the targets phase AB left: every wave but the factor wave (the waves without Schur tiles first: low item indices)
       const int apos = is_upd ? (15 - NU) + uw : uw - NU;
       if (wv >= 1 && k + 2 < NS) assemble_targets(A, sbuf, dbuf, QTOS_AB_ROUNDS * (15 - NT) * 64, 1 << 30, apos * 64 + lane, 15 * 64);
@@ -398,6 +530,21 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gd + min(c * 1024 + lane * 16, nbd - 16)), (__attribute__((address_space(3))) void *)(ld + c * 1024), 16, 0, 0);
       for (int c = wi; c * 1024 < nbs; c += 2)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gs + min(c * 1024 + lane * 16, nbs - 16)), (__attribute__((address_space(3))) void *)(ls + c * 1024), 16, 0, 0);
+    }
+    // the second part of the inequality blocks of record k+2, one tile type per wave (condense_type), while the records travel
+    if (MODE == 0 && !(wv & 3) && wv != 0 && k + 2 < NS) {
+      typedef __attribute__((address_space(3))) double lds_double;
+      const unsigned abase = (unsigned)(size_t)(lds_double *)A;
+#ifdef QTOS_STAMPS
+      unsigned long long *stp = &st2[wv][0];
+#else
+      unsigned long long *stp = nullptr;
+#endif
+#if !(defined(QTOS_IQ_ABL) && (QTOS_IQ_ABL & 4))
+      if (wv == 4) condense_type<0>(abase, sbuf, dbuf, lane, 1, stp);
+      else if (wv == 8) condense_type<1>(abase, sbuf, dbuf, lane, 1, stp);
+      else condense_type<2>(abase, sbuf, dbuf, lane, 1, stp);
+#endif
     }
     if (wv == 8 || wv == 12) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wv == 12) {

@@ -1,0 +1,51 @@
+# round 6 (ADVICE medium, verdict item 4): where the GPU <-> oracle gap of the time-shifted warm starts comes from.
+# The shifted replans of test_shifted_windows_match_oracle_over_five_replans, with (a) the oracle's eps_dual varied and (b) both
+# solvers stopped after 1, 2, ... iterations: gap per iteration prefix, step lengths of both.
+import dataclasses, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.oracle import Oracle, oracle_dict, oracle_options
+from oracle.projection import project_nodes
+from qtos_amd import workloads
+from qtos_amd.capi import Planner
+from qtos_amd.config import PlannerConfig
+from qtos_amd.replan import ShiftedWindows
+
+cfg = PlannerConfig.knots200()
+maps, cell = workloads.random_terrains()
+P = Planner(cfg, max_batch=4)
+P.set_heightfields(maps, cell)
+start, goal, map_id = workloads.mpc_goals(4, seed=5, terrains=(maps, cell))
+W = ShiftedWindows(P, start, goal - start[:, 0:3], map_id, advance=2.5)
+oracles = [Oracle(oracle_dict(cfg), height=maps[m], hcell=cell) for m in map_id]
+var_free = P.structure()[1]
+prefix = {}
+for mi in range(1, 9):
+    prefix[mi] = Planner(dataclasses.replace(cfg, max_iter=mi), max_batch=4)
+    prefix[mi].set_heightfields(maps, cell)
+for k in range(6):
+    W.warm_mode = "shifted" if k >= 4 else "none"
+    nodes, status = W.replan()
+    torch.cuda.synchronize()
+    if k < 4:
+        continue
+    st, gl = W.start.cpu().numpy(), W.goal.cpu().numpy()
+    warm_raw = W.warm.cpu().numpy()
+    warm = project_nodes(warm_raw, oracles[0].L, var_free)
+    it = W.iters.cpu().numpy()
+    print("replan %d: gpu iterations %s" % (k, it.tolist()))
+    for b in range(4):
+        O = oracles[b]
+        q = O.problem(st[b, 0:3], st[b, 3:6], st[b, 6:18].reshape(4, 3), gl[b])
+        for eps in (1e-8, 1e-10, 1e-12):
+            opts = oracle_options(cfg, O)
+            opts.eps_dual = eps
+            xo, info = O.solve(q, x0=warm[b], opts=opts)
+            print("  window %d oracle eps_dual %.0e: iters %d (gpu %d) gap %.2e" % (b, eps, info.iters, it[b], np.abs(nodes[b].cpu().numpy() - xo).max()))
+        for mi in range(1, min(int(it[b]), 8) + 1):
+            n_g, s_g, i_g, v_g = prefix[mi].plan(st[b:b + 1], gl[b:b + 1], map_id=map_id[b:b + 1], warm=warm_raw[b:b + 1])
+            opts = oracle_options(dataclasses.replace(cfg, max_iter=mi), O)
+            xo, info = O.solve(q, x0=warm[b], opts=opts)
+            tr = prefix[mi].trace(0)
+            print("    after %d iteration(s): gap %.2e   gpu viol %.3e alpha %.4f   oracle inf_pr %.3e" % (mi, np.abs(n_g[0] - xo).max(), tr[-1, 0], tr[-1, 2], info.inf_pr))
