@@ -355,15 +355,14 @@ def main():
         args.inflight = 4 if mpc else 1
     if args.chord_tol is not None:
         kw["chord_tol"] = args.chord_tol
-    elif mpc:
-        # replanned windows are at different points of their solves in every iteration: a chord step saves no launch
-        # there (the batch still factors for the others) and a discarded one costs an iteration
-        kw["chord_tol"] = 0.0
-        # ... and without a chord step to finish, Ipopt's superlinear decrease of the barrier parameter has nothing to gain here (it
-        # is what lets the iterate behind the third factorisation converge by a chord step) and lengthens the tail: the slowest of
-        # 256 windows takes 9.0 instead of 8.45 factorisations per replan; --superlinear-mu overrides
-        if not args.superlinear_mu:
-            kw["mu_superlinear"] = False
+    if mpc:
+        # the receding windows' solver settings are the PRODUCT's, in one place: PlannerConfig.receding_windows (no chord steps,
+        # plain barrier update; config.py says why).  --superlinear-mu / --chord-tol override them for the A/B lines of DESIGN.md
+        if args.superlinear_mu:
+            kw["mu_superlinear"] = True
+        rw = PlannerConfig.receding_windows(**kw)
+        kw.setdefault("chord_tol", rw.chord_tol)
+        kw.setdefault("mu_superlinear", rw.mu_superlinear)
     if args.gait == "trot":
         kw["gait"] = "trot"
     if args.full_system:

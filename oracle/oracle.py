@@ -59,6 +59,7 @@ class QoOptions(C.Structure):
         ("warm_start", C.c_int), ("verbose", C.c_int), ("stall_iters", C.c_int),
         ("hold_from", C.c_int), ("hold_weight", C.c_double), ("hold_tol", C.c_double), ("chord_tol", C.c_double),
         ("stall_alpha", C.c_double), ("chord_max", C.c_int), ("chord_shrink", C.c_double), ("swing_start_on_rule", C.c_int),
+        ("eps_dual_swing", C.c_double), ("eps_dual_acc", C.c_double),
         ("mu_superlinear", C.c_int),
     ]
 
@@ -125,9 +126,16 @@ def oracle_dict(cfg):
                 swing_start_on_rule=bool(getattr(cfg, "reduce_swing", False)) and cfg.terrain_mode == 1)
 
 
-def oracle_options(cfg, O):
-    """qo_options of the oracle O with the solver settings of a PlannerConfig."""
+def oracle_options(cfg, O, match_eliminated=False):
+    """qo_options of the oracle O with the solver settings of a PlannerConfig.  match_eliminated: the multipliers of the rows the
+    product's reduce_swing / reduce_base eliminate from its KKT system get a regularisation of 1e-13 instead of eps_dual (the
+    product has no multipliers for them: eps = 0), so the two Newton steps agree to rounding instead of to eps x multiplier."""
     o = O.default_options()
+    if match_eliminated:
+        if bool(getattr(cfg, "reduce_swing", False)) and cfg.terrain_mode == 1:
+            o.eps_dual_swing = 1e-13
+        if bool(getattr(cfg, "reduce_base", False)):
+            o.eps_dual_acc = 1e-13
     o.max_iter, o.tol, o.mu_init, o.mu_min = cfg.max_iter, cfg.tol, cfg.mu_init, cfg.mu_min
     o.delta_x, o.eps_dual, o.slack_push, o.warm_slack_push = cfg.delta_x, cfg.eps_dual, cfg.slack_push, cfg.warm_slack_push
     o.stall_iters, o.hold_from, o.hold_weight, o.hold_tol = (cfg.stall_iters, cfg.foothold_hold_from,

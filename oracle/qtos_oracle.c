@@ -938,6 +938,8 @@ void qo_default_options(qo_options *o) {
   o->warm_start = 0;
   o->verbose = 0;
   o->swing_start_on_rule = 0;
+  o->eps_dual_swing = -1.0;
+  o->eps_dual_acc = -1.0;
   o->mu_superlinear = 1;
 }
 
@@ -1270,7 +1272,13 @@ int qo_solve(const qo_params *p, const qo_problem *q, const qo_options *o, doubl
       const double *Jr = J + (size_t)r * n;
       rhs[pe] = -g[r];
       if (chord) continue;
-      *sky_at(&K, pe, pe) = -o->eps_dual;
+      {
+        /* rows the product may have eliminated from its system carry their own eps (qo_options.eps_dual_swing / _acc) */
+        double eps = o->eps_dual;
+        if (o->eps_dual_swing >= 0 && r >= L->off_swing[0]) eps = o->eps_dual_swing;
+        if (o->eps_dual_acc >= 0 && r >= L->off_acc_lin && r < L->off_rom[0]) eps = o->eps_dual_acc;
+        *sky_at(&K, pe, pe) = -eps;
+      }
       for (int a = rp[r]; a < rp[r + 1]; ++a) {
         int pv = vpos[ci[a]];
         if (pv < pe) *sky_at(&K, pe, pv) += Jr[ci[a]];
