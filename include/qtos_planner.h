@@ -121,6 +121,15 @@ int qtos_analyze(const QtosParams *params, QtosDims *dims, int *stage_active, in
  * of its columns in elimination order.  Arrays may be NULL.  0, or -4: no schedule for this transcription, -5: the packed
  * copy of the column positions disagrees with the list. */
 int qtos_analyze_sweep(const QtosParams *params, int *n_rounds, int *rows, int *entries, int *pos_min, int *pos_max, int max_places);
+/* Host-only (round 6, analysis only -- no kernel follows this order yet): what a TWO-ENDED elimination of this model's KKT matrix
+ * would look like -- a chain from t = 0 forward, a chain from t = T backward, the unknowns alive across the split time (the
+ * separator) last -- and the LDS a workgroup that runs both chains would need.  out (n_out >= 20 ints):
+ *   [0] stages today  [1] front today  [2] split stage  [3] stages of chain L  [4] of chain R  [5] separator unknowns
+ *   [6] separator stages  [7] front of L  [8] of R  [9] of the separator  [10] serial steps = max([3], [4]) + [6]
+ *   [11] populated peak of L  [12] of R;  LDS bytes: [13] today's kernel, of which [14] panels, [15] record buffers, [16] cells;
+ *   [17] two chains with today's layouts  [18] two chains with a lean layout (two panels + the blanked copy, one dynamic-only
+ *   record buffer per chain, gather tables from L2)  [19] the limit (160 KB - 256 B).  DESIGN.md section 5. */
+int qtos_analyze_two_ended(const QtosParams *params, int *out, int n_out);
 /* Host-only: the Kronecker structure of the range-of-motion blocks (experiment QTOS_KRON of round 4): inequality blocks in all,
  * blocks with the structure, the most of them in one stage record, and the largest relative difference between an entry formed
  * through a block's 33 sums and the direct three-term sum on random data. */

@@ -62,7 +62,7 @@ EXPORTS = [
     "qtos_last_timing_chord", "qtos_debug_chord", "qtos_plan_totals",
     "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation", "qtos_debug_residual", "qtos_project_nodes",
     "qtos_debug_stream_len", "qtos_debug_read_stream", "qtos_debug_read_rhs", "qtos_build_flags", "qtos_kkt_kernel",
-    "qtos_last_timing_detail", "qtos_set_pattern_speculation", "qtos_env",
+    "qtos_last_timing_detail", "qtos_set_pattern_speculation", "qtos_env", "qtos_analyze_two_ended",
 ]
 
 _lib = None
@@ -133,6 +133,8 @@ def load():
         lib.qtos_last_timing_detail.argtypes = [vp, dp, C.c_int]
         lib.qtos_set_pattern_speculation.argtypes = [vp, C.c_int]
         lib.qtos_env.argtypes = [vp, C.c_char_p, C.c_int]
+    if hasattr(lib, "qtos_analyze_two_ended"):
+        lib.qtos_analyze_two_ended.argtypes = [C.POINTER(QtosParams), ip, C.c_int]
     if hasattr(lib, "qtos_shift_warm"):   # (absent from older builds loaded through QTOS_LIB for A/B timing)
         lib.qtos_shift_warm.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, dp]
         lib.qtos_shift_warm_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
@@ -214,6 +216,21 @@ def analyze(cfg):
     if rc != 0:
         raise ValueError("qtos_analyze failed (%d)" % rc)
     return d, act[:d.n_stages].copy()
+
+
+def analyze_two_ended(cfg):
+    """Host-only: what a two-ended elimination of this model's KKT matrix would look like (qtos_analyze_two_ended): a dict of the
+    chain lengths, fronts, the separator and the LDS a workgroup running both chains would need."""
+    lib = load()
+    p = params_from_config(cfg)
+    a = np.zeros(20, np.int32)
+    rc = lib.qtos_analyze_two_ended(C.byref(p), _ip(a), a.size)
+    if rc != 0:
+        raise ValueError("qtos_analyze_two_ended failed (%d)" % rc)
+    keys = ("stages_now", "front_now", "split_stage", "stages_left", "stages_right", "sep_unknowns", "stages_sep", "front_left", "front_right",
+            "front_sep", "serial_steps", "peak_left", "peak_right", "lds_now", "lds_panels", "lds_records", "lds_cells", "lds_two_chains_as_is",
+            "lds_two_chains_lean", "lds_limit")
+    return {k: int(v) for k, v in zip(keys, a)}
 
 
 def analyze_kron(cfg):

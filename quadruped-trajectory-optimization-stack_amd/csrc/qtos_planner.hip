@@ -750,6 +750,39 @@ int qtos_analyze(const QtosParams *params, QtosDims *d, int *stage_active, int m
   return 0;
 }
 
+// Host-only: what a TWO-ENDED elimination of this model's KKT matrix would look like (Symbolic::analyze_two_ended: a chain from
+// t = 0 forward, a chain from t = T backward, the unknowns alive across the split time last), and the LDS a workgroup that runs
+// both chains would need with the layouts of today's kernel.  out (>= 20 ints):
+//   [0] stages today  [1] front today  [2] split stage  [3] stages of chain L  [4] of chain R  [5] separator unknowns
+//   [6] separator stages  [7] front of L  [8] of R  [9] of the separator  [10] serial steps  [11] populated peak of L  [12] of R
+//   LDS bytes: [13] today's kernel for this model, of which [14] panels, [15] record buffers, [16] cells;
+//   [17] two chains with today's layouts (panels, cells and both record buffers twice, the fixed part twice)
+//   [18] two chains, LEAN: per chain two panels + the blanked copy, one record buffer holding the dynamic record only (gather
+//        tables read from L2), the cells; the fixed part twice   [19] the limit (160 KB - 256 B)
+int qtos_analyze_two_ended(const QtosParams *params, int *out, int n_out) {
+  if (!params || !out || n_out < 20) return -1;
+  HostModel M;
+  Symbolic S;
+  S.env = QtosEnv::parse();
+  if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
+  if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
+  const Symbolic::TwoEnded t = S.analyze_two_ended(M);
+  const int F = S.front, Fc = std::max(t.front_left, t.front_right);
+  auto panel_b = [](int f, int n_pan) { return (size_t)((f + 1) * PLD * n_pan + f * PLD) * sizeof(double); };
+  const size_t rec_b = 2 * (kkt2_dbuf_doubles(F, S.max_drec) * sizeof(double) + kkt2_sbuf_ints(F, S.max_srec) * sizeof(int));
+  const size_t cells_b = (((size_t)S.n_cells + 1) & ~(size_t)1) * sizeof(double);
+  const size_t total = kkt2_lds_bytes(F, S.n_stages, S.max_srec, S.max_drec, S.n_cells);
+  const size_t fixed_b = total > panel_b(F, 3) + rec_b + cells_b ? total - panel_b(F, 3) - rec_b - cells_b : 0;
+  out[0] = S.n_stages; out[1] = F; out[2] = t.split_stage; out[3] = t.stages_left; out[4] = t.stages_right; out[5] = t.sep_unknowns;
+  out[6] = t.stages_sep; out[7] = t.front_left; out[8] = t.front_right; out[9] = t.front_sep; out[10] = t.serial_steps;
+  out[11] = t.peak_left; out[12] = t.peak_right;
+  out[13] = (int)total; out[14] = (int)panel_b(F, 3); out[15] = (int)rec_b; out[16] = (int)cells_b;
+  out[17] = (int)(2 * (panel_b(Fc, 3) + rec_b + cells_b + fixed_b));
+  out[18] = (int)(2 * (panel_b(Fc, 2) + kkt2_dbuf_doubles(F, S.max_drec) * sizeof(double) + cells_b + fixed_b));
+  out[19] = 160 * 1024 - 256;
+  return 0;
+}
+
 // Host-only: the Kronecker structure of the range-of-motion blocks (Symbolic::kron_meta, QTOS_KRON): how many inequality
 // blocks have it, the most in one stage record, and the largest relative difference between an entry of G' S G / G' w formed
 // through the 33 sums of a block and the direct three-term sum, on random matrices and weights (Symbolic::check_kron).

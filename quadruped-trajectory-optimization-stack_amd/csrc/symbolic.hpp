@@ -1313,6 +1313,98 @@ struct Symbolic {
     algorithmic_bytes += 8LL * 2 * n_real_unknowns;
     return 0;
   }
+
+  // ---- two-ended elimination: ANALYSIS ONLY (round 6, DESIGN.md section 5 "Two chains per compute unit") --------------------
+  // The KKT matrix is block-banded in time: a chain L that eliminates from t = 0 forward and a chain R that eliminates from t = T
+  // backward meet nothing of each other until they reach the unknowns that are alive across a split time -- the SEPARATOR, which
+  // receives the Schur complements of both and is eliminated last.  This function answers what such an order would look like
+  // for this model (it emits no kernel tables): for every stage boundary s of the current order
+  //   S  = positions >= s whose envelope reaches below s (alive across the split),
+  //   L  = positions < s in the current order (its fronts are the current ones, cut at s),
+  //   R  = the other positions >= s, re-ordered for the mirrored problem -- by time stamp descending, a long-lived unknown
+  //        (one whose envelope starts more than `long_life` seconds before its own time stamp: footholds, spline coefficients)
+  //        at the START of its life instead of its end --, fronts by the mirrored envelope rule;
+  // the split with the fewest serial steps max(stages L, stages R) + stages S is reported.
+  struct TwoEnded {
+    int split_stage = 0, stages_now = 0, front_now = 0;
+    int stages_left = 0, stages_right = 0, stages_sep = 0, sep_unknowns = 0;
+    int front_left = 0, front_right = 0, front_sep = 0;     // slots (multiples of 16)
+    int serial_steps = 0;
+    int peak_left = 0, peak_right = 0;                      // populated slots at the largest front of either chain
+  };
+  TwoEnded analyze_two_ended(const HostModel &M, double long_life = 0.3) const {
+    TwoEnded best;
+    const int N = n_unknowns, n = M.n_sol;
+    best.stages_now = n_stages; best.front_now = front;
+    // adjacency by position (pattern of K: an inequality block is a clique of its columns, an equality row couples its
+    // multiplier with its columns, static entries couple two variables)
+    std::vector<std::vector<int>> adj(N);
+    auto link = [&](int a, int b) { if (a >= 0 && b >= 0 && a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
+    for (const Block &b : M.blocks) {
+      if (b.kind == 1) {
+        for (int a = 0; a < b.n; ++a)
+          for (int c = 0; c < a; ++c) link(var_pos[M.block_cols[b.col_off + a]], var_pos[M.block_cols[b.col_off + c]]);
+      } else {
+        for (int r = 0; r < b.m; ++r)
+          for (int a = 0; a < b.n; ++a) link(row_pos[b.row0 + r], var_pos[M.block_cols[b.col_off + a]]);
+      }
+    }
+    for (const HostModel::SymEntry &e : M.sym_static) link(var_pos[e.a], var_pos[e.b]);
+    std::vector<double> tp(N, 0.0);
+    for (int p = 0; p < N; ++p) tp[p] = order[p] < 0 ? (p ? tp[p - 1] : 0.0) : (order[p] < n ? M.var_time[order[p]] : M.con_time[order[p] - n] + 1e-7);
+    std::vector<int> lo(N), hi(N);
+    for (int p = 0; p < N; ++p) {
+      lo[p] = hi[p] = p;
+      for (int q : adj[p]) { lo[p] = std::min(lo[p], q); hi[p] = std::max(hi[p], q); }
+    }
+    // (envelope: an unknown is in the front from the stage of the smallest position it is coupled with; fill stays inside)
+    best.serial_steps = 1 << 30;
+    for (int ks = n_stages / 4; ks <= (3 * n_stages) / 4; ++ks) {
+      const int s = ks * PIV;
+      TwoEnded t;
+      t.split_stage = ks; t.stages_now = n_stages; t.front_now = front;
+      std::vector<char> inS(N, 0);
+      for (int j = s; j < N; ++j) if (lo[j] < s) { inS[j] = 1; t.sep_unknowns++; }
+      // chain L: the current order cut at s
+      t.stages_left = ks;
+      for (int k = 0; k < ks; ++k) {
+        int live = PIV;
+        for (int j = (k + 1) * PIV; j < N; ++j) live += lo[j] < (k + 1) * PIV && (j < s || inS[j]);
+        t.peak_left = std::max(t.peak_left, live);
+      }
+      // chain R: the mirrored order
+      std::vector<int> R;
+      for (int j = s; j < N; ++j) if (!inS[j] && order[j] >= 0) R.push_back(j);
+      std::vector<double> key(N, 0.0);
+      for (int j : R) {
+        const double t_start = tp[lo[j]];
+        key[j] = (tp[j] - t_start > long_life) ? t_start : tp[j];
+      }
+      std::stable_sort(R.begin(), R.end(), [&](int a, int b) { return key[a] > key[b] || (key[a] == key[b] && a > b); });
+      std::vector<int> posr(N, 1 << 29);      // mirrored position; the separator's members are never eliminated by this chain
+      for (size_t i = 0; i < R.size(); ++i) posr[R[i]] = (int)i;
+      std::vector<int> firstr(N, 1 << 29);
+      for (int j = s; j < N; ++j) {
+        if (order[j] < 0) continue;
+        firstr[j] = posr[j];
+        for (int q : adj[j]) if (q >= s) firstr[j] = std::min(firstr[j], posr[q]);
+      }
+      t.stages_right = ((int)R.size() + PIV - 1) / PIV;
+      for (int k = 0; k < t.stages_right; ++k) {
+        int live = PIV;
+        for (int j = s; j < N; ++j) live += order[j] >= 0 && posr[j] >= (k + 1) * PIV && firstr[j] < (k + 1) * PIV;
+        t.peak_right = std::max(t.peak_right, live);
+      }
+      t.stages_sep = (t.sep_unknowns + PIV - 1) / PIV;
+      t.front_left = ((t.peak_left + PIV - 1) / PIV) * PIV;
+      t.front_right = ((t.peak_right + PIV - 1) / PIV) * PIV;
+      t.front_sep = t.stages_sep * PIV;
+      t.serial_steps = std::max(t.stages_left, t.stages_right) + t.stages_sep;
+      const int fb = std::max(best.front_left, best.front_right), ft = std::max(t.front_left, t.front_right);
+      if (t.serial_steps < best.serial_steps || (t.serial_steps == best.serial_steps && ft < fb)) best = t;
+    }
+    return best;
+  }
 };
 
 }  // namespace qtos

@@ -1,0 +1,36 @@
+"""Round-5 verdict item 2(i), host side: what a two-ended elimination of the KKT matrix would look like (Symbolic::analyze_two_ended
+through the C ABI's qtos_analyze_two_ended -- analysis only, no kernel tables): a chain from t = 0 forward, a chain from t = T
+backward, the unknowns alive across the split last.  Pins the numbers DESIGN.md section 5 quotes."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.mark.parametrize("name", ["walk", "trot", "knots200", "reference_compat"])
+def test_two_ended_order_halves_the_chain_and_does_not_fit_the_lds(name):
+    from qtos_amd.capi import analyze, analyze_two_ended
+    from qtos_amd.config import PlannerConfig
+    cfg = {"walk": PlannerConfig.knots100(gait="walk"), "trot": PlannerConfig.knots100(gait="trot"), "knots200": PlannerConfig.knots200(),
+           "reference_compat": PlannerConfig.reference_compat()}[name]
+    d, _ = analyze(cfg)
+    t = analyze_two_ended(cfg)
+    assert (t["stages_now"], t["front_now"]) == (d.n_stages, d.front)
+    # every position of the current order is in exactly one of the three parts (dummy pivots of short stages stay with L or vanish from R)
+    assert t["stages_left"] == t["split_stage"] and 16 * (t["stages_left"] + t["stages_right"]) + t["sep_unknowns"] >= d.n_unknowns
+    assert 16 * (t["stages_left"] + t["stages_right"] - 1) + t["sep_unknowns"] <= 16 * d.n_stages
+    # the two chains are balanced and the serial chain is little more than half of today's
+    assert abs(t["stages_left"] - t["stages_right"]) <= 2
+    assert t["serial_steps"] == max(t["stages_left"], t["stages_right"]) + t["stages_sep"] <= 0.56 * t["stages_now"]
+    # the separator is well under one front; chain L keeps today's front, the mirrored chain needs at most two groups more
+    # (its order is the mirrored time-stamp rule without the forward order's dynamic programming over the stage boundaries)
+    assert t["sep_unknowns"] <= 80 and t["front_sep"] <= t["front_now"]
+    assert t["front_left"] == t["front_now"] and t["front_now"] <= t["front_right"] <= t["front_now"] + 32
+    # LDS: today's kernel fills the 160 KB of a compute unit with ONE chain (panels + record buffers + cells + fixed part);
+    # two chains do not fit, neither as they are nor with the lean layout (two panels, one dynamic-only record buffer per chain)
+    assert t["lds_panels"] + t["lds_records"] + t["lds_cells"] <= t["lds_now"] <= t["lds_limit"]
+    assert t["lds_two_chains_as_is"] > 1.7 * t["lds_limit"] and t["lds_two_chains_lean"] > t["lds_limit"]
+    print(name, t)
