@@ -258,9 +258,10 @@ def percentile(xs, q):
     return xs[min(len(xs) - 1, int(round(q * (len(xs) - 1))))] if xs else None
 
 
-def settle(step_fn, sync_fn, max_steps, tol):
+def settle(step_fn, sync_fn, max_steps, tol, agree=None):
     """Adaptive warm-up: untimed steps until three in a row lie within `tol` of each other (host clock around a step that ends
-    with the device idle), at most max_steps.  Returns the number of steps run."""
+    with the device idle), at most max_steps.  agree(done) -> bool: with several ranks every rank runs the SAME number of steps
+    (a step holds a collective): the decision to stop is the ranks' AND, taken after every step.  Returns the steps run."""
     import time as _t
     last, n = [], 0
     while n < max_steps:
@@ -270,7 +271,10 @@ def settle(step_fn, sync_fn, max_steps, tol):
         sync_fn()
         last.append(_t.perf_counter() - t0)
         n += 1
-        if len(last) >= 3 and max(last[-3:]) <= (1.0 + tol) * min(last[-3:]):
+        done = len(last) >= 3 and max(last[-3:]) <= (1.0 + tol) * min(last[-3:])
+        if agree is not None:
+            done = agree(done)
+        if done:
             break
     return n
 
@@ -521,13 +525,13 @@ def main():
     # 0.5 ms per batch between the kernels (BENCH_r05) -- host clocks, first touches -- and a 20-step window must not average that in
     warmup_extra = 0
     if args.settle > 0 and not mpc and not (args.inflight > 1):
-        warmup_extra = settle(step, sync, args.settle, args.settle_tol)
+        agree = None
         if use_dist:   # (every rank runs the same number of steps: the collective inside a step must pair up)
-            we = torch.tensor([warmup_extra], dtype=torch.int64, device=dev)
-            dist.all_reduce(we, op=dist.ReduceOp.MAX)
-            for _ in range(int(we.item()) - warmup_extra):
-                step()
-            warmup_extra = int(we.item())
+            def agree(done):
+                f = torch.tensor([1 if done else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(f, op=dist.ReduceOp.MIN)
+                return bool(f.item())
+        warmup_extra = settle(step, sync, args.settle, args.settle_tol, agree)
     sync()
     state["timed"] = 0
     solved_dev.zero_()

@@ -650,6 +650,7 @@ struct Symbolic {
           if (best[a] + 1 < best[a + r]) { best[a + r] = best[a] + 1; prev[a + r] = a; }
         }
       }
+      if (env.debug) fprintf(stderr, "qtos: short stages: a front of %d slots takes %d stages (%d at %d slots)\n", target, best[N], NS0, F0);
       if (best[N] > (no_extra_stage ? NS0 : NS0 + NS0 / 50)) break;
       cut.clear();
       for (int b = N; b > 0; b = prev[b]) cut.push_back(b);

@@ -62,3 +62,42 @@ def test_world_size_2_gloo_allgather(tmp_path):
         assert np.array_equal(np.load(tmp_path / ("nodes%d.npy" % r)), want_nodes)
         assert np.array_equal(np.load(tmp_path / ("status%d.npy" % r)), want_status)
         assert np.load(tmp_path / ("reuse%d.npy" % r)).all()
+
+
+def _settle_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import time
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a "step" holds a collective, as bench.py's does for N > 1; rank 0's steps settle at once, rank 1's take three steps longer
+    durations = [0.010] * 12 if rank == 0 else [0.030, 0.022, 0.016, 0.010, 0.010, 0.010, 0.010, 0.010, 0.010, 0.010, 0.010, 0.010]
+    count = {"n": 0}
+
+    def step():
+        time.sleep(durations[count["n"]])
+        count["n"] += 1
+        t = torch.ones(1)
+        dist.all_reduce(t)            # (ranks that ran different numbers of steps would pair this with the wrong collective)
+        assert float(t.item()) == world
+
+    def agree(done):
+        f = torch.tensor([1 if done else 0], dtype=torch.int32)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item())
+    n = bench.settle(step, dist.barrier, 10, 0.2, agree)
+    np.save(os.path.join(tmp, "settle%d.npy" % rank), np.array([n, count["n"]]))
+    dist.destroy_process_group()
+
+
+def test_adaptive_warmup_runs_the_same_number_of_steps_on_every_rank(tmp_path):
+    """bench.py's adaptive warm-up (settle) with two ranks over gloo: a step holds a collective, so the decision to stop is the
+    ranks' AND after every step -- the rank whose steps are steady from the start keeps stepping until the other one has settled."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_settle_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "settle0.npy"), np.load(tmp_path / "settle1.npy")
+    assert a[0] == b[0] == a[1] == b[1] and 4 <= a[0] <= 8, (a, b)

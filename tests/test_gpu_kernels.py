@@ -106,6 +106,34 @@ def test_default_selection_and_fallback():
         P.close()
 
 
+def test_environment_is_read_once_at_creation_and_read_back():
+    """Round 6: every QTOS_* switch is parsed in one place when the planner is created (csrc/env.hpp) and the handle says what it
+    runs with (qtos_env); a change of the environment behind an existing handle does not reach it."""
+    import os
+    from qtos_amd.config import PlannerConfig
+    P0 = _planner(PlannerConfig.knots100(), 2, None)
+    e0 = P0.env()
+    assert e0["QTOS_KKT"] == "0" and e0["QTOS_LANES"] == "1" and e0["QTOS_SHORT_STAGES"] == "unset" and e0["QTOS_SPEC_PATTERN"] == "1"
+    assert e0["QTOS_SWEEP_DS"] == "1" and e0["QTOS_SPEC_JAC"] == "1"
+    old = {k: os.environ.get(k) for k in ("QTOS_KKT", "QTOS_LANES", "QTOS_SPEC_PATTERN", "QTOS_SHORT_STAGES")}
+    os.environ.update(QTOS_KKT="2", QTOS_LANES="3", QTOS_SPEC_PATTERN="0", QTOS_SHORT_STAGES="0")
+    try:
+        assert P0.env() == e0 and P0.kkt_kernel() == EXPECT[(None, "walk")]     # the old handle keeps what it was created with
+        from qtos_amd.capi import Planner
+        P1 = Planner(PlannerConfig.knots100(), max_batch=2)
+        e1 = P1.env()
+        assert (e1["QTOS_KKT"], e1["QTOS_LANES"], e1["QTOS_SPEC_PATTERN"], e1["QTOS_SHORT_STAGES"]) == ("2", "3", "0", "0")
+        assert P1.kkt_kernel().startswith("k_kkt2<128") and P1.dims.front == 128     # (no short stages: the walk's 128 slots; k_kkt2 forced)
+        P1.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    P0.close()
+
+
 @pytest.mark.parametrize("kkt", ["2", "6"])
 def test_factor_panels_of_either_kernel_match_the_block_elimination(kkt, oracle, gv1, cfg):
     """test_gpu_parity.check_factor_panels (w and V of every ninth stage against a numpy block elimination in the planner's own
