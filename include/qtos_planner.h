@@ -121,6 +121,11 @@ int qtos_analyze(const QtosParams *params, QtosDims *dims, int *stage_active, in
  * of its columns in elimination order.  Arrays may be NULL.  0, or -4: no schedule for this transcription, -5: the packed
  * copy of the column positions disagrees with the list. */
 int qtos_analyze_sweep(const QtosParams *params, int *n_rounds, int *rows, int *entries, int *pos_min, int *pos_max, int max_places);
+/* Host-only: the elimination order by position, as qtos_debug_structure reports it for a planner (a solver variable's index,
+ * n_sol + row for a multiplier -- n_sol = n_vars without reduce_base --, -1 for a dummy pivot): up to max_positions entries into
+ * `order`; returns the number of positions (n_stages * pivots) or < 0.  tests/test_order_stability.py eliminates the KKT matrix
+ * in this order with numpy, without pivoting, as the chain of fronts does. */
+int qtos_analyze_order(const QtosParams *params, int *order, int max_positions);
 /* Host-only (round 6, analysis only -- no kernel follows this order yet): what a TWO-ENDED elimination of this model's KKT matrix
  * would look like -- a chain from t = 0 forward, a chain from t = T backward, the unknowns alive across the split time (the
  * separator) last -- and the LDS a workgroup that runs both chains would need.  out (n_out >= 20 ints):

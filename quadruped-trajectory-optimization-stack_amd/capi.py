@@ -62,7 +62,7 @@ EXPORTS = [
     "qtos_last_timing_chord", "qtos_debug_chord", "qtos_plan_totals",
     "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation", "qtos_debug_residual", "qtos_project_nodes",
     "qtos_debug_stream_len", "qtos_debug_read_stream", "qtos_debug_read_rhs", "qtos_build_flags", "qtos_kkt_kernel",
-    "qtos_last_timing_detail", "qtos_set_pattern_speculation", "qtos_env", "qtos_analyze_two_ended",
+    "qtos_last_timing_detail", "qtos_set_pattern_speculation", "qtos_env", "qtos_analyze_two_ended", "qtos_analyze_order",
 ]
 
 _lib = None
@@ -135,6 +135,8 @@ def load():
         lib.qtos_env.argtypes = [vp, C.c_char_p, C.c_int]
     if hasattr(lib, "qtos_analyze_two_ended"):
         lib.qtos_analyze_two_ended.argtypes = [C.POINTER(QtosParams), ip, C.c_int]
+    if hasattr(lib, "qtos_analyze_order"):
+        lib.qtos_analyze_order.argtypes = [C.POINTER(QtosParams), ip, C.c_int]
     if hasattr(lib, "qtos_shift_warm"):   # (absent from older builds loaded through QTOS_LIB for A/B timing)
         lib.qtos_shift_warm.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, dp]
         lib.qtos_shift_warm_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
@@ -216,6 +218,17 @@ def analyze(cfg):
     if rc != 0:
         raise ValueError("qtos_analyze failed (%d)" % rc)
     return d, act[:d.n_stages].copy()
+
+
+def analyze_order(cfg):
+    """Host-only: the elimination order by position (solver variable, n_sol + row for a multiplier, -1 = dummy pivot)."""
+    lib = load()
+    p = params_from_config(cfg)
+    a = np.full(1 << 15, -2, np.int32)
+    n = lib.qtos_analyze_order(C.byref(p), _ip(a), a.size)
+    if n < 0 or n > a.size:
+        raise ValueError("qtos_analyze_order failed (%d)" % n)
+    return a[:n].copy()
 
 
 def analyze_two_ended(cfg):

@@ -788,18 +788,6 @@ struct HostModel {
         }
       }
     }
-#ifdef QTOS_EXP_FIX_STANCE_Z
-    // EXPERIMENT (round 6, scratch/devbuild.sh -DQTOS_EXP_FIX_STANCE_Z; never in the product library): what the stance-z
-    // elimination of the round-5 verdict would buy.  On FLAT ground a stance foothold's z starts on the terrain and its row
-    // z = h(cell) never moves it: taking z and the row out of the KKT system leaves the iterates what they are, with the
-    // unknowns and stages a real elimination (affine recovery dz = -(z - h), right-hand-side corrections of the rows that see
-    // z) would have.  WRONG on any terrain with steps.
-    for (int e = 0; e < NEE; ++e) {
-      const Spline &S = eem[e];
-      for (int node = 1; node <= S.n_polys; ++node)
-        if (S.idx[node][3] < 0 && S.idx[node][2] >= 0) replaced[S.idx[node][2]] = 1;
-    }
-#endif
     if (n_sol > (int)sol_diag.size()) sol_diag.resize(n_sol, 0.0);
     {
       // the proximal term delta |dx|^2 over the recovered node values in the unknowns they are recovered from
@@ -853,9 +841,6 @@ struct HostModel {
         bool dup = !swing && node >= 1 && S.idx[node - 1][0] == ti.vx;  // second node of a stance
         if (swing) { con_hi[row] = BIG; row_kind[row] = 2; }
         if (ti.ncol == 0 || dup) row_kind[row] = 0;
-#ifdef QTOS_EXP_FIX_STANCE_Z
-        if (!swing) row_kind[row] = 0;   // (experiment above: the stance rows leave the working set with their z)
-#endif
         ti.in_kkt = row_kind[row] != 0;
         ti.goff = -1;
         if (ti.in_kkt) ti.goff = add_block(swing ? 1 : 0, 1, row, cb.cols, false, nullptr);

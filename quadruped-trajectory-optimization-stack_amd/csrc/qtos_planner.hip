@@ -750,6 +750,20 @@ int qtos_analyze(const QtosParams *params, QtosDims *d, int *stage_active, int m
   return 0;
 }
 
+// Host-only: the elimination order by position (qtos_debug_structure's `order` without a planner handle): var index, n_vars + row
+// for a multiplier, -1 for a dummy pivot; returns the number of positions (n_stages * pivots) or < 0.
+int qtos_analyze_order(const QtosParams *params, int *order, int max_positions) {
+  if (!params || !order) return -1;
+  HostModel M;
+  Symbolic S;
+  S.env = QtosEnv::parse();
+  if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
+  if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
+  const int np = S.n_stages * PIV;
+  for (int i = 0; i < np && i < max_positions; ++i) order[i] = i < (int)S.order.size() ? S.order[i] : -1;   // (as qtos_debug_structure)
+  return np;
+}
+
 // Host-only: what a TWO-ENDED elimination of this model's KKT matrix would look like (Symbolic::analyze_two_ended: a chain from
 // t = 0 forward, a chain from t = T backward, the unknowns alive across the split time last), and the LDS a workgroup that runs
 // both chains would need with the layouts of today's kernel.  out (>= 20 ints):
