@@ -80,6 +80,9 @@ def parse_args(argv=None):
     ap.add_argument("--advance", type=float, default=2.5,
                     help="mpc_random: seconds into its newest plan at which a window's next plan starts (the reference's "
                          "f_steps = 2500 rows, scripts/main.py:177; moved on until all feet are in contact)")
+    ap.add_argument("--warm", default="none", choices=["none", "shifted"],
+                    help="mpc_random: starting point of a replan -- towr's straight-line guess (the reference's behaviour, default) or the "
+                         "previous plan shifted to the hand-over time (qtos_shift_warm)")
     ap.add_argument("--full-system", action="store_true",
                     help="every row of the reference's NLP in the KKT system (PlannerConfig.reduce_base off: 2885 unknowns / 181 "
                          "stages instead of 1721 / 108 on the 100-knot transcription) -- the system rounds 1 and 2 solved")
@@ -440,7 +443,7 @@ def main():
             if j:
                 Pj.set_heightfields(terrain[0], terrain[1])
             sl = slice(j * per, (j + 1) * per)
-            windows.append(ShiftedWindows(Pj, start_np[sl], gstep[sl], map_id_np[sl], advance=args.advance, x_range=(0.0, 2.2),   # walk up and down the ledges
+            windows.append(ShiftedWindows(Pj, start_np[sl], gstep[sl], map_id_np[sl], advance=args.advance, x_range=(0.0, 2.2), warm=args.warm,   # walk up and down the ledges
                                           stream=torch.cuda.current_stream(dev) if nset == 1 else torch.cuda.Stream(dev)))
         # several sets: one host thread per set (every replan queues ~40 small kernels -- sampling, hand-over rows, the
         # solve --: issued by ONE thread in turn for four sets the launches arrive too slowly, 31 ms per replan of all
@@ -618,7 +621,7 @@ def main():
                         "constraint rows), %s" %
                         (B, {"exp1_flat": "exp_1 flat-ground", "exp5_step": "exp_5 step-climb",
                              "mixed": "mixed exp_1/exp_3/exp_5",
-                             "mpc_random": "receding-window replans (hand-over row %.1f s into the newest plan as the reference's stitcher picks it, cold start) on randomized exp_5 heightfields: ledge" % args.advance}[args.workload],
+                             "mpc_random": "receding-window replans (hand-over row %.1f s into the newest plan as the reference's stitcher picks it, %s) on randomized exp_5 heightfields: ledge" % (args.advance, "cold start" if args.warm == "none" else "start = the previous plan shifted to the hand-over time")}[args.workload],
                          args.transcription, d.n_base_nodes - 1, d.n_vars, d.n_cons,
                          "walk gait of the reference's golden plans" if args.gait == "walk" else "diagonal-pair trot (config.TROT_UNNORMALISED, unpinned)"),
             "global_batch": total_plans, "plans_timed": total_plans * args.steps, "converged": n_solved,

@@ -230,7 +230,8 @@ struct HostModel {
   int off_terrain[NEE], off_dyn = 0, off_acc_lin = 0, off_acc_ang = 0, off_rom[NEE],
       off_force[NEE], off_swing[NEE];
   std::vector<double> t_dyn, t_rom;
-  std::vector<double> var_time, con_time, con_lo, con_hi;
+  std::vector<double> var_time, con_time, con_lo, con_hi;   // var_time / con_time: the time KEYS of the elimination order (Symbolic), not physics
+  std::vector<double> node_time;                            // the time of the node a model variable belongs to (k_shift_warm samples the previous plan there)
   std::vector<int> row_kind;  // 0 dropped from the working set, 1 equality, 2 inequality
   std::vector<InitDesc> init;
   // instances
@@ -303,6 +304,17 @@ struct HostModel {
   // projection of a starting point onto the rule: x[psw_var] = psw_w[2 i] x[psw_src[2 i]] + psw_w[2 i + 1] x[psw_src[2 i + 1]]
   std::vector<int> psw_var, psw_src;
   std::vector<double> psw_w;
+  // Time keys of the elimination order (Symbolic orders the unknowns by var_time / con_time).  Rule 0 (rounds 1 - 5): a force node
+  // at its node time, a B-spline coefficient at the knot in the middle of its support, a multiplier at its row's time.  Rule 1
+  // (round 6, "late force nodes"): a force node half a polynomial LATER -- eliminated at its node time it pulls the dynamics rows
+  // of the next polynomial (0.35 s: 48 multipliers) into the front at once --, the coefficients one base polynomial earlier, and
+  // the multipliers of the FIRST dynamics knot behind every variable of their block: the base state is fixed at t = 0, and
+  // with the force nodes later those six rows would be the first pivots, -eps alone under the block's largest entries (growth
+  // 1e11 in the factors, KKT residuals of 1 .. 1e7: profiles/r06_experiments/order_keys.log).  With it the 100-knot walk and the
+  // 200-knot transcription fit 96 slots instead of 112 at the same number of stages (-10 % per KKT launch), one KKT solve is
+  // accurate to 2e-8 (4e-9 with rule 0).  The trot and the 51-node transcription are smaller under rule 0: the planner builds
+  // both orders and keeps the smaller front (qtos_planner.hip pick_order_rule; QTOS_ORDER forces one).
+  int order_rule = 0;
   mutable bool foot_sol_overflow = false;   // make_foot_sol met more than four (variable, weight) pairs in one dimension
   VecInW make_foot_sol(int e, double t) const {
     const VecIn in = make_in(eem[e], t, 0);
@@ -595,6 +607,20 @@ struct HostModel {
     book(ang, 1);
     for (int e = 0; e < NEE; ++e) book(eem[e], 2 + e);
     for (int e = 0; e < NEE; ++e) book(eef[e], 6 + e);
+    // (the keys below move: reduce_swing puts a foothold's key at the end of the swing behind its stance, order rule 1 the force
+    //  nodes' half a polynomial later -- the node times themselves are kept for the time-shifted warm start.  Up to round 5
+    //  k_shift_warm read the keys: a foothold in front of a swing was sampled at the START of the next stance, i.e. it got the
+    //  next foothold's position)
+    node_time = var_time;
+    if (order_rule == 1)   // late force nodes: half a polynomial behind the node's time
+      for (int e = 0; e < NEE; ++e) {
+        const Spline &S = eef[e];
+        for (int node = 0; node <= S.n_polys; ++node) {
+          const double dn = S.dur[std::min(node, S.n_polys - 1)];
+          for (int i = 0; i < 6; ++i)
+            if (S.idx[node][i] >= 0) var_time[S.idx[node][i]] = S.node_time(node) + 0.5 * dn;
+        }
+      }
     for (int d = 0; d < 3; ++d) {
       init[off_lin + d].fix_src = d;                                   // start CoM
       init[off_lin + 3 + d].fix_src = P.honor_start_velocity ? 18 + d : 26;
@@ -667,7 +693,8 @@ struct HostModel {
             // elimination time: the knot in the middle of the coefficient's support -- each dynamics row then finds coefficients
             // of its polynomial eliminated in front of it (eliminated at the END of their support the multipliers of the rows
             // come first with pivots of -eps_dual: the factorisation without pivoting breaks down)
-            var_time[id] = knots[std::min(j + 3, (int)knots.size() - 1)];
+            // (order rule 1: one base polynomial earlier)
+            var_time[id] = knots[std::min(j + 3, (int)knots.size() - 1)] - (order_rule == 1 ? P.dt_base : 0.0);
           }
           // end states: p(t_0) = c_0, p'(t_0) = 3 (c_1 - c_0) / h_0; p(T) = c_last, p'(T) = 3 (c_last - c_last-1) / h_last.
           // A fixed position removes c_0 (c_last); a fixed velocity ties c_1 to c_0 (c_last-1 to c_last): no freedom if that
@@ -873,8 +900,12 @@ struct HostModel {
       // the grid repeats T when floor(T/dt)*dt == T: the repeated block is the same six equations
       bool dup = k > 0 && std::fabs(t - t_dyn[k - 1]) < 1e-9;
       di.in_kkt = !dup;
+      // (order rule 1: the first knot's multipliers behind every variable of their block -- see order_rule)
+      double t_row = t;
+      if (order_rule == 1 && k == 0)
+        for (int c : cb.cols) t_row = std::max(t_row, var_time[c]);
       for (int i = 0; i < 6; ++i) {
-        con_time[di.row0 + i] = t;
+        con_time[di.row0 + i] = t_row;
         if (dup) row_kind[di.row0 + i] = 0;
       }
       di.goff = -1;

@@ -188,6 +188,28 @@ static int upload_spline(QtosPlanner *p, const Spline &S, SampleSpline *out) {
   return 0;
 }
 
+// Which time keys the elimination order uses (model.hpp HostModel::order_rule): both rules are analysed, the smaller front wins,
+// then the fewer stages; a tie keeps rule 0 (the order of rounds 1 - 5).  QTOS_ORDER=0 | 1 forces one.
+static int pick_order_rule(const QtosParams &params, const QtosEnv &env) {
+  if (env.order >= 0) return env.order;
+  // (rule 1 moves the B-spline coefficients of the reduced base: without it -- every base row in the system, the configuration
+  //  the internals' tests pin -- the order of rounds 1 - 5 stays)
+  if (!params.reduce_base) return 0;
+  int best = 0, best_front = 1 << 30, best_stages = 1 << 30;
+  for (int rule = 0; rule < 2; ++rule) {
+    HostModel M;
+    Symbolic S;
+    S.env = env;
+    S.env.debug = 0;
+    S.env.dump_first.clear();
+    M.order_rule = rule;
+    if (M.build(params) || S.build(M)) continue;
+    if (S.front < best_front || (S.front == best_front && S.n_stages < best_stages)) { best = rule; best_front = S.front; best_stages = S.n_stages; }
+  }
+  if (env.debug) fprintf(stderr, "qtos: elimination order rule %d (front %d, %d stages)\n", best, best_front, best_stages);
+  return best;
+}
+
 extern "C" {
 __global__ void k_debug_eval(DevPlan P, DevWork W, int B);
 
@@ -295,6 +317,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   p->env = QtosEnv::parse();   // the ONE place a planner reads the environment
   const QtosEnv &env = p->env;
   p->spec_pattern = env.spec_pattern != 0;
+  const int order_rule = pick_order_rule(*params, env);
   {
     int forced = env.kkt;
     if (forced == 3 || forced == 5) { fprintf(stderr, "qtos: QTOS_KKT=%d selected an experiment of rounds 4 - 5 that left the library (scratch/experiments/): default kernel\n", forced); forced = 0; }
@@ -304,7 +327,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
       p->M = HostModel();
       p->S = Symbolic();
       p->S.env = env;
-      if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
+      if ((p->M.order_rule = order_rule, p->M.build(*params))) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
       p->S.cell_mode = 2;
       p->S.pair_mode = true;
       bool ok = p->S.build(p->M) == 0 && kkt5_kernel(p->S.front) != nullptr && !(p->S.pack_src.size() & 1);
@@ -320,7 +343,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
       p->M = HostModel();
       p->S = Symbolic();
       p->S.env = env;
-      if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
+      if ((p->M.order_rule = order_rule, p->M.build(*params))) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
       p->S.cell_mode = 2;
       bool ok = p->S.build(p->M) == 0 && p->S.front <= (forced ? 128 : 112) && !(p->S.pack_src.size() & 1);
       if (ok) {
@@ -342,7 +365,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
     p->M = HostModel();
     p->S = Symbolic();
     p->S.env = env;
-    if (p->M.build(*params)) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
+    if ((p->M.order_rule = order_rule, p->M.build(*params))) { fprintf(stderr, "qtos: %s\n", p->M.err.c_str()); delete p; return -1; }
     p->S.cell_mode = 2;
     p->S.rec_cap_ints = cap;
     p->S.kron = want_kron;
@@ -357,7 +380,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
         want_kron = false;
         p->M = HostModel(); p->S = Symbolic();
         p->S.env = env;
-        if (p->M.build(*params)) { delete p; return -1; }
+        if ((p->M.order_rule = order_rule, p->M.build(*params))) { delete p; return -1; }
         p->S.cell_mode = 2; p->S.rec_cap_ints = cap;
         if (p->S.build(p->M)) { delete p; return -1; }
       }
@@ -533,7 +556,7 @@ int qtos_planner_create(const QtosParams *params, int max_batch, int device, Qto
   TRY(p->upload(S.iq_blocks, &D.iq_blocks)); TRY(p->upload(S.iq_slots, &D.iq_slots));
   TRY(p->upload(M.con_lo, &D.con_lo)); TRY(p->upload(M.con_hi, &D.con_hi));
   TRY(p->upload(M.row_kind, &D.row_kind)); TRY(p->upload(M.init, &D.init));
-  TRY(p->upload(M.var_time, &D.var_time));
+  TRY(p->upload(M.node_time, &D.var_time));   // (node times, not the order's keys: model.hpp node_time)
   D.max_stage_g = S.max_stage_g;
   TRY(p->upload(S.srec, &D.srec)); TRY(p->upload(S.srec_off, &D.srec_off));
   TRY(p->upload(S.pack_src, &D.pack_src)); TRY(p->upload(S.drec_off, &D.drec_off));
@@ -733,7 +756,7 @@ int qtos_analyze(const QtosParams *params, QtosDims *d, int *stage_active, int m
   HostModel M;
   Symbolic S;
   S.env = QtosEnv::parse();
-  if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
+  if ((M.order_rule = pick_order_rule(*params, S.env), M.build(*params))) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
   if (S.env.debug_kron) S.kron = true;
   if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
   if (S.env.debug_kron) {
@@ -757,7 +780,7 @@ int qtos_analyze_order(const QtosParams *params, int *order, int max_positions) 
   HostModel M;
   Symbolic S;
   S.env = QtosEnv::parse();
-  if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
+  if ((M.order_rule = pick_order_rule(*params, S.env), M.build(*params))) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
   if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
   const int np = S.n_stages * PIV;
   for (int i = 0; i < np && i < max_positions; ++i) order[i] = i < (int)S.order.size() ? S.order[i] : -1;   // (as qtos_debug_structure)
@@ -778,7 +801,7 @@ int qtos_analyze_two_ended(const QtosParams *params, int *out, int n_out) {
   HostModel M;
   Symbolic S;
   S.env = QtosEnv::parse();
-  if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
+  if ((M.order_rule = pick_order_rule(*params, S.env), M.build(*params))) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
   if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
   const Symbolic::TwoEnded t = S.analyze_two_ended(M);
   const int F = S.front, Fc = std::max(t.front_left, t.front_right);
@@ -805,7 +828,7 @@ int qtos_analyze_kron(const QtosParams *params, int *n_blocks, int *n_kron, int 
   HostModel M;
   Symbolic S;
   S.env = QtosEnv::parse();
-  if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
+  if ((M.order_rule = pick_order_rule(*params, S.env), M.build(*params))) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
   S.kron = true;
   if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
   *n_blocks = 0;
@@ -823,7 +846,7 @@ int qtos_analyze_sweep(const QtosParams *params, int *n_rounds, int *rows, int *
   HostModel M;
   Symbolic S;
   S.env = QtosEnv::parse();
-  if (M.build(*params)) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
+  if ((M.order_rule = pick_order_rule(*params, S.env), M.build(*params))) { fprintf(stderr, "qtos: %s\n", M.err.c_str()); return -1; }
   if (S.build(M)) { fprintf(stderr, "qtos: %s\n", S.err.c_str()); return -1; }
   std::vector<SwTask> tasks;
   std::vector<int> cpos, c16;

@@ -26,12 +26,13 @@ for g in os.environ.get("GAITS", "walk trot").split():
           (tag, g, P.dims.front, P.dims.n_stages, P.kkt_kernel(), 1e3 * t["kkt_seconds"] / max(t["kkt_launches"], 1), float(res.max()), int((st == 0).sum()), int(it.min()), int(it.max())))
     P.close()
 '''
-cands = [("product", {})] + [(" ".join("%s=%s" % kv for kv in c.items()), c) for c in [
-    dict(QTOS_EXP_TLO="0.4", QTOS_EXP_TF="0.5", QTOS_EXP_TB="-1.0"),
-    dict(QTOS_EXP_TLO="0.4", QTOS_EXP_TLOB="0.4", QTOS_EXP_TF="0.5", QTOS_EXP_TB="-1.0"),
-    dict(QTOS_EXP_TLO="0.7", QTOS_EXP_TLOB="0.7", QTOS_EXP_TF="0.5", QTOS_EXP_TB="-1.0"),
-    dict(QTOS_EXP_TLO="0.4", QTOS_EXP_TLOB="0.4", QTOS_EXP_TF="0.5", QTOS_EXP_TFD="0.75", QTOS_EXP_TB="-1.0"),
-    dict(QTOS_EXP_TLOB="0.4", QTOS_EXP_TB="-1.0")]]
+cands = [("product", {})] + [(" ".join("%s=%s" % (k[9:], v) for k, v in c.items()), c) for c in [
+    dict(QTOS_EXP_GUARD="2", QTOS_EXP_NB="30", QTOS_EXP_TF="0.5", QTOS_EXP_TB="-1.0"),
+    dict(QTOS_EXP_GUARD="2", QTOS_EXP_NB="48", QTOS_EXP_TF="0.5", QTOS_EXP_TB="-1.0"),
+    dict(QTOS_EXP_GUARD="2", QTOS_EXP_NB="60", QTOS_EXP_TF="0.5", QTOS_EXP_TB="-1.0"),
+    dict(QTOS_EXP_GUARD="2", QTOS_EXP_NB="48", QTOS_EXP_TF="0.5", QTOS_EXP_TB="-1.0", QTOS_EXP_TLOB="0.2"),
+    dict(QTOS_EXP_GUARD="2", QTOS_EXP_NB="48", QTOS_EXP_TF="0.5", QTOS_EXP_TFD="0.75", QTOS_EXP_TB="-1.0"),
+    dict(QTOS_EXP_GUARD="2", QTOS_EXP_NB="48", QTOS_EXP_TF="0.75", QTOS_EXP_TFD="0.5", QTOS_EXP_TB="-1.0")]]
 for tag, c in cands:
     env = dict(os.environ, TAG=tag[:60], QTOS_LIB="libqtos_exptf.so" if c else "libqtos_planner.so", GAITS="walk", **c)
     subprocess.run([sys.executable, "-c", code], env=env)

@@ -125,9 +125,16 @@ def test_knots200_structure(hip_lib):
     assert (d.n_base_nodes, d.n_dyn_times, d.n_vars, d.n_cons) == (201, 202, 3160, 4558)
     assert act.max() <= d.front == 128 and d.n_stages == 356
     dr, actr = capi.analyze(dataclasses.replace(cfg, reduce_swing=False))     # reduced base: 5685 -> 3321 unknowns
-    assert (dr.n_vars, dr.n_cons) == (3160, 4558) and actr.max() <= dr.front == 128 and dr.n_stages == 208
-    ds, acts = capi.analyze(cfg)     # ... and reduced swings (the default): 32 swings x 8 unknowns fewer
-    assert (ds.n_unknowns, ds.n_stages) == (dr.n_unknowns - 8 * 32, 192) and acts.max() <= ds.front == 112
+    # (round 6: the order with the late force nodes, HostModel::order_rule 1, is the smaller one here -- 112 slots instead of 128)
+    assert (dr.n_vars, dr.n_cons) == (3160, 4558) and actr.max() <= dr.front == 112 and dr.n_stages == 208
+    ds, acts = capi.analyze(cfg)     # ... and reduced swings (the default): 32 swings x 8 unknowns fewer; 96 slots (112 with rule 0)
+    assert (ds.n_unknowns, ds.n_stages) == (dr.n_unknowns - 8 * 32, 192) and acts.max() <= ds.front == 96
+    os.environ["QTOS_ORDER"] = "0"
+    try:
+        d0, _ = capi.analyze(cfg)
+    finally:
+        del os.environ["QTOS_ORDER"]
+    assert (d0.n_stages, d0.front) == (192, 112)
     d2, _ = capi.analyze(PlannerConfig.knots100(duration=10.0, reduce_base=False))
     assert d2.front > 128
 

@@ -40,11 +40,12 @@ def _workload(name, B):
     return PlannerConfig.knots100(), ter, (start, goal, mid)
 
 
-EXPECT = {   # kernel each choice resolves to on the front of the workload (reduced swings + short stages: walk 112 slots, trot 96;
-             # the pair-mode analysis of k_kkt5: 128 / 112)
-    ("2", "walk"): "k_kkt2<112>", ("4", "walk"): "k_kkt3<112, 1>", ("6", "walk"): "k_kkt5<128>", (None, "walk"): "k_kkt3<112, 1>",
+EXPECT = {   # kernel each choice resolves to on the front of the workload (reduced swings + short stages + round 6's order with the late
+             # force nodes where it is the smaller one: walk 96 slots (112 by the order of rounds 1 - 5), trot 96; pair-mode analysis of
+             # k_kkt5: 112 / 112)
+    ("2", "walk"): "k_kkt2<96>", ("4", "walk"): "k_kkt3<96, 1>", ("6", "walk"): "k_kkt5<112>", (None, "walk"): "k_kkt3<96, 1>",
     ("2", "trot"): "k_kkt2<96>", ("4", "trot"): "k_kkt3<96, 1>", ("6", "trot"): "k_kkt5<112>", (None, "trot"): "k_kkt3<96, 1>",
-    ("2", "mixed"): "k_kkt2<112>", ("4", "mixed"): "k_kkt3<112, 1>", ("6", "mixed"): "k_kkt5<128>", (None, "mixed"): "k_kkt3<112, 1>",
+    ("2", "mixed"): "k_kkt2<96>", ("4", "mixed"): "k_kkt3<96, 1>", ("6", "mixed"): "k_kkt5<112>", (None, "mixed"): "k_kkt3<96, 1>",
 }
 
 
@@ -114,16 +115,16 @@ def test_environment_is_read_once_at_creation_and_read_back():
     P0 = _planner(PlannerConfig.knots100(), 2, None)
     e0 = P0.env()
     assert e0["QTOS_KKT"] == "0" and e0["QTOS_LANES"] == "1" and e0["QTOS_SHORT_STAGES"] == "unset" and e0["QTOS_SPEC_PATTERN"] == "1"
-    assert e0["QTOS_SWEEP_DS"] == "1" and e0["QTOS_SPEC_JAC"] == "1"
-    old = {k: os.environ.get(k) for k in ("QTOS_KKT", "QTOS_LANES", "QTOS_SPEC_PATTERN", "QTOS_SHORT_STAGES")}
-    os.environ.update(QTOS_KKT="2", QTOS_LANES="3", QTOS_SPEC_PATTERN="0", QTOS_SHORT_STAGES="0")
+    assert e0["QTOS_SWEEP_DS"] == "1" and e0["QTOS_SPEC_JAC"] == "1" and e0["QTOS_ORDER"] == "unset"
+    old = {k: os.environ.get(k) for k in ("QTOS_KKT", "QTOS_LANES", "QTOS_SPEC_PATTERN", "QTOS_SHORT_STAGES", "QTOS_ORDER")}
+    os.environ.update(QTOS_KKT="2", QTOS_LANES="3", QTOS_SPEC_PATTERN="0", QTOS_SHORT_STAGES="0", QTOS_ORDER="0")
     try:
         assert P0.env() == e0 and P0.kkt_kernel() == EXPECT[(None, "walk")]     # the old handle keeps what it was created with
         from qtos_amd.capi import Planner
         P1 = Planner(PlannerConfig.knots100(), max_batch=2)
         e1 = P1.env()
-        assert (e1["QTOS_KKT"], e1["QTOS_LANES"], e1["QTOS_SPEC_PATTERN"], e1["QTOS_SHORT_STAGES"]) == ("2", "3", "0", "0")
-        assert P1.kkt_kernel().startswith("k_kkt2<128") and P1.dims.front == 128     # (no short stages: the walk's 128 slots; k_kkt2 forced)
+        assert (e1["QTOS_KKT"], e1["QTOS_LANES"], e1["QTOS_SPEC_PATTERN"], e1["QTOS_SHORT_STAGES"], e1["QTOS_ORDER"]) == ("2", "3", "0", "0", "0")
+        assert P1.kkt_kernel().startswith("k_kkt2<128") and P1.dims.front == 128     # (the order of rounds 1 - 5 without short stages: the walk's 128 slots; k_kkt2 forced)
         P1.close()
     finally:
         for k, v in old.items():
