@@ -220,6 +220,9 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
  *   QTOS_SPEC_PATTERN=0      qtos_plan_submit queues the first iteration only and the host reads the counts in front of every
  *                            further one (default 1: the launch pattern below; qtos_set_pattern_speculation does the same per handle)
  *   QTOS_PLACE=1..4          slot placement rule of the analysis (0 = the measured best: a group that hosts the stage's siblings)
+ *   QTOS_ORDER=0 | 1         time keys of the elimination order: 0 = rounds 1 - 5 (force nodes at their node time), 1 = round 6's order
+ *                            with the late force nodes (csrc/model.hpp HostModel::order_rule: the 100-knot walk and the 200-knot
+ *                            transcription fit 96 slots instead of 112).  Unset: both are analysed, the smaller front is kept
  *   QTOS_KRON=1              experiment builds only (128-slot fronts, k_kkt2): the range-of-motion blocks are assembled through
  *                            their Kronecker structure -- 33 sums per block and one product of static weights per entry instead
  *                            of a three-term sum per entry; plans equal to rounding (1e-8), -0.4 % per launch
