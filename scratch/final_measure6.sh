@@ -40,6 +40,11 @@ b lanes2 $X --inflight 2
 b nochord $X --chord-tol 0
 b steps500 $X --steps 500
 b torchrun1 $X --force-torchrun
+QTOS_ORDER=0 b order0_walk $X --gait walk
+QTOS_ORDER=0 b order0_exp5 $X --workload exp5_step
+QTOS_ORDER=0 b order0_mixed $X --workload mixed
+QTOS_ORDER=0 b order0_knots200 $X --transcription knots200
+QTOS_ORDER=0 b order0_mpc $X --transcription knots200 --workload mpc_random --steps 200
 QTOS_KKT=6 b kkt5_walk $X --gait walk
 QTOS_KKT=6 b kkt5_trot $X
 QTOS_KKT=2 b kkt2_trot $X
