@@ -42,6 +42,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Host threads that are not part of the measurement must not spin: the timed loop is ONE host thread submitting a batch and waiting
+# for one word, inside a container whose CPU quota (cgroup cpu.max: 16 CPUs of time on the GPU boxes) is far below the CPUs it may run
+# on (256).  OpenMP / MKL worker teams that numpy or torch started for the set-up (workloads, parity) busy-wait behind their last
+# parallel region (KMP_BLOCKTIME 200 ms, libgomp's spin count); a few hundred spinning threads spend the group's quota within a CFS
+# period and the kernel throttles the WHOLE group -- this thread included -- until the next one: 9 - 11 ms stalls every ~130 ms
+# (profiles/r06_bench_steps500.json of the first pass: step 13 of the series; BENCH_r05's walk leg lost exactly one such stall in its
+# 20 steps).  Set before numpy / torch are imported; `cgroup_throttled_ms` on the line says what the timed region still lost.
+for _k, _v in (("OMP_WAIT_POLICY", "passive"), ("KMP_BLOCKTIME", "0"), ("GOMP_SPINCOUNT", "0"), ("MKL_NUM_THREADS", "16"), ("OPENBLAS_NUM_THREADS", "16")):
+    os.environ.setdefault(_k, _v)
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 REF_LOG_PLANS_PER_S = 1.0 / 0.745  # logs/towr_log.out:81-82, unknown CPU -- not this metric's baseline
 
@@ -140,6 +150,21 @@ def physical_cores():
         return len(seen)
     except (OSError, AttributeError, ValueError):
         return None
+
+
+def cgroup_throttled():
+    """(periods in which this container was throttled, microseconds it spent throttled) so far -- cgroup v2 cpu.stat / v1 cpu.stat;
+    None if unknown."""
+    for f in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            d = dict(ln.split()[:2] for ln in open(f) if len(ln.split()) >= 2)
+            us = d.get("throttled_usec")
+            if us is None and "throttled_time" in d:
+                us = int(d["throttled_time"]) / 1000.0
+            return int(d.get("nr_throttled", 0)), float(us or 0.0)
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def cpu_quota():
@@ -310,6 +335,10 @@ class LegTimes:
         ms = [1e3 * x for x in self.step_s]
         out = {"step_ms": {"min": round(min(ms), 4), "p50": round(percentile(ms, 0.5), 4), "p90": round(percentile(ms, 0.9), 4), "max": round(max(ms), 4)} if ms else None,
                "step_ms_series": [round(x, 3) for x in ms[:25]],
+               # steps that took more than 1.5 x the median (a host stall: the device time of a step does not show them) and what
+               # they cost the timed region in all: on some leases a 9 - 11 ms stall arrives every ~130 ms (round 6, first pass)
+               "stalled_steps": {"count": sum(1 for x in ms if x > 1.5 * percentile(ms, 0.5)),
+                                 "excess_ms": round(sum(x - percentile(ms, 0.5) for x in ms if x > 1.5 * percentile(ms, 0.5)), 3)} if ms else None,
                # the timed region also holds, per step, the read-out of the planner's events (hipEventSynchronize + elapsed times)
                "timed_region_minus_steps_ms_per_step": round(1e3 * (elapsed - sum(self.step_s)) / n, 4)}
         if self.have_detail:
@@ -580,12 +609,14 @@ def main():
         iters = torch.cat([Wj.iters for Wj in windows])
     else:
         t0 = time.perf_counter()
+    thr0 = cgroup_throttled()
     for _ in range(0 if (lanes or (mpc and mpc_pool is not None)) else args.steps):
         ts = time.perf_counter()
         all_nodes, all_status = step()
         leg.add(P, time.perf_counter() - ts)
     sync()
     elapsed = time.perf_counter() - t0
+    thr1 = cgroup_throttled()
     kkt_s, kkt_n, tot_s, chord_s, chord_n = leg.kkt_s, leg.kkt_n, leg.tot_s, leg.chord_s, leg.chord_n
     if not mpc and not lanes:
         tc, ti = P.totals()
@@ -639,6 +670,9 @@ def main():
     if leg.step_s:
         # where a step's time went, per step: distribution over the timed steps, the first 25 of them, the gaps between the kernels
         out.update(leg.summary(elapsed))
+        if thr0 is not None and thr1 is not None:   # CFS throttling of the container during the timed steps (0 = none)
+            out["cgroup_throttled_ms"] = round((thr1[1] - thr0[1]) / 1e3, 3)
+            out["cgroup_throttled_periods"] = thr1[0] - thr0[0]
         out["launch_pattern"] = "off (--no-pattern): the host reads the counts in front of every iteration" if args.no_pattern else \
             "qtos_plan_submit queues the kernels the handle's last two calls both needed per launch slot; informed launches behind that prefix"
         if use_dist and leg.have_detail:   # a slow rank shows here, a slow collective in allgather_ms
@@ -752,6 +786,7 @@ def main():
         dev_sync()
         Pt.totals(reset=True)
         leg2 = LegTimes()
+        thr2 = cgroup_throttled()
         tt0 = time.perf_counter()
         for i in range(args.steps):
             ts = time.perf_counter()
@@ -777,6 +812,10 @@ def main():
                          "chord_avg_launch_ms": round(1e3 * leg2.chord_s / leg2.chord_n, 4) if leg2.chord_n else None},
         }
         out[other].update(leg2.summary(tel))
+        thr3 = cgroup_throttled()
+        if thr2 is not None and thr3 is not None:
+            out[other]["cgroup_throttled_ms"] = round((thr3[1] - thr2[1]) / 1e3, 3)
+            out[other]["cgroup_throttled_periods"] = thr3[0] - thr2[0]
         # HBM traffic and SQ counters of this gait's kernel from the committed PMC passes of its own bench command (separate
         # rocprofv3 runs: profiles/rNN_[trot_]pmc_*.json)
         ft = newest("r[0-9][0-9]_%spmc_hbm.json" % tag2, kkt_kernel_name(Pt))
