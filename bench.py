@@ -319,16 +319,18 @@ class LegTimes:
 
     def add(self, P, wall):
         self.step_s.append(wall)
-        tm = P.timing()   # HIP events recorded on the launch stream around every k_kkt launch
-        self.kkt_s += tm["kkt_seconds"]; self.kkt_n += tm["kkt_launches"]; self.tot_s += tm["total_seconds"]
-        self.chord_s += tm.get("chord_seconds", 0.0); self.chord_n += tm.get("chord_launches", 0)
         if self.have_detail and hasattr(P.lib, "qtos_last_timing_detail"):
-            d = P.timing_detail()
+            d = P.timing_detail()   # HIP events recorded on the launch stream around every kernel of the call: ONE read-out per step
+            self.kkt_s += d["kkt_seconds"]; self.kkt_n += d["kkt_launches"]; self.tot_s += d["total_seconds"]
+            self.chord_s += d["chord_seconds"]; self.chord_n += d["chord_launches"]
             self.gap_s += d["gap_seconds"]; self.solve_s += d["solve_seconds"]; self.stepk_s += d["step_seconds"]; self.start_s += d["start_seconds"]
             self.informed += d["informed_launches"]; self.at_submit += d["slots_at_submit"]; self.slots += d["slots"]
             self.pattern_calls, self.pattern_misses = d["pattern_calls"], d["pattern_misses"]
         else:
             self.have_detail = False
+            tm = P.timing()
+            self.kkt_s += tm["kkt_seconds"]; self.kkt_n += tm["kkt_launches"]; self.tot_s += tm["total_seconds"]
+            self.chord_s += tm.get("chord_seconds", 0.0); self.chord_n += tm.get("chord_launches", 0)
 
     def summary(self, elapsed):
         n = max(len(self.step_s), 1)

@@ -280,7 +280,9 @@ int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, dou
  * guess, out[2] solve kernels, out[3] line-search / linearisation kernels with their counts, out[4] GAPS (a slot's last event
  * -> the next slot's first: the host reading the counts and launching; zero between slots queued at submit time), then counts:
  * out[5] launch slots with work, out[6] slots queued at submit time, out[7] launches that waited for the host, out[8] calls of
- * the handle that followed a launch pattern so far, out[9] of those, calls in which a problem sat a slot out.  n_out >= 10. */
+ * the handle that followed a launch pattern so far, out[9] of those, calls in which a problem sat a slot out.  n_out >= 10; with
+ * n_out >= 14 also out[10] seconds / out[11] launches of the factorising kernel and out[12] / out[13] of k_chord (what
+ * qtos_last_timing and qtos_last_timing_chord report: one call instead of three inside a timed loop). */
 int qtos_last_timing_detail(QtosPlanner *p, double *out, int n_out);
 /* The same for the chord-step launches (k_chord, QtosParams.chord_tol) of the last call. */
 int qtos_last_timing_chord(QtosPlanner *p, double *chord_seconds, int *chord_launches);

@@ -359,11 +359,11 @@ class Planner:
 
     def timing_detail(self):
         """Where the time of the last call went (qtos_last_timing_detail): seconds and launch counts."""
-        a = (C.c_double * 10)()
-        self._chk(self.lib.qtos_last_timing_detail(self.h, a, 10), "last_timing_detail")
+        a = (C.c_double * 14)()
+        self._chk(self.lib.qtos_last_timing_detail(self.h, a, 14), "last_timing_detail")
         keys = ("total_seconds", "start_seconds", "solve_seconds", "step_seconds", "gap_seconds", "slots", "slots_at_submit",
-                "informed_launches", "pattern_calls", "pattern_misses")
-        return {k: (a[i] if i < 5 else int(a[i])) for i, k in enumerate(keys)}
+                "informed_launches", "pattern_calls", "pattern_misses", "kkt_seconds", "kkt_launches", "chord_seconds", "chord_launches")
+        return {k: (a[i] if i < 5 or i in (10, 12) else int(a[i])) for i, k in enumerate(keys)}
 
     def sample(self, nodes, t0, hz=1000.0, n_rows=None):
         nodes = np.ascontiguousarray(nodes, np.float64).reshape(-1, self.n)

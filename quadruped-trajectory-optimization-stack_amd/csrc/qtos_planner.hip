@@ -1238,6 +1238,8 @@ int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, dou
 //          launching (zero between slots queued at submit time) -- plus whatever lies between the last slot and the end event
 //   out[5] launch slots with work, out[6] slots queued at submit time (pattern / blind), out[7] launches that waited for the host
 //   out[8] calls of the handle that followed a pattern so far, out[9] of those, calls in which a problem sat a slot out
+//   n_out >= 14: out[10] seconds / out[11] launches of the factorising kernel, out[12] / out[13] of k_chord (qtos_last_timing's and
+//   qtos_last_timing_chord's numbers: one call instead of three in a timed loop)
 int qtos_last_timing_detail(QtosPlanner *p, double *out, int n_out) {
   if (!p || !out || n_out < 10) return -1;
   HIPCHK(p, hipSetDevice(p->device));
@@ -1245,7 +1247,8 @@ int qtos_last_timing_detail(QtosPlanner *p, double *out, int n_out) {
   const QtosPlanner::Lane &L = p->lanes[0];
   const int ev_start = 2 + 5 * p->max_slots;
   auto ms = [&](hipEvent_t a, hipEvent_t b, double *d) { float t = 0; hipError_t e = hipEventElapsedTime(&t, a, b); *d = t * 1e-3; return e; };
-  double tot = 0, start = 0, solve = 0, step = 0, gaps = 0;
+  double tot = 0, start = 0, solve = 0, step = 0, gaps = 0, kkt_s = 0, chord_s = 0;
+  int kkt_n = 0, chord_n = 0;
   HIPCHK(p, ms(L.ev[0], L.ev[1], &tot));
   HIPCHK(p, ms(L.ev[0], L.ev[ev_start], &start));
   hipEvent_t prev = L.ev[ev_start];
@@ -1257,6 +1260,10 @@ int qtos_last_timing_detail(QtosPlanner *p, double *out, int n_out) {
       HIPCHK(p, ms(prev, b0, &g));
       if (L.was_kkt[i]) HIPCHK(p, ms(b0, L.ev[3 + 5 * i], &sk));
       if (L.was_chord[i]) HIPCHK(p, ms(b0, L.ev[5 + 5 * i], &sc));
+      if (i < L.last_launches) {
+        if (L.was_kkt[i]) { kkt_s += sk; ++kkt_n; }
+        if (L.was_chord[i]) { double own = sc; if (L.was_kkt[i]) HIPCHK(p, ms(L.ev[4 + 5 * i], L.ev[5 + 5 * i], &own)); chord_s += own; ++chord_n; }
+      }
       const double sv = std::max(sk, sc);
       double whole = 0;
       HIPCHK(p, ms(b0, L.ev[6 + 5 * i], &whole));
@@ -1272,6 +1279,7 @@ int qtos_last_timing_detail(QtosPlanner *p, double *out, int n_out) {
   out[0] = tot; out[1] = start; out[2] = solve; out[3] = step; out[4] = gaps;
   out[5] = L.last_launches; out[6] = L.spec; out[7] = L.n_informed;
   out[8] = (double)p->n_pattern_calls; out[9] = (double)p->n_pattern_misses;
+  if (n_out >= 14) { out[10] = kkt_s; out[11] = kkt_n; out[12] = chord_s; out[13] = chord_n; }
   return 0;
 }
 
