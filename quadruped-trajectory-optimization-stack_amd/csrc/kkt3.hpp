@@ -63,6 +63,11 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
 #endif
   // (MODE 1: the number of update waves may be overridden for experiments -- waves 4, 8, 12 join as update indices 12 .. 14)
   constexpr int NT = CF::NT, NU = (MODE == 1 && QTOS_NU3 > 0 && F == 128) ? QTOS_NU3 : CF::NU, MAXT2 = (CF::NTILE + NU - 1) / NU, FR = CF::FR, PSZ = LY::PSZ;
+  // targets of the gather table assembled in phase AB by the waves that idle there.  Fronts of up to 96 slots: none -- with the
+  // records of round 5 (reduced swings) and six tile waves the idle waves' assembly lengthens phase AB by more than it takes off
+  // phase C: -0.6 % (trot) .. -1.5 % (walk, knots200, reference_compat, exp_5, mixed) per launch without it (round 6,
+  // profiles/r06_experiments/kkt96_tuning.log); the equality entries stay in phase AB.  112 and 128 slots: as measured in round 4.
+  constexpr int AB_R = F <= 96 ? 0 : QTOS_AB_ROUNDS;
   const int tid = threadIdx.x, NS = P.n_stages, n = P.n_sol;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
   double *Lib = lds + LY::LIB, *dvb = lds + LY::DVB, *dgb = lds + LY::DGB, *UF = lds + LY::UF, *xs = lds + LY::XS;
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
       //      or retired by the tile waves here: those belong to the columns of stage k+1, and a retired cell is handed out
       //      again two stages later (Symbolic::compact_cells).
       assemble_eq(A, sbuf, dbuf, (wv - NT - 1) * 64 + lane, (15 - NT) * 64);
-      assemble_targets(A, sbuf, dbuf, 0, QTOS_AB_ROUNDS * (15 - NT) * 64, (wv - NT - 1) * 64 + lane, (15 - NT) * 64);
+      assemble_targets(A, sbuf, dbuf, 0, AB_R * (15 - NT) * 64, (wv - NT - 1) * 64 + lane, (15 - NT) * 64);
     }
     KS2(0);
     lds_barrier();
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(KT2) void k_kkt3(DevPlan P, DevWork W, int B) {
     {
       // the targets phase AB left: every wave but the factor wave (the waves without Schur tiles first: low item indices)
       const int apos = is_upd ? (15 - NU) + uw : uw - NU;
-      if (wv >= 1 && k + 2 < NS) assemble_targets(A, sbuf, dbuf, QTOS_AB_ROUNDS * (15 - NT) * 64, 1 << 30, apos * 64 + lane, 15 * 64);
+      if (wv >= 1 && k + 2 < NS) assemble_targets(A, sbuf, dbuf, AB_R * (15 - NT) * 64, 1 << 30, apos * 64 + lane, 15 * 64);
     }
     // LDS-DMA of the records of stage k+3 into the other buffer by waves 8 and 12 (1 KB per instruction, chunk c of a record
     // by wave c mod 2; wave 12 takes the chunks with the header it publishes below)

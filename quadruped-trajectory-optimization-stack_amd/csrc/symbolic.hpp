@@ -35,8 +35,15 @@ constexpr int PIV = 16;
 #ifndef QTOS_NU112
 #define QTOS_NU112 0
 #endif
+#ifndef QTOS_NU96
+#define QTOS_NU96 0
+#endif
 constexpr int kkt_pick_nu(int ntile) {
   if (QTOS_NU112 > 0 && ntile == 28) return QTOS_NU112;   // (experiment: update waves of a 112-slot front)
+  if (QTOS_NU96 > 0 && ntile == 21) return QTOS_NU96;     // (experiment: of a 96-slot front)
+  // 96 slots (21 tiles; both benchmark gaits since round 6): twelve update waves -- nine with two tiles, three with one -- instead of
+  // the eleven the rule below picks: -0.7 % per launch; 7, 9, 10, 13, 14 waves: +2 .. +8 % (profiles/r06_experiments/kkt96_tuning.log)
+  if (ntile == 21) return 12;
   int best = 14, best_t = (ntile + 13) / 14;
   for (int nu = 14; nu >= 8; --nu) {
     const int t = (ntile + nu - 1) / nu;
