@@ -1,7 +1,7 @@
 """Every factor + solve kernel the product library can select (QTOS_KKT, include/qtos_planner.h: qtos_kkt_kernel) on the
 driver's box: k_kkt2 (forced: 2), k_kkt3 MODE 1 (forced: 4; the default up to 112 slots) and k_kkt5 (6: two 16-pivot stages
-per set of barriers, pair-mode analysis).  The kernels that were built, measured and lost (k_kkt3 MODE 0, k_kkt4, the
-Kronecker assembly) live in the experiment build only (scratch/build.sh -DQTOS_EXPERIMENTS)."""
+per set of barriers, pair-mode analysis).  The kernels that were built, measured and lost (k_kkt3 MODE 0, k_kkt4) left csrc/ in
+round 6 (scratch/experiments/); the environment is read once per planner (csrc/env.hpp) and read back through qtos_env."""
 import os
 
 import numpy as np
