@@ -98,7 +98,9 @@ typedef struct QtosDims {
   long long kkt_algorithmic_bytes;  /* w*[sum_k (p+c_k)*p + 2M], SURVEY.md 8d formula          */
   long long kkt_flops;              /* 2*sum_k p*(p+c_k)^2                                     */
   long long envelope;               /* skyline size of K in the elimination order             */
-  int max_active, pad;              /* largest front actually populated                       */
+  int max_active;                   /* largest front actually populated                       */
+  int order_rule;                   /* time keys of the elimination order the analysis kept: 0 = rounds 1 - 5, 1 = late force
+                                       nodes (round 6; csrc/model.hpp HostModel::order_rule, QTOS_ORDER)                     */
   double duration;
 } QtosDims;
 

@@ -48,7 +48,7 @@ class QtosDims(C.Structure):
         ("n_rows_csv", C.c_int),
         ("panel_doubles", C.c_longlong), ("g_doubles", C.c_longlong),
         ("kkt_algorithmic_bytes", C.c_longlong), ("kkt_flops", C.c_longlong),
-        ("envelope", C.c_longlong), ("max_active", C.c_int), ("pad", C.c_int),
+        ("envelope", C.c_longlong), ("max_active", C.c_int), ("order_rule", C.c_int),
         ("duration", C.c_double),
     ]
 

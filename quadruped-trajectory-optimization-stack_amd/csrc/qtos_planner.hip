@@ -741,7 +741,7 @@ static void fill_dims(const HostModel &M, const Symbolic &S, QtosDims *d) {
   d->n_rows_csv = (int)std::llround(M.T * 1000.0) + 1;
   d->panel_doubles = (long long)S.n_stages * (S.front + 1) * PIV; d->g_doubles = S.g_doubles;
   d->kkt_algorithmic_bytes = S.algorithmic_bytes; d->kkt_flops = S.flops;
-  d->envelope = S.envelope; d->max_active = S.max_active;
+  d->envelope = S.envelope; d->max_active = S.max_active; d->order_rule = M.order_rule;
   d->duration = M.T;
 }
 

@@ -110,6 +110,18 @@ def test_knots100_structure(hip_lib):
     d, act = capi.analyze(PlannerConfig.knots100())
     assert d.n_base_nodes == 101 and d.n_dyn_times == 102 and d.n_vars == 1640
     assert act.max() <= d.front <= 128
+    # round 6: the analysis builds both elimination orders and keeps the smaller front (QtosDims.order_rule): the walk and the
+    # 200-knot transcription take the order with the late force nodes (96 slots instead of 112), the trot, the reference's own
+    # transcription and every full-base system the order of rounds 1 - 5
+    assert (d.order_rule, d.front, d.n_stages) == (1, 96, 100)
+    dt, _ = capi.analyze(PlannerConfig.knots100(gait="trot"))
+    assert (dt.order_rule, dt.front, dt.n_stages) == (0, 96, 113)
+    dc, _ = capi.analyze(PlannerConfig.reference_compat())
+    assert (dc.order_rule, dc.front, dc.n_stages) == (0, 96, 63)
+    df, _ = capi.analyze(PlannerConfig.knots100(reduce_base=False))
+    assert df.order_rule == 0
+    dk, _ = capi.analyze(PlannerConfig.knots200())
+    assert (dk.order_rule, dk.front) == (1, 96)
 
 
 def test_knots200_structure(hip_lib):
