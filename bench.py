@@ -22,6 +22,8 @@ Extra objects on the JSON line:
   step_ms, step_ms_series, gap_ms_per_step, device_ms_per_step, host_round_trips_per_step ...
                where a step's time went: the host's clock around every timed step (distribution + the first 25)
                and the planner's own HIP events split into kernels and the gaps between them.
+               (The per-kernel events are recorded on every --events-every-th timed step, default 4: thirteen event packets
+               between the kernels of a batch cost it 1.9 %; `steps_with_kernel_events` says how many steps carried them.)
   roofline     dominant kernel (k_kkt3 / k_kkt2): algorithmic bytes per launch (SURVEY.md 8d formula on the
                planner's actual stage sizes) / average launch duration from HIP events; counter-based
                matrix-pipe utilisation from the newest profiles/*_pmc_sq.json (same command).
@@ -116,6 +118,10 @@ def parse_args(argv=None):
                     help="adaptive warm-up: behind the --warmup untimed steps, further untimed steps until three in a row lie within "
                          "--settle-tol of each other, at most this many (0 = none); the line reports how many ran")
     ap.add_argument("--settle-tol", type=float, default=0.02)
+    ap.add_argument("--events-every", type=int, default=4,
+                    help="the planner's per-kernel HIP events (what `roofline.avg_launch_ms`, `gap_ms_per_step`, `kernel_ms_per_step` are "
+                         "measured from) are recorded on every N-th timed step, the first included (qtos_set_kernel_events): thirteen "
+                         "event packets between the kernels of a batch cost it 0.046 ms = 1.9 %% (scratch/r6_events.py); 1 = every step")
     ap.add_argument("--no-pattern", action="store_true",
                     help="qtos_set_pattern_speculation(0): the host reads the counts in front of every Newton iteration and launches it "
                          "(rounds 1 - 5) instead of queueing the handle's launch pattern at submit time")
@@ -316,9 +322,15 @@ class LegTimes:
         self.gap_s, self.solve_s, self.stepk_s, self.start_s, self.informed, self.at_submit, self.slots = 0.0, 0.0, 0.0, 0.0, 0, 0, 0
         self.pattern_calls = self.pattern_misses = 0
         self.have_detail = True
+        self.n_ev = 0          # steps whose kernels carried HIP events (--events-every)
+        self.wall_ev_s = 0.0
 
-    def add(self, P, wall):
+    def add(self, P, wall, sampled=True):
         self.step_s.append(wall)
+        if not sampled:        # (a step without per-kernel events: its wall time only)
+            return
+        self.n_ev += 1
+        self.wall_ev_s += wall
         if self.have_detail and hasattr(P.lib, "qtos_last_timing_detail"):
             d = P.timing_detail()   # HIP events recorded on the launch stream around every kernel of the call: ONE read-out per step
             self.kkt_s += d["kkt_seconds"]; self.kkt_n += d["kkt_launches"]; self.tot_s += d["total_seconds"]
@@ -334,6 +346,7 @@ class LegTimes:
 
     def summary(self, elapsed):
         n = max(len(self.step_s), 1)
+        ne = max(self.n_ev, 1)     # the event-based figures are means over the steps that carried events
         ms = [1e3 * x for x in self.step_s]
         out = {"step_ms": {"min": round(min(ms), 4), "p50": round(percentile(ms, 0.5), 4), "p90": round(percentile(ms, 0.9), 4), "max": round(max(ms), 4)} if ms else None,
                "step_ms_series": [round(x, 3) for x in ms[:25]],
@@ -345,16 +358,17 @@ class LegTimes:
                "timed_region_minus_steps_ms_per_step": round(1e3 * (elapsed - sum(self.step_s)) / n, 4)}
         if self.have_detail:
             out.update({
-                "device_ms_per_step": round(1e3 * self.tot_s / n, 4),
+                "steps_with_kernel_events": self.n_ev,
+                "device_ms_per_step": round(1e3 * self.tot_s / ne, 4),
                 # between the kernels of a call: a launch slot's last event -> the next slot's first (the host reading the counts and
                 # launching; ~0 between slots queued at submit time) + what lies between the last slot and the end of the call
-                "gap_ms_per_step": round(1e3 * self.gap_s / n, 4),
-                "kernel_ms_per_step": {"k_start": round(1e3 * self.start_s / n, 4), "solve": round(1e3 * self.solve_s / n, 4), "k_step_and_counts": round(1e3 * self.stepk_s / n, 4)},
-                "launch_slots_per_step": round(self.slots / n, 2), "slots_queued_at_submit_per_step": round(self.at_submit / n, 2),
-                "host_round_trips_per_step": round(self.informed / n + 1, 2),   # (launches that waited for the counts + the end of the call)
+                "gap_ms_per_step": round(1e3 * self.gap_s / ne, 4),
+                "kernel_ms_per_step": {"k_start": round(1e3 * self.start_s / ne, 4), "solve": round(1e3 * self.solve_s / ne, 4), "k_step_and_counts": round(1e3 * self.stepk_s / ne, 4)},
+                "launch_slots_per_step": round(self.slots / ne, 2), "slots_queued_at_submit_per_step": round(self.at_submit / ne, 2),
+                "host_round_trips_per_step": round(self.informed / ne + 1, 2),   # (launches that waited for the counts + the end of the call)
                 "pattern_calls": self.pattern_calls, "pattern_misses": self.pattern_misses,
-                # the host's share of a step: submit latency + the wait for the word that says the batch is finished
-                "host_ms_per_step_outside_device_time": round(1e3 * (sum(self.step_s) - self.tot_s) / n, 4),
+                # the host's share of a step: submit latency + the wait for the word that says the batch is finished (steps with events)
+                "host_ms_per_step_outside_device_time": round(1e3 * (self.wall_ev_s - self.tot_s) / ne, 4),
             })
         return out
 
@@ -474,6 +488,8 @@ def main():
             if j:
                 Pj.set_heightfields(terrain[0], terrain[1])
             sl = slice(j * per, (j + 1) * per)
+            if nset > 1:
+                Pj.set_kernel_events(False)   # (several sets: no per-kernel figures are read on this line, the event packets between the kernels are left out)
             windows.append(ShiftedWindows(Pj, start_np[sl], gstep[sl], map_id_np[sl], advance=args.advance, x_range=(0.0, 2.2), warm=args.warm,   # walk up and down the ledges
                                           stream=torch.cuda.current_stream(dev) if nset == 1 else torch.cuda.Stream(dev)))
         # several sets: one host thread per set (every replan queues ~40 small kernels -- sampling, hand-over rows, the
@@ -542,6 +558,7 @@ def main():
             lane.iters_acc.add_(lane.iters[:lane.n].sum())
         lanes = PlannerPool(cfg, n_lanes=args.inflight, max_batch=B, device=local_rank, heightfields=(terrain[0], terrain[1]), on_done=pool_done)
         for L in lanes.lanes:
+            L.P.set_kernel_events(False)      # (a pool of handles: no per-kernel figures are read on this line)
             with torch.cuda.stream(L.stream):
                 L.solved_acc = torch.zeros((), dtype=torch.int64, device=dev)
                 L.iters_acc = torch.zeros((), dtype=torch.int64, device=dev)
@@ -612,10 +629,16 @@ def main():
     else:
         t0 = time.perf_counter()
     thr0 = cgroup_throttled()
-    for _ in range(0 if (lanes or (mpc and mpc_pool is not None)) else args.steps):
+    ev_every = max(1, args.events_every)
+    for k_ in range(0 if (lanes or (mpc and mpc_pool is not None)) else args.steps):
+        sampled = mpc or k_ % ev_every == 0
+        if not mpc:
+            P.set_kernel_events(sampled)
         ts = time.perf_counter()
         all_nodes, all_status = step()
-        leg.add(P, time.perf_counter() - ts)
+        leg.add(P, time.perf_counter() - ts, sampled)
+    if not mpc:
+        P.set_kernel_events(True)
     sync()
     elapsed = time.perf_counter() - t0
     thr1 = cgroup_throttled()
@@ -663,7 +686,8 @@ def main():
             "iterations_mean": round(float(iters_dev.item()) / max(B * args.steps, 1), 3) if (solved_inflight is None or lanes) else None,
             "parallelism": "batch-shard x%d + 1 %s" % (world, "RCCL all-gather" if use_dist else "all-gather (not launched under torch.distributed: single process)"),
             "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front, "reduce_base": bool(cfg.reduce_base), "reduce_swing": bool(cfg.reduce_swing), "mu_superlinear": bool(cfg.mu_superlinear),
-            "batches_in_flight": args.inflight, "max_iter": cfg.max_iter, "chord_tol": cfg.chord_tol, "chord_max": cfg.chord_max,
+            "batches_in_flight": args.inflight, "kernel_events": ("off: no per-kernel figures on this line" if (lanes or (mpc and args.inflight > 1)) else "every %d-th timed step" % max(1, args.events_every)),
+            "max_iter": cfg.max_iter, "chord_tol": cfg.chord_tol, "chord_max": cfg.chord_max,
             "initial_guess": "towr straight line" if args.init == "straight_line" else
                              "interpolated table of %d nominal plans (solved before the timed region)" % (P.init_table[2].shape[0] * P.init_table[2].shape[1]),
         },
@@ -745,10 +769,11 @@ def main():
             # 1721 instead of 2885 unknowns, so `achieved` above (the SURVEY.md 8d formula on the stages actually run) counts fewer bytes
             "full_system": full_sys,
             "kkt_share_of_device_time": round(kkt_s / max(tot_s, 1e-12), 3),
-            "launches_per_step": round(kkt_n / max(args.steps, 1), 2),
+            "launches_per_step": round(kkt_n / max(leg.n_ev, 1), 2),
+            "events_every": ev_every,
             # k_chord: a solve that re-uses the factor panels of the preceding k_kkt2 launch (no assembly,
             # no factorisation); it reads the panels once more: same algorithmic read bytes, no write
-            "chord_launches_per_step": round(chord_n / max(args.steps, 1), 2),
+            "chord_launches_per_step": round(chord_n / max(leg.n_ev, 1), 2),
             "chord_avg_launch_ms": round(1e3 * chord_s / chord_n, 4) if chord_n else None,
         }
         f = newest("r[0-9][0-9]_%spmc_sq.json" % prof_tag, kernel_here) if headline else None
@@ -791,9 +816,11 @@ def main():
         thr2 = cgroup_throttled()
         tt0 = time.perf_counter()
         for i in range(args.steps):
+            sampled = i % ev_every == 0
+            Pt.set_kernel_events(sampled)
             ts = time.perf_counter()
             leg2_step()
-            leg2.add(Pt, time.perf_counter() - ts)
+            leg2.add(Pt, time.perf_counter() - ts, sampled)
         dev_sync()
         tel = time.perf_counter() - tt0
         tconv, titer = Pt.totals()

@@ -286,6 +286,10 @@ int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, dou
  * n_out >= 14 also out[10] seconds / out[11] launches of the factorising kernel and out[12] / out[13] of k_chord (what
  * qtos_last_timing and qtos_last_timing_chord report: one call instead of three inside a timed loop). */
 int qtos_last_timing_detail(QtosPlanner *p, double *out, int n_out);
+/* The HIP events the three timing entry points read are recorded around every solve kernel and behind every launch slot of a
+ * call (default on: bench.py's roofline figure is measured from them).  on = 0 keeps the call's first and last event only -- a
+ * caller that does not read kernel times saves the event packets between its kernels; the timing entry points then return -1. */
+int qtos_set_kernel_events(QtosPlanner *p, int on);
 /* The same for the chord-step launches (k_chord, QtosParams.chord_tol) of the last call. */
 int qtos_last_timing_chord(QtosPlanner *p, double *chord_seconds, int *chord_launches);
 /* Running totals over all qtos_plan_batch* calls of the handle since the last reset: problems returned with

@@ -62,7 +62,7 @@ EXPORTS = [
     "qtos_last_timing_chord", "qtos_debug_chord", "qtos_plan_totals",
     "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation", "qtos_debug_residual", "qtos_project_nodes",
     "qtos_debug_stream_len", "qtos_debug_read_stream", "qtos_debug_read_rhs", "qtos_build_flags", "qtos_kkt_kernel",
-    "qtos_last_timing_detail", "qtos_set_pattern_speculation", "qtos_env", "qtos_analyze_two_ended", "qtos_analyze_order",
+    "qtos_last_timing_detail", "qtos_set_pattern_speculation", "qtos_env", "qtos_analyze_two_ended", "qtos_analyze_order", "qtos_set_kernel_events",
 ]
 
 _lib = None
@@ -132,6 +132,8 @@ def load():
     if hasattr(lib, "qtos_last_timing_detail"):   # (round 6)
         lib.qtos_last_timing_detail.argtypes = [vp, dp, C.c_int]
         lib.qtos_set_pattern_speculation.argtypes = [vp, C.c_int]
+        if hasattr(lib, "qtos_set_kernel_events"):
+            lib.qtos_set_kernel_events.argtypes = [vp, C.c_int]
         lib.qtos_env.argtypes = [vp, C.c_char_p, C.c_int]
     if hasattr(lib, "qtos_analyze_two_ended"):
         lib.qtos_analyze_two_ended.argtypes = [C.POINTER(QtosParams), ip, C.c_int]
@@ -350,6 +352,10 @@ class Planner:
     def set_pattern_speculation(self, on):
         """The launch pattern of qtos_plan_submit on / off (off forgets what was learnt)."""
         self._chk(self.lib.qtos_set_pattern_speculation(self.h, int(bool(on))), "set_pattern_speculation")
+
+    def set_kernel_events(self, on):
+        """Per-kernel HIP events (what timing() / timing_detail() read) on / off; off = the call's first and last event only."""
+        self._chk(self.lib.qtos_set_kernel_events(self.h, int(bool(on))), "set_kernel_events")
 
     def env(self):
         """The environment switches the handle runs with (read once at creation), as a dict of strings."""

@@ -84,6 +84,7 @@ struct QtosPlanner {
   // every time.  qtos_plan_submit queues that prefix at once, without a look at the counts; the counts behind its last slot
   // say whether anything is left (qtos_plan_poll goes on informed) and whether a problem found the wrong kernel (it sat the
   // launch out, kernels.hpp k_step: the pattern is cut in front of that slot).
+  bool per_kernel_events = true;     // HIP events around every solve kernel and behind every slot (qtos_last_timing*); qtos_set_kernel_events(0): only the call's first and last
   bool spec_pattern = true;
   std::vector<char> pat, obs_prev;   // the prefix queued blind by the next call; the kinds the last call's slots ran
   int max_slots = 0;                 // launch slots a call may use (iterations + launches a problem sat out)
@@ -939,14 +940,14 @@ static int queue_iteration(QtosPlanner *p, QtosPlanner::Lane &c, int it, int kin
     HIPCHK(p, hipStreamWaitEvent(cs, c.ev_fork, 0));
   }
   if (do_kkt) {
-    HIPCHK(p, hipEventRecord(c.ev[2 + 5 * it], st));
+    if (p->per_kernel_events) HIPCHK(p, hipEventRecord(c.ev[2 + 5 * it], st));
     hipLaunchKernelGGL(p->kkt_fn, dim3(c.B), dim3(p->kkt_threads), p->kkt_lds, st, D, c.W, c.B);
-    HIPCHK(p, hipEventRecord(c.ev[3 + 5 * it], st));
+    if (p->per_kernel_events) HIPCHK(p, hipEventRecord(c.ev[3 + 5 * it], st));
   }
   if (do_chord) {
-    HIPCHK(p, hipEventRecord(c.ev[4 + 5 * it], cs));
+    if (p->per_kernel_events) HIPCHK(p, hipEventRecord(c.ev[4 + 5 * it], cs));
     hipLaunchKernelGGL(p->chord_fn, dim3(c.B), dim3(KTC), chord_lds_bytes(p->S.n_stages, p->dp.sw_on ? p->dp.sw_steps : 0), cs, D, c.W, c.B);
-    HIPCHK(p, hipEventRecord(c.ev[5 + 5 * it], cs));
+    if (p->per_kernel_events) HIPCHK(p, hipEventRecord(c.ev[5 + 5 * it], cs));
   }
   if (fork) {
     HIPCHK(p, hipEventRecord(c.ev_join, cs));
@@ -954,7 +955,7 @@ static int queue_iteration(QtosPlanner *p, QtosPlanner::Lane &c, int it, int kin
   }
   hipLaunchKernelGGL(k_step, dim3(c.B), dim3(ET), p->eval_lds, st, D, c.W, c.B, it, kinds);
   if (post) hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, st, c.W.n_active, c.h_active_dev + 4 * it, p->seq);
-  HIPCHK(p, hipEventRecord(c.ev[6 + 5 * it], st));
+  if (p->per_kernel_events) HIPCHK(p, hipEventRecord(c.ev[6 + 5 * it], st));
   return 0;
 }
 
@@ -1023,7 +1024,7 @@ int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double 
     // counts after k_start (slot max_slots of the pinned array), event ev_start; a call that follows the pattern reads no
     // counts in front of the pattern's last slot and posts none
     if (!by_pattern) hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, c.st, c.W.n_active, c.h_active_dev + 4 * p->max_slots, p->seq);
-    SUBCHK(hipEventRecord(c.ev[ev_start], c.st));
+    if (p->per_kernel_events) SUBCHK(hipEventRecord(c.ev[ev_start], c.st));
     if (by_pattern) {
       // the prefix of launch slots the handle's last two calls agree on, queued at once
       c.spec = std::min((int)p->pat.size(), p->max_slots);
@@ -1206,6 +1207,7 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
 // total = first kernel of lane 0 to the end of the call, iterations = the slowest lane's.
 int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, double *total_seconds, int *iterations) {
   if (!p) return -1;
+  if (!p->per_kernel_events) { p->err = "per-kernel events are off (qtos_set_kernel_events)"; return -1; }
   HIPCHK(p, hipSetDevice(p->device));
   HIPCHK(p, hipEventSynchronize(p->lanes[0].ev[1]));
   double kkt = 0;
@@ -1242,6 +1244,7 @@ int qtos_last_timing(QtosPlanner *p, double *kkt_seconds, int *kkt_launches, dou
 //   qtos_last_timing_chord's numbers: one call instead of three in a timed loop)
 int qtos_last_timing_detail(QtosPlanner *p, double *out, int n_out) {
   if (!p || !out || n_out < 10) return -1;
+  if (!p->per_kernel_events) { p->err = "per-kernel events are off (qtos_set_kernel_events)"; return -1; }
   HIPCHK(p, hipSetDevice(p->device));
   HIPCHK(p, hipEventSynchronize(p->lanes[0].ev[1]));
   const QtosPlanner::Lane &L = p->lanes[0];
@@ -1283,6 +1286,12 @@ int qtos_last_timing_detail(QtosPlanner *p, double *out, int n_out) {
   return 0;
 }
 
+int qtos_set_kernel_events(QtosPlanner *p, int on) {
+  if (!p) return -1;
+  p->per_kernel_events = on != 0;
+  return 0;
+}
+
 int qtos_set_pattern_speculation(QtosPlanner *p, int on) {
   if (!p) return -1;
   p->spec_pattern = on != 0;
@@ -1299,6 +1308,7 @@ int qtos_env(const QtosPlanner *p, char *buf, int n) {
 
 int qtos_last_timing_chord(QtosPlanner *p, double *chord_seconds, int *chord_launches) {
   if (!p) return -1;
+  if (!p->per_kernel_events) { p->err = "per-kernel events are off (qtos_set_kernel_events)"; return -1; }
   HIPCHK(p, hipSetDevice(p->device));
   HIPCHK(p, hipEventSynchronize(p->lanes[0].ev[1]));
   double t = 0;

@@ -18,6 +18,7 @@ def test_defaults_are_the_headline_run():
     assert (a.transcription, a.gait, a.workload) == ("knots100", "trot", "exp1_flat")
     assert not a.no_second_gait and not hasattr(a, "trot_steps")
     assert a.settle == 50 and a.settle_tol == 0.02 and not a.no_pattern     # adaptive warm-up on, launch pattern on
+    assert a.events_every == 4     # per-kernel HIP events on every fourth timed step (they cost a batch 1.9 %)
     # the terrain workloads and the receding windows keep the walk (their goals, schedules and parity tests are the walk's)
     assert bench.parse_args(["--workload", "exp5_step"]).gait == "walk"
     assert bench.parse_args(["--workload", "mixed"]).gait == "walk"
