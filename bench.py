@@ -558,7 +558,6 @@ def main():
             lane.iters_acc.add_(lane.iters[:lane.n].sum())
         lanes = PlannerPool(cfg, n_lanes=args.inflight, max_batch=B, device=local_rank, heightfields=(terrain[0], terrain[1]), on_done=pool_done)
         for L in lanes.lanes:
-            L.P.set_kernel_events(False)      # (a pool of handles: no per-kernel figures are read on this line)
             with torch.cuda.stream(L.stream):
                 L.solved_acc = torch.zeros((), dtype=torch.int64, device=dev)
                 L.iters_acc = torch.zeros((), dtype=torch.int64, device=dev)

@@ -46,6 +46,7 @@ class PlannerPool:
         self.lanes = []
         for _ in range(n_lanes):
             P = make()
+            P.set_kernel_events(False)   # (the pool reads no per-kernel times: capi.Planner.set_kernel_events(True) on a lane's planner turns them back on)
             if heightfields is not None:
                 P.set_heightfields(*heightfields)
             self.lanes.append(Lane(P, torch.cuda.Stream(self.dev), max_batch, self.dev))
