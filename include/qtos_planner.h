@@ -99,8 +99,9 @@ typedef struct QtosDims {
   long long kkt_flops;              /* 2*sum_k p*(p+c_k)^2                                     */
   long long envelope;               /* skyline size of K in the elimination order             */
   int max_active;                   /* largest front actually populated                       */
-  int order_rule;                   /* time keys of the elimination order the analysis kept: 0 = rounds 1 - 5, 1 = late force
-                                       nodes (round 6; csrc/model.hpp HostModel::order_rule, QTOS_ORDER)                     */
+  int order_rule;                   /* time keys of the elimination order the analysis kept: 0 = rounds 1 - 5 (full-base systems),
+                                       1 = late force nodes, 2 = early coefficients (round 6; csrc/model.hpp
+                                       HostModel::order_rule, QTOS_ORDER)                                                     */
   double duration;
 } QtosDims;
 
@@ -222,9 +223,13 @@ int qtos_plan_batch(QtosPlanner *p, int B, const double *start, const double *go
  *   QTOS_SPEC_PATTERN=0      qtos_plan_submit queues the first iteration only and the host reads the counts in front of every
  *                            further one (default 1: the launch pattern below; qtos_set_pattern_speculation does the same per handle)
  *   QTOS_PLACE=1..4          slot placement rule of the analysis (0 = the measured best: a group that hosts the stage's siblings)
- *   QTOS_ORDER=0 | 1         time keys of the elimination order: 0 = rounds 1 - 5 (force nodes at their node time), 1 = round 6's order
- *                            with the late force nodes (csrc/model.hpp HostModel::order_rule: the 100-knot walk and the 200-knot
- *                            transcription fit 96 slots instead of 112).  Unset: both are analysed, the smaller front is kept
+ *   QTOS_ORDER=0 | 1 | 2     time keys of the elimination order: 0 = rounds 1 - 5 (force nodes at their node time, B-spline coefficients
+ *                            in the middle of their support), 1 = round 6's order with the late force nodes (csrc/model.hpp
+ *                            HostModel::order_rule: the 100-knot walk and the 200-knot transcription fit 96 slots instead of 112),
+ *                            2 = rule 1 without the late force nodes (coefficients one polynomial earlier, first-knot guard).
+ *                            Unset: on a reduced base rules 2 and 1 are analysed and the smaller front is kept (rule 0 loses up to
+ *                            six digits of a KKT solve on short trot horizons and is not in the automatic choice there); full-base
+ *                            systems keep rule 0
  *   QTOS_KRON=1              experiment builds only (128-slot fronts, k_kkt2): the range-of-motion blocks are assembled through
  *                            their Kronecker structure -- 33 sums per block and one product of static weights per entry instead
  *                            of a three-term sum per entry; plans equal to rounding (1e-8), -0.4 % per launch

@@ -20,8 +20,9 @@ struct QtosEnv {
   int spec_jac = 1;       // QTOS_SPEC_JAC       0: the first trial point of a line search is evaluated without its Jacobian
   int spec_pattern = 1;   // QTOS_SPEC_PATTERN   0: qtos_plan_submit queues the first iteration only (no launch pattern)
   int kron = 0;           // QTOS_KRON           experiment builds only: Kronecker assembly of the range-of-motion blocks
-  int order = -1;         // QTOS_ORDER          time keys of the elimination order: -1 unset (both rules are built, the smaller front is kept), 0 | 1 force
-                          //                     rule 0 (rounds 1 - 5) / rule 1 (late force nodes; model.hpp HostModel::order_rule)
+  int order = -1;         // QTOS_ORDER          time keys of the elimination order: -1 unset (reduced base: rules 2 and 1 are built, the smaller front
+                          //                     is kept), 0 | 1 | 2 force rule 0 (rounds 1 - 5) / rule 1 (late force nodes) / rule 2 (early
+                          //                     coefficients; model.hpp HostModel::order_rule)
   int place = 0;          // QTOS_PLACE          slot placement rule of the analysis (0 = the measured best; 1 .. 4 variants)
   int debug = 0;          // QTOS_DEBUG_SYMBOLIC (1), QTOS_DEBUG_SYMBOLIC2 (2): the analysis talks on stderr
   int debug_kron = 0;     // QTOS_DEBUG_KRON     qtos_analyze reports the Kronecker structure
@@ -39,7 +40,7 @@ struct QtosEnv {
     e.spec_pattern = num("QTOS_SPEC_PATTERN", 1) != 0;
     e.kron = num("QTOS_KRON", 0) != 0;
     e.place = num("QTOS_PLACE", 0);
-    if (getenv("QTOS_ORDER")) e.order = num("QTOS_ORDER", 0) != 0;
+    if (getenv("QTOS_ORDER")) e.order = std::max(0, std::min(2, num("QTOS_ORDER", 0)));
     e.debug = getenv("QTOS_DEBUG_SYMBOLIC2") ? 2 : (getenv("QTOS_DEBUG_SYMBOLIC") ? 1 : 0);
     e.debug_kron = getenv("QTOS_DEBUG_KRON") != nullptr;
     if (const char *v = getenv("QTOS_DUMP_FIRST")) e.dump_first = v;
@@ -49,7 +50,7 @@ struct QtosEnv {
     char b[320];
     snprintf(b, sizeof(b), "QTOS_KKT=%d QTOS_LANES=%d QTOS_SHORT_STAGES=%s QTOS_SWEEP_DS=%d QTOS_SPEC_JAC=%d QTOS_SPEC_PATTERN=%d QTOS_KRON=%d QTOS_PLACE=%d QTOS_ORDER=%s QTOS_DEBUG_SYMBOLIC=%d",
              kkt, lanes, short_stages < 0 ? "unset" : (short_stages ? "1" : "0"), sweep_ds, spec_jac, spec_pattern, kron, place,
-             order < 0 ? "unset" : (order ? "1" : "0"), debug);
+             order < 0 ? "unset" : (order == 2 ? "2" : order ? "1" : "0"), debug);
     return b;
   }
 };

@@ -312,9 +312,17 @@ struct HostModel {
   // with the force nodes later those six rows would be the first pivots, -eps alone under the block's largest entries (growth
   // 1e11 in the factors, KKT residuals of 1 .. 1e7: profiles/r06_experiments/order_keys.log).  With it the 100-knot walk and the
   // 200-knot transcription fit 96 slots instead of 112 at the same number of stages (-10 % per KKT launch), one KKT solve is
-  // accurate to 2e-8 (4e-9 with rule 0).  The trot and the 51-node transcription are smaller under rule 0: the planner builds
-  // both orders and keeps the smaller front (qtos_planner.hip pick_order_rule; QTOS_ORDER forces one).
+  // accurate to 2e-8 (4e-9 with rule 0).  Rule 2 (round 6, second half): rule 1 WITHOUT the late force nodes -- the early
+  // coefficients and the guard alone.  Under rule 0 the multipliers of the second dynamics knot and of the first junction's
+  // acceleration rows are eliminated behind ONE coefficient per dimension: a 12 x 12 block that rests on six coefficients and
+  // whatever stance forces the gait has at t = 0 -- accurate on the walk, 1e-3 .. 7e-3 on short trot horizons
+  // (profiles/r06_experiments/order_fuzz.log); with the coefficients one polynomial earlier two per dimension come first and
+  // every transcription of the fuzz is accurate to 6e-9.  On a reduced base the planner builds rules 2 and 1 and keeps the smaller
+  // front (qtos_planner.hip pick_order_rule; QTOS_ORDER forces one); rule 0 stays the order of the full-base systems.
   int order_rule = 0;
+  bool order_late_force() const { return order_rule == 1; }
+  bool order_early_coef() const { return order_rule == 1 || order_rule == 2; }
+  bool order_guard() const { return order_rule == 1 || order_rule == 2; }
   mutable bool foot_sol_overflow = false;   // make_foot_sol met more than four (variable, weight) pairs in one dimension
   VecInW make_foot_sol(int e, double t) const {
     const VecIn in = make_in(eem[e], t, 0);
@@ -612,7 +620,7 @@ struct HostModel {
     //  k_shift_warm read the keys: a foothold in front of a swing was sampled at the START of the next stance, i.e. it got the
     //  next foothold's position)
     node_time = var_time;
-    if (order_rule == 1)   // late force nodes: half a polynomial behind the node's time
+    if (order_late_force())   // late force nodes: half a polynomial behind the node's time
       for (int e = 0; e < NEE; ++e) {
         const Spline &S = eef[e];
         for (int node = 0; node <= S.n_polys; ++node) {
@@ -694,7 +702,7 @@ struct HostModel {
             // of its polynomial eliminated in front of it (eliminated at the END of their support the multipliers of the rows
             // come first with pivots of -eps_dual: the factorisation without pivoting breaks down)
             // (order rule 1: one base polynomial earlier)
-            var_time[id] = knots[std::min(j + 3, (int)knots.size() - 1)] - (order_rule == 1 ? P.dt_base : 0.0);
+            var_time[id] = knots[std::min(j + 3, (int)knots.size() - 1)] - (order_early_coef() ? P.dt_base : 0.0);
           }
           // end states: p(t_0) = c_0, p'(t_0) = 3 (c_1 - c_0) / h_0; p(T) = c_last, p'(T) = 3 (c_last - c_last-1) / h_last.
           // A fixed position removes c_0 (c_last); a fixed velocity ties c_1 to c_0 (c_last-1 to c_last): no freedom if that
@@ -902,7 +910,7 @@ struct HostModel {
       di.in_kkt = !dup;
       // (order rule 1: the first knot's multipliers behind every variable of their block -- see order_rule)
       double t_row = t;
-      if (order_rule == 1 && k == 0)
+      if (order_guard() && k == 0)
         for (int c : cb.cols) t_row = std::max(t_row, var_time[c]);
       for (int i = 0; i < 6; ++i) {
         con_time[di.row0 + i] = t_row;

@@ -189,23 +189,32 @@ static int upload_spline(QtosPlanner *p, const Spline &S, SampleSpline *out) {
   return 0;
 }
 
-// Which time keys the elimination order uses (model.hpp HostModel::order_rule): both rules are analysed, the smaller front wins,
-// then the fewer stages; a tie keeps rule 0 (the order of rounds 1 - 5).  QTOS_ORDER=0 | 1 forces one.
+// Which time keys the elimination order uses (model.hpp HostModel::order_rule).  On a reduced base rules 2 and 1 are analysed:
+// the smaller front wins, then the fewer stages, then the order that needs no continuation records, then rule 2.  Rule 0 -- the
+// order of rounds 1 - 5 -- has the smallest front on some short horizons and is NOT in the automatic choice there: its KKT solve
+// loses up to six digits on short trots (model.hpp).  QTOS_ORDER=0 | 1 | 2 forces one.
 static int pick_order_rule(const QtosParams &params, const QtosEnv &env) {
   if (env.order >= 0) return env.order;
-  // (rule 1 moves the B-spline coefficients of the reduced base: without it -- every base row in the system, the configuration
-  //  the internals' tests pin -- the order of rounds 1 - 5 stays)
+  // (rules 1 and 2 move the B-spline coefficients of the reduced base: without it -- every base row in the system, the
+  //  configuration the internals' tests pin -- the order of rounds 1 - 5 stays)
   if (!params.reduce_base) return 0;
-  int best = 0, best_front = 1 << 30, best_stages = 1 << 30;
-  for (int rule = 0; rule < 2; ++rule) {
+  int best = 2, best_front = 1 << 30, best_stages = 1 << 30, best_cont = 1 << 30;
+  for (int rule : {2, 1}) {
     HostModel M;
     Symbolic S;
     S.env = env;
     S.env.debug = 0;
     S.env.dump_first.clear();
+    S.cell_mode = 2;
     M.order_rule = rule;
     if (M.build(params) || S.build(M)) continue;
-    if (S.front < best_front || (S.front == best_front && S.n_stages < best_stages)) { best = rule; best_front = S.front; best_stages = S.n_stages; }
+    if (!M.reduce_base) return 0;   // (the model kept the full base: a short horizon or unequal polynomial durations)
+    int n_cont = 0;
+    for (int k = 0; k < S.n_records; ++k) n_cont += S.srec[S.srec_off[k] + 6];
+    const int cont = n_cont > 0;
+    if (S.front < best_front || (S.front == best_front && (S.n_stages < best_stages || (S.n_stages == best_stages && cont < best_cont)))) {
+      best = rule; best_front = S.front; best_stages = S.n_stages; best_cont = cont;
+    }
   }
   if (env.debug) fprintf(stderr, "qtos: elimination order rule %d (front %d, %d stages)\n", best, best_front, best_stages);
   return best;

@@ -110,14 +110,17 @@ def test_knots100_structure(hip_lib):
     d, act = capi.analyze(PlannerConfig.knots100())
     assert d.n_base_nodes == 101 and d.n_dyn_times == 102 and d.n_vars == 1640
     assert act.max() <= d.front <= 128
-    # round 6: the analysis builds both elimination orders and keeps the smaller front (QtosDims.order_rule): the walk and the
-    # 200-knot transcription take the order with the late force nodes (96 slots instead of 112), the trot, the reference's own
-    # transcription and every full-base system the order of rounds 1 - 5
+    # round 6: on a reduced base the analysis builds two elimination orders and keeps the smaller front (QtosDims.order_rule): the
+    # walk and the 200-knot transcription take the order with the late force nodes (rule 1: 96 slots instead of 112), the trot and
+    # the reference's own transcription the one with the early coefficients alone (rule 2); every full-base system keeps the order
+    # of rounds 1 - 5 (rule 0), which is no longer chosen on a reduced base (short trots: a KKT solve accurate to 1e-3 only)
     assert (d.order_rule, d.front, d.n_stages) == (1, 96, 100)
     dt, _ = capi.analyze(PlannerConfig.knots100(gait="trot"))
-    assert (dt.order_rule, dt.front, dt.n_stages) == (0, 96, 113)
+    assert (dt.order_rule, dt.front, dt.n_stages) == (2, 96, 113)
     dc, _ = capi.analyze(PlannerConfig.reference_compat())
-    assert (dc.order_rule, dc.front, dc.n_stages) == (0, 96, 63)
+    assert (dc.order_rule, dc.front, dc.n_stages) == (2, 96, 63)
+    dct, _ = capi.analyze(PlannerConfig.reference_compat(gait="trot"))
+    assert (dct.order_rule, dct.front, dct.n_stages) == (2, 96, 75)      # (rule 0: 80 slots, one KKT solve accurate to 1.2e-3)
     df, _ = capi.analyze(PlannerConfig.knots100(reduce_base=False))
     assert df.order_rule == 0
     dk, _ = capi.analyze(PlannerConfig.knots200())

@@ -1163,10 +1163,10 @@ def test_second_chord_step_finishes_the_trot_batch():
 def test_trot_gait_batch_matches_oracle(reduce_base):
     """The gait BASELINE.json's metric names (diagonal-pair trot, config.TROT_UNNORMALISED; the reference's committed
     plans are the walk), at the benchmark's transcription and batch size: all 256 seeded flat goals converge, and the
-    first 32 take the oracle's iterations to the oracle's nodes: to 1e-6 with every row of the NLP in the KKT system, to
-    5e-6 with the reduced base (the default) -- the oracle regularises the multipliers of the acceleration-continuity rows
-    with eps_dual = 1e-8 (its plans keep a continuity residual of eps_dual times those multipliers), the reduced system
-    satisfies the rows identically; over the trot's 4 .. 5 iterations the two drift 1e-6 apart (the walk: 2e-8)."""
+    first 32 take the oracle's iterations to the oracle's nodes to 1e-6, with every row of the NLP in the KKT system and with
+    the reduced base (the default).  Rounds 3 - 5 held the reduced base to 5e-6 and blamed the oracle's regularisation, then the
+    rounding sensitivity of a cost-free NLP; round 6 found the cause -- the elimination order of those rounds loses digits of the
+    trot's KKT solve (model.hpp order_rule; under rule 2 the gap is the full system's 5e-8) -- and took the gate back to 1e-6."""
     from qtos_amd import workloads
     from qtos_amd.capi import Planner
     from qtos_amd.config import PlannerConfig
@@ -1180,8 +1180,7 @@ def test_trot_gait_batch_matches_oracle(reduce_base):
     assert (status == 0).all() and viol.max() <= cfg.tol
     # (round 5, Ipopt's update of the barrier parameter: the whole batch in four iterations -- it was 4: 58 %, 5: 42 %)
     assert iters.max() <= (4 if reduce_base else 6)
-    # (reduce_swing moves the full system's 1e-6 to the reduced base's 5e-6: the oracle's multipliers of the swing rows)
-    same, worst = _batch_vs_oracle(cfg, start, goal, range(32), status=status, iters=iters, nodes=nodes, tol=5e-6)
+    same, worst = _batch_vs_oracle(cfg, start, goal, range(32), status=status, iters=iters, nodes=nodes, tol=1e-6)
     assert same == 32, (same, worst)
 
 
@@ -1191,7 +1190,7 @@ def test_unmirrored_pair_full_swings_against_the_plain_oracle(gait):
     """The round-4 pair stays pinned while the mirrored pair evolves (round-5 verdict): the product with reduce_swing OFF --
     every swing row an equality row with its multiplier, towr's straight-line guess as the starting point as it is -- against
     the oracle WITHOUT the mirror of round 5 (swing_start_on_rule = 0: nothing of the product's elimination is written into the
-    checker), at the benchmark's transcription: same statuses, same iteration counts, nodes to 1e-6 (walk) / 5e-6 (trot)."""
+    checker), at the benchmark's transcription: same statuses, same iteration counts, nodes to 1e-6 (measured 2e-10 on both gaits)."""
     from oracle.oracle import Oracle, oracle_dict, oracle_options
     from qtos_amd import workloads
     from qtos_amd.capi import Planner
@@ -1206,50 +1205,53 @@ def test_unmirrored_pair_full_swings_against_the_plain_oracle(gait):
     nodes, status, iters, viol = P.plan(start, goal)
     P.close()
     assert (status == 0).all()
-    same, worst = _batch_vs_oracle(cfg, start, goal, range(B), status=status, iters=iters, nodes=nodes, tol=1e-6 if gait == "walk" else 5e-6)
+    same, worst = _batch_vs_oracle(cfg, start, goal, range(B), status=status, iters=iters, nodes=nodes, tol=1e-6)
     assert same == B, (same, worst)
 
 
 @pytest.mark.gpu
-def test_trot_gap_to_the_oracle_is_rounding_sensitivity_not_the_oracles_regularisation():
-    """Where the 5e-6 of the trot (2e-8 on the walk) comes from.  Round 3 blamed the oracle's eps_dual = 1e-8 on the
-    multipliers of the acceleration-continuity rows (the reduced base satisfies those rows identically).  Measured here, that
-    is NOT it: with the ORACLE's eps_dual taken to 1e-10 (the product untouched) the gap stays where it was.  What the gap is:
-    the sensitivity of the iterates of a cost-free NLP to rounding -- two KKT kernels of the product (k_kkt2, and k_kkt5
-    through QTOS_KKT=6: the same system, the same algorithm, another slot assignment and another order of every sum: two
-    stages per step in W form) already differ by a good part of it on the trot and by 1e-8 on the walk.  Both kernels' plans are feasible to the tolerance and take the
-    same iterations; neither side of the comparison is 'the wrong one' at this level."""
+def test_trot_gap_to_the_oracle_was_the_elimination_order():
+    """Where the 5e-6 of the trot in rounds 3 - 5 came from.  Round 3 blamed the oracle's eps_dual on the multipliers of the
+    acceleration-continuity rows, round 5 the sensitivity of a cost-free NLP's iterates to rounding (two KKT kernels of the product
+    -- k_kkt2 and k_kkt5: the same system, another slot assignment and order of every sum -- differed by 2.6e-6 on the trot).
+    Round 6 measured the KKT solve itself over a spread of transcriptions and found the order of rounds 1 - 5 (rule 0) losing up
+    to six digits on trots with a reduced base: the multipliers of the second dynamics knot and of the first junction's
+    acceleration rows were eliminated behind one B-spline coefficient per dimension.  With the coefficients one polynomial
+    earlier (rule 2, what the planner keeps now) the trot's plans equal the oracle's to 5e-8 -- the gap of the FULL system, i.e.
+    the oracle's regularisation and nothing else -- and two kernels of the product agree to 4e-12.  Pinned here: the new order
+    at 5e-7 / 1e-9, and the old order (QTOS_ORDER=0) showing the old gap, so that the cause stays on record."""
     from qtos_amd import workloads
     from qtos_amd.capi import Planner
     from qtos_amd.config import PlannerConfig
     res = {}
+    B = 32
+    start, goal = workloads.flat_goals(B, seed=0)
     for gait in ("trot", "walk"):
         cfg = PlannerConfig.knots100(gait=gait)
-        B = 32
-        start, goal = workloads.flat_goals(B, seed=0)
-        plans = {}
-        for kkt in ("2", "6"):
-            os.environ["QTOS_KKT"] = kkt
-            try:
-                P = Planner(cfg, max_batch=B)
-            finally:
-                del os.environ["QTOS_KKT"]
-            plans[kkt] = P.plan(start, goal)
-            P.close()
-        (n2, s2, i2, v2), (n3, s3, i3, v3) = plans["2"], plans["6"]
-        assert (s2 == 0).all() and (s3 == 0).all() and np.array_equal(i2, i3) and max(v2.max(), v3.max()) <= cfg.tol
-        order_gap = float(np.abs(n2 - n3).max())
-        gaps = {}
-        for eps in (1e-8, 1e-10):
-            same, worst = _batch_vs_oracle(cfg, start, goal, range(16), status=s2, iters=i2, nodes=n2, tol=1e-4, eps_dual=eps)
-            assert same == 16, (gait, eps, same)
-            gaps[eps] = worst
-        res[gait] = (order_gap, gaps)
-    (ot, gt), (ow, gw) = res["trot"], res["walk"]
-    assert gt[1e-8] < 5e-6 and gw[1e-8] < 1e-6, res
-    assert 0.3 < gt[1e-10] / gt[1e-8] < 3.0, res                 # the regularisation does not move the gap
-    assert ot > 0.02 * gt[1e-8] and ot < 5e-6, res               # another order of summation alone gives a good part of it
-    assert ow < 1e-6, res
+        for order in (None, "0"):
+            plans = {}
+            for kkt in ("2", "6"):
+                os.environ["QTOS_KKT"] = kkt
+                if order is not None:
+                    os.environ["QTOS_ORDER"] = order
+                try:
+                    P = Planner(cfg, max_batch=B)
+                finally:
+                    del os.environ["QTOS_KKT"]
+                    os.environ.pop("QTOS_ORDER", None)
+                assert P.dims.order_rule == (0 if order == "0" else 2 if gait == "trot" else 1)
+                plans[kkt] = P.plan(start, goal)
+                P.close()
+            (n2, s2, i2, v2), (n6, s6, i6, v6) = plans["2"], plans["6"]
+            assert (s2 == 0).all() and (s6 == 0).all() and np.array_equal(i2, i6) and max(v2.max(), v6.max()) <= cfg.tol
+            same, worst = _batch_vs_oracle(cfg, start, goal, range(16), status=s2, iters=i2, nodes=n2, tol=1e-4)
+            assert same == 16, (gait, order, same)
+            res[(gait, order)] = (worst, float(np.abs(n2 - n6).max()))
+    (gt, kt), (gt0, kt0) = res[("trot", None)], res[("trot", "0")]
+    (gw, kw), (gw0, kw0) = res[("walk", None)], res[("walk", "0")]
+    assert gt < 5e-7 and kt < 1e-9 and gw < 1e-6 and kw < 1e-9, res          # the orders the planner keeps (measured 5.1e-8 / 3.6e-12, 1.8e-7 / 3.5e-12)
+    assert 3e-7 < gt0 < 5e-6 and kt0 > 100 * kt, res                          # the trot under the order of rounds 1 - 5 (measured 1.1e-6, kernels 2.6e-6 apart)
+    assert gw0 < 1e-6 and kw0 < 1e-8, res                                     # the walk never had the problem
 
 
 @pytest.mark.gpu

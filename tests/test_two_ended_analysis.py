@@ -30,7 +30,12 @@ def test_two_ended_order_halves_the_chain_and_does_not_fit_the_lds(name):
     assert t["sep_unknowns"] <= 80 and t["front_sep"] <= t["front_now"]
     assert t["front_left"] == t["front_now"] and t["front_now"] <= t["front_right"] <= t["front_now"] + 32
     # LDS: today's kernel fills the 160 KB of a compute unit with ONE chain (panels + record buffers + cells + fixed part);
-    # two chains do not fit, neither as they are nor with the lean layout (two panels, one dynamic-only record buffer per chain)
+    # two chains do not fit as they are; with the lean layout (two panels, one dynamic-only record buffer per chain) the walk-based
+    # transcriptions are over by 7 - 9 %, the trot -- under the order with the early coefficients, rule 2 -- is at the limit (1 % under)
     assert t["lds_panels"] + t["lds_records"] + t["lds_cells"] <= t["lds_now"] <= t["lds_limit"]
-    assert t["lds_two_chains_as_is"] > 1.7 * t["lds_limit"] and t["lds_two_chains_lean"] > t["lds_limit"]
+    assert t["lds_two_chains_as_is"] > 1.7 * t["lds_limit"]
+    if name == "trot":
+        assert 0.97 * t["lds_limit"] < t["lds_two_chains_lean"] <= t["lds_limit"]
+    else:
+        assert t["lds_two_chains_lean"] > 1.05 * t["lds_limit"]
     print(name, t)
