@@ -14,7 +14,7 @@ names = {"default": "bench", "driver_cmd": "bench_driver_cmd", "trot": "bench_tr
          "superlinear_mu_mpc": "bench_superlinear_mu_knots200_mpc_random",
          "nochord": "bench_no_chord_step", "torchrun1": "bench_torchrun_1rank", "full_system": "bench_full_system",
          "exp5_lanes3": "bench_exp5_lanes3", "exp5_batch1024": "bench_exp5_batch1024", "mixed_batch1024": "bench_mixed_batch1024", "mixed_lanes3": "bench_mixed_lanes3", "lanes2": "bench_flat_lanes2", "steps500": "bench_steps500",
-         "order0_walk": "bench_order0_walk", "order0_exp5": "bench_order0_exp5", "order0_mixed": "bench_order0_mixed", "order0_knots200": "bench_order0_knots200",
+         "order0_walk": "bench_order0_walk", "order0_trot": "bench_order0_trot", "order0_compat": "bench_order0_reference_compat", "order0_compat_trot": "bench_order0_reference_compat_trot", "order0_exp5": "bench_order0_exp5", "order0_mixed": "bench_order0_mixed", "order0_knots200": "bench_order0_knots200",
          "order0_mpc": "bench_order0_knots200_mpc_random",
          "kkt5_walk": "bench_kkt5_walk", "kkt5_trot": "bench_kkt5_trot", "kkt2_trot": "bench_kkt2_trot", "kkt2_walk": "bench_kkt2_walk"}
 for src, dst in names.items():

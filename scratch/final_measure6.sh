@@ -41,6 +41,9 @@ b nochord $X --chord-tol 0
 b steps500 $X --steps 500
 b torchrun1 $X --force-torchrun
 QTOS_ORDER=0 b order0_walk $X --gait walk
+QTOS_ORDER=0 b order0_trot $X
+QTOS_ORDER=0 b order0_compat $X --gait walk --transcription reference_compat
+QTOS_ORDER=0 b order0_compat_trot $X --transcription reference_compat
 QTOS_ORDER=0 b order0_exp5 $X --workload exp5_step
 QTOS_ORDER=0 b order0_mixed $X --workload mixed
 QTOS_ORDER=0 b order0_knots200 $X --transcription knots200
