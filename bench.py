@@ -684,7 +684,7 @@ def main():
             "iterations_max_last_step": int(itn.max()),
             "iterations_mean": round(float(iters_dev.item()) / max(B * args.steps, 1), 3) if (solved_inflight is None or lanes) else None,
             "parallelism": "batch-shard x%d + 1 %s" % (world, "RCCL all-gather" if use_dist else "all-gather (not launched under torch.distributed: single process)"),
-            "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front, "reduce_base": bool(cfg.reduce_base), "reduce_swing": bool(cfg.reduce_swing), "mu_superlinear": bool(cfg.mu_superlinear),
+            "kkt_unknowns": d.n_unknowns, "kkt_stages": d.n_stages, "front": d.front, "order_rule": d.order_rule, "reduce_base": bool(cfg.reduce_base), "reduce_swing": bool(cfg.reduce_swing), "mu_superlinear": bool(cfg.mu_superlinear),
             "batches_in_flight": args.inflight, "kernel_events": ("off: no per-kernel figures on this line" if (lanes or (mpc and args.inflight > 1)) else "every %d-th timed step" % max(1, args.events_every)),
             "max_iter": cfg.max_iter, "chord_tol": cfg.chord_tol, "chord_max": cfg.chord_max,
             "initial_guess": "towr straight line" if args.init == "straight_line" else
@@ -830,7 +830,7 @@ def main():
             "ms_per_step": round(1e3 * tel / args.steps, 4),
             "timed_region_s": round(tel, 4), "plans_timed": B * args.steps, "converged": int(tconv),
             "iterations_mean": round(titer / max(B * args.steps, 1), 3),
-            "kkt_unknowns": dt_.n_unknowns, "kkt_stages": dt_.n_stages, "front": dt_.front, "n_vars": dt_.n_vars,
+            "kkt_unknowns": dt_.n_unknowns, "kkt_stages": dt_.n_stages, "front": dt_.front, "order_rule": dt_.order_rule, "n_vars": dt_.n_vars,
             "gait": "walk of the reference's golden plans (config.REFERENCE_WALK_UNNORMALISED: the gait the oracle is pinned on and the `parity` block re-solves)" if other == "walk"
                     else "diagonal-pair trot (config.TROT_UNNORMALISED; not pinned by any reference artefact)",
             "roofline": {"kernel": kkt_kernel_name(Pt), "bound": "hbm", "achieved": round(B * dt_.kkt_algorithmic_bytes / tavg / 1e9, 2), "peak": HBM_PEAK_GBS,
