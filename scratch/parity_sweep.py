@@ -27,6 +27,8 @@ B = 256
 s, g = workloads.flat_goals(B, 0)
 sweep("flat knots100", PlannerConfig.knots100(), s, g)
 sweep("flat ref_compat", PlannerConfig.reference_compat(), s, g)
+sweep("flat trot knots100", PlannerConfig.knots100(gait="trot"), s, g)
+sweep("flat trot compat", PlannerConfig.reference_compat(gait="trot"), s, g)
 t = workloads.exp5_terrain(); s5, g5 = workloads.step_goals(B, seed=1, terrain=t)
 sweep("exp5 knots100", PlannerConfig.knots100(), s5, g5, t[0], t[1])
 maps, cell = workloads.mixed_terrains(); sm, gm, mid = workloads.mixed_goals(B, seed=2, terrains=(maps, cell))
