@@ -262,6 +262,13 @@ int qtos_sample_csv(QtosPlanner *p, int B, const double *nodes, const double *t0
 int qtos_sample_csv_device(QtosPlanner *p, int B, const double *d_nodes, const double *d_t0,
                            double hz, int n_rows, double *d_rows_out, void *stream);
 
+/* The plan as the text file the reference copies out of its container (`docker cp <id>:.../build/traj.csv ./data/traj/towr.csv`,
+ * scripts/main.py:90-92; consumers scripts/run.py:129-137, QTOS/combiner.py:263-274): rows is n_rows x 37 (one plan of
+ * qtos_sample_csv), every number printed as the solver's C++ stream prints it (default precision 6 = printf "%g"), comma
+ * separated, no header.  Host only, needs no planner and no GPU.  n_threads <= 0: chosen from n_rows (at most 8).
+ * Returns 0, -1 bad arguments, -2 the file cannot be opened, -3 a short write. */
+int qtos_write_csv(const char *path, const double *rows, int n_rows, int n_threads);
+
 int qtos_plan_submit(QtosPlanner *p, int B, const double *d_start, const double *d_goal,
                      const int *d_map_id, const double *d_warm, double *d_nodes_out,
                      int *d_status_out, int *d_iters_out, double *d_viol_out, void *stream);

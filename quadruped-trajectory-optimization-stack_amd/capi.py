@@ -63,6 +63,7 @@ EXPORTS = [
     "qtos_plan_submit", "qtos_plan_poll", "qtos_plan_wait", "qtos_set_speculation", "qtos_debug_residual", "qtos_project_nodes",
     "qtos_debug_stream_len", "qtos_debug_read_stream", "qtos_debug_read_rhs", "qtos_build_flags", "qtos_kkt_kernel",
     "qtos_last_timing_detail", "qtos_set_pattern_speculation", "qtos_env", "qtos_analyze_two_ended", "qtos_analyze_order", "qtos_set_kernel_events",
+    "qtos_write_csv",
 ]
 
 _lib = None
@@ -103,6 +104,7 @@ def load():
     lib.qtos_plan_batch.argtypes = [vp, C.c_int, dp, dp, ip, dp, dp, ip, ip, dp]
     lib.qtos_plan_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.qtos_sample_csv.argtypes = [vp, C.c_int, dp, dp, C.c_double, C.c_int, dp]
+    lib.qtos_write_csv.argtypes = [C.c_char_p, dp, C.c_int, C.c_int]
     lib.qtos_sample_csv_device.argtypes = [vp, C.c_int, vp, vp, C.c_double, C.c_int, vp, vp]
     lib.qtos_last_timing.argtypes = [vp, dp, ip, dp, ip]
     lib.qtos_debug_eval.argtypes = [vp, C.c_int, dp, dp, ip, dp, dp, dp]

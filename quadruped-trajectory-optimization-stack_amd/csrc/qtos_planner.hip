@@ -14,6 +14,7 @@
 #include "kkt2.hpp"
 #include "kkt3.hpp"
 #include "kkt5.hpp"
+#include "csv_writer.hpp"
 
 using namespace qtos;
 
@@ -1345,6 +1346,12 @@ int qtos_sample_csv_device(QtosPlanner *p, int B, const double *d_nodes, const d
   hipLaunchKernelGGL(k_sample, grid, dim3(256), 0, (hipStream_t)stream_, p->sp, d_nodes, d_t0, hz, n_rows, d_rows_out, B);
   HIPCHK(p, hipGetLastError());
   return 0;
+}
+
+// The plan as the text file the reference fetches from its container (build/traj.csv -> ./data/traj/towr.csv: scripts/main.py:90-92):
+// n_rows x 37 numbers printed like the solver's C++ stream prints them ("%g"), csv_writer.hpp.  Host only, no planner handle.
+int qtos_write_csv(const char *path, const double *rows, int n_rows, int n_threads) {
+  return write_csv_file(path, rows, n_rows, QTOS_CSV_COLS, n_threads);
 }
 
 int qtos_sample_csv(QtosPlanner *p, int B, const double *nodes, const double *t0, double hz, int n_rows, double *rows_out) {

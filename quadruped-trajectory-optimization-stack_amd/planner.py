@@ -107,8 +107,11 @@ class LocalPlanner:
                     nodes_o[i], iters_o[i], viol_o[i], t0_o[i] = nodes[j], iters[j], viol[j], t0s[c + j]
                     rows_o[i] = None if rows is None else rows[j]
         same = len(order) == 1
+        # (one horizon solved in one call of the library -- the usual case: the sampler's array is the result; re-stacking the
+        #  per-problem views copied 1.5 MB per plan twice over)
+        whole = same and n <= self.max_batch
         self.last = dict(nodes=np.stack(nodes_o) if same else nodes_o,
-                         rows=(np.stack(rows_o) if same else rows_o) if sample else None,
+                         rows=(rows if whole else (np.stack(rows_o) if same else rows_o)) if sample else None,
                          status=np.array(statuses), iters=np.array(iters_o), viol=np.array(viol_o), t0=np.array(t0_o),
                          r=[a.get('-r') for a in args_list])
         return statuses

@@ -69,6 +69,46 @@ def test_csv_format(tmp_path):
     assert csvio.COLUMN_MAP["HR_force"] == slice(34, 37)
 
 
+def test_native_csv_writer_prints_every_number_like_percent_g(tmp_path, hip_lib):
+    """qtos_write_csv (csrc/csv_writer.hpp: the native writer behind csvio.write_csv -- a "%g" of its own with snprintf for the
+    values near a rounding boundary) against Python's "%g", byte for byte: random values over 36 decades, the switch points of the
+    format (1e-5 / 1e-4, 999999.5 / 1e6), ties and near-ties of the sixth digit, zeros of both signs, inf / nan, a golden plan's rows;
+    one thread and several; the error codes."""
+    from conftest import load_gv
+    from qtos_amd import csvio
+    rng = np.random.default_rng(7)
+    big = rng.standard_normal((20000, 37)) * 10.0 ** rng.integers(-18, 18, (20000, 37))
+    big[::7, 3] = np.round(big[::7, 3], 3)                     # short decimals (trailing zeros stripped)
+    edge = np.zeros((8, 37))
+    edge[0, :12] = [0.0, -0.0, 1.0, -1.0, 123456.5, 1e-4, 1e-5, 999999.5, 999999.4999, 9.999995e-5, 99999.95, 0.24]
+    edge[1, :10] = [1e5, 1e6, 1e-5, 1e-4, np.inf, -np.inf, np.nan, 3.756, 1e29, 1e-29]
+    edge[2, :8] = [0.1234565, 0.1234575, 2.5e-5, 1234565.0, 1234575.0, 0.5, 1.5e300, 4e-310]
+    edge[3, :] = 100000.5 + np.arange(37)                      # exact ties of the sixth digit: round half to even
+    edge[4, :] = (100000.5 + np.arange(37)) * 1e-9
+    edge[5, :] = np.nextafter(100000.5 + np.arange(37), 0)     # one ulp under a tie
+    edge[6, :] = np.nextafter(100000.5 + np.arange(37), 1e9)   # one ulp over
+    edge[7, :] = 10.0 ** np.arange(-18, 19)                    # the powers of ten themselves
+    gv = load_gv("gv1")
+    golden = np.asarray(gv["rows"], float)
+    for name, rows in (("big", big), ("edge", edge), ("golden", golden)):
+        assert rows.shape[1] == 37
+        ref = tmp_path / (name + "_py.csv")
+        csvio.write_csv_python(str(ref), rows)
+        want = open(ref, "rb").read()
+        for nt in (1, 3, 0):
+            out = tmp_path / ("%s_%d.csv" % (name, nt))
+            csvio.write_csv(str(out), rows, n_threads=nt)
+            got = open(out, "rb").read()
+            if got != want:
+                la, lb = got.decode().splitlines(), want.decode().splitlines()
+                bad = [(i, [(u, v) for u, v in zip(x.split(","), y.split(",")) if u != v][:3]) for i, (x, y) in enumerate(zip(la, lb)) if x != y][:3]
+                raise AssertionError((name, nt, len(la), len(lb), bad))
+    csvio.write_csv(str(tmp_path / "empty.csv"), np.zeros((0, 37)))
+    assert open(tmp_path / "empty.csv").read() == ""
+    with pytest.raises(OSError):
+        csvio.write_csv(str(tmp_path / "no_such_dir" / "x.csv"), edge)
+
+
 def test_c_abi_exports_every_declared_symbol(hip_lib):
     hdr = open(os.path.join(ROOT, "include", "qtos_planner.h")).read()
     names = sorted(set(re.findall(r"\b(qtos_[a-z_0-9]+)\s*\(", hdr)))
