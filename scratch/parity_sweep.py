@@ -4,7 +4,7 @@ import numpy as np
 from oracle.oracle import Oracle, oracle_dict
 from qtos_amd import capi, workloads
 from qtos_amd.config import PlannerConfig
-def sweep(tag, cfg, start, goal, maps=None, cell=None, mid=None, n=96):
+def sweep(tag, cfg, start, goal, maps=None, cell=None, mid=None, n=int(__import__("os").environ.get("SWEEP_N", 96))):
     P = capi.Planner(cfg, max_batch=len(start))
     if maps is not None: P.set_heightfields(maps, cell)
     nodes, status, iters, viol = P.plan(start, goal, map_id=mid)
