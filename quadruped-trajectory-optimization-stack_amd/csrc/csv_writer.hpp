@@ -19,6 +19,15 @@
 
 namespace qtos {
 
+// snprintf's "%g" with the decimal point of the C locale whatever LC_NUMERIC the host application has set (a comma there would
+// be a column separator here)
+inline int format_g6_libc(double v, char *out) {
+  const int k = std::snprintf(out, 32, "%g", v);
+  for (int i = 0; i < k; ++i)
+    if (out[i] == ',') out[i] = '.';
+  return k;
+}
+
 // "%g" of v into out (no terminator); returns the number of characters
 inline int format_g6(double v, char *out) {
   if (v == 0.0) {
@@ -27,7 +36,7 @@ inline int format_g6(double v, char *out) {
     return 1;
   }
   const double a = std::fabs(v);
-  if (!(a >= 1e-30 && a < 1e30)) return std::snprintf(out, 32, "%g", v);   // inf, nan, the far ends of the range
+  if (!(a >= 1e-30 && a < 1e30)) return format_g6_libc(v, out);   // inf, nan, the far ends of the range
   static const double P10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18,
                                1e19, 1e20, 1e21, 1e22, 1e23, 1e24, 1e25, 1e26, 1e27, 1e28, 1e29, 1e30, 1e31, 1e32, 1e33, 1e34, 1e35, 1e36, 1e37};
   // decimal exponent from the binary one (floor(e2 log10 2) is e or e - 1), settled by the range of the scaled value.  The
@@ -40,7 +49,7 @@ inline int format_g6(double v, char *out) {
   else if (s < 100000.0) { --e; s = scaled(e); }
   uint32_t n = (uint32_t)s;
   const double frac = s - (double)n;
-  if (std::fabs(frac - 0.5) < 1e-6 || !(s >= 100000.0 && s < 1000000.0)) return std::snprintf(out, 32, "%g", v);   // a tie to the eye: printf decides
+  if (std::fabs(frac - 0.5) < 1e-6 || !(s >= 100000.0 && s < 1000000.0)) return format_g6_libc(v, out);   // a tie to the eye: printf decides
   if (frac > 0.5) ++n;
   if (n == 1000000u) { n = 100000u; ++e; }
   char dg[6];
